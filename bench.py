@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF node-sampling throughput of the HIP path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole grid: every lattice node of a
+CubicLagrangeDiscreteGrid gets the signed distance to the mesh (the addFunction node loop),
+with the mesh/BVH already resident in HBM.  Workload (BASELINE.json configs[2], the one the
+metric is quoted on): synthetic class-I geodesic icosphere, nu = 71 -> 100 820 triangles,
+unit radius; grid 256^3 over the reference's default domain -> 118 425 857 nodes per GPU.
+For N > 1 (weak scaling, BASELINE configs[3]) the grid grows with N -- (256a, 256b, 256c),
+abc = N, i.e. 512^3 at N = 8 -- the lattice is dealt to the ranks in 4-plane slabs, every
+rank samples its shard, ONE RCCL all-gather assembles the packed shards on every GPU and an
+unpack kernel restores reference node order.  value = total nodes / time, max over ranks.
+
+Also on the JSON line:
+  roofline      achieved = ALGORITHMIC bytes of the reference traversal per launch
+                (B_alg = Vbar*72 + Lbar*84 + 8 bytes/node, SURVEY.md 8(d), frozen in
+                profiles/balg_icosphere71_256.json) / mean K1 kernel duration measured with
+                HIP events on the launch stream; peak = 8 TB/s HBM3E.
+  cpu_baseline  the unmodified reference (oracle/_ref, kind "reference") or this repo's CPU
+                restatement (kind "port") timed on this box's host cores on a bounded,
+                evenly spread sample of the same lattice (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def grid_for(n_gpus):
+    dims = [256, 256, 256]
+    k, axis = n_gpus, 2
+    while k > 1:
+        if k % 2:
+            raise SystemExit("--gpus must be a power of two")
+        dims[axis] *= 2
+        axis = (axis - 1) % 3
+        k //= 2
+    return dims
+
+
+def load_balg():
+    p = os.path.join(ROOT, "profiles", "balg_icosphere71_256.json")
+    with open(p) as f:
+        return json.load(f)
+
+
+def cpu_baseline(V, F, dom, res, budget_s):
+    """Reference (or port) node loop on the host cores over an evenly spread sample."""
+    import dgtest as T
+    n = T.n_nodes(res)
+    if T.ref_available():
+        kind = "reference"
+        g = T.RefGrid(V, F, dom, res)
+
+        def run(b, e):
+            g.sample_nodes(b, e)
+            return g.last_seconds
+    else:
+        kind = "port"
+        om = T.OracleMesh(V, F)
+
+        def run(b, e):
+            om.sample_nodes(dom, res, b, e)
+            return om.last_seconds
+    n_chunks = 32
+    # calibrate on a small spread sample, then size the sample for ~budget_s seconds
+    probe = 4096
+    starts = [int((i + 0.5) * n / n_chunks) for i in range(n_chunks)]
+    t = sum(run(s, s + probe) for s in starts)
+    rate = n_chunks * probe / max(t, 1e-9)
+    per_chunk = int(min(max(rate * budget_s / n_chunks, probe), n // n_chunks))
+    t = sum(run(s, min(n, s + per_chunk)) for s in starts)
+    nodes = sum(min(n, s + per_chunk) - s for s in starts)
+    return {
+        "value": nodes / t / 1e6, "unit": "Mnodes/s", "cores": os.cpu_count(), "kind": kind,
+        "sample": "%d nodes = %d evenly spaced runs of %d consecutive lattice nodes of the same %s grid, "
+                  "OpenMP schedule(static), %.1f s" % (nodes, n_chunks, per_chunk, "x".join(map(str, res)), t),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--pcie", action="store_true", help="also report the PCIe-inclusive rate on stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dgtest as T
+    import discregrid_amd as dg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dg.load_library()
+    dg.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    V, F = T.icosphere(71)
+    dom = T.oracle_default_domain(V)      # cmd/generate_sdf/main.cpp:83-91
+    res = grid_for(world)
+    grid = dg.grid_desc(dom[:3], dom[3:], res)
+    n_nodes = dg.n_nodes(grid)
+    mesh = dg.Mesh(V, F)
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+
+    field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
+    if world > 1:
+        count, stride = dg.shard_layout(grid, rank, world)
+        gathered = torch.empty(world * stride, dtype=torch.float64, device="cuda")
+        mine = gathered[rank * stride:(rank + 1) * stride]
+        launch_nodes = count
+    else:
+        launch_nodes = n_nodes
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record(stream)
+        if world > 1:
+            mesh.sample_shard_device(grid, rank, world, mine.data_ptr(), stream=s)
+        else:
+            mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
+        if i is not None:
+            ev[i][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)          # ONE RCCL collective over xGMI
+            dg.unpack_shards_device(grid, world, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # sanity of the result that was just timed (cheap, outside the timed region)
+    probe = field[:: max(1, n_nodes // 1000)].cpu().numpy()
+    assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0
+
+    if rank == 0:
+        balg = load_balg()
+        achieved = balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mnodes/s SDF sampling (256\u00b3 grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
+            "value": n_nodes * args.steps / elapsed / 1e6,
+            "unit": "Mnodes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "icosphere nu=71 (100820 tris) SDF node sampling, grid %s = %d nodes"
+                            % ("x".join(map(str, res)), n_nodes),
+                "nodes_per_gpu_launch": launch_nodes,
+                "sharding": "none" if world == 1 else "4-plane slabs round-robin + 1 all_gather + unpack",
+                "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": balg.get("measured_hbm_bytes_per_launch") if world == 1 else None,
+                "kernel": "k_sample_nodes", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_node": balg["bytes_per_node"],
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(V, F, dom, res, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        if args.pcie and world == 1:
+            host = torch.empty(n_nodes, dtype=torch.float64).pin_memory()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
+            host.copy_(field, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print("PCIe-inclusive (kernel + D2H into pinned host memory): %.1f Mnodes/s" % (n_nodes / dt / 1e6),
+                  file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

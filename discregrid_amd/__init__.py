@@ -1,0 +1,260 @@
+"""discregrid_amd -- MI355X (gfx950) implementation of Discregrid's SDF-discretisation hot path.
+
+The product is the C-ABI shared library ``libdiscregrid_hip.so`` (hand-written HIP kernels,
+``include/discregrid_hip.h``) plus the Discregrid-compatible C++ host API under
+``discregrid_amd/cpp``.  This Python module is a thin ``ctypes`` binding of that C ABI used
+by the tests and by ``bench.py``; it adds no compute of its own and has NO fallback: if the
+library is missing or no HIP device is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiscregrid_hip.so")
+NO_VALUE = float(np.finfo(np.float64).max)
+
+DG_OK, DG_ERR_INVALID, DG_ERR_NO_DEVICE, DG_ERR_HIP, DG_ERR_ALLOC = range(5)
+
+
+class DiscregridError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("discregrid_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+class GridDesc(C.Structure):
+    """dg_grid_desc: the serialised members of Discregrid::DiscreteGrid."""
+    _fields_ = [("domain_min", C.c_double * 3), ("domain_max", C.c_double * 3), ("resolution", C.c_uint32 * 3),
+                ("reserved_", C.c_uint32), ("cell_size", C.c_double * 3), ("inv_cell_size", C.c_double * 3)]
+
+
+class MeshInfo(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint64), ("n_triangles", C.c_uint64), ("n_bvh_nodes", C.c_uint64),
+                ("bvh_depth", C.c_uint32), ("not_watertight", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("build_seconds", C.c_double)]
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("stride", C.c_uint64)]
+
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/discregrid_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "dg_version": (C.c_char_p, []),
+    "dg_last_error": (C.c_char_p, []),
+    "dg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dg_set_device": (C.c_int, [C.c_int]),
+    "dg_grid_desc_init": (C.c_int, [_dp, _dp, _u32p, C.POINTER(GridDesc)]),
+    "dg_grid_n_nodes": (C.c_uint64, [C.POINTER(GridDesc)]),
+    "dg_grid_n_cells": (C.c_uint64, [C.POINTER(GridDesc)]),
+    "dg_mesh_create": (C.c_int, [_dp, C.c_size_t, _u32p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dg_mesh_get_info": (C.c_int, [C.c_void_p, C.POINTER(MeshInfo)]),
+    "dg_mesh_destroy": (None, [C.c_void_p]),
+    "dg_sdf_sample_nodes": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_uint64, C.c_uint64, _u8p, _dp]),
+    "dg_sdf_sample_nodes_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_uint64, C.c_uint64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_signed_distance": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _i32p, _i32p, _dp]),
+    "dg_signed_distance_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
+    "dg_shard_layout": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_int, C.POINTER(ShardInfo)]),
+    "dg_sdf_sample_shard_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p]),
+    "dg_unpack_shards_device": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                          C.c_void_p]),
+    "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
+                                  C.POINTER(C.c_void_p)]),
+    "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dg_field_destroy": (None, [C.c_void_p]),
+    "dg_interpolate_batch": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _dp]),
+    "dg_interpolate_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
+    "dg_last_kernel_ms": (C.c_double, []),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libdiscregrid_hip.so and types every entry point.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    # PyTorch wheels bundle their own libamdhip64.so.7; a process must use ONE HIP runtime.  When
+    # torch is installed (tests, bench.py use it for device memory / streams / torch.distributed)
+    # let it load its runtime first so that this library binds to the same one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `python -m discregrid_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != DG_OK:
+        raise DiscregridError(status, load_library().dg_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(load_library().dg_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    _check(load_library().dg_set_device(int(i)))
+
+
+def grid_desc(domain_min, domain_max, resolution):
+    """dg_grid_desc_init: cell_size = (max - min) / n, inv_cell_size = 1 / cell_size."""
+    g = GridDesc()
+    mn, mx = _f64(domain_min), _f64(domain_max)
+    res = np.ascontiguousarray(resolution, dtype=np.uint32)
+    _check(load_library().dg_grid_desc_init(mn.ctypes.data_as(_dp), mx.ctypes.data_as(_dp), res.ctypes.data_as(_u32p),
+                                            C.byref(g)))
+    return g
+
+
+def n_nodes(grid):
+    return int(load_library().dg_grid_n_nodes(C.byref(grid)))
+
+
+def shard_layout(grid, rank, nranks):
+    s = ShardInfo()
+    _check(load_library().dg_shard_layout(C.byref(grid), rank, nranks, C.byref(s)))
+    return int(s.count), int(s.stride)
+
+
+class Mesh:
+    """dg_mesh handle: pseudonormals + flattened BVH + triangle packets on the current device."""
+
+    def __init__(self, vertices, triangles):
+        self._lib = load_library()
+        V = _f64(vertices).reshape(-1, 3)
+        F = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+        h = C.c_void_p()
+        _check(self._lib.dg_mesh_create(V.ctypes.data_as(_dp), len(V), F.ctypes.data_as(_u32p), len(F), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.dg_mesh_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def info(self):
+        i = MeshInfo()
+        _check(self._lib.dg_mesh_get_info(self.handle, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in MeshInfo._fields_}
+
+    # ---- host-pointer entry points -----------------------------------------------------------
+    def sample_nodes(self, grid, begin=0, end=None, invert=False, mask=None):
+        if end is None:
+            end = n_nodes(grid)
+        out = np.empty(end - begin, dtype=np.float64)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert len(m) == end - begin
+        _check(self._lib.dg_sdf_sample_nodes(self.handle, C.byref(grid), int(invert), begin, end,
+                                             None if m is None else m.ctypes.data_as(_u8p), out.ctypes.data_as(_dp)))
+        return out
+
+    def signed_distance(self, points, full=False):
+        P = _f64(points).reshape(-1, 3)
+        n = len(P)
+        d = np.empty(n)
+        tri = np.empty(n, dtype=np.int32) if full else None
+        ent = np.empty(n, dtype=np.int32) if full else None
+        near = np.empty((n, 3)) if full else None
+        _check(self._lib.dg_signed_distance(self.handle, P.ctypes.data_as(_dp), n, d.ctypes.data_as(_dp),
+                                            None if tri is None else tri.ctypes.data_as(_i32p),
+                                            None if ent is None else ent.ctypes.data_as(_i32p),
+                                            None if near is None else near.ctypes.data_as(_dp)))
+        return (d, tri, ent, near) if full else d
+
+    # ---- device-pointer entry points (ints = device addresses, stream = hipStream_t address) ---
+    def sample_nodes_device(self, grid, begin, end, d_out, invert=False, d_mask=None, stream=0):
+        _check(self._lib.dg_sdf_sample_nodes_device(self.handle, C.byref(grid), int(invert), begin, end,
+                                                    C.c_void_p(d_mask or 0), C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def sample_shard_device(self, grid, rank, nranks, d_packed, invert=False, stream=0):
+        _check(self._lib.dg_sdf_sample_shard_device(self.handle, C.byref(grid), int(invert), rank, nranks,
+                                                    C.c_void_p(d_packed), C.c_void_p(stream)))
+
+    def signed_distance_device(self, d_xyz, n, d_dist, d_tri=0, d_entity=0, d_nearest=0, stream=0):
+        _check(self._lib.dg_signed_distance_device(self.handle, C.c_void_p(d_xyz), n, C.c_void_p(d_dist),
+                                                   C.c_void_p(d_tri), C.c_void_p(d_entity), C.c_void_p(d_nearest),
+                                                   C.c_void_p(stream)))
+
+
+def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):
+    _check(load_library().dg_unpack_shards_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
+                                                  C.c_void_p(d_field), C.c_void_p(stream)))
+
+
+class Field:
+    """dg_field handle: one coefficient vector (+ optional cell table / cell map)."""
+
+    def __init__(self, grid, coeffs=None, cells=None, cell_map=None, d_coeffs=None, n_coeffs=None, d_cells=None,
+                 n_cell_rows=0, d_cell_map=None):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if d_coeffs is not None:  # non-owning attach of device arrays
+            _check(self._lib.dg_field_attach_device(C.byref(grid), C.c_void_p(d_coeffs), n_coeffs,
+                                                    C.c_void_p(d_cells or 0), n_cell_rows,
+                                                    C.c_void_p(d_cell_map or 0), C.byref(h)))
+        else:
+            c = _f64(coeffs)
+            ce = None if cells is None else np.ascontiguousarray(cells, dtype=np.uint32)
+            cm = None if cell_map is None else np.ascontiguousarray(cell_map, dtype=np.uint32)
+            _check(self._lib.dg_field_create(C.byref(grid), c.ctypes.data_as(_dp), len(c),
+                                             None if ce is None else ce.ctypes.data_as(_u32p),
+                                             0 if ce is None else len(ce.reshape(-1, 32)),
+                                             None if cm is None else cm.ctypes.data_as(_u32p), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.dg_field_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def interpolate(self, points, grad=False):
+        P = _f64(points).reshape(-1, 3)
+        phi = np.empty(len(P))
+        g = np.empty((len(P), 3)) if grad else None
+        _check(self._lib.dg_interpolate_batch(self.handle, P.ctypes.data_as(_dp), len(P), phi.ctypes.data_as(_dp),
+                                              None if g is None else g.ctypes.data_as(_dp)))
+        return (phi, g) if grad else phi
+
+    def interpolate_device(self, d_xyz, n, d_phi, d_grad=0, stream=0):
+        _check(self._lib.dg_interpolate_batch_device(self.handle, C.c_void_p(d_xyz), n, C.c_void_p(d_phi),
+                                                     C.c_void_p(d_grad), C.c_void_p(stream)))
+
+
+def last_kernel_ms():
+    return float(load_library().dg_last_kernel_ms())

@@ -1,0 +1,261 @@
+// dg_build.cpp -- see dg_build.h.  Host code; compile with -ffp-contract=off.
+#include "dg_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+
+namespace dg
+{
+namespace
+{
+
+struct D3
+{
+	double x, y, z;
+};
+inline D3 sub(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 add(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline double dot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline D3 cross3(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x}; }
+inline D3 over(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline D3 times(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline D3 unit3(D3 a) { return over(a, std::sqrt(dot3(a, a))); }
+
+// Pseudonormals in the caller's triangle order: out[t*8 + slot], slots per dg_geom.h.
+// Accumulation order = triangle index order, as in the reference's single loop.
+void pseudonormals(const std::vector<D3>& V, const uint32_t* T, size_t nt, std::vector<D3>& out, uint32_t& flags)
+{
+	const uint64_t nv = V.size();
+	std::vector<D3> vsum(V.size(), D3{0, 0, 0});
+	std::unordered_map<uint64_t, std::pair<D3, int>> edges;
+	edges.reserve(nt * 2);
+	auto key = [nv](uint32_t i, uint32_t j) { return (uint64_t)std::min(i, j) * nv + (uint64_t)std::max(i, j); };
+	auto add_edge = [&](uint32_t i, uint32_t j, D3 n) {
+		auto it = edges.find(key(i, j));
+		if (it == edges.end())
+			edges.emplace(key(i, j), std::make_pair(n, 1));
+		else
+		{
+			it->second.first = add(it->second.first, n);
+			it->second.second += 1;
+		}
+	};
+	out.assign(nt * kPnSlots, D3{0, 0, 0});
+	for (size_t t = 0; t < nt; ++t)
+	{
+		const uint32_t i0 = T[3 * t], i1 = T[3 * t + 1], i2 = T[3 * t + 2];
+		const D3 a = V[i0], b = V[i1], c = V[i2];
+		const D3 n = unit3(cross3(sub(b, a), sub(c, a)));
+		out[t * kPnSlots + kFace] = n;
+		const double al0 = std::acos(std::abs(dot3(unit3(sub(b, a)), unit3(sub(c, a)))));
+		const double al1 = std::acos(std::abs(dot3(unit3(sub(a, b)), unit3(sub(c, b)))));
+		const double al2 = std::acos(std::abs(dot3(unit3(sub(b, c)), unit3(sub(a, c)))));
+		vsum[i0] = add(vsum[i0], times(al0, n));
+		vsum[i1] = add(vsum[i1], times(al1, n));
+		vsum[i2] = add(vsum[i2], times(al2, n));
+		add_edge(i0, i1, n);
+		add_edge(i1, i2, n);
+		add_edge(i0, i2, n);
+	}
+	for (auto& n : vsum)
+	{
+		const double l = std::sqrt(dot3(n, n));
+		n = {n.x / l, n.y / l, n.z / l};
+	}
+	flags = 0;
+	for (auto const& kv : edges)
+	{
+		if (kv.second.second == 1)
+			flags |= 1u;
+		else if (kv.second.second > 2)
+			flags |= 2u;
+	}
+	for (size_t t = 0; t < nt; ++t)
+	{
+		const uint32_t i0 = T[3 * t], i1 = T[3 * t + 1], i2 = T[3 * t + 2];
+		out[t * kPnSlots + kV0] = vsum[i0];
+		out[t * kPnSlots + kV1] = vsum[i1];
+		out[t * kPnSlots + kV2] = vsum[i2];
+		out[t * kPnSlots + kE01] = unit3(edges.find(key(i0, i1))->second.first);
+		out[t * kPnSlots + kE12] = unit3(edges.find(key(i1, i2))->second.first);
+		out[t * kPnSlots + kE02] = unit3(edges.find(key(i0, i2))->second.first);
+	}
+}
+
+inline float round_down(double v)
+{
+	float f = (float)v;
+	if ((double)f > v)
+		f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+	return f;
+}
+inline float round_up(double v)
+{
+	float f = (float)v;
+	if ((double)f < v)
+		f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+	return f;
+}
+
+struct Prim
+{
+	double lo[3], hi[3], c[3];
+	uint32_t tri;
+};
+
+struct Builder
+{
+	std::vector<Prim> prims;
+	std::vector<BvhNode> nodes;
+	std::vector<uint32_t> order; // leaf order -> caller triangle index
+	const double* origin;
+	int max_leaf;
+	uint32_t depth = 0;
+
+	void emit_box(BvhNode& n, size_t b, size_t e)
+	{
+		double lo[3], hi[3];
+		for (int d = 0; d < 3; ++d)
+		{
+			lo[d] = std::numeric_limits<double>::max();
+			hi[d] = std::numeric_limits<double>::lowest();
+		}
+		for (size_t i = b; i < e; ++i)
+			for (int d = 0; d < 3; ++d)
+			{
+				lo[d] = std::min(lo[d], prims[i].lo[d]);
+				hi[d] = std::max(hi[d], prims[i].hi[d]);
+			}
+		for (int d = 0; d < 3; ++d)
+		{
+			n.lo[d] = round_down(lo[d] - origin[d]);
+			n.hi[d] = round_up(hi[d] - origin[d]);
+			// one more ulp outward: the subtraction above rounds too
+			n.lo[d] = std::nextafterf(n.lo[d], -std::numeric_limits<float>::infinity());
+			n.hi[d] = std::nextafterf(n.hi[d], std::numeric_limits<float>::infinity());
+		}
+	}
+
+	// Depth-first emission.  Split: object median along the largest extent of the centroid
+	// bounds (balanced tree, depth = ceil(log2(n / max_leaf))).
+	void build(size_t b, size_t e, uint32_t level)
+	{
+		depth = std::max(depth, level);
+		const size_t me = nodes.size();
+		nodes.push_back(BvhNode());
+		emit_box(nodes[me], b, e);
+		if (e - b <= (size_t)max_leaf)
+		{
+			const uint32_t first = (uint32_t)order.size();
+			for (size_t i = b; i < e; ++i)
+				order.push_back(prims[i].tri);
+			nodes[me].info = ~(int32_t)((first << 3) | (uint32_t)(e - b - 1));
+			nodes[me].skip = (int32_t)nodes.size();
+			return;
+		}
+		double clo[3], chi[3];
+		for (int d = 0; d < 3; ++d)
+		{
+			clo[d] = std::numeric_limits<double>::max();
+			chi[d] = std::numeric_limits<double>::lowest();
+		}
+		for (size_t i = b; i < e; ++i)
+			for (int d = 0; d < 3; ++d)
+			{
+				clo[d] = std::min(clo[d], prims[i].c[d]);
+				chi[d] = std::max(chi[d], prims[i].c[d]);
+			}
+		int axis = 0;
+		for (int d = 1; d < 3; ++d)
+			if (chi[d] - clo[d] > chi[axis] - clo[axis])
+				axis = d;
+		// keep leaves full: left half gets a multiple of max_leaf when possible
+		size_t half = (e - b) / 2;
+		if ((e - b) > (size_t)(2 * max_leaf))
+			half = ((half + max_leaf - 1) / max_leaf) * max_leaf;
+		const size_t mid = b + half;
+		std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
+						 [axis](const Prim& p, const Prim& q) {
+							 return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.tri < q.tri);
+						 });
+		build(b, mid, level + 1);
+		nodes[me].info = (int32_t)nodes.size(); // right child
+		build(mid, e, level + 1);
+		nodes[me].skip = (int32_t)nodes.size();
+	}
+};
+
+} // namespace
+
+bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles, int max_leaf,
+				MeshBuild& out)
+{
+	if (!verts || !tris || n_triangles == 0 || n_vertices == 0 || n_triangles >= (1u << 28))
+		return false;
+	max_leaf = std::max(1, std::min(8, max_leaf));
+	for (size_t i = 0; i < 3 * n_triangles; ++i)
+		if (tris[i] >= n_vertices)
+			return false;
+	std::vector<D3> V(n_vertices);
+	for (size_t i = 0; i < n_vertices; ++i)
+		V[i] = {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
+
+	std::vector<D3> pn;
+	pseudonormals(V, tris, n_triangles, pn, out.not_watertight);
+
+	Builder B;
+	B.max_leaf = max_leaf;
+	B.prims.resize(n_triangles);
+	double lo[3], hi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		lo[d] = std::numeric_limits<double>::max();
+		hi[d] = std::numeric_limits<double>::lowest();
+	}
+	for (size_t t = 0; t < n_triangles; ++t)
+	{
+		Prim& p = B.prims[t];
+		p.tri = (uint32_t)t;
+		for (int d = 0; d < 3; ++d)
+		{
+			const double a = verts[3 * tris[3 * t] + d], b = verts[3 * tris[3 * t + 1] + d],
+						 c = verts[3 * tris[3 * t + 2] + d];
+			p.lo[d] = std::min(a, std::min(b, c));
+			p.hi[d] = std::max(a, std::max(b, c));
+			p.c[d] = 0.5 * (p.lo[d] + p.hi[d]);
+			lo[d] = std::min(lo[d], p.lo[d]);
+			hi[d] = std::max(hi[d], p.hi[d]);
+		}
+	}
+	for (int d = 0; d < 3; ++d)
+		out.origin[d] = 0.5 * (lo[d] + hi[d]);
+	B.origin = out.origin;
+	B.nodes.reserve(2 * n_triangles / max_leaf + 16);
+	B.order.reserve(n_triangles);
+	B.build(0, n_triangles, 0);
+
+	out.nodes.swap(B.nodes);
+	out.depth = B.depth;
+	out.n_vertices = n_vertices;
+	out.n_triangles = n_triangles;
+	out.tris.resize(n_triangles);
+	out.pn.assign(n_triangles * kPnSlots * 3, 0.0);
+	for (size_t k = 0; k < n_triangles; ++k)
+	{
+		const uint32_t t = B.order[k];
+		make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
+					out.tris[k]);
+		for (int s = 0; s < kPnSlots; ++s)
+		{
+			out.pn[(k * kPnSlots + s) * 3 + 0] = pn[t * kPnSlots + s].x;
+			out.pn[(k * kPnSlots + s) * 3 + 1] = pn[t * kPnSlots + s].y;
+			out.pn[(k * kPnSlots + s) * 3 + 2] = pn[t * kPnSlots + s].z;
+		}
+	}
+	return true;
+}
+
+} // namespace dg

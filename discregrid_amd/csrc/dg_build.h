@@ -1,0 +1,33 @@
+// dg_build.h -- host-side construction of the device data set for one triangle mesh:
+//   * angle-weighted pseudonormals, computed exactly as the reference does
+//     (discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:359-420) -- the sign of the
+//     distance depends on them bit for bit;
+//   * triangle packets (dg_geom.h) in BVH leaf order;
+//   * a flattened AABB BVH of this library's own design (the reference's bounding-sphere tree
+//     is not reproduced: traversal order and bounding volumes only prune).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+#include "dg_geom.h"
+
+namespace dg
+{
+
+struct MeshBuild
+{
+	std::vector<BvhNode> nodes;    // depth-first, skip pointers
+	std::vector<TriPacket> tris;   // leaf order
+	std::vector<double> pn;        // kPnSlots * 3 doubles per triangle, leaf order
+	double origin[3];              // boxes are relative to this point
+	uint32_t depth = 0;
+	uint32_t not_watertight = 0;   // bit0 single edge, bit1 edge shared by > 2 faces
+	uint64_t n_vertices = 0, n_triangles = 0;
+};
+
+// max_leaf: triangles per leaf (1..8).  Returns false on invalid input (no triangles, index
+// out of range).
+bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles, int max_leaf,
+				MeshBuild& out);
+
+} // namespace dg

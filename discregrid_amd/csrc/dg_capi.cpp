@@ -1,0 +1,569 @@
+// dg_capi.cpp -- the C ABI of include/discregrid_hip.h: handles, host-side preparation
+// (BVH/pseudonormal construction, lattice decomposition into bricks, shard bookkeeping) and
+// kernel launches.  No CPU compute path exists here: without a gfx950 device every compute
+// entry point fails with DG_ERR_NO_DEVICE.
+#include "../../include/discregrid_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dg_build.h"
+#include "dg_kernels.h"
+#include "dg_layout.h"
+
+struct dg_mesh
+{
+	dg::MeshDev dev;
+	void* d_nodes = nullptr;
+	void* d_tris = nullptr;
+	void* d_pn = nullptr;
+	int device = -1;
+	dg_mesh_info info;
+};
+
+struct dg_field
+{
+	dg::FieldDev dev;
+	void* owned[3] = {nullptr, nullptr, nullptr};
+	uint64_t n_coeffs = 0;
+	int device = -1;
+};
+
+namespace
+{
+
+thread_local std::string g_error;
+thread_local double g_last_ms = -1.0;
+
+dg_status fail(dg_status s, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_error = buf;
+	return s;
+}
+
+#define DG_HIP(call)                                                                                         \
+	do                                                                                                       \
+	{                                                                                                        \
+		hipError_t e_ = (call);                                                                              \
+		if (e_ != hipSuccess)                                                                                \
+			return fail(DG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+dg_status require_device()
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+	{
+		(void)hipGetLastError();
+		return fail(DG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+					e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+	}
+	return DG_OK;
+}
+
+bool valid_grid(const dg_grid_desc* g)
+{
+	if (!g)
+		return false;
+	for (int d = 0; d < 3; ++d)
+		if (g->resolution[d] == 0)
+			return false;
+	// the reference indexes nodes with unsigned int (cubic_lagrange_discrete_grid.cpp:796-809)
+	dg::ClassGeom cg[4];
+	return dg::class_geometry(g->resolution, cg) < (1ull << 32);
+}
+
+} // namespace
+
+extern "C"
+{
+
+const char* dg_version(void) { return "discregrid_hip 0.1 (gfx950)"; }
+const char* dg_last_error(void) { return g_error.c_str(); }
+double dg_last_kernel_ms(void) { return g_last_ms; }
+
+dg_status dg_device_count(int* count)
+{
+	if (!count)
+		return fail(DG_ERR_INVALID, "count is null");
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		n = 0;
+	}
+	*count = n;
+	return DG_OK;
+}
+
+dg_status dg_set_device(int device)
+{
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	DG_HIP(hipSetDevice(device));
+	return DG_OK;
+}
+
+dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
+							dg_grid_desc* out)
+{
+	if (!domain_min || !domain_max || !resolution || !out)
+		return fail(DG_ERR_INVALID, "null argument");
+	std::memset(out, 0, sizeof(*out));
+	for (int d = 0; d < 3; ++d)
+	{
+		if (resolution[d] == 0)
+			return fail(DG_ERR_INVALID, "resolution[%d] == 0", d);
+		out->domain_min[d] = domain_min[d];
+		out->domain_max[d] = domain_max[d];
+		out->resolution[d] = resolution[d];
+		// discrete_grid.hpp:26-27: cell_size = diagonal ./ n ; inv_cell_size = 1 ./ cell_size
+		out->cell_size[d] = (domain_max[d] - domain_min[d]) / (double)resolution[d];
+		out->inv_cell_size[d] = 1.0 / out->cell_size[d];
+	}
+	return DG_OK;
+}
+
+uint64_t dg_grid_n_nodes(const dg_grid_desc* grid)
+{
+	if (!grid)
+		return 0;
+	dg::ClassGeom cg[4];
+	return dg::class_geometry(grid->resolution, cg);
+}
+
+uint64_t dg_grid_n_cells(const dg_grid_desc* grid)
+{
+	return grid ? (uint64_t)grid->resolution[0] * grid->resolution[1] * grid->resolution[2] : 0;
+}
+
+// ---- mesh ------------------------------------------------------------------------------------------
+dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
+						 dg_mesh** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!verts || !tris || n_vertices == 0 || n_triangles == 0)
+		return fail(DG_ERR_INVALID, "empty triangle list"); // reference: message + exit(-1), TriangleMeshDistance.h:338-341
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+
+	auto t0 = std::chrono::high_resolution_clock::now();
+	dg::MeshBuild B;
+	if (!dg::build_mesh(verts, n_vertices, tris, n_triangles, 4, B))
+		return fail(DG_ERR_INVALID, "invalid mesh (vertex index out of range or too many triangles)");
+	auto t1 = std::chrono::high_resolution_clock::now();
+
+	dg_mesh* m = new (std::nothrow) dg_mesh;
+	if (!m)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	std::memset(&m->info, 0, sizeof(m->info));
+	const size_t nb = B.nodes.size() * sizeof(dg::BvhNode);
+	const size_t tb = B.tris.size() * sizeof(dg::TriPacket);
+	const size_t pb = B.pn.size() * sizeof(double);
+	hipError_t e = hipGetDevice(&m->device);
+	if (e == hipSuccess) e = hipMalloc(&m->d_nodes, nb);
+	if (e == hipSuccess) e = hipMalloc(&m->d_tris, tb);
+	if (e == hipSuccess) e = hipMalloc(&m->d_pn, pb);
+	if (e == hipSuccess) e = hipMemcpy(m->d_nodes, B.nodes.data(), nb, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(m->d_tris, B.tris.data(), tb, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(m->d_pn, B.pn.data(), pb, hipMemcpyHostToDevice);
+	if (e != hipSuccess)
+	{
+		dg_mesh_destroy(m);
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "mesh upload failed: %s",
+					hipGetErrorString(e));
+	}
+	m->dev.nodes = static_cast<const dg::BvhNode*>(m->d_nodes);
+	m->dev.tris = static_cast<const dg::TriPacket*>(m->d_tris);
+	m->dev.pn = static_cast<const double*>(m->d_pn);
+	m->dev.n_nodes = (int32_t)B.nodes.size();
+	m->dev.n_tris = (int32_t)B.tris.size();
+	for (int d = 0; d < 3; ++d)
+		m->dev.origin[d] = B.origin[d];
+	m->info.n_vertices = n_vertices;
+	m->info.n_triangles = n_triangles;
+	m->info.n_bvh_nodes = B.nodes.size();
+	m->info.bvh_depth = B.depth;
+	m->info.not_watertight = B.not_watertight;
+	m->info.device_bytes = nb + tb + pb;
+	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
+	*out = m;
+	return DG_OK;
+}
+
+dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info)
+{
+	if (!mesh || !info)
+		return fail(DG_ERR_INVALID, "null argument");
+	*info = mesh->info;
+	return DG_OK;
+}
+
+void dg_mesh_destroy(dg_mesh* m)
+{
+	if (!m)
+		return;
+	if (m->d_nodes) (void)hipFree(m->d_nodes);
+	if (m->d_tris) (void)hipFree(m->d_tris);
+	if (m->d_pn) (void)hipFree(m->d_pn);
+	delete m;
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------------
+dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream)
+{
+	if (!mesh || !grid || !d_out)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid (zero resolution or >= 2^32 nodes)");
+	const uint64_t total = dg_grid_n_nodes(grid);
+	if (node_begin > node_end || node_end > total)
+		return fail(DG_ERR_INVALID, "node range [%llu, %llu) outside [0, %llu)", (unsigned long long)node_begin,
+					(unsigned long long)node_end, (unsigned long long)total);
+	if (node_begin == node_end)
+		return DG_OK;
+
+	dg::SampleParams P;
+	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
+	dg::layout_range(P, grid->resolution, node_begin, node_end);
+	P.mask = d_pred_mask;
+	P.out = d_out;
+	DG_HIP(dg::launch_sample_nodes(P, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
+dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+							  uint64_t node_end, const uint8_t* pred_mask, double* out)
+{
+	if (!mesh || !grid || !out)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (node_begin > node_end)
+		return fail(DG_ERR_INVALID, "node_begin > node_end");
+	const uint64_t n = node_end - node_begin;
+	if (n == 0)
+		return DG_OK;
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	double* d_out = nullptr;
+	uint8_t* d_mask = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	dg_status st = DG_OK;
+	hipError_t e = hipMalloc((void**)&d_out, n * sizeof(double));
+	if (e == hipSuccess && pred_mask)
+	{
+		e = hipMalloc((void**)&d_mask, n);
+		if (e == hipSuccess) e = hipMemcpy(d_mask, pred_mask, n, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+	if (e == hipSuccess)
+	{
+		st = dg_sdf_sample_nodes_device(mesh, grid, invert, node_begin, node_end, d_mask, d_out, nullptr);
+		if (st == DG_OK)
+		{
+			e = hipEventRecord(e1, nullptr);
+			if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost);
+			float ms = -1.f;
+			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+				g_last_ms = ms;
+		}
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (d_out) (void)hipFree(d_out);
+	if (d_mask) (void)hipFree(d_mask);
+	if (st != DG_OK)
+		return st;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes: %s",
+					hipGetErrorString(e));
+	return DG_OK;
+}
+
+dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
+									int32_t* d_tri, int32_t* d_entity, double* d_nearest, void* stream)
+{
+	if (!mesh || (n && (!d_xyz || !d_dist)))
+		return fail(DG_ERR_INVALID, "null argument");
+	DG_HIP(dg::launch_signed_distance(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest,
+									  static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
+dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n, double* dist, int32_t* tri,
+							 int32_t* entity, double* nearest)
+{
+	if (!mesh || (n && (!xyz || !dist)))
+		return fail(DG_ERR_INVALID, "null argument");
+	if (n == 0)
+		return DG_OK;
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	double *d_xyz = nullptr, *d_dist = nullptr, *d_near = nullptr;
+	int32_t *d_tri = nullptr, *d_ent = nullptr;
+	hipError_t e = hipMalloc((void**)&d_xyz, 3 * n * sizeof(double));
+	if (e == hipSuccess) e = hipMalloc((void**)&d_dist, n * sizeof(double));
+	if (e == hipSuccess && tri) e = hipMalloc((void**)&d_tri, n * sizeof(int32_t));
+	if (e == hipSuccess && entity) e = hipMalloc((void**)&d_ent, n * sizeof(int32_t));
+	if (e == hipSuccess && nearest) e = hipMalloc((void**)&d_near, 3 * n * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpy(d_xyz, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+	dg_status st = DG_OK;
+	if (e == hipSuccess)
+	{
+		st = dg_signed_distance_device(mesh, d_xyz, n, d_dist, d_tri, d_ent, d_near, nullptr);
+		if (st == DG_OK)
+		{
+			e = hipMemcpy(dist, d_dist, n * sizeof(double), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && tri) e = hipMemcpy(tri, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && entity) e = hipMemcpy(entity, d_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && nearest) e = hipMemcpy(nearest, d_near, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
+		}
+	}
+	if (d_xyz) (void)hipFree(d_xyz);
+	if (d_dist) (void)hipFree(d_dist);
+	if (d_tri) (void)hipFree(d_tri);
+	if (d_ent) (void)hipFree(d_ent);
+	if (d_near) (void)hipFree(d_near);
+	if (st != DG_OK)
+		return st;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_signed_distance: %s",
+					hipGetErrorString(e));
+	return DG_OK;
+}
+
+// ---- sharding -------------------------------------------------------------------------------------------
+dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_shard_info* out)
+{
+	if (!grid || !out)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (nranks < 1 || nranks > dg::kMaxRanks || rank < 0 || rank >= nranks)
+		return fail(DG_ERR_INVALID, "rank %d / nranks %d out of range (max %d ranks)", rank, nranks, dg::kMaxRanks);
+	uint64_t mx = 0;
+	for (int r = 0; r < nranks; ++r)
+	{
+		const uint64_t cnt = dg::shard_count(grid->resolution, r, nranks);
+		if (r == rank)
+			out->count = cnt;
+		mx = std::max(mx, cnt);
+	}
+	out->stride = (mx + 63) / 64 * 64;
+	return DG_OK;
+}
+
+dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
+									 double* d_packed, void* stream)
+{
+	if (!mesh || !grid || !d_packed)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (nranks < 1 || nranks > dg::kMaxRanks || rank < 0 || rank >= nranks)
+		return fail(DG_ERR_INVALID, "rank %d / nranks %d out of range", rank, nranks);
+	dg::SampleParams P;
+	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
+	dg::layout_shard(P, grid->resolution, rank, nranks);
+	P.mask = nullptr;
+	P.out = d_packed;
+	DG_HIP(dg::launch_sample_nodes(P, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
+dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+								  double* d_field, void* stream)
+{
+	if (!grid || !d_gathered || !d_field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (nranks < 1 || nranks > dg::kMaxRanks)
+		return fail(DG_ERR_INVALID, "nranks %d out of range", nranks);
+	dg::UnpackParams U;
+	dg::layout_unpack(U, grid->resolution, nranks);
+	for (int r = 0; r < nranks; ++r)
+		if (dg::shard_count(grid->resolution, r, nranks) > stride)
+			return fail(DG_ERR_INVALID, "stride %llu smaller than rank %d's shard", (unsigned long long)stride, r);
+	U.nranks = nranks;
+	U.stride = stride;
+	U.gathered = d_gathered;
+	U.field = d_field;
+	DG_HIP(dg::launch_unpack(U, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
+// ---- field + K2 ---------------------------------------------------------------------------------------------
+static void fill_field(dg::FieldDev& F, const dg_grid_desc* g)
+{
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = g->domain_min[d];
+		F.dmax[d] = g->domain_max[d];
+		F.cell[d] = g->cell_size[d];
+		F.inv_cell[d] = g->inv_cell_size[d];
+		F.res[d] = g->resolution[d];
+	}
+}
+
+dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeffs, uint64_t n_coeffs,
+								 const uint32_t* d_cells, uint64_t n_cell_rows, const uint32_t* d_cell_map,
+								 dg_field** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!grid || !d_coeffs)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if ((d_cells == nullptr) != (d_cell_map == nullptr))
+		return fail(DG_ERR_INVALID, "cells and cell_map must be given together");
+	if (!d_cells && n_coeffs != dg_grid_n_nodes(grid))
+		return fail(DG_ERR_INVALID, "an unreduced field needs %llu coefficients, got %llu",
+					(unsigned long long)dg_grid_n_nodes(grid), (unsigned long long)n_coeffs);
+	(void)n_cell_rows;
+	dg_field* f = new (std::nothrow) dg_field;
+	if (!f)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	fill_field(f->dev, grid);
+	f->dev.coeffs = d_coeffs;
+	f->dev.cells = d_cells;
+	f->dev.cell_map = d_cell_map;
+	f->n_coeffs = n_coeffs;
+	(void)hipGetDevice(&f->device);
+	*out = f;
+	return DG_OK;
+}
+
+dg_status dg_field_create(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, const uint32_t* cells,
+						  uint64_t n_cell_rows, const uint32_t* cell_map, dg_field** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!grid || !coeffs)
+		return fail(DG_ERR_INVALID, "null argument");
+	if ((cells == nullptr) != (cell_map == nullptr))
+		return fail(DG_ERR_INVALID, "cells and cell_map must be given together");
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	void *d_c = nullptr, *d_cells = nullptr, *d_map = nullptr;
+	const uint64_t ncell = dg_grid_n_cells(grid);
+	hipError_t e = hipMalloc(&d_c, n_coeffs * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpy(d_c, coeffs, n_coeffs * sizeof(double), hipMemcpyHostToDevice);
+	if (e == hipSuccess && cells)
+	{
+		e = hipMalloc(&d_cells, std::max<uint64_t>(n_cell_rows, 1) * 32 * sizeof(uint32_t));
+		if (e == hipSuccess && n_cell_rows)
+			e = hipMemcpy(d_cells, cells, n_cell_rows * 32 * sizeof(uint32_t), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMalloc(&d_map, ncell * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMemcpy(d_map, cell_map, ncell * sizeof(uint32_t), hipMemcpyHostToDevice);
+	}
+	dg_status st = DG_OK;
+	if (e == hipSuccess)
+		st = dg_field_attach_device(grid, (const double*)d_c, n_coeffs, (const uint32_t*)d_cells, n_cell_rows,
+									(const uint32_t*)d_map, out);
+	if (e != hipSuccess || st != DG_OK)
+	{
+		if (d_c) (void)hipFree(d_c);
+		if (d_cells) (void)hipFree(d_cells);
+		if (d_map) (void)hipFree(d_map);
+		if (st != DG_OK)
+			return st;
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_field_create: %s", hipGetErrorString(e));
+	}
+	(*out)->owned[0] = d_c;
+	(*out)->owned[1] = d_cells;
+	(*out)->owned[2] = d_map;
+	return DG_OK;
+}
+
+void dg_field_destroy(dg_field* f)
+{
+	if (!f)
+		return;
+	for (void* p : f->owned)
+		if (p)
+			(void)hipFree(p);
+	delete f;
+}
+
+dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
+									  double* d_grad, void* stream)
+{
+	if (!field || (n && (!d_xyz || !d_phi)))
+		return fail(DG_ERR_INVALID, "null argument");
+	DG_HIP(dg::launch_interpolate(field->dev, d_xyz, n, d_phi, d_grad, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
+dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad)
+{
+	if (!field || (n && (!xyz || !phi)))
+		return fail(DG_ERR_INVALID, "null argument");
+	if (n == 0)
+		return DG_OK;
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	double *d_xyz = nullptr, *d_phi = nullptr, *d_grad = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipMalloc((void**)&d_xyz, 3 * n * sizeof(double));
+	if (e == hipSuccess) e = hipMalloc((void**)&d_phi, n * sizeof(double));
+	if (e == hipSuccess && grad) e = hipMalloc((void**)&d_grad, 3 * n * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpy(d_xyz, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+	dg_status st = DG_OK;
+	if (e == hipSuccess)
+	{
+		st = dg_interpolate_batch_device(field, d_xyz, n, d_phi, d_grad, nullptr);
+		if (st == DG_OK)
+		{
+			e = hipEventRecord(e1, nullptr);
+			if (e == hipSuccess) e = hipMemcpy(phi, d_phi, n * sizeof(double), hipMemcpyDeviceToHost);
+			if (e == hipSuccess && grad) e = hipMemcpy(grad, d_grad, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
+			float ms = -1.f;
+			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+				g_last_ms = ms;
+		}
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (d_xyz) (void)hipFree(d_xyz);
+	if (d_phi) (void)hipFree(d_phi);
+	if (d_grad) (void)hipFree(d_grad);
+	if (st != DG_OK)
+		return st;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_interpolate_batch: %s",
+					hipGetErrorString(e));
+	return DG_OK;
+}
+
+} // extern "C"

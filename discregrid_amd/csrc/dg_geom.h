@@ -1,0 +1,573 @@
+// dg_geom.h -- per-lane arithmetic shared by the HIP kernels (device) and the host-side
+// structure builders.  Everything here is written for bit parity with the reference's CPU
+// path: every floating-point expression keeps the reference's association order and must be
+// compiled with -ffp-contract=off (an FMA changes d^2 by up to 8e-9 relative near the zero
+// level set).  No function in this header touches memory other than its
+// arguments.
+//
+// Reference lines restated (paths relative to the Discregrid tree):
+//   point/triangle distance  discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:564-820
+//   node positions           discregrid/src/cubic_lagrange_discrete_grid.cpp:604-665
+//   shape functions          discregrid/src/cubic_lagrange_discrete_grid.cpp:339-580
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIP__)
+#define DG_HD __host__ __device__ __attribute__((always_inline)) inline
+#else
+#define DG_HD inline
+#endif
+
+namespace dg
+{
+
+// ---- data layouts (shared by host builder and device kernels) ------------------------------
+// One BVH node = 32 bytes = two 16-byte scalar loads.  Boxes are float, relative to the mesh
+// origin, rounded OUTWARD: they are only ever used to prune, so their arithmetic is free.
+// Nodes are stored in depth-first order; `skip` is the index of the next node when the
+// subtree is pruned (stackless traversal: next = hit ? idx + 1 : skip).
+struct alignas(32) BvhNode
+{
+	float lo[3];
+	float hi[3];
+	int32_t skip;
+	int32_t info; // >= 0: index of the right child (left child = idx + 1);  < 0: leaf, ~info = (first << 3) | (count - 1)
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
+
+// One triangle packet = 128 bytes, in BVH leaf order.  The point-independent terms of the
+// Eberly test are precomputed on the host WITH THE REFERENCE'S OWN OPERATIONS (same inputs,
+// same order => same bits as recomputing them per query, TriangleMeshDistance.h:566-575,
+// 675, 693).
+struct alignas(128) TriPacket
+{
+	double v0[3];
+	double e0[3]; // v1 - v0
+	double e1[3]; // v2 - v0
+	double a00, a01, a11;
+	double det;     // |a00*a11 - a01*a01|
+	double inv_det; // 1 / det
+	double denom;   // a00 - 2*a01 + a11
+	int32_t tri_id; // index in the caller's triangle array
+	int32_t pad_;
+};
+static_assert(sizeof(TriPacket) == 128, "TriPacket must be 128 bytes");
+
+// Pseudonormals, 8 slots of 3 doubles per triangle (leaf order), slot = nearest entity:
+// 0..2 vertex normals of v0,v1,v2; 3..5 edge normals E01,E12,E02; 6 face normal; 7 unused.
+static const int kPnSlots = 8;
+
+enum Entity : int { kV0 = 0, kV1 = 1, kV2 = 2, kE01 = 3, kE12 = 4, kE02 = 5, kFace = 6 };
+
+DG_HD void make_packet(const double v0[3], const double v1[3], const double v2[3], int32_t id, TriPacket& t)
+{
+	for (int d = 0; d < 3; ++d)
+	{
+		t.v0[d] = v0[d];
+		t.e0[d] = v1[d] - v0[d];
+		t.e1[d] = v2[d] - v0[d];
+	}
+	t.a00 = t.e0[0] * t.e0[0] + t.e0[1] * t.e0[1] + t.e0[2] * t.e0[2];
+	t.a01 = t.e0[0] * t.e1[0] + t.e0[1] * t.e1[1] + t.e0[2] * t.e1[2];
+	t.a11 = t.e1[0] * t.e1[0] + t.e1[1] * t.e1[1] + t.e1[2] * t.e1[2];
+	const double dd = t.a00 * t.a11 - t.a01 * t.a01;
+	t.det = __builtin_fabs(dd); // std::abs
+	t.inv_det = 1 / t.det;
+	t.denom = t.a00 - 2 * t.a01 + t.a11;
+	t.tri_id = id;
+	t.pad_ = 0;
+}
+
+// ---- squared distance point <-> triangle ------------------------------------------------------
+// FULL = false: only d^2 (the traversal inner loop).  FULL = true: also the barycentric
+// parameters and the nearest entity (run once per query on the winning triangle).
+struct Hit
+{
+	double d2, s, t;
+	int entity;
+};
+
+template <bool FULL>
+DG_HD Hit tri_closest(double v0x, double v0y, double v0z, double e0x, double e0y, double e0z, double e1x, double e1y,
+					  double e1z, double a00, double a01, double a11, double det, double inv_det, double denom,
+					  double px, double py, double pz)
+{
+	const double dx = v0x - px, dy = v0y - py, dz = v0z - pz;
+	const double b0 = dx * e0x + dy * e0y + dz * e0z;
+	const double b1 = dx * e1x + dy * e1y + dz * e1z;
+	const double c = dx * dx + dy * dy + dz * dz;
+	double s = a01 * b1 - a11 * b0;
+	double t = a01 * b0 - a00 * b1;
+	// vertex / edge candidates shared by several regions
+	const double d2_v1 = a00 + 2 * b0 + c;
+	const double d2_v2 = a11 + 2 * b1 + c;
+	Hit h;
+	h.s = 0;
+	h.t = 0;
+	h.entity = kV0;
+	h.d2 = c;
+	if (s + t <= det)
+	{
+		if (s < 0 || t < 0)
+		{
+			// regions 3, 4, 5: the minimum lies on edge v0-v1 (t = 0) or v0-v2 (s = 0)
+			const bool use01 = (s < 0) ? (t < 0 && b0 < 0) : true;
+			if (use01)
+			{
+				// region 4 enters with b0 < 0 already known; region 5 tests it (same outcome)
+				if (b0 >= 0)
+				{ /* V0 */
+				}
+				else if (-b0 >= a00)
+				{
+					h.d2 = d2_v1;
+					h.s = 1;
+					h.entity = kV1;
+				}
+				else
+				{
+					h.s = -b0 / a00;
+					h.d2 = b0 * h.s + c;
+					h.entity = kE01;
+				}
+			}
+			else
+			{
+				if (b1 >= 0)
+				{ /* V0 */
+				}
+				else if (-b1 >= a11)
+				{
+					h.d2 = d2_v2;
+					h.t = 1;
+					h.entity = kV2;
+				}
+				else
+				{
+					h.t = -b1 / a11;
+					h.d2 = b1 * h.t + c;
+					h.entity = kE02;
+				}
+			}
+		}
+		else
+		{
+			// region 0: interior
+			s *= inv_det;
+			t *= inv_det;
+			h.d2 = s * (a00 * s + a01 * t + 2 * b0) + t * (a01 * s + a11 * t + 2 * b1) + c;
+			h.s = s;
+			h.t = t;
+			h.entity = kFace;
+		}
+	}
+	else if (s < 0)
+	{
+		// region 2
+		const double tmp0 = a01 + b0;
+		const double tmp1 = a11 + b1;
+		if (tmp1 > tmp0)
+		{
+			const double numer = tmp1 - tmp0;
+			if (numer >= denom)
+			{
+				h.d2 = d2_v1;
+				h.s = 1;
+				h.entity = kV1;
+			}
+			else
+			{
+				s = numer / denom;
+				t = 1 - s;
+				h.d2 = s * (a00 * s + a01 * t + 2 * b0) + t * (a01 * s + a11 * t + 2 * b1) + c;
+				h.s = s;
+				h.t = t;
+				h.entity = kE12;
+			}
+		}
+		else if (tmp1 <= 0)
+		{
+			h.d2 = d2_v2;
+			h.t = 1;
+			h.entity = kV2;
+		}
+		else if (b1 >= 0)
+		{ /* V0 */
+		}
+		else
+		{
+			h.t = -b1 / a11;
+			h.d2 = b1 * h.t + c;
+			h.entity = kE02;
+		}
+	}
+	else if (t < 0)
+	{
+		// region 6
+		const double tmp0 = a01 + b1;
+		const double tmp1 = a00 + b0;
+		if (tmp1 > tmp0)
+		{
+			const double numer = tmp1 - tmp0;
+			if (numer >= denom)
+			{
+				h.d2 = d2_v2;
+				h.t = 1;
+				h.entity = kV2;
+			}
+			else
+			{
+				t = numer / denom;
+				s = 1 - t;
+				h.d2 = s * (a00 * s + a01 * t + 2 * b0) + t * (a01 * s + a11 * t + 2 * b1) + c;
+				h.s = s;
+				h.t = t;
+				h.entity = kE12;
+			}
+		}
+		else if (tmp1 <= 0)
+		{
+			h.d2 = d2_v1;
+			h.s = 1;
+			h.entity = kV1;
+		}
+		else if (b0 >= 0)
+		{ /* V0 */
+		}
+		else
+		{
+			h.s = -b0 / a00;
+			h.d2 = b0 * h.s + c;
+			h.entity = kE01;
+		}
+	}
+	else
+	{
+		// region 1
+		const double numer = a11 + b1 - a01 - b0;
+		if (numer <= 0)
+		{
+			h.d2 = d2_v2;
+			h.t = 1;
+			h.entity = kV2;
+		}
+		else if (numer >= denom)
+		{
+			h.d2 = d2_v1;
+			h.s = 1;
+			h.entity = kV1;
+		}
+		else
+		{
+			s = numer / denom;
+			t = 1 - s;
+			h.d2 = s * (a00 * s + a01 * t + 2 * b0) + t * (a01 * s + a11 * t + 2 * b1) + c;
+			h.s = s;
+			h.t = t;
+			h.entity = kE12;
+		}
+	}
+	if (h.d2 < 0) // "account for numerical round-off error"
+		h.d2 = 0;
+	return h;
+}
+
+template <bool FULL>
+DG_HD Hit tri_closest(const TriPacket& T, double px, double py, double pz)
+{
+	return tri_closest<FULL>(T.v0[0], T.v0[1], T.v0[2], T.e0[0], T.e0[1], T.e0[2], T.e1[0], T.e1[1], T.e1[2], T.a00,
+							 T.a01, T.a11, T.det, T.inv_det, T.denom, px, py, pz);
+}
+
+// ---- conservative float box test ------------------------------------------------------------------
+// The query point, relative to the mesh origin, is carried as an interval [plo, phi] in float
+// that strictly contains it; node boxes are rounded outward.  The returned value is a lower
+// bound of the squared distance to anything inside the box up to a relative 2^-22, which the
+// caller absorbs by inflating its float copy of the running best (best_as_float()).
+struct FPoint
+{
+	float lo[3], hi[3];
+};
+DG_HD FPoint make_fpoint(double rx, double ry, double rz) // r = p - origin (double)
+{
+	FPoint f;
+	const float x = (float)rx, y = (float)ry, z = (float)rz;
+	const float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
+	float m = ax > ay ? ax : ay;
+	m = m > az ? m : az;
+	const float e = m * 4.76837158203125e-07f + 1.0e-37f; // 2^-21 * max|coord|  (>= 4 float ulps)
+	f.lo[0] = x - e;
+	f.lo[1] = y - e;
+	f.lo[2] = z - e;
+	f.hi[0] = x + e;
+	f.hi[1] = y + e;
+	f.hi[2] = z + e;
+	return f;
+}
+DG_HD float fmax2(float a, float b) { return a > b ? a : b; }
+DG_HD float box_lb2(const float blo[3], const float bhi[3], const FPoint& p)
+{
+	const float dx = fmax2(fmax2(blo[0] - p.hi[0], p.lo[0] - bhi[0]), 0.0f);
+	const float dy = fmax2(fmax2(blo[1] - p.hi[1], p.lo[1] - bhi[1]), 0.0f);
+	const float dz = fmax2(fmax2(blo[2] - p.hi[2], p.lo[2] - bhi[2]), 0.0f);
+	return dx * dx + dy * dy + dz * dz;
+}
+// float upper bound of the running best d^2 (strictly above it unless it is 0 or inf)
+DG_HD float best_as_float(double d2)
+{
+	const float b = (float)d2;
+	return b * 1.0000019073486328125f; // * (1 + 2^-19)
+}
+
+// ---- per-lane query state and epilogue ------------------------------------------------------------------
+struct LaneQuery
+{
+	double px, py, pz; // query point
+	FPoint fp;         // float interval of (p - origin)
+	double best_d2;
+	float bestf;       // float upper bound of best_d2; < 0 => lane inactive (never hits a box)
+	int best_tri;      // packet index of the best triangle so far
+};
+DG_HD void init_query(const double origin[3], bool active, double px, double py, double pz, LaneQuery& q)
+{
+	q.px = px;
+	q.py = py;
+	q.pz = pz;
+	q.fp = make_fpoint(px - origin[0], py - origin[1], pz - origin[2]);
+	q.best_d2 = active ? 1.7976931348623157e308 : 0.0;
+	q.bestf = active ? __builtin_inff() : -1.0f;
+	q.best_tri = -1;
+}
+// strict '<': of several exactly tied triangles the first one visited wins
+DG_HD void offer(LaneQuery& q, double d2, int packet_index)
+{
+	if (d2 < q.best_d2)
+	{
+		q.best_d2 = d2;
+		q.best_tri = packet_index;
+		q.bestf = best_as_float(d2);
+	}
+}
+
+struct LaneResult
+{
+	double signed_dist;
+	double nearest[3];
+	int tri_id;
+	int entity;
+};
+// Once per query: re-run the test on the winning triangle to recover (s, t, entity), then the
+// sign from the angle-weighted pseudonormal (TriangleMeshDistance.h:274-305, :818).
+// `sqrt_fn` is the correctly rounded double sqrt of the platform.
+template <class Sqrt>
+DG_HD LaneResult finish_query(const TriPacket* tris, const double* pn_all, const LaneQuery& q, Sqrt sqrt_fn)
+{
+	LaneResult r;
+	const TriPacket T = tris[q.best_tri];
+	const Hit h = tri_closest<true>(T, q.px, q.py, q.pz);
+	const double nx = T.v0[0] + h.s * T.e0[0] + h.t * T.e1[0];
+	const double ny = T.v0[1] + h.s * T.e0[1] + h.t * T.e1[1];
+	const double nz = T.v0[2] + h.s * T.e0[2] + h.t * T.e1[2];
+	const double* pn = pn_all + ((size_t)q.best_tri * kPnSlots + (size_t)h.entity) * 3;
+	const double ux = q.px - nx, uy = q.py - ny, uz = q.pz - nz;
+	const double dotp = ux * pn[0] + uy * pn[1] + uz * pn[2];
+	const double dist = sqrt_fn(h.d2);
+	r.signed_dist = dist * ((dotp >= 0.0) ? 1.0 : -1.0);
+	r.nearest[0] = nx;
+	r.nearest[1] = ny;
+	r.nearest[2] = nz;
+	r.tri_id = T.tri_id;
+	r.entity = h.entity;
+	return r;
+}
+
+// ---- lattice node positions ---------------------------------------------------------------------------
+// Node class c in {0:V, 1:X, 2:Y, 3:Z}; (a, b, s) are the class' own (fastest, middle, slowest)
+// lattice coordinates, i.e. class-local flat index = (s*D1 + b)*D0 + a with
+//   V: (i, j, k)         D = (nx+1, ny+1, nz+1)
+//   X: (2i+h, j, k)      D = (2nx,  ny+1, nz+1)      h = 0: node at 1/3, h = 1: at 2/3 of the edge
+//   Y: (2j+h, k, i)      D = (2ny,  nz+1, nx+1)
+//   Z: (2k+h, i, j)      D = (2nz,  nx+1, ny+1)
+// which is exactly the order indexToNodePosition() enumerates (cubic_lagrange_discrete_grid.cpp:618-662).
+DG_HD void class_dims(int c, const uint32_t res[3], uint32_t D[3])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	if (c == 0) { D[0] = nx + 1; D[1] = ny + 1; D[2] = nz + 1; }
+	else if (c == 1) { D[0] = 2 * nx; D[1] = ny + 1; D[2] = nz + 1; }
+	else if (c == 2) { D[0] = 2 * ny; D[1] = nz + 1; D[2] = nx + 1; }
+	else { D[0] = 2 * nz; D[1] = nx + 1; D[2] = ny + 1; }
+}
+DG_HD void node_position(int c, uint32_t a, uint32_t b, uint32_t s, const double dmin[3], const double cell[3],
+						 double x[3])
+{
+	uint32_t i, j, k, h = a & 1u;
+	if (c == 0) { i = a; j = b; k = s; }
+	else if (c == 1) { i = a >> 1; j = b; k = s; }
+	else if (c == 2) { j = a >> 1; k = b; i = s; }
+	else { k = a >> 1; i = b; j = s; }
+	x[0] = dmin[0] + cell[0] * (double)i;
+	x[1] = dmin[1] + cell[1] * (double)j;
+	x[2] = dmin[2] + cell[2] * (double)k;
+	if (c > 0)
+		x[c - 1] += (1.0 + (double)h) / 3.0 * cell[c - 1];
+}
+
+// ---- 32 serendipity-cubic shape functions (+ derivatives) -------------------------------------------------
+// N[j], j = 0..31 in the reference's node order; dN (if GRAD) as dNx[32], dNy[32], dNz[32].
+// Same products in the same order as shape_function_() (cubic_lagrange_discrete_grid.cpp:339-580);
+// everything is fully unrolled so the arrays live in registers.
+template <bool GRAD>
+DG_HD void shape_functions(double x, double y, double z, double N[32], double dNx[32], double dNy[32], double dNz[32])
+{
+	const double x2 = x * x, y2 = y * y, z2 = z * z;
+	const double mx = 1.0 - x, my = 1.0 - y, mz = 1.0 - z;
+	const double px = 1.0 + x, py = 1.0 + y, pz = 1.0 + z;
+	const double m3x = 1.0 - 3.0 * x, m3y = 1.0 - 3.0 * y, m3z = 1.0 - 3.0 * z;
+	const double p3x = 1.0 + 3.0 * x, p3y = 1.0 + 3.0 * y, p3z = 1.0 + 3.0 * z;
+	const double mxmy = mx * my, mxpy = mx * py, pxmy = px * my, pxpy = px * py;
+	const double mxmz = mx * mz, mxpz = mx * pz, pxmz = px * mz, pxpz = px * pz;
+	const double mymz = my * mz, mypz = my * pz, pymz = py * mz, pypz = py * pz;
+	const double omx2 = 1.0 - x2, omy2 = 1.0 - y2, omz2 = 1.0 - z2;
+
+	double fac = 1.0 / 64.0 * (9.0 * (x2 + y2 + z2) - 19.0);
+	N[0] = fac * mxmy * mz;
+	N[1] = fac * pxmy * mz;
+	N[2] = fac * mxpy * mz;
+	N[3] = fac * pxpy * mz;
+	N[4] = fac * mxmy * pz;
+	N[5] = fac * pxmy * pz;
+	N[6] = fac * mxpy * pz;
+	N[7] = fac * pxpy * pz;
+
+	fac = 9.0 / 64.0 * omx2;
+	const double fm3x = fac * m3x, fp3x = fac * p3x;
+	N[8] = fm3x * mymz;
+	N[9] = fp3x * mymz;
+	N[10] = fm3x * mypz;
+	N[11] = fp3x * mypz;
+	N[12] = fm3x * pymz;
+	N[13] = fp3x * pymz;
+	N[14] = fm3x * pypz;
+	N[15] = fp3x * pypz;
+
+	fac = 9.0 / 64.0 * omy2;
+	const double fm3y = fac * m3y, fp3y = fac * p3y;
+	N[16] = fm3y * mxmz;
+	N[17] = fp3y * mxmz;
+	N[18] = fm3y * pxmz;
+	N[19] = fp3y * pxmz;
+	N[20] = fm3y * mxpz;
+	N[21] = fp3y * mxpz;
+	N[22] = fm3y * pxpz;
+	N[23] = fp3y * pxpz;
+
+	fac = 9.0 / 64.0 * omz2;
+	const double fm3z = fac * m3z, fp3z = fac * p3z;
+	N[24] = fm3z * mxmy;
+	N[25] = fp3z * mxmy;
+	N[26] = fm3z * mxpy;
+	N[27] = fp3z * mxpy;
+	N[28] = fm3z * pxmy;
+	N[29] = fp3z * pxmy;
+	N[30] = fm3z * pxpy;
+	N[31] = fp3z * pxpy;
+
+	if (!GRAD)
+		return;
+
+	const double gx = 9.0 * (3.0 * x2 + y2 + z2) - 19.0;
+	const double gy = 9.0 * (x2 + 3.0 * y2 + z2) - 19.0;
+	const double gz = 9.0 * (x2 + y2 + 3.0 * z2) - 19.0;
+	const double x18 = 18.0 * x, y18 = 18.0 * y, z18 = 18.0 * z;
+	const double hxm = x18 - gx, hxp = x18 + gx;
+	const double hym = y18 - gy, hyp = y18 + gy;
+	const double hzm = z18 - gz, hzp = z18 + gz;
+	// corners: value / 64 (topRows(8) /= 64)
+	dNx[0] = hxm * mymz / 64.0; dNy[0] = mxmz * hym / 64.0; dNz[0] = mxmy * hzm / 64.0;
+	dNx[1] = hxp * mymz / 64.0; dNy[1] = pxmz * hym / 64.0; dNz[1] = pxmy * hzm / 64.0;
+	dNx[2] = hxm * pymz / 64.0; dNy[2] = mxmz * hyp / 64.0; dNz[2] = mxpy * hzm / 64.0;
+	dNx[3] = hxp * pymz / 64.0; dNy[3] = pxmz * hyp / 64.0; dNz[3] = pxpy * hzm / 64.0;
+	dNx[4] = hxm * mypz / 64.0; dNy[4] = mxpz * hym / 64.0; dNz[4] = mxmy * hzp / 64.0;
+	dNx[5] = hxp * mypz / 64.0; dNy[5] = pxpz * hym / 64.0; dNz[5] = pxmy * hzp / 64.0;
+	dNx[6] = hxm * pypz / 64.0; dNy[6] = mxpz * hyp / 64.0; dNz[6] = mxpy * hzp / 64.0;
+	dNx[7] = hxp * pypz / 64.0; dNy[7] = pxpz * hyp / 64.0; dNz[7] = pxpy * hzp / 64.0;
+
+	const double k = 9.0 / 64.0; // bottomRows(24) *= 9/64
+	const double t3x = 3.0 - 9.0 * x2, t3y = 3.0 - 9.0 * y2, t3z = 3.0 - 9.0 * z2;
+	const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+	const double qxm = -t3x - tx, qxp = t3x - tx;
+	const double qym = -t3y - ty, qyp = t3y - ty;
+	const double qzm = -t3z - tz, qzp = t3z - tz;
+	const double wxm = omx2 * m3x, wxp = omx2 * p3x;
+	const double wym = omy2 * m3y, wyp = omy2 * p3y;
+	const double wzm = omz2 * m3z, wzp = omz2 * p3z;
+	// x-edges
+	dNx[8] = qxm * mymz * k;  dNy[8] = -wxm * mz * k;  dNz[8] = -wxm * my * k;
+	dNx[9] = qxp * mymz * k;  dNy[9] = -wxp * mz * k;  dNz[9] = -wxp * my * k;
+	dNx[10] = qxm * mypz * k; dNy[10] = -wxm * pz * k; dNz[10] = wxm * my * k;
+	dNx[11] = qxp * mypz * k; dNy[11] = -wxp * pz * k; dNz[11] = wxp * my * k;
+	dNx[12] = qxm * pymz * k; dNy[12] = wxm * mz * k;  dNz[12] = -wxm * py * k;
+	dNx[13] = qxp * pymz * k; dNy[13] = wxp * mz * k;  dNz[13] = -wxp * py * k;
+	dNx[14] = qxm * pypz * k; dNy[14] = wxm * pz * k;  dNz[14] = wxm * py * k;
+	dNx[15] = qxp * pypz * k; dNy[15] = wxp * pz * k;  dNz[15] = wxp * py * k;
+	// y-edges
+	dNx[16] = -wym * mz * k; dNy[16] = qym * mxmz * k; dNz[16] = -wym * mx * k;
+	dNx[17] = -wyp * mz * k; dNy[17] = qyp * mxmz * k; dNz[17] = -wyp * mx * k;
+	dNx[18] = wym * mz * k;  dNy[18] = qym * pxmz * k; dNz[18] = -wym * px * k;
+	dNx[19] = wyp * mz * k;  dNy[19] = qyp * pxmz * k; dNz[19] = -wyp * px * k;
+	dNx[20] = -wym * pz * k; dNy[20] = qym * mxpz * k; dNz[20] = wym * mx * k;
+	dNx[21] = -wyp * pz * k; dNy[21] = qyp * mxpz * k; dNz[21] = wyp * mx * k;
+	dNx[22] = wym * pz * k;  dNy[22] = qym * pxpz * k; dNz[22] = wym * px * k;
+	dNx[23] = wyp * pz * k;  dNy[23] = qyp * pxpz * k; dNz[23] = wyp * px * k;
+	// z-edges
+	dNx[24] = -wzm * my * k; dNy[24] = -wzm * mx * k; dNz[24] = qzm * mxmy * k;
+	dNx[25] = -wzp * my * k; dNy[25] = -wzp * mx * k; dNz[25] = qzp * mxmy * k;
+	dNx[26] = -wzm * py * k; dNy[26] = wzm * mx * k;  dNz[26] = qzm * mxpy * k;
+	dNx[27] = -wzp * py * k; dNy[27] = wzp * mx * k;  dNz[27] = qzp * mxpy * k;
+	dNx[28] = wzm * my * k;  dNy[28] = -wzm * px * k; dNz[28] = qzm * pxmy * k;
+	dNx[29] = wzp * my * k;  dNy[29] = -wzp * px * k; dNz[29] = qzp * pxmy * k;
+	dNx[30] = wzm * py * k;  dNy[30] = wzm * px * k;  dNz[30] = qzm * pxpy * k;
+	dNx[31] = wzp * py * k;  dNy[31] = wzp * px * k;  dNz[31] = qzp * pxpy * k;
+}
+
+// 32 node indices of grid cell (i,j,k) for an unreduced field -- the rows the reference's
+// serial loop materialises (cubic_lagrange_discrete_grid.cpp:836-886).  Entries come in
+// adjacent pairs (2m, 2m+1) for m >= 4, and corner pairs (0,1),(2,3),(4,5),(6,7) are adjacent
+// too: the evaluator fetches 16 x 16-byte segments.
+DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t res[3], uint32_t out[32])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
+	const uint32_t nex = nx * (ny + 1) * (nz + 1);
+	const uint32_t ney = (nx + 1) * ny * (nz + 1);
+	const uint32_t r0 = (nx + 1) * (ny + 1) * k + (nx + 1) * j + i;
+	out[0] = r0;
+	out[1] = r0 + 1;
+	out[2] = r0 + (nx + 1);
+	out[3] = r0 + (nx + 1) + 1;
+	const uint32_t r1 = r0 + (nx + 1) * (ny + 1);
+	out[4] = r1;
+	out[5] = r1 + 1;
+	out[6] = r1 + (nx + 1);
+	out[7] = r1 + (nx + 1) + 1;
+	uint32_t off = nv;
+	out[8] = off + 2 * (nx * (ny + 1) * k + nx * j + i);
+	out[10] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * j + i);
+	out[12] = off + 2 * (nx * (ny + 1) * k + nx * (j + 1) + i);
+	out[14] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * (j + 1) + i);
+	off += 2 * nex;
+	out[16] = off + 2 * (ny * (nz + 1) * i + ny * k + j);
+	out[18] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * k + j);
+	out[20] = off + 2 * (ny * (nz + 1) * i + ny * (k + 1) + j);
+	out[22] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * (k + 1) + j);
+	off += 2 * ney;
+	out[24] = off + 2 * (nz * (nx + 1) * j + nz * i + k);
+	out[26] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * i + k);
+	out[28] = off + 2 * (nz * (nx + 1) * j + nz * (i + 1) + k);
+	out[30] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * (i + 1) + k);
+	for (int m = 8; m < 32; m += 2)
+		out[m + 1] = out[m] + 1;
+}
+
+} // namespace dg

@@ -1,0 +1,208 @@
+// dg_kernels.h -- launch interface between the C ABI (dg_capi.cpp) and the gfx950 kernels
+// (dg_kernels.hip).  Plain C++ structs, no HIP types in the signatures except the stream.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+#include "dg_geom.h"
+
+namespace dg
+{
+
+static const int kMaxRanks = 16;   // shard table size
+static const int kSlabPlanes = 4;  // planes per slab == brick depth
+
+struct MeshDev
+{
+	const BvhNode* nodes;
+	const TriPacket* tris;
+	const double* pn;
+	int32_t n_nodes;
+	int32_t n_tris;
+	double origin[3];
+};
+
+// One of the four node classes of the lattice as the K1 kernel sees it (see dg_geom.h
+// node_position() for the (a, b, s) coordinates).  The kernel walks "packed planes"
+// q in [q_begin, q_end); plane q is lattice plane s = q (whole-grid / range mode) or the
+// q-th plane owned by this rank (shard mode).
+struct ClassDesc
+{
+	uint32_t D0, D1, D2;      // lattice extents (fastest, middle, slowest)
+	uint32_t nb0, nb1, nbq;   // bricks of 4x4x4 nodes along a, b, q
+	uint32_t q_begin, q_end;
+	uint64_t l_begin, l_end;  // valid class-local flat node range (range mode; full range otherwise)
+	int64_t out_base;         // out index = out_base + (q*D1 + b)*D0 + a
+	uint64_t brick_prefix;    // first brick id of this class in the launch
+};
+
+struct SampleParams
+{
+	MeshDev mesh;
+	double dmin[3];
+	double cell[3];
+	ClassDesc cls[4];
+	uint64_t total_bricks;
+	uint32_t n_blocks;       // ceil(total_bricks / 4)
+	uint32_t blocks_per_xcd; // ceil(n_blocks / 8)
+	int32_t shard_rank, shard_n; // shard_n == 1: identity plane map
+	int32_t invert;
+	const uint8_t* mask;     // indexed like out; nullable
+	double* out;
+};
+
+// Which lattice node does `lane` of brick `brick` own?  Shared by the kernel and by the host-side
+// wave emulator used in the CPU tests.
+struct LaneNode
+{
+	int cls;
+	uint32_t a, b, s;  // clamped class-lattice coordinates (always a valid node)
+	bool valid;        // lane owns a node of the requested range
+	int64_t out_idx;
+};
+DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
+{
+	LaneNode n;
+	int c = 0;
+	if (brick >= P.cls[1].brick_prefix) c = 1;
+	if (brick >= P.cls[2].brick_prefix) c = 2;
+	if (brick >= P.cls[3].brick_prefix) c = 3;
+	const ClassDesc& C = P.cls[c];
+	const uint32_t local = (uint32_t)(brick - C.brick_prefix);
+	const uint32_t b0 = local % C.nb0;
+	const uint32_t b1 = (local / C.nb0) % C.nb1;
+	const uint32_t bq = local / (C.nb0 * C.nb1);
+	const uint32_t a = b0 * 4u + (uint32_t)(lane & 3);
+	const uint32_t b = b1 * 4u + (uint32_t)((lane >> 2) & 3);
+	const uint32_t qp = C.q_begin + bq * 4u + (uint32_t)(lane >> 4);
+	// plane map: identity, or the qp-th plane owned by this rank (slabs of 4 dealt round-robin)
+	uint32_t s = qp;
+	if (P.shard_n > 1)
+		s = ((qp / (uint32_t)kSlabPlanes) * (uint32_t)P.shard_n + (uint32_t)P.shard_rank) * (uint32_t)kSlabPlanes +
+			(qp % (uint32_t)kSlabPlanes);
+	bool valid = (a < C.D0) && (b < C.D1) && (qp < C.q_end) && (s < C.D2);
+	const uint64_t l_class = ((uint64_t)s * C.D1 + b) * C.D0 + a;
+	valid = valid && (l_class >= C.l_begin) && (l_class < C.l_end);
+	n.cls = c;
+	n.a = a < C.D0 ? a : C.D0 - 1;
+	n.b = b < C.D1 ? b : C.D1 - 1;
+	n.s = s < C.D2 ? s : C.D2 - 1;
+	n.valid = valid;
+	n.out_idx = C.out_base + (int64_t)(((uint64_t)qp * C.D1 + b) * C.D0 + a);
+	return n;
+}
+
+struct UnpackParams
+{
+	uint32_t D0[4], D1[4], D2[4];
+	uint64_t class_off[5];            // global node offset of each class (+ total)
+	uint64_t pack_off[4][kMaxRanks];  // offset of class c inside rank r's packed buffer
+	int32_t nranks;
+	uint64_t stride;
+	const double* gathered;
+	double* field;
+};
+
+struct FieldDev
+{
+	double dmin[3], dmax[3];
+	double cell[3], inv_cell[3];
+	uint32_t res[3];
+	const double* coeffs;
+	const uint32_t* cells;    // nullable => closed-form rows
+	const uint32_t* cell_map; // nullable => identity
+};
+
+// Per-query body of K2 = CubicLagrangeDiscreteGrid::interpolate(field, x, gradient*)
+// (discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063).  The 32-term sum runs in j order
+// (parity), the 32 coefficients are fetched as 16 adjacent pairs for unreduced fields.  Returns
+// DBL_MAX ("no value") outside the domain, in removed cells, or if a coefficient is DBL_MAX;
+// the gradient is zero in those cases.
+template <bool GRAD>
+DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
+{
+	const double NOVAL = 1.7976931348623157e308;
+	g[0] = g[1] = g[2] = 0.0;
+	for (int d = 0; d < 3; ++d)
+		if (!((F.dmin[d] <= x[d]) && (x[d] <= F.dmax[d]))) // AlignedBox::contains, inclusive (:981)
+			return NOVAL;
+	uint32_t mi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		mi[d] = (uint32_t)((x[d] - F.dmin[d]) * F.inv_cell[d]); // :984
+		if (mi[d] >= F.res[d])
+			mi[d] = F.res[d] - 1;
+	}
+	const uint32_t ci = F.res[1] * F.res[0] * mi[2] + F.res[0] * mi[1] + mi[0];
+	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
+	if (cm == 0xffffffffu)
+		return NOVAL;
+	double c0[3], xi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		const double lo = F.dmin[d] + (double)mi[d] * F.cell[d]; // subdomain(), discrete_grid.cpp:26-32
+		const double hi = lo + F.cell[d];
+		const double den = hi - lo; // :1000
+		c0[d] = 2.0 / den;
+		const double c1 = (hi + lo) / den;
+		xi[d] = c0[d] * x[d] - c1;
+	}
+	double cf[32];
+	if (F.cells)
+	{
+		const uint32_t* row = F.cells + 32 * (size_t)cm;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int j = 0; j < 32; ++j)
+			cf[j] = F.coeffs[row[j]];
+	}
+	else
+	{
+		uint32_t idx[32];
+		cell_node_indices(mi[0], mi[1], mi[2], F.res, idx);
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int m = 0; m < 32; m += 2)
+		{
+			cf[m] = F.coeffs[idx[m]]; // adjacent pair: one 16-byte segment
+			cf[m + 1] = F.coeffs[idx[m] + 1];
+		}
+	}
+	double N[32], dNx[32], dNy[32], dNz[32];
+	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
+	bool ok = true;
+	double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 32; ++j)
+	{
+		ok = ok && (cf[j] != NOVAL);
+		phi += cf[j] * N[j];
+		if (GRAD)
+		{
+			gx += cf[j] * dNx[j];
+			gy += cf[j] * dNy[j];
+			gz += cf[j] * dNz[j];
+		}
+	}
+	if (!ok)
+		return NOVAL;
+	if (GRAD)
+	{
+		g[0] = gx * c0[0];
+		g[1] = gy * c0[1];
+		g[2] = gz * c0[2];
+	}
+	return phi;
+}
+
+hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream);
+hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
+								  int32_t* d_entity, double* d_nearest, hipStream_t stream);
+hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream);
+hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+							  hipStream_t stream);
+
+} // namespace dg

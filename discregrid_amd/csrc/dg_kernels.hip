@@ -1,0 +1,331 @@
+// dg_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the SDF-discretisation hot path.
+//
+//   K1  k_sample_nodes     lattice node -> signed distance to the mesh   (addFunction node loop,
+//                          discregrid/src/cubic_lagrange_discrete_grid.cpp:806-831 +
+//                          TriangleMeshDistance.h:269-308, 514-562, 564-820)
+//   K1p k_signed_distance  same traversal for caller-supplied points (TriangleMeshDistance.h:269-314)
+//   K2  k_interpolate      batched CubicLagrangeDiscreteGrid::interpolate (:977-1063)
+//   U   k_unpack_shards    packed all-gather buffer -> reference node order (multi-GPU)
+//
+// Design of K1 (wave64, no MFMA: this is point-vs-BVH, not a contraction):
+//   * ONE WAVEFRONT = ONE 4x4x4 BRICK of lattice nodes.  The 64 query points are spatially
+//     compact, so the wave walks the BVH as a packet: control flow is wave-uniform, every BVH
+//     node (32 B) and triangle packet (128 B) is fetched ONCE per wave through the scalar
+//     unit (s_load_dwordx8 / x16 into SGPRs) and broadcast to all lanes for free; lanes only
+//     differ in their query point and running best.  No per-lane stack, no divergent gathers
+//     in the loop.
+//   * Stackless depth-first walk over a skip-pointer BVH (next = any-lane-hit ? idx+1 : skip),
+//     seeded by a greedy root-to-leaf descent so the bound is tight from the first node on.
+//   * Box tests in conservative float (they only prune); triangle tests in double with the
+//     reference's exact operation order (no FMA contraction) so d^2, the winning feature and
+//     the sign reproduce the reference bit for bit.
+//   * Positions are computed from the lattice index (nothing is read from HBM but the mesh);
+//     the only HBM traffic is the 8-byte result per node.
+//   * blockIdx is remapped so that each XCD works on a contiguous chunk of bricks: the BVH
+//     subtrees an XCD touches stay in its private 4 MiB L2.
+//
+// Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dg_kernels.h"
+
+namespace dg
+{
+namespace
+{
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define DG_CONST_AS __attribute__((address_space(4)))
+
+// Wave-uniform loads through the scalar data cache.  The address must be uniform across the
+// wave (callers pass indices that went through readfirstlane); the data is immutable for the
+// lifetime of the kernel.
+__device__ __forceinline__ v8i sload8(const void* p)
+{
+	return *(const DG_CONST_AS v8i*)(uintptr_t)p;
+}
+__device__ __forceinline__ v16i sload16(const void* p)
+{
+	return *(const DG_CONST_AS v16i*)(uintptr_t)p;
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double pack_double(int lo, int hi)
+{
+	return __hiloint2double(hi, lo);
+}
+
+struct SNode
+{
+	float lo[3], hi[3];
+	int skip, info;
+};
+__device__ __forceinline__ SNode load_node(const BvhNode* nodes, int idx)
+{
+	const v8i v = sload8(nodes + idx);
+	SNode n;
+	n.lo[0] = __int_as_float(v[0]);
+	n.lo[1] = __int_as_float(v[1]);
+	n.lo[2] = __int_as_float(v[2]);
+	n.hi[0] = __int_as_float(v[3]);
+	n.hi[1] = __int_as_float(v[4]);
+	n.hi[2] = __int_as_float(v[5]);
+	n.skip = v[6];
+	n.info = v[7];
+	return n;
+}
+
+// All lanes test the `cnt` triangles starting at packet `first` (wave-uniform arguments).
+__device__ __forceinline__ void test_leaf(const TriPacket* tris, int first, int cnt, LaneQuery& q)
+{
+	for (int t = 0; t < cnt; ++t)
+	{
+		const char* base = (const char*)(tris + first + t);
+		const v16i a = sload16(base);
+		const v16i b = sload16(base + 64);
+		const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
+		const double e0x = pack_double(a[6], a[7]), e0y = pack_double(a[8], a[9]), e0z = pack_double(a[10], a[11]);
+		const double e1x = pack_double(a[12], a[13]), e1y = pack_double(a[14], a[15]), e1z = pack_double(b[0], b[1]);
+		const double a00 = pack_double(b[2], b[3]), a01 = pack_double(b[4], b[5]), a11 = pack_double(b[6], b[7]);
+		const double det = pack_double(b[8], b[9]), inv_det = pack_double(b[10], b[11]);
+		const double denom = pack_double(b[12], b[13]);
+		const Hit h = tri_closest<false>(v0x, v0y, v0z, e0x, e0y, e0z, e1x, e1y, e1z, a00, a01, a11, det, inv_det,
+										 denom, q.px, q.py, q.pz);
+		offer(q, h.d2, first + t);
+	}
+}
+
+// Packet traversal: on return every active lane holds the minimum squared distance over all
+// triangles (q.best_d2) and the packet index attaining it.
+__device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q)
+{
+	const BvhNode* nodes = M.nodes;
+	const TriPacket* tris = M.tris;
+	const int n_nodes = M.n_nodes;
+
+	// (1) greedy descent: follow the child most lanes are closer to, down to one leaf
+	{
+		int g = 0;
+		SNode nd = load_node(nodes, 0);
+		while (nd.info >= 0)
+		{
+			const int li = g + 1, ri = nd.info;
+			const SNode l = load_node(nodes, li);
+			const SNode r = load_node(nodes, ri);
+			const float dl = box_lb2(l.lo, l.hi, q.fp);
+			const float dr = box_lb2(r.lo, r.hi, q.fp);
+			const unsigned long long act = __ballot(q.bestf >= 0.0f);
+			const unsigned long long pref_l = __ballot(dl <= dr) & act;
+			const bool go_left = 2 * __popcll(pref_l) >= __popcll(act);
+			g = go_left ? li : ri;
+			nd = go_left ? l : r;
+		}
+		const unsigned code = ~(unsigned)nd.info;
+		test_leaf(tris, (int)(code >> 3), (int)(code & 7u) + 1, q);
+	}
+
+	// (2) stackless depth-first sweep with the bound from (1)
+	int idx = 0;
+	while (idx < n_nodes)
+	{
+		const SNode nd = load_node(nodes, idx);
+		const float lb2 = box_lb2(nd.lo, nd.hi, q.fp);
+		const bool hit = lb2 < q.bestf;
+		if (__ballot(hit) == 0ull)
+		{
+			idx = nd.skip;
+			continue;
+		}
+		if (nd.info < 0)
+		{
+			const unsigned code = ~(unsigned)nd.info;
+			test_leaf(tris, (int)(code >> 3), (int)(code & 7u) + 1, q);
+		}
+		idx = idx + 1;
+	}
+}
+
+struct DeviceSqrt
+{
+	__device__ __forceinline__ double operator()(double x) const { return sqrt(x); } // correctly rounded (OCML)
+};
+__device__ __forceinline__ LaneResult finish(const MeshDev& M, const LaneQuery& q)
+{
+	return finish_query(M.tris, M.pn, q, DeviceSqrt());
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one wave per 4x4x4 brick of one node class.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_nodes(const SampleParams P)
+{
+	// XCD-aware remap: hardware deals blockIdx round-robin over the 8 XCDs; give XCD x the
+	// contiguous chunk [x*blocks_per_xcd, (x+1)*blocks_per_xcd) of logical blocks.
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t within = blockIdx.x >> 3;
+	const uint32_t blk = xcd * P.blocks_per_xcd + within;
+	if (within >= P.blocks_per_xcd || blk >= P.n_blocks)
+		return;
+	const int wave = uniform((int)(threadIdx.x >> 6));
+	const int lane = (int)(threadIdx.x & 63u);
+	const uint64_t brick = (uint64_t)blk * 4u + (uint64_t)wave;
+	if (brick >= P.total_bricks)
+		return;
+
+	const LaneNode ln = map_lane(P, brick, lane);
+	const bool valid = ln.valid;
+	const int64_t out_idx = ln.out_idx;
+	bool sample = valid;
+	if (valid && P.mask != nullptr)
+		sample = P.mask[out_idx] != 0;
+	// masked-off lanes still carry a sane (clamped) point; they never hit anything
+	double x[3];
+	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+
+	LaneQuery q;
+	init_query(P.mesh.origin, sample, x[0], x[1], x[2], q);
+	if (__ballot(sample) != 0ull)
+		traverse(P.mesh, q);
+
+	if (valid)
+	{
+		double v = 1.7976931348623157e308; // predicate-rejected node (:817)
+		if (sample && q.best_tri >= 0)
+		{
+			const LaneResult r = finish(P.mesh, q);
+			v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+		}
+		P.out[out_idx] = v;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1p: caller-supplied points, 64 consecutive points per wave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const double* __restrict__ xyz, uint64_t n,
+														  double* __restrict__ dist, int32_t* __restrict__ tri,
+														  int32_t* __restrict__ entity, double* __restrict__ nearest)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool valid = gid < n;
+	const uint64_t g = valid ? gid : (n - 1);
+	LaneQuery q;
+	init_query(M.origin, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
+	traverse(M, q);
+	if (!valid)
+		return;
+	if (q.best_tri < 0)
+	{
+		dist[gid] = 1.7976931348623157e308;
+		if (tri) tri[gid] = -1;
+		if (entity) entity[gid] = -1;
+		return;
+	}
+	const LaneResult r = finish(M, q);
+	dist[gid] = r.signed_dist;
+	if (tri) tri[gid] = r.tri_id;
+	if (entity) entity[gid] = r.entity;
+	if (nearest)
+	{
+		nearest[3 * gid] = r.nearest[0];
+		nearest[3 * gid + 1] = r.nearest[1];
+		nearest[3 * gid + 2] = r.nearest[2];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// U: gathered packed shards -> reference node order.  One thread per node, coalesced stores,
+// reads are contiguous runs of one plane row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unpack_shards(const UnpackParams P)
+{
+	const uint64_t total = P.class_off[4];
+	for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < total;
+		 l += (uint64_t)gridDim.x * blockDim.x)
+	{
+		int c = 0;
+		if (l >= P.class_off[1]) c = 1;
+		if (l >= P.class_off[2]) c = 2;
+		if (l >= P.class_off[3]) c = 3;
+		const uint64_t lc = l - P.class_off[c];
+		const uint64_t plane = (uint64_t)P.D0[c] * P.D1[c];
+		const uint32_t s = (uint32_t)(lc / plane);
+		const uint64_t inplane = lc - (uint64_t)s * plane;
+		const uint32_t slab = s / kSlabPlanes;
+		const uint32_t r = slab % (uint32_t)P.nranks;
+		const uint32_t q = (slab / (uint32_t)P.nranks) * kSlabPlanes + (s % kSlabPlanes);
+		P.field[l] = P.gathered[(uint64_t)r * P.stride + P.pack_off[c][r] + (uint64_t)q * plane + inplane];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: one thread per query point.  The 32-term sum must run in j order for parity, so the
+// evaluation is per-lane; the 32 coefficients are fetched as 16 x 16-byte pairs (closed-form
+// rows) with all loads issued before the first use.
+// ------------------------------------------------------------------------------------------------
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+													  double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n)
+		return;
+	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
+	double g[3];
+	phi_out[gid] = interpolate_point<GRAD>(F, x, g);
+	if (GRAD)
+	{
+		grad_out[3 * gid] = g[0];
+		grad_out[3 * gid + 1] = g[1];
+		grad_out[3 * gid + 2] = g[2];
+	}
+}
+
+} // namespace
+
+hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
+{
+	if (p.total_bricks == 0)
+		return hipSuccess;
+	const uint32_t grid = p.blocks_per_xcd * 8u;
+	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
+								  int32_t* d_entity, double* d_nearest, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), 0, stream, m, d_xyz, n, d_dist, d_tri, d_entity,
+					   d_nearest);
+	return hipGetLastError();
+}
+
+hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream)
+{
+	const uint64_t total = p.class_off[4];
+	if (total == 0)
+		return hipSuccess;
+	uint64_t blocks = (total + 255) / 256;
+	if (blocks > 256ull * 32ull)
+		blocks = 256ull * 32ull;
+	hipLaunchKernelGGL(k_unpack_shards, dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+							  hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	if (d_grad)
+		hipLaunchKernelGGL(k_interpolate<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	else
+		hipLaunchKernelGGL(k_interpolate<false>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	return hipGetLastError();
+}
+
+} // namespace dg

@@ -1,0 +1,186 @@
+// dg_layout.h -- host-side decomposition of the node lattice into the 4x4x4 bricks the K1
+// kernel consumes, for (a) a flat node range [node_begin, node_end) and (b) one rank's shard
+// of a multi-GPU run.  Pure index arithmetic, no device work.  Shared by the C ABI
+// (dg_capi.cpp) and the wave emulator of the CPU tests.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include "dg_kernels.h"
+
+namespace dg
+{
+
+struct ClassGeom
+{
+	uint32_t D[3];
+	uint64_t off;  // global node offset of the class: [V | X | Y | Z]
+	uint64_t size;
+};
+
+inline uint64_t class_geometry(const uint32_t res[3], ClassGeom cg[4])
+{
+	uint64_t off = 0;
+	for (int c = 0; c < 4; ++c)
+	{
+		class_dims(c, res, cg[c].D);
+		cg[c].off = off;
+		cg[c].size = (uint64_t)cg[c].D[0] * cg[c].D[1] * cg[c].D[2];
+		off += cg[c].size;
+	}
+	return off;
+}
+
+// number of planes s in [0, D2) owned by `rank` when slabs of kSlabPlanes planes are dealt
+// round-robin to `nranks` ranks
+inline uint32_t owned_planes(uint32_t D2, int rank, int nranks)
+{
+	const uint32_t T = kSlabPlanes;
+	const uint32_t n_slabs = (D2 + T - 1) / T;
+	uint32_t n = 0;
+	for (uint32_t slab = (uint32_t)rank; slab < n_slabs; slab += (uint32_t)nranks)
+		n += std::min(T, D2 - slab * T);
+	return n;
+}
+
+inline uint64_t shard_count(const uint32_t res[3], int rank, int nranks)
+{
+	ClassGeom cg[4];
+	class_geometry(res, cg);
+	uint64_t cnt = 0;
+	for (int c = 0; c < 4; ++c)
+		cnt += (uint64_t)owned_planes(cg[c].D[2], rank, nranks) * cg[c].D[0] * cg[c].D[1];
+	return cnt;
+}
+
+inline void finish_bricks(SampleParams& P)
+{
+	uint64_t prefix = 0;
+	for (int c = 0; c < 4; ++c)
+	{
+		ClassDesc& C = P.cls[c];
+		const uint32_t nq = C.q_end > C.q_begin ? C.q_end - C.q_begin : 0;
+		C.nb0 = (C.D0 + 3) / 4;
+		C.nb1 = (C.D1 + 3) / 4;
+		C.nbq = (nq + 3) / 4;
+		C.brick_prefix = prefix; // an empty class shares its prefix with the next one; the
+		                         // kernel picks the LAST class whose prefix <= brick
+		prefix += (uint64_t)C.nb0 * C.nb1 * C.nbq;
+	}
+	P.total_bricks = prefix;
+	P.n_blocks = (uint32_t)((prefix + 3) / 4);
+	P.blocks_per_xcd = (P.n_blocks + 7) / 8;
+}
+
+inline void init_params(SampleParams& P, const MeshDev& mesh, const double dmin[3], const double cell[3], int invert)
+{
+	std::memset(&P, 0, sizeof(P));
+	P.mesh = mesh;
+	for (int d = 0; d < 3; ++d)
+	{
+		P.dmin[d] = dmin[d];
+		P.cell[d] = cell[d];
+	}
+	P.invert = invert ? 1 : 0;
+	P.shard_rank = 0;
+	P.shard_n = 1;
+}
+
+// out[l - node_begin] for l in [node_begin, node_end)
+inline void layout_range(SampleParams& P, const uint32_t res[3], uint64_t node_begin, uint64_t node_end)
+{
+	ClassGeom cg[4];
+	class_geometry(res, cg);
+	for (int c = 0; c < 4; ++c)
+	{
+		ClassDesc& C = P.cls[c];
+		C.D0 = cg[c].D[0];
+		C.D1 = cg[c].D[1];
+		C.D2 = cg[c].D[2];
+		const uint64_t lo = std::max(node_begin, cg[c].off), hi = std::min(node_end, cg[c].off + cg[c].size);
+		if (lo < hi)
+		{
+			const uint64_t plane = (uint64_t)C.D0 * C.D1;
+			C.l_begin = lo - cg[c].off;
+			C.l_end = hi - cg[c].off;
+			C.q_begin = (uint32_t)(C.l_begin / plane);
+			C.q_end = (uint32_t)((C.l_end + plane - 1) / plane);
+		}
+		else
+		{
+			C.l_begin = C.l_end = 0;
+			C.q_begin = C.q_end = 0;
+		}
+		C.out_base = (int64_t)cg[c].off - (int64_t)node_begin;
+	}
+	P.shard_rank = 0;
+	P.shard_n = 1;
+	finish_bricks(P);
+}
+
+// packed buffer of rank `rank`: [V planes | X planes | Y planes | Z planes] it owns
+inline void layout_shard(SampleParams& P, const uint32_t res[3], int rank, int nranks)
+{
+	ClassGeom cg[4];
+	class_geometry(res, cg);
+	uint64_t pack = 0;
+	for (int c = 0; c < 4; ++c)
+	{
+		ClassDesc& C = P.cls[c];
+		C.D0 = cg[c].D[0];
+		C.D1 = cg[c].D[1];
+		C.D2 = cg[c].D[2];
+		C.l_begin = 0;
+		C.l_end = cg[c].size;
+		C.q_begin = 0;
+		C.q_end = owned_planes(C.D2, rank, nranks);
+		C.out_base = (int64_t)pack;
+		pack += (uint64_t)C.q_end * C.D0 * C.D1;
+	}
+	P.shard_rank = rank;
+	P.shard_n = nranks;
+	finish_bricks(P);
+}
+
+inline void layout_unpack(UnpackParams& U, const uint32_t res[3], int nranks)
+{
+	std::memset(&U, 0, sizeof(U));
+	ClassGeom cg[4];
+	const uint64_t total = class_geometry(res, cg);
+	for (int c = 0; c < 4; ++c)
+	{
+		U.D0[c] = cg[c].D[0];
+		U.D1[c] = cg[c].D[1];
+		U.D2[c] = cg[c].D[2];
+		U.class_off[c] = cg[c].off;
+	}
+	U.class_off[4] = total;
+	for (int r = 0; r < nranks; ++r)
+	{
+		uint64_t pack = 0;
+		for (int c = 0; c < 4; ++c)
+		{
+			U.pack_off[c][r] = pack;
+			pack += (uint64_t)owned_planes(cg[c].D[2], r, nranks) * cg[c].D[0] * cg[c].D[1];
+		}
+	}
+	U.nranks = nranks;
+}
+
+// the source index k_unpack_shards reads for global node l (host mirror, used by tests)
+inline uint64_t unpack_source(const UnpackParams& U, uint64_t l)
+{
+	int c = 0;
+	if (l >= U.class_off[1]) c = 1;
+	if (l >= U.class_off[2]) c = 2;
+	if (l >= U.class_off[3]) c = 3;
+	const uint64_t lc = l - U.class_off[c];
+	const uint64_t plane = (uint64_t)U.D0[c] * U.D1[c];
+	const uint32_t s = (uint32_t)(lc / plane);
+	const uint64_t inplane = lc - (uint64_t)s * plane;
+	const uint32_t slab = s / kSlabPlanes;
+	const uint32_t r = slab % (uint32_t)U.nranks;
+	const uint32_t q = (slab / (uint32_t)U.nranks) * kSlabPlanes + (s % kSlabPlanes);
+	return (uint64_t)r * U.stride + U.pack_off[c][r] + (uint64_t)q * plane + inplane;
+}
+
+} // namespace dg

@@ -1,0 +1,165 @@
+/* discregrid_hip.h -- C ABI of the MI355X (gfx950) SDF-discretisation hot path.
+ *
+ * Drop-in boundary for Discregrid's node-sampling / interpolation path.  Every entry
+ * point names the reference interface it replaces (paths relative to the Discregrid
+ * source tree, InteractiveComputerGraphics/Discregrid @ v1):
+ *
+ *   dg_mesh_create            TriangleMeshDistance(TriangleMesh const&)  +  _construct()
+ *                             discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:227-230, 336-441
+ *   dg_sdf_sample_nodes[_device]
+ *                             the `omp for` node loop of CubicLagrangeDiscreteGrid::addFunction with
+ *                             func = +-TriangleMeshDistance::signed_distance(x).distance
+ *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:806-831, :604-665
+ *                             TriangleMeshDistance.h:269-308, 514-562, 564-820; cmd/generate_sdf/main.cpp:95-105
+ *   dg_signed_distance[_device]
+ *                             TriangleMeshDistance::signed_distance for a batch of points
+ *                             TriangleMeshDistance.h:269-314
+ *   dg_field_create / dg_field_attach_device
+ *                             the per-field storage m_nodes / m_cells / m_cell_map
+ *                             discregrid/include/Discregrid/cubic_lagrange_discrete_grid.hpp:69-71
+ *   dg_interpolate_batch[_device]
+ *                             CubicLagrangeDiscreteGrid::interpolate(field_id, x, gradient*)
+ *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063 (shape functions :339-580)
+ *   dg_shard_* / dg_unpack_shards_device
+ *                             no counterpart (the reference is single-process OpenMP): lattice sharding
+ *                             for one-process-per-GPU runs, the exchange itself is one RCCL all-gather
+ *                             issued by the caller.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a dg_status (0 = ok)
+ * and never throws or exits; dg_last_error() gives a thread-local message.  Functions
+ * suffixed _device take DEVICE pointers and a hipStream_t (passed as void*; NULL = the
+ * default stream) and are asynchronous; the unsuffixed forms take HOST pointers, stage
+ * through device memory and synchronise before returning.  All work runs on the HIP
+ * device that is current on the calling thread (hipSetDevice / dg_set_device).
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point returns
+ * DG_ERR_NO_DEVICE.
+ *
+ * Sentinel: DG_NO_VALUE == std::numeric_limits<double>::max() marks "no value" exactly
+ * like the reference (cubic_lagrange_discrete_grid.cpp:817, 982, 994, 1017).
+ */
+#ifndef DISCREGRID_HIP_H
+#define DISCREGRID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_NO_VALUE 1.7976931348623157e308
+
+typedef enum dg_status {
+	DG_OK = 0,
+	DG_ERR_INVALID = 1,   /* bad argument (null pointer, empty mesh, range out of bounds, ...) */
+	DG_ERR_NO_DEVICE = 2, /* no usable HIP device / wrong architecture */
+	DG_ERR_HIP = 3,       /* a HIP runtime call failed; see dg_last_error() */
+	DG_ERR_ALLOC = 4      /* host or device allocation failed */
+} dg_status;
+
+/* The serialised members of Discregrid::DiscreteGrid (discrete_grid.hpp:91-96).  Pass the
+ * SAME doubles the host grid holds: parity at 1e-10 depends on it. */
+typedef struct dg_grid_desc {
+	double domain_min[3];
+	double domain_max[3];
+	uint32_t resolution[3];
+	uint32_t reserved_;
+	double cell_size[3];
+	double inv_cell_size[3];
+} dg_grid_desc;
+
+typedef struct dg_mesh dg_mesh;   /* device-resident flattened BVH + triangle packets + pseudonormals */
+typedef struct dg_field dg_field; /* device-resident coefficient vector (+ optional cell table / map) */
+
+typedef struct dg_mesh_info {
+	uint64_t n_vertices;
+	uint64_t n_triangles;
+	uint64_t n_bvh_nodes;
+	uint32_t bvh_depth;
+	uint32_t not_watertight;  /* bit0: an edge with one face, bit1: an edge with >2 faces (TriangleMeshDistance.h:422-438) */
+	uint64_t device_bytes;
+	double build_seconds;     /* host BVH + pseudonormal construction */
+} dg_mesh_info;
+
+typedef struct dg_shard_info {
+	uint64_t count;       /* nodes owned by (rank, nranks) */
+	uint64_t stride;      /* max count over ranks, rounded up to 64: per-rank slot size for the all-gather */
+} dg_shard_info;
+
+/* ---- runtime ------------------------------------------------------------------------- */
+const char* dg_version(void);
+const char* dg_last_error(void);
+dg_status dg_device_count(int* count);
+dg_status dg_set_device(int device);
+
+/* ---- grid helpers (host arithmetic of discrete_grid.hpp:22-29, no device work) ---------- */
+dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
+							dg_grid_desc* out);
+uint64_t dg_grid_n_nodes(const dg_grid_desc* grid); /* (N+1)^3 + 6N(N+1)^2 generalised, :790-796 */
+uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
+
+/* ---- mesh / BVH handle ----------------------------------------------------------------- */
+/* verts: 3*n_vertices doubles (xyzxyz...), tris: 3*n_triangles vertex indices.  Builds the
+ * pseudonormals exactly as the reference does and a flattened AABB BVH of this library's own
+ * design on the host, then uploads everything to the current device. */
+dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
+						 dg_mesh** out);
+dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info);
+void dg_mesh_destroy(dg_mesh* mesh);
+
+/* ---- K1: SDF node sampling --------------------------------------------------------------- */
+/* out[l - node_begin] = (invert ? -1 : 1) * signed_distance(indexToNodePosition(l)) for
+ * l in [node_begin, node_end); nodes whose pred_mask byte (indexed l - node_begin, nullable)
+ * is 0 receive DG_NO_VALUE, mirroring the SamplePredicate branch (:814-817). */
+dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+							  uint64_t node_end, const uint8_t* pred_mask, double* out);
+dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream);
+
+/* Signed distance at arbitrary points (3*n doubles) -> dist[n]; optional nearest triangle id
+ * (original index), nearest entity (0..6 = V0,V1,V2,E01,E12,E02,F) and nearest point. */
+dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n, double* dist, int32_t* tri,
+							 int32_t* entity, double* nearest);
+dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
+									int32_t* d_tri, int32_t* d_entity, double* d_nearest, void* stream);
+
+/* ---- multi-GPU sharding of the node lattice (one process per GPU) -------------------------- */
+/* The lattice of each of the four node classes [V | X | Y | Z] is cut into slabs of 4 planes
+ * along its slowest-varying index (k, k, i, j -- i.e. Z-slabs for V and X) and the slabs are
+ * dealt round-robin to the ranks.  A rank writes its nodes into a packed buffer of
+ * `count` doubles; after ONE all-gather of `stride` doubles per rank,
+ * dg_unpack_shards_device() scatters the gathered buffer into reference node order. */
+dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_shard_info* out);
+dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
+									 double* d_packed, void* stream);
+dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+								  double* d_field, void* stream);
+
+/* ---- field handle + K2: batched interpolate ------------------------------------------------ */
+/* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both
+ * be NULL for an unreduced field: the kernel then uses the closed-form node indices the
+ * reference's own table holds right after addFunction (:833-891). */
+dg_status dg_field_create(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, const uint32_t* cells,
+						  uint64_t n_cell_rows, const uint32_t* cell_map, dg_field** out);
+/* Non-owning: wraps device arrays that stay valid for the lifetime of the handle. */
+dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeffs, uint64_t n_coeffs,
+								 const uint32_t* d_cells, uint64_t n_cell_rows, const uint32_t* d_cell_map,
+								 dg_field** out);
+void dg_field_destroy(dg_field* field);
+
+/* phi[q] = interpolate(field, x_q [, &grad_q]); DG_NO_VALUE outside the domain, in removed
+ * cells or when a coefficient is DG_NO_VALUE (grad_q is then zero).  grad may be NULL. */
+dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad);
+dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
+									  double* d_grad, void* stream);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+/* Device time (HIP events on the launch stream) of the most recent K1 / K2 kernel launch issued
+ * by this thread through the HOST entry points, in milliseconds; <0 if none. */
+double dg_last_kernel_ms(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCREGRID_HIP_H */

@@ -1,0 +1,146 @@
+"""ctypes binding of tests/emu/wave_emu.cpp (CPU lock-step emulation of the HIP kernels,
+TEST INFRASTRUCTURE ONLY -- see the header of that file)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import dgtest as T
+
+HERE = os.path.join(T.ROOT, "tests", "emu")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HERE, "libwave_emu.so")
+        csrc = os.path.join(T.ROOT, "discregrid_amd", "csrc")
+        deps = [os.path.join(HERE, "wave_emu.cpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+                                   "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                                   os.path.join(HERE, "wave_emu.cpp"), os.path.join(csrc, "dg_build.cpp"), "-o", so])
+        L = C.CDLL(so)
+        L.emu_mesh_create.restype = C.c_void_p
+        L.emu_mesh_create.argtypes = [T.c_dp, C.c_size_t, T.c_up, C.c_size_t, C.c_int]
+        L.emu_mesh_free.argtypes = [C.c_void_p]
+        L.emu_mesh_info.argtypes = [C.c_void_p, T.c_u64p, T.c_up, T.c_up]
+        L.emu_mesh_pseudonormals.argtypes = [C.c_void_p, T.c_dp]
+        L.emu_mesh_check.argtypes = [C.c_void_p, T.c_dp, T.c_up]
+        L.emu_sample_nodes.argtypes = [C.c_void_p, T.c_dp, T.c_dp, T.c_up, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                       C.c_void_p, T.c_dp, C.c_void_p, T.c_u64p]
+        L.emu_signed_distance.argtypes = [C.c_void_p, T.c_dp, C.c_uint64, T.c_dp, T.c_ip, T.c_ip, T.c_dp]
+        L.emu_shard_count.restype = C.c_uint64
+        L.emu_shard_count.argtypes = [T.c_up, C.c_int, C.c_int]
+        L.emu_unpack.argtypes = [T.c_up, C.c_int, T.c_dp, C.c_uint64, T.c_dp]
+        L.emu_interpolate.argtypes = [T.c_dp, T.c_dp, T.c_dp, T.c_up, T.c_dp, T.c_up, T.c_up, T.c_dp, C.c_uint64,
+                                      T.c_dp, T.c_dp]
+        _lib = L
+    return _lib
+
+
+class EmuMesh:
+    def __init__(self, V, F, max_leaf=4):
+        self.L = lib()
+        self.V = np.ascontiguousarray(V, dtype=np.float64)
+        self.F = np.ascontiguousarray(F, dtype=np.uint32)
+        self.h = self.L.emu_mesh_create(T.dp(self.V), len(self.V), T.up(self.F), len(self.F), max_leaf)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.emu_mesh_free(self.h)
+            self.h = None
+
+    def check(self):
+        return self.L.emu_mesh_check(self.h, T.dp(self.V), T.up(self.F))
+
+    def info(self):
+        n = C.c_uint64()
+        d = C.c_uint()
+        f = C.c_uint()
+        self.L.emu_mesh_info(self.h, C.byref(n), C.byref(d), C.byref(f))
+        return dict(n_nodes=n.value, depth=d.value, flags=f.value)
+
+    def pseudonormals(self):
+        pn = np.zeros((len(self.F), 8, 3))
+        self.L.emu_mesh_pseudonormals(self.h, T.dp(pn))
+        return pn
+
+    def _grid(self, domain, res):
+        domain = np.ascontiguousarray(domain, dtype=np.float64)
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        cell = np.empty(3)
+        inv = np.empty(3)
+        T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+        return domain, res, cell, inv
+
+    def sample_range(self, domain, res, begin=0, end=None, invert=False, mask=None, stats=False):
+        domain, res, cell, _ = self._grid(domain, res)
+        if end is None:
+            end = T.n_nodes(res)
+        out = np.full(end - begin, np.nan)
+        written = np.zeros(end - begin, dtype=np.uint8)
+        st = np.zeros(5, dtype=np.uint64)
+        dmin = np.ascontiguousarray(domain[:3])
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.emu_sample_nodes(self.h, T.dp(dmin), T.dp(cell), T.up(res), int(invert), 0, begin, end,
+                                None if m is None else m.ctypes.data_as(C.c_void_p), T.dp(out),
+                                written.ctypes.data_as(C.c_void_p), st.ctypes.data_as(T.c_u64p))
+        self.written = written
+        self.stats = dict(zip(("bricks", "node_visits", "leaf_visits", "tri_tests", "descent_nodes"), st.tolist()))
+        return out
+
+    def sample_shard(self, domain, res, rank, nranks, invert=False):
+        domain, res, cell, _ = self._grid(domain, res)
+        cnt = self.L.emu_shard_count(T.up(res), rank, nranks)
+        out = np.full(cnt, np.nan)
+        written = np.zeros(cnt, dtype=np.uint8)
+        dmin = np.ascontiguousarray(domain[:3])
+        self.L.emu_sample_nodes(self.h, T.dp(dmin), T.dp(cell), T.up(res), int(invert), 1, rank, nranks, None,
+                                T.dp(out), written.ctypes.data_as(C.c_void_p), None)
+        self.written = written
+        return out
+
+    def signed_distance(self, P, full=False):
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+        n = len(P)
+        d = np.empty(n)
+        tri = np.empty(n, dtype=np.int32)
+        ent = np.empty(n, dtype=np.int32)
+        near = np.empty((n, 3))
+        self.L.emu_signed_distance(self.h, T.dp(P), n, T.dp(d), T.ip(tri), T.ip(ent), T.dp(near))
+        return (d, tri, ent, near) if full else d
+
+
+def unpack(res, nranks, gathered, stride):
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    gathered = np.ascontiguousarray(gathered, dtype=np.float64)
+    field = np.empty(T.n_nodes(res))
+    lib().emu_unpack(T.up(res), nranks, T.dp(gathered), stride, T.dp(field))
+    return field
+
+
+def shard_count(res, rank, nranks):
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    return lib().emu_shard_count(T.up(res), rank, nranks)
+
+
+def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    cell = np.empty(3)
+    inv = np.empty(3)
+    T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+    phi = np.empty(len(P))
+    g = np.empty((len(P), 3)) if grad else None
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell_map = np.ascontiguousarray(cell_map, dtype=np.uint32)
+    lib().emu_interpolate(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), T.up(cells), T.up(cell_map),
+                          T.dp(P), len(P), T.dp(phi), T.dp(g))
+    return (phi, g) if grad else phi

@@ -1,0 +1,100 @@
+"""The C-ABI shared library: builds for gfx950, loads, exports every symbol that
+include/discregrid_hip.h declares, does its host-side arithmetic like the reference, and
+FAILS LOUDLY (no CPU fallback) when there is no HIP device.  CPU only, no compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import dgtest as T
+
+
+@pytest.fixture(scope="module")
+def dg():
+    from discregrid_amd.build import build
+    build()
+    import discregrid_amd
+    discregrid_amd.load_library()
+    return discregrid_amd
+
+
+def header_symbols():
+    src = open(os.path.join(T.ROOT, "include", "discregrid_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(dg):
+    names = header_symbols()
+    assert len(names) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dg.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (dg_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(dg.SYMBOLS), set(names) ^ set(dg.SYMBOLS)
+    # only dg_* is exported from the C ABI surface (C++ internals stay in namespace dg)
+    assert all(n.startswith("dg_") for n in exported if not n.startswith("_"))
+
+
+def test_library_contains_gfx950_code_object(dg):
+    blob = open(dg.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"k_sample_nodes" in blob and b"k_interpolate" in blob
+
+
+def test_grid_desc_matches_reference_ctor(dg, golden):
+    for name in ("box", "bunny", "torus"):
+        dom, res = golden[name + "_domain"], golden[name + "_res"]
+        g = dg.grid_desc(dom[:3], dom[3:], res)
+        cell = np.empty(3)
+        inv = np.empty(3)
+        T.oracle_lib().dgo_grid_header(T.dp(np.ascontiguousarray(dom)), T.up(np.ascontiguousarray(res)), T.dp(cell),
+                                       T.dp(inv))
+        np.testing.assert_array_equal(np.array(g.cell_size), cell)
+        np.testing.assert_array_equal(np.array(g.inv_cell_size), inv)
+        assert dg.n_nodes(g) == T.n_nodes(res) == len(golden[name + "_coeffs"])
+    assert dg.n_nodes(dg.grid_desc([0] * 3, [1] * 3, [256] * 3)) == 118425857
+    assert dg.n_nodes(dg.grid_desc([0] * 3, [1] * 3, [512] * 3)) == 943460865
+
+
+def test_invalid_arguments_are_reported(dg):
+    with pytest.raises(dg.DiscregridError) as e:
+        dg.grid_desc([0] * 3, [1] * 3, [4, 0, 4])
+    assert e.value.status == dg.DG_ERR_INVALID
+    g = dg.grid_desc([0] * 3, [1] * 3, [4, 4, 4])
+    with pytest.raises(dg.DiscregridError):
+        dg.shard_layout(g, 3, 2)
+    counts = [dg.shard_layout(g, r, 3)[0] for r in range(3)]
+    assert sum(counts) == dg.n_nodes(g)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_device_fails_loudly(dg):
+    """No CPU path: on a machine without a HIP device compute entry points return
+    DG_ERR_NO_DEVICE instead of silently computing on the host."""
+    assert dg.device_count() == 0
+    V, F = T.box_mesh()
+    with pytest.raises(dg.DiscregridError) as e:
+        dg.Mesh(V, F)
+    assert e.value.status == dg.DG_ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+    g = dg.grid_desc([0] * 3, [1] * 3, [2, 2, 2])
+    with pytest.raises(dg.DiscregridError) as e:
+        dg.Field(g, np.zeros(dg.n_nodes(g)))
+    assert e.value.status == dg.DG_ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must not import/link/execute anything under oracle/ or tests/."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(T.ROOT, "discregrid_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                if re.search(r"oracle/|libdiscregrid_oracle|libdiscregrid_ref|wave_emu|dgtest", txt):
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
+    out = subprocess.check_output(["ldd", os.path.join(T.ROOT, "discregrid_amd", "libdiscregrid_hip.so")]).decode()
+    assert "oracle" not in out and "libamdhip64" in out

@@ -1,0 +1,165 @@
+"""CPU lock-step emulation of the HIP kernels (tests/emu/wave_emu.cpp) against the oracle.
+Validates, without a GPU, everything about the product that is not the GPU's own
+instruction execution: the host-built BVH / triangle packets / pseudonormals, the
+conservative float box test, the packet traversal's pruning logic, the per-lane arithmetic
+in dg_geom.h, the brick decomposition (every node exactly once, incl. the XCD block remap),
+flat ranges, predicate masks, shard packing and unpacking, and the K2 per-query body."""
+import numpy as np
+import pytest
+
+import dgtest as T
+import emu
+
+DBL_MAX = np.finfo(np.float64).max
+MESHES = {"box": T.box_mesh, "ico8": lambda: T.icosphere(8), "torus": T.torus, "bunny": T.bunny_mesh}
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_bvh_structure_and_pseudonormals(name):
+    V, F = MESHES[name]()
+    for leaf in (1, 4, 8):
+        em = emu.EmuMesh(V, F, max_leaf=leaf)
+        assert em.check() == 0
+    em = emu.EmuMesh(V, F)
+    c = T.OracleMesh(V, F).construction()
+    pn = em.pseudonormals()
+    np.testing.assert_array_equal(pn[:, 6], c["pn_tri"])
+    np.testing.assert_array_equal(pn[:, 3:6], c["pn_edge"])
+    for k in range(3):
+        np.testing.assert_array_equal(pn[:, k], c["pn_vert"][F[:, k]])
+    assert em.info()["flags"] == 0
+
+
+def test_open_mesh_is_flagged():
+    V, F = T.box_mesh()
+    assert emu.EmuMesh(V, F[:-1]).info()["flags"] & 1
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_sampling_bit_exact_vs_golden(golden, name):
+    V, F = MESHES[name]()
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    em = emu.EmuMesh(V, F)
+    got = em.sample_range(dom, res)
+    assert (em.written == 1).all()          # every node exactly once
+    np.testing.assert_array_equal(got, golden[name + "_coeffs"])
+
+
+@pytest.mark.parametrize("name", ["ico8", "torus", "bunny"])
+def test_ranges_masks_invert(name):
+    V, F = MESHES[name]()
+    dom = T.oracle_default_domain(V)
+    res = [9, 6, 11]
+    n = T.n_nodes(res)
+    ref = T.OracleMesh(V, F).sample_nodes(dom, res)
+    em = emu.EmuMesh(V, F)
+    rng = np.random.default_rng(11)
+    cuts = sorted(rng.integers(0, n, size=6).tolist() + [0, n])
+    for b, e in zip(cuts[:-1], cuts[1:]):   # ragged ranges crossing class boundaries
+        if e > b:
+            np.testing.assert_array_equal(em.sample_range(dom, res, b, e), ref[b:e])
+            assert (em.written == 1).all()
+    np.testing.assert_array_equal(em.sample_range(dom, res, 5, 5), np.empty(0))
+    mask = rng.integers(0, 2, size=n).astype(np.uint8)
+    got = em.sample_range(dom, res, mask=mask)
+    np.testing.assert_array_equal(got[mask == 1], ref[mask == 1])
+    assert (got[mask == 0] == DBL_MAX).all()
+    np.testing.assert_array_equal(em.sample_range(dom, res, invert=True), -1.0 * ref)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
+def test_shard_pack_unpack(nranks):
+    V, F = T.torus()
+    dom = T.oracle_default_domain(V)
+    res = [10, 7, 13]
+    ref = T.OracleMesh(V, F).sample_nodes(dom, res)
+    em = emu.EmuMesh(V, F)
+    parts = []
+    for r in range(nranks):
+        p = em.sample_shard(dom, res, r, nranks)
+        assert (em.written == 1).all() and len(p) == emu.shard_count(res, r, nranks)
+        parts.append(p)
+    assert sum(len(p) for p in parts) == len(ref)
+    stride = (max(len(p) for p in parts) + 63) // 64 * 64
+    G = np.full(stride * nranks, np.nan)
+    for r, p in enumerate(parts):
+        G[r * stride:r * stride + len(p)] = p
+    np.testing.assert_array_equal(emu.unpack(res, nranks, G, stride), ref)
+
+
+def test_signed_distance_points(golden):
+    for name in MESHES:
+        V, F = MESHES[name]()
+        P = golden[name + "_P"]
+        d, tri, ent, near = emu.EmuMesh(V, F).signed_distance(P, full=True)
+        np.testing.assert_array_equal(d, golden[name + "_sd"])
+        # exact ties (shared vertices/edges, or equidistant features) may resolve to another
+        # triangle than the reference's walk: same distance, and where the
+        # triangle agrees everything agrees
+        same = tri == golden[name + "_tri"]
+        assert same.mean() > 0.5
+        np.testing.assert_array_equal(ent[same], golden[name + "_ent"][same])
+        np.testing.assert_array_equal(near[same], golden[name + "_near"][same])
+        np.testing.assert_allclose(np.linalg.norm(P - near, axis=1), np.abs(d), rtol=1e-9, atol=1e-9)  # d^2 formula cancels near the surface
+
+
+def test_far_and_degenerate_queries():
+    """Points far outside the mesh (float box test must stay conservative), exactly on
+    vertices / edges / faces (d = 0), and a mesh far from the origin."""
+    V, F = T.icosphere(6)
+    for shift, scale in ((0.0, 1.0), (1000.0, 1.0), (-3.0e4, 250.0), (0.5, 1e-3)):
+        W = V * scale + shift
+        om, em = T.OracleMesh(W, F), emu.EmuMesh(W, F)
+        rng = np.random.default_rng(4)
+        P = np.concatenate([
+            rng.uniform(-2, 2, size=(400, 3)) * scale + shift,
+            rng.uniform(-1, 1, size=(50, 3)) * scale * 1e4 + shift,     # very far
+            W[:100],                                                      # on vertices
+            0.5 * (W[F[:50, 0]] + W[F[:50, 1]]),                          # on edges
+            (W[F[:50, 0]] + W[F[:50, 1]] + W[F[:50, 2]]) / 3.0,           # on faces
+        ])
+        a, b = em.signed_distance(P), om.signed_distance(P)
+        np.testing.assert_array_equal(np.abs(a), np.abs(b))
+        # the sign of a point lying ON the surface (|d| ~ 1e-12) depends on which of the
+        # tied triangles wins; everywhere else it must agree
+        off = np.abs(b) > 1e-9 * (scale + abs(shift))
+        np.testing.assert_array_equal(a[off], b[off])
+
+
+def test_interpolate_body_bit_exact(golden):
+    for name in MESHES:
+        dom, res = golden[name + "_domain"], golden[name + "_res"]
+        coeffs, P = golden[name + "_coeffs"], golden[name + "_P"]
+        phi, grad = emu.interpolate(dom, res, coeffs, P, grad=True)
+        np.testing.assert_array_equal(phi, golden[name + "_phi"])
+        inside = golden[name + "_phi"] != DBL_MAX
+        np.testing.assert_array_equal(grad[inside], golden[name + "_grad"][inside])
+        assert (grad[~inside] == 0).all()
+        np.testing.assert_array_equal(emu.interpolate(dom, res, coeffs, P), golden[name + "_phi"])
+        # table mode == closed-form mode on an unreduced field
+        cells = T.oracle_cell_table(res)
+        cmap = np.arange(len(cells), dtype=np.uint32)
+        np.testing.assert_array_equal(emu.interpolate(dom, res, coeffs, P, cells=cells, cell_map=cmap),
+                                      golden[name + "_phi"])
+        # removed cells and DBL_MAX coefficients
+        cmap2 = cmap.copy()
+        cmap2[::3] = 0xFFFFFFFF
+        c2 = coeffs.copy()
+        c2[::7] = DBL_MAX
+        a, ga = emu.interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap2)
+        b, gb = T.oracle_interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap2)
+        np.testing.assert_array_equal(a, b)
+        ok = b != DBL_MAX
+        np.testing.assert_array_equal(ga[ok], gb[ok])
+
+
+def test_config3_planes_bit_exact():
+    """Icosphere nu=71 (100 820 triangles) at 256^3: four V planes through the costly centre
+    and two X planes, against the oracle (bit-exact)."""
+    V, F = T.icosphere(71)
+    dom = T.oracle_default_domain(V)
+    res = [256] * 3
+    om, em = T.OracleMesh(V, F), emu.EmuMesh(V, F)
+    plane = 257 * 257
+    for b, e in ((127 * plane, 128 * plane + 1000), (257 ** 3 + 2 * 256 * 257 * 100, 257 ** 3 + 2 * 256 * 257 * 100 + 70000)):
+        np.testing.assert_array_equal(em.sample_range(dom, res, b, e), om.sample_nodes(dom, res, b, e))

@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (libdiscregrid_hip.so), against
+the CPU oracle and the committed golden vectors of the unmodified reference.
+
+Tolerance (BASELINE.json north_star): coefficients and interpolated values within 1e-10
+RELATIVE of the reference in double precision.  The kernels keep the reference's operation
+order, so the tests additionally assert BIT equality wherever no exact tie between triangles
+is involved; the relative bound is what is contractually required."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import dgtest as T
+
+pytestmark = pytest.mark.gpu
+DBL_MAX = np.finfo(np.float64).max
+TOL = 1e-10
+MESHES = {"box": T.box_mesh, "ico8": lambda: T.icosphere(8), "torus": T.torus, "bunny": T.bunny_mesh}
+
+
+@pytest.fixture(scope="module")
+def dg():
+    import discregrid_amd
+    discregrid_amd.load_library()          # raises if the HIP extension is missing
+    assert discregrid_amd.device_count() >= 1, "no HIP device: the product has no CPU path"
+    return discregrid_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def grid_of(dg, dom, res):
+    return dg.grid_desc(dom[:3], dom[3:], res)
+
+
+def assert_parity(got, want, what):
+    rel = T.rel_err(got, want)
+    nbad = int((got != want).sum())
+    print("%s: max rel err %.3e, %d / %d not bit-equal" % (what, rel, nbad, len(want)))
+    assert rel <= TOL, "%s: relative error %.3e > %g" % (what, rel, TOL)
+    np.testing.assert_array_equal(got == DBL_MAX, want == DBL_MAX)
+    return nbad
+
+
+def test_box_cdf_known_answer(dg, tmp_path):
+    """The reference's only golden file, reproduced byte for byte from GPU coefficients."""
+    V, F = T.box_mesh()
+    dom = T.oracle_default_domain(V)
+    coeffs = dg.Mesh(V, F).sample_nodes(grid_of(dg, dom, [5, 5, 5]))
+    p = str(tmp_path / "box_gpu.cdf")
+    assert T.oracle_write_cdf(p, dom, [5, 5, 5], [coeffs]) == 27040
+    assert open(p, "rb").read() == open(os.path.join(T.GOLDEN, "box.cdf"), "rb").read()
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_sampling_vs_golden(dg, golden, name):
+    V, F = MESHES[name]()
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    got = dg.Mesh(V, F).sample_nodes(grid_of(dg, dom, res))
+    assert assert_parity(got, golden[name + "_coeffs"], name) == 0   # bit-exact
+
+
+@pytest.mark.parametrize("name", ["ico8", "torus", "bunny"])
+def test_ranges_masks_invert(dg, name):
+    V, F = MESHES[name]()
+    dom = T.oracle_default_domain(V)
+    res = [9, 6, 11]
+    g = grid_of(dg, dom, res)
+    n = T.n_nodes(res)
+    ref = T.OracleMesh(V, F).sample_nodes(dom, res)
+    m = dg.Mesh(V, F)
+    rng = np.random.default_rng(11)
+    cuts = sorted(rng.integers(0, n, size=6).tolist() + [0, n])
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        np.testing.assert_array_equal(m.sample_nodes(g, b, e), ref[b:e])
+    assert len(m.sample_nodes(g, 7, 7)) == 0
+    mask = rng.integers(0, 2, size=n).astype(np.uint8)
+    got = m.sample_nodes(g, mask=mask)
+    np.testing.assert_array_equal(got[mask == 1], ref[mask == 1])
+    assert (got[mask == 0] == DBL_MAX).all()
+    np.testing.assert_array_equal(m.sample_nodes(g, invert=True), -1.0 * ref)
+    with pytest.raises(dg.DiscregridError):
+        m.sample_nodes(g, 0, n + 1)
+
+
+def test_signed_distance_points(dg, golden):
+    for name in MESHES:
+        V, F = MESHES[name]()
+        P = golden[name + "_P"]
+        d, tri, ent, near = dg.Mesh(V, F).signed_distance(P, full=True)
+        assert_parity(d, golden[name + "_sd"], name + " signed_distance")
+        np.testing.assert_array_equal(d, golden[name + "_sd"])
+        same = tri == golden[name + "_tri"]
+        assert same.mean() > 0.5
+        np.testing.assert_array_equal(ent[same], golden[name + "_ent"][same])
+        np.testing.assert_array_equal(near[same], golden[name + "_near"][same])
+
+
+def test_far_and_on_surface_queries(dg):
+    V, F = T.icosphere(6)
+    for shift, scale in ((0.0, 1.0), (1000.0, 1.0), (-3.0e4, 250.0), (0.5, 1e-3)):
+        W = V * scale + shift
+        om, m = T.OracleMesh(W, F), dg.Mesh(W, F)
+        rng = np.random.default_rng(4)
+        P = np.concatenate([
+            rng.uniform(-2, 2, size=(400, 3)) * scale + shift,
+            rng.uniform(-1, 1, size=(50, 3)) * scale * 1e4 + shift,
+            W[:100], 0.5 * (W[F[:50, 0]] + W[F[:50, 1]]), (W[F[:50, 0]] + W[F[:50, 1]] + W[F[:50, 2]]) / 3.0])
+        a, b = m.signed_distance(P), om.signed_distance(P)
+        np.testing.assert_array_equal(np.abs(a), np.abs(b))
+        off = np.abs(b) > 1e-9 * (scale + abs(shift))
+        np.testing.assert_array_equal(a[off], b[off])
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_interpolate_vs_golden(dg, golden, name):
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    coeffs, P = golden[name + "_coeffs"], golden[name + "_P"]
+    g = grid_of(dg, dom, res)
+    f = dg.Field(g, coeffs)
+    phi, grad = f.interpolate(P, grad=True)
+    assert assert_parity(phi, golden[name + "_phi"], name + " interpolate") == 0
+    inside = golden[name + "_phi"] != DBL_MAX
+    assert T.rel_err(grad[inside], golden[name + "_grad"][inside]) <= TOL
+    np.testing.assert_array_equal(grad[inside], golden[name + "_grad"][inside])
+    assert (grad[~inside] == 0).all()
+    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    # table mode, removed cells, DBL_MAX coefficients
+    cells = T.oracle_cell_table(res)
+    cmap = np.arange(len(cells), dtype=np.uint32)
+    np.testing.assert_array_equal(dg.Field(g, coeffs, cells, cmap).interpolate(P), golden[name + "_phi"])
+    cmap2 = cmap.copy()
+    cmap2[::3] = 0xFFFFFFFF
+    c2 = coeffs.copy()
+    c2[::7] = DBL_MAX
+    a, ga = dg.Field(g, c2, cells, cmap2).interpolate(P, grad=True)
+    b, gb = T.oracle_interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap2)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ga[b != DBL_MAX], gb[b != DBL_MAX])
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks):
+    """Multi-GPU path exercised on one device: every rank's shard is computed in turn, the
+    all-gather is a concatenation, the unpack kernel restores reference order -- bit for bit
+    the unsharded result."""
+    V, F = T.torus()
+    dom = T.oracle_default_domain(V)
+    res = [21, 18, 26]
+    g = grid_of(dg, dom, res)
+    m = dg.Mesh(V, F)
+    n = dg.n_nodes(g)
+    ref = m.sample_nodes(g)
+    stride = dg.shard_layout(g, 0, nranks)[1]
+    gathered = torch.full((nranks * stride,), float("nan"), dtype=torch.float64, device="cuda")
+    total = 0
+    for r in range(nranks):
+        cnt, st = dg.shard_layout(g, r, nranks)
+        assert st == stride
+        total += cnt
+        m.sample_shard_device(g, r, nranks, gathered.data_ptr() + 8 * r * stride,
+                              stream=torch.cuda.current_stream().cuda_stream)
+    assert total == n
+    field = torch.empty(n, dtype=torch.float64, device="cuda")
+    dg.unpack_shards_device(g, nranks, gathered.data_ptr(), stride, field.data_ptr(),
+                            stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(field.cpu().numpy(), ref)
+    np.testing.assert_array_equal(ref, T.OracleMesh(V, F).sample_nodes(dom, res))
+
+
+def test_config2_bunny_128(dg, torch, golden):
+    """BASELINE config 2: Stanford bunny (69 630 triangles), 128^3 grid = 14 926 977 nodes."""
+    V, F = T.bunny_mesh()
+    dom = golden["bunny128_domain"]
+    res = [128] * 3
+    g = grid_of(dg, dom, res)
+    m = dg.Mesh(V, F)
+    n = dg.n_nodes(g)
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    m.sample_nodes_device(g, 0, n, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print("bunny 128^3: %.1f ms, %.1f Mnodes/s" % (dt * 1e3, n / dt / 1e6))
+    got = out.cpu().numpy()
+    idx = golden["bunny128_lattice_idx"]
+    np.testing.assert_array_equal(got[idx], golden["bunny128_lattice_sd"])   # reference itself
+    sel = np.random.default_rng(8).integers(0, n, size=20000)
+    om = T.OracleMesh(V, F)
+    pos = T.oracle_node_positions(dom, res)[sel]
+    want = om.signed_distance(pos)
+    assert_parity(got[sel], want, "bunny128 random nodes")
+    np.testing.assert_array_equal(got[sel], want)
+
+
+def test_config3_icosphere_256(dg, torch, golden):
+    """BASELINE config 3 (headline): icosphere nu=71 (100 820 triangles), 256^3 grid =
+    118 425 857 nodes, full size.  Checked against (a) the reference's values on a strided
+    lattice sample, (b) the analytic sphere distance everywhere, (c) bit equality of the
+    sharded and the unsharded evaluation."""
+    V, F = T.icosphere(71)
+    dom = golden["ico71_domain"]
+    res = [256] * 3
+    g = grid_of(dg, dom, res)
+    m = dg.Mesh(V, F)
+    n = dg.n_nodes(g)
+    assert n == 118425857
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    m.sample_nodes_device(g, 0, n, out.data_ptr(), stream=s)       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.time()
+    m.sample_nodes_device(g, 0, n, out.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print("icosphere 256^3: %.1f ms, %.1f Mnodes/s" % (dt * 1e3, n / dt / 1e6))
+    idx = torch.from_numpy(golden["ico71_lattice_idx"].astype(np.int64)).cuda()
+    np.testing.assert_array_equal(out[idx].cpu().numpy(), golden["ico71_lattice_sd"])
+    # (b) analytic: |sdf - (|x| - 1)| <= sagitta of a facet (edge^2 / 8 ~ 3e-5)
+    got = out.cpu().numpy()
+    for b, e in ((0, 2000000), (n // 2, n // 2 + 2000000), (n - 2000000, n)):
+        pos = T.oracle_node_positions(dom, res, b, e)
+        assert np.abs(got[b:e] - (np.linalg.norm(pos, axis=1) - 1.0)).max() < 1e-4
+    # (c) sharded == unsharded
+    nr = 4
+    stride = dg.shard_layout(g, 0, nr)[1]
+    gathered = torch.empty(nr * stride, dtype=torch.float64, device="cuda")
+    for r in range(nr):
+        m.sample_shard_device(g, r, nr, gathered.data_ptr() + 8 * r * stride, stream=s)
+    field = torch.empty(n, dtype=torch.float64, device="cuda")
+    dg.unpack_shards_device(g, nr, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(field, out)
+    # random nodes against the oracle
+    sel = np.random.default_rng(9).integers(0, n, size=3000)
+    pos = np.stack([T.oracle_node_positions(dom, res, int(l), int(l) + 1)[0] for l in sel])
+    want = T.OracleMesh(V, F).signed_distance(pos)
+    assert_parity(got[sel], want, "ico71 256^3 random nodes")
+    np.testing.assert_array_equal(got[sel], want)
