@@ -103,6 +103,8 @@ inline float round_up(double v)
 struct Prim
 {
 	double lo[3], hi[3], c[3];
+	double v[3][3]; // vertices
+	double an[3];   // area-weighted normal (cross product of the edges)
 	uint32_t tri;
 };
 
@@ -136,6 +138,33 @@ struct Builder
 			// one more ulp outward: the subtraction above rounds too
 			n.lo[d] = std::nextafterf(n.lo[d], -std::numeric_limits<float>::infinity());
 			n.hi[d] = std::nextafterf(n.hi[d], std::numeric_limits<float>::infinity());
+		}
+		// slab along the area-weighted mean normal of the subtree
+		double m[3] = {0, 0, 0};
+		for (size_t i = b; i < e; ++i)
+			for (int d = 0; d < 3; ++d)
+				m[d] += prims[i].an[d];
+		const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+		n.su[0] = n.su[1] = n.su[2] = 0.0f;
+		n.slo = n.shi = 0.0f;
+		n.pad_[0] = n.pad_[1] = n.pad_[2] = 0.0f;
+		if (len > 0 && std::isfinite(len))
+		{
+			const double sc = (1.0 - 1.0e-6) / len;
+			for (int d = 0; d < 3; ++d)
+				n.su[d] = (float)(m[d] * sc);
+			double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
+			for (size_t i = b; i < e; ++i)
+				for (int k = 0; k < 3; ++k)
+				{
+					const double pr = (double)n.su[0] * (prims[i].v[k][0] - origin[0]) +
+									  (double)n.su[1] * (prims[i].v[k][1] - origin[1]) +
+									  (double)n.su[2] * (prims[i].v[k][2] - origin[2]);
+					plo = std::min(plo, pr);
+					phi = std::max(phi, pr);
+				}
+			n.slo = std::nextafterf(round_down(plo), -std::numeric_limits<float>::infinity());
+			n.shi = std::nextafterf(round_up(phi), std::numeric_limits<float>::infinity());
 		}
 	}
 
@@ -223,12 +252,25 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 		{
 			const double a = verts[3 * tris[3 * t] + d], b = verts[3 * tris[3 * t + 1] + d],
 						 c = verts[3 * tris[3 * t + 2] + d];
+			p.v[0][d] = a;
+			p.v[1][d] = b;
+			p.v[2][d] = c;
 			p.lo[d] = std::min(a, std::min(b, c));
 			p.hi[d] = std::max(a, std::max(b, c));
 			p.c[d] = 0.5 * (p.lo[d] + p.hi[d]);
 			lo[d] = std::min(lo[d], p.lo[d]);
 			hi[d] = std::max(hi[d], p.hi[d]);
 		}
+	}
+	for (size_t t = 0; t < n_triangles; ++t)
+	{
+		Prim& p = B.prims[t];
+		const D3 e0 = {p.v[1][0] - p.v[0][0], p.v[1][1] - p.v[0][1], p.v[1][2] - p.v[0][2]};
+		const D3 e1 = {p.v[2][0] - p.v[0][0], p.v[2][1] - p.v[0][1], p.v[2][2] - p.v[0][2]};
+		const D3 n = cross3(e0, e1);
+		p.an[0] = std::isfinite(n.x) ? n.x : 0.0;
+		p.an[1] = std::isfinite(n.y) ? n.y : 0.0;
+		p.an[2] = std::isfinite(n.z) ? n.z : 0.0;
 	}
 	for (int d = 0; d < 3; ++d)
 		out.origin[d] = 0.5 * (lo[d] + hi[d]);
@@ -243,9 +285,45 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	out.n_triangles = n_triangles;
 	out.tris.resize(n_triangles);
 	out.pn.assign(n_triangles * kPnSlots * 3, 0.0);
+	double l1 = 0.0;
+	for (size_t i = 0; i < n_vertices; ++i)
+		l1 = std::max(l1, std::fabs(V[i].x - out.origin[0]) + std::fabs(V[i].y - out.origin[1]) +
+							  std::fabs(V[i].z - out.origin[2]));
+	out.mesh_l1 = std::nextafterf(round_up(l1), std::numeric_limits<float>::infinity());
+	out.slabs.assign(n_triangles + 4, TriSlab());
+	for (auto& sl : out.slabs)
+	{
+		sl.u[0] = sl.u[1] = sl.u[2] = 0.0f; // u = 0: lower bound 0, never prunes (padding, degenerate triangles)
+		sl.lo = sl.hi = 0.0f;
+		sl.pad_[0] = sl.pad_[1] = sl.pad_[2] = 0.0f;
+	}
 	for (size_t k = 0; k < n_triangles; ++k)
 	{
 		const uint32_t t = B.order[k];
+		{
+			// slab direction: the face normal shrunk by 1e-6 so that |u| <= 1 after rounding to float
+			const D3 a = V[tris[3 * t]], b = V[tris[3 * t + 1]], c = V[tris[3 * t + 2]];
+			const D3 n = cross3(sub(b, a), sub(c, a));
+			const double len = std::sqrt(dot3(n, n));
+			TriSlab& sl = out.slabs[k];
+			if (len > 0 && std::isfinite(len))
+			{
+				const double sc = (1.0 - 1.0e-6) / len;
+				sl.u[0] = (float)(n.x * sc);
+				sl.u[1] = (float)(n.y * sc);
+				sl.u[2] = (float)(n.z * sc);
+				double lo = std::numeric_limits<double>::max(), hi = std::numeric_limits<double>::lowest();
+				for (const D3& v : {a, b, c})
+				{
+					const double pr = (double)sl.u[0] * (v.x - out.origin[0]) + (double)sl.u[1] * (v.y - out.origin[1]) +
+									  (double)sl.u[2] * (v.z - out.origin[2]);
+					lo = std::min(lo, pr);
+					hi = std::max(hi, pr);
+				}
+				sl.lo = std::nextafterf(round_down(lo), -std::numeric_limits<float>::infinity());
+				sl.hi = std::nextafterf(round_up(hi), std::numeric_limits<float>::infinity());
+			}
+		}
 		make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
 					out.tris[k]);
 		for (int s = 0; s < kPnSlots; ++s)

@@ -18,8 +18,10 @@ struct MeshBuild
 {
 	std::vector<BvhNode> nodes;    // depth-first, skip pointers
 	std::vector<TriPacket> tris;   // leaf order
+	std::vector<TriSlab> slabs;    // leaf order, padded by 4 entries (leaves are read 4 at a time)
 	std::vector<double> pn;        // kPnSlots * 3 doubles per triangle, leaf order
 	double origin[3];              // boxes are relative to this point
+	float mesh_l1 = 0;             // max over vertices of |v - origin|_1, rounded up
 	uint32_t depth = 0;
 	uint32_t not_watertight = 0;   // bit0 single edge, bit1 edge shared by > 2 faces
 	uint64_t n_vertices = 0, n_triangles = 0;

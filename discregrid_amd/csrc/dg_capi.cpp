@@ -24,6 +24,7 @@ struct dg_mesh
 	dg::MeshDev dev;
 	void* d_nodes = nullptr;
 	void* d_tris = nullptr;
+	void* d_slabs = nullptr;
 	void* d_pn = nullptr;
 	int device = -1;
 	dg_mesh_info info;
@@ -178,10 +179,13 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	const size_t nb = B.nodes.size() * sizeof(dg::BvhNode);
 	const size_t tb = B.tris.size() * sizeof(dg::TriPacket);
 	const size_t pb = B.pn.size() * sizeof(double);
+	const size_t sb = B.slabs.size() * sizeof(dg::TriSlab);
 	hipError_t e = hipGetDevice(&m->device);
 	if (e == hipSuccess) e = hipMalloc(&m->d_nodes, nb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_tris, tb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_pn, pb);
+	if (e == hipSuccess) e = hipMalloc(&m->d_slabs, sb);
+	if (e == hipSuccess) e = hipMemcpy(m->d_slabs, B.slabs.data(), sb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_nodes, B.nodes.data(), nb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_tris, B.tris.data(), tb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_pn, B.pn.data(), pb, hipMemcpyHostToDevice);
@@ -194,6 +198,9 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->dev.nodes = static_cast<const dg::BvhNode*>(m->d_nodes);
 	m->dev.tris = static_cast<const dg::TriPacket*>(m->d_tris);
 	m->dev.pn = static_cast<const double*>(m->d_pn);
+	m->dev.slabs = static_cast<const dg::TriSlab*>(m->d_slabs);
+	m->dev.mesh_l1 = B.mesh_l1;
+	m->dev.pad_ = 0.0f;
 	m->dev.n_nodes = (int32_t)B.nodes.size();
 	m->dev.n_tris = (int32_t)B.tris.size();
 	for (int d = 0; d < 3; ++d)
@@ -203,7 +210,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->info.n_bvh_nodes = B.nodes.size();
 	m->info.bvh_depth = B.depth;
 	m->info.not_watertight = B.not_watertight;
-	m->info.device_bytes = nb + tb + pb;
+	m->info.device_bytes = nb + tb + pb + sb;
 	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
 	*out = m;
 	return DG_OK;
@@ -224,6 +231,7 @@ void dg_mesh_destroy(dg_mesh* m)
 	if (m->d_nodes) (void)hipFree(m->d_nodes);
 	if (m->d_tris) (void)hipFree(m->d_tris);
 	if (m->d_pn) (void)hipFree(m->d_pn);
+	if (m->d_slabs) (void)hipFree(m->d_slabs);
 	delete m;
 }
 

@@ -23,18 +23,23 @@ namespace dg
 {
 
 // ---- data layouts (shared by host builder and device kernels) ------------------------------
-// One BVH node = 32 bytes = two 16-byte scalar loads.  Boxes are float, relative to the mesh
-// origin, rounded OUTWARD: they are only ever used to prune, so their arithmetic is free.
-// Nodes are stored in depth-first order; `skip` is the index of the next node when the
-// subtree is pruned (stackless traversal: next = hit ? idx + 1 : skip).
-struct alignas(32) BvhNode
+// One BVH node = 64 bytes = one s_load_dwordx16.  Bounds are float, relative to the mesh origin,
+// rounded OUTWARD: they are only ever used to prune, so their arithmetic is free.  A node
+// carries an axis-aligned box AND one slab (see TriSlab) along the area-weighted mean normal of
+// its subtree: a smooth surface patch is thin along its normal however it is oriented, which
+// the box cannot express.  Nodes are stored in depth-first order; `skip` is the index of the
+// next node when the subtree is pruned (stackless traversal: next = hit ? idx + 1 : skip).
+struct alignas(64) BvhNode
 {
 	float lo[3];
 	float hi[3];
 	int32_t skip;
 	int32_t info; // >= 0: index of the right child (left child = idx + 1);  < 0: leaf, ~info = (first << 3) | (count - 1)
+	float su[3];  // slab direction, |su| <= 1 (0 = no slab)
+	float slo, shi;
+	float pad_[3];
 };
-static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
 // One triangle packet = 128 bytes, in BVH leaf order.  The point-independent terms of the
 // Eberly test are precomputed on the host WITH THE REFERENCE'S OWN OPERATIONS (same inputs,
@@ -53,6 +58,19 @@ struct alignas(128) TriPacket
 	int32_t pad_;
 };
 static_assert(sizeof(TriPacket) == 128, "TriPacket must be 128 bytes");
+
+// One slab per triangle = 32 bytes, leaf order: a float direction u (|u| <= 1, ~ the face normal)
+// and the interval [lo, hi] of u.(x - origin) over the triangle's vertices, rounded outward.
+// For ANY |u| <= 1:  dist(p, triangle) >= max(u.p - hi, lo - u.p, 0)  -- a one-direction k-DOP
+// that is tight exactly where boxes are loose (queries on the concave side of a curved surface
+// see dozens of nearly equidistant facets whose AABBs all overlap the search sphere).
+struct alignas(32) TriSlab
+{
+	float u[3];
+	float lo, hi;
+	float pad_[3];
+};
+static_assert(sizeof(TriSlab) == 32, "TriSlab must be 32 bytes");
 
 // Pseudonormals, 8 slots of 3 doubles per triangle (leaf order), slot = nearest entity:
 // 0..2 vertex normals of v0,v1,v2; 3..5 edge normals E01,E12,E02; 6 face normal; 7 unused.
@@ -288,8 +306,11 @@ DG_HD Hit tri_closest(const TriPacket& T, double px, double py, double pz)
 struct FPoint
 {
 	float lo[3], hi[3];
+	float x[3]; // the rounded point itself (slab test)
+	float es;   // absolute error bound of a slab projection u.x, incl. the subtractions against lo/hi
 };
-DG_HD FPoint make_fpoint(double rx, double ry, double rz) // r = p - origin (double)
+// r = p - origin (double); mesh_l1 = max L1 norm of (vertex - origin) over the mesh
+DG_HD FPoint make_fpoint(double rx, double ry, double rz, float mesh_l1)
 {
 	FPoint f;
 	const float x = (float)rx, y = (float)ry, z = (float)rz;
@@ -297,6 +318,10 @@ DG_HD FPoint make_fpoint(double rx, double ry, double rz) // r = p - origin (dou
 	float m = ax > ay ? ax : ay;
 	m = m > az ? m : az;
 	const float e = m * 4.76837158203125e-07f + 1.0e-37f; // 2^-21 * max|coord|  (>= 4 float ulps)
+	f.x[0] = x;
+	f.x[1] = y;
+	f.x[2] = z;
+	f.es = ((ax + ay) + az + mesh_l1) * 9.5367431640625e-07f + 1.0e-37f; // 2^-20 * (|p|_1 + |mesh|_1)
 	f.lo[0] = x - e;
 	f.lo[1] = y - e;
 	f.lo[2] = z - e;
@@ -312,6 +337,18 @@ DG_HD float box_lb2(const float blo[3], const float bhi[3], const FPoint& p)
 	const float dy = fmax2(fmax2(blo[1] - p.hi[1], p.lo[1] - bhi[1]), 0.0f);
 	const float dz = fmax2(fmax2(blo[2] - p.hi[2], p.lo[2] - bhi[2]), 0.0f);
 	return dx * dx + dy * dy + dz * dz;
+}
+// squared slab lower bound (see TriSlab)
+DG_HD float slab_lb2(float ux, float uy, float uz, float lo, float hi, const FPoint& p)
+{
+	const float t = ux * p.x[0] + uy * p.x[1] + uz * p.x[2];
+	const float d = fmax2(fmax2(t - p.es - hi, lo - t - p.es), 0.0f);
+	return d * d;
+}
+// node bound = max(box bound, slab bound)
+DG_HD float node_lb2(const float blo[3], const float bhi[3], const float su[3], float slo, float shi, const FPoint& p)
+{
+	return fmax2(box_lb2(blo, bhi, p), slab_lb2(su[0], su[1], su[2], slo, shi, p));
 }
 // float upper bound of the running best d^2 (strictly above it unless it is 0 or inf)
 DG_HD float best_as_float(double d2)
@@ -329,12 +366,13 @@ struct LaneQuery
 	float bestf;       // float upper bound of best_d2; < 0 => lane inactive (never hits a box)
 	int best_tri;      // packet index of the best triangle so far
 };
-DG_HD void init_query(const double origin[3], bool active, double px, double py, double pz, LaneQuery& q)
+DG_HD void init_query(const double origin[3], float mesh_l1, bool active, double px, double py, double pz,
+					  LaneQuery& q)
 {
 	q.px = px;
 	q.py = py;
 	q.pz = pz;
-	q.fp = make_fpoint(px - origin[0], py - origin[1], pz - origin[2]);
+	q.fp = make_fpoint(px - origin[0], py - origin[1], pz - origin[2], mesh_l1);
 	q.best_d2 = active ? 1.7976931348623157e308 : 0.0;
 	q.bestf = active ? __builtin_inff() : -1.0f;
 	q.best_tri = -1;

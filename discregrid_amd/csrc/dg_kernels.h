@@ -15,10 +15,13 @@ struct MeshDev
 {
 	const BvhNode* nodes;
 	const TriPacket* tris;
+	const TriSlab* slabs; // n_tris + 4 entries
 	const double* pn;
 	int32_t n_nodes;
 	int32_t n_tris;
 	double origin[3];
+	float mesh_l1;
+	float pad_;
 };
 
 // One of the four node classes of the lattice as the K1 kernel sees it (see dg_geom.h

@@ -14,8 +14,9 @@
 //     unit (s_load_dwordx8 / x16 into SGPRs) and broadcast to all lanes for free; lanes only
 //     differ in their query point and running best.  No per-lane stack, no divergent gathers
 //     in the loop.
-//   * Stackless depth-first walk over a skip-pointer BVH (next = any-lane-hit ? idx+1 : skip),
-//     seeded by a greedy root-to-leaf descent so the bound is tight from the first node on.
+//   * Near-first traversal with one wave-shared stack held in a single VGPR (v_writelane /
+//     v_readlane), so the bound tightens after the first leaf; nodes carry a box AND a slab
+//     along the mean normal of their subtree, triangles a slab along their own normal.
 //   * Box tests in conservative float (they only prune); triangle tests in double with the
 //     reference's exact operation order (no FMA contraction) so d^2, the winning feature and
 //     the sign reproduce the reference bit for bit.
@@ -59,11 +60,17 @@ struct SNode
 {
 	float lo[3], hi[3];
 	int skip, info;
+	float su[3], slo, shi;
 };
 __device__ __forceinline__ SNode load_node(const BvhNode* nodes, int idx)
 {
-	const v8i v = sload8(nodes + idx);
+	const v16i v = sload16(nodes + idx);
 	SNode n;
+	n.su[0] = __int_as_float(v[8]);
+	n.su[1] = __int_as_float(v[9]);
+	n.su[2] = __int_as_float(v[10]);
+	n.slo = __int_as_float(v[11]);
+	n.shi = __int_as_float(v[12]);
 	n.lo[0] = __int_as_float(v[0]);
 	n.lo[1] = __int_as_float(v[1]);
 	n.lo[2] = __int_as_float(v[2]);
@@ -75,12 +82,32 @@ __device__ __forceinline__ SNode load_node(const BvhNode* nodes, int idx)
 	return n;
 }
 
-// All lanes test the `cnt` triangles starting at packet `first` (wave-uniform arguments).
-__device__ __forceinline__ void test_leaf(const TriPacket* tris, int first, int cnt, LaneQuery& q)
+// Leaf of `cnt` <= 4 triangles starting at packet `first` (wave-uniform arguments).  A triangle
+// gets the full double-precision test only if some lane's float lower bound -- the larger of
+// the leaf box bound and the triangle's own slab bound -- is below that lane's running best.
+__device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
 {
+	// the 4 slabs of the leaf in two scalar loads (the array is padded, cnt < 4 reads neighbours)
+	const char* sbase = (const char*)(M.slabs + first);
+	const v16i s0 = sload16(sbase);
+	const v16i s1 = sload16(sbase + 64);
+	unsigned want = 0;
+#pragma unroll
+	for (int t = 0; t < 4; ++t)
+	{
+		const v16i& sv = (t < 2) ? s0 : s1;
+		const int o = (t & 1) * 8;
+		const float lb = slab_lb2(__int_as_float(sv[o + 0]), __int_as_float(sv[o + 1]), __int_as_float(sv[o + 2]),
+								  __int_as_float(sv[o + 3]), __int_as_float(sv[o + 4]), q.fp);
+		const bool hit = fmax2(lb, leaf_lb2) < q.bestf;
+		if (t < cnt && __ballot(hit) != 0ull)
+			want |= 1u << t;
+	}
 	for (int t = 0; t < cnt; ++t)
 	{
-		const char* base = (const char*)(tris + first + t);
+		if (!((want >> t) & 1u))
+			continue;
+		const char* base = (const char*)(M.tris + first + t);
 		const v16i a = sload16(base);
 		const v16i b = sload16(base + 64);
 		const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
@@ -95,53 +122,73 @@ __device__ __forceinline__ void test_leaf(const TriPacket* tris, int first, int 
 	}
 }
 
-// Packet traversal: on return every active lane holds the minimum squared distance over all
-// triangles (q.best_d2) and the packet index attaining it.
+// Packet traversal, near-first.  On return every active lane holds the minimum squared distance
+// over all triangles (q.best_d2) and the packet index attaining it.
+//
+// The wave walks the tree with ONE shared stack that lives in a single VGPR (entry i in lane i,
+// pushed with a lane-select, popped with v_readlane under a wave-uniform stack pointer): no LDS, no
+// scratch.  At an inner node both children are fetched (2 x s_load_dwordx16) and bounded per
+// lane; a child is entered if ANY lane may still improve there, the child most lanes are
+// closer to first, the other one is pushed.  A popped node is re-tested against the (by then
+// tighter) running bests before its children are fetched.
 __device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q)
 {
 	const BvhNode* nodes = M.nodes;
-	const TriPacket* tris = M.tris;
-	const int n_nodes = M.n_nodes;
-
-	// (1) greedy descent: follow the child most lanes are closer to, down to one leaf
+	const int lane_id = (int)__lane_id();
+	int stackv = 0; // the stack: lane i holds entry i
+	int sp = 0;     // wave-uniform
+	int node = 0;
+	SNode nd = load_node(nodes, 0);
+	float lbcur = 0.0f; // this lane's lower bound for `node`
+	bool have = true;   // `node`/`nd`/`lbcur` describe a node some lane still needs
+	while (true)
 	{
-		int g = 0;
-		SNode nd = load_node(nodes, 0);
-		while (nd.info >= 0)
+		if (!have)
 		{
-			const int li = g + 1, ri = nd.info;
-			const SNode l = load_node(nodes, li);
-			const SNode r = load_node(nodes, ri);
-			const float dl = box_lb2(l.lo, l.hi, q.fp);
-			const float dr = box_lb2(r.lo, r.hi, q.fp);
-			const unsigned long long act = __ballot(q.bestf >= 0.0f);
-			const unsigned long long pref_l = __ballot(dl <= dr) & act;
-			const bool go_left = 2 * __popcll(pref_l) >= __popcll(act);
-			g = go_left ? li : ri;
-			nd = go_left ? l : r;
-		}
-		const unsigned code = ~(unsigned)nd.info;
-		test_leaf(tris, (int)(code >> 3), (int)(code & 7u) + 1, q);
-	}
-
-	// (2) stackless depth-first sweep with the bound from (1)
-	int idx = 0;
-	while (idx < n_nodes)
-	{
-		const SNode nd = load_node(nodes, idx);
-		const float lb2 = box_lb2(nd.lo, nd.hi, q.fp);
-		const bool hit = lb2 < q.bestf;
-		if (__ballot(hit) == 0ull)
-		{
-			idx = nd.skip;
-			continue;
+			if (sp == 0)
+				break;
+			--sp;
+			node = __builtin_amdgcn_readlane(stackv, sp);
+			nd = load_node(nodes, node);
+			lbcur = node_lb2(nd.lo, nd.hi, nd.su, nd.slo, nd.shi, q.fp);
+			if (__ballot(lbcur < q.bestf) == 0ull)
+				continue;
 		}
 		if (nd.info < 0)
 		{
 			const unsigned code = ~(unsigned)nd.info;
-			test_leaf(tris, (int)(code >> 3), (int)(code & 7u) + 1, q);
+			test_leaf(M, (int)(code >> 3), (int)(code & 7u) + 1, lbcur, q);
+			have = false;
+			continue;
 		}
-		idx = idx + 1;
+		const int li = node + 1, ri = nd.info;
+		const SNode l = load_node(nodes, li);
+		const SNode r = load_node(nodes, ri);
+		const float lbl = node_lb2(l.lo, l.hi, l.su, l.slo, l.shi, q.fp);
+		const float lbr = node_lb2(r.lo, r.hi, r.su, r.slo, r.shi, q.fp);
+		const bool hl = lbl < q.bestf, hr = lbr < q.bestf;
+		const unsigned long long bl = __ballot(hl), br = __ballot(hr);
+		if (bl != 0ull && br != 0ull)
+		{
+			const unsigned long long pref = __ballot((hl || hr) && (lbl <= lbr));
+			const bool left_first = 2 * __popcll(pref) >= __popcll(bl | br);
+			stackv = (lane_id == sp) ? (left_first ? ri : li) : stackv; // v_writelane equivalent
+			++sp;
+			node = left_first ? li : ri;
+			nd = left_first ? l : r;
+			lbcur = left_first ? lbl : lbr;
+			have = true;
+		}
+		else if ((bl | br) != 0ull)
+		{
+			const bool left = bl != 0ull;
+			node = left ? li : ri;
+			nd = left ? l : r;
+			lbcur = left ? lbl : lbr;
+			have = true;
+		}
+		else
+			have = false;
 	}
 }
 
@@ -183,7 +230,7 @@ __global__ __launch_bounds__(256) void k_sample_nodes(const SampleParams P)
 	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
 
 	LaneQuery q;
-	init_query(P.mesh.origin, sample, x[0], x[1], x[2], q);
+	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
 	if (__ballot(sample) != 0ull)
 		traverse(P.mesh, q);
 
@@ -210,7 +257,7 @@ __global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const 
 	const bool valid = gid < n;
 	const uint64_t g = valid ? gid : (n - 1);
 	LaneQuery q;
-	init_query(M.origin, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
+	init_query(M.origin, M.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
 	traverse(M, q);
 	if (!valid)
 		return;

@@ -25,7 +25,7 @@ namespace
 
 struct Stats
 {
-	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0;
+	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0;
 };
 
 struct HostSqrt
@@ -38,12 +38,34 @@ struct Wave
 	LaneQuery q[64];
 };
 
-void test_leaf(const TriPacket* tris, int first, int cnt, Wave& w, Stats& st)
+void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane or null*/, Wave& w, Stats& st)
 {
+	unsigned want = 0;
+	for (int t = 0; t < 4; ++t)
+	{
+		const TriSlab& sl = M.slabs[first + t];
+		bool any = false;
+		int n_int = 0;
+		for (int l = 0; l < 64; ++l)
+		{
+			const float lb = slab_lb2(sl.u[0], sl.u[1], sl.u[2], sl.lo, sl.hi, w.q[l].fp);
+			const bool hit = (fmax2(lb, leaf_lb2 ? leaf_lb2[l] : 0.0f) < w.q[l].bestf);
+			any = any || hit;
+			n_int += hit;
+		}
+		if (t < cnt && any)
+		{
+			want |= 1u << t;
+			st.lane_interest += n_int;
+		}
+	}
 	for (int t = 0; t < cnt; ++t)
 	{
+		st.slab_tests++;
+		if (!((want >> t) & 1u))
+			continue;
 		st.tri_tests++;
-		const TriPacket& T = tris[first + t];
+		const TriPacket& T = M.tris[first + t];
 		for (int l = 0; l < 64; ++l)
 		{
 			const Hit h = tri_closest<false>(T, w.q[l].px, w.q[l].py, w.q[l].pz);
@@ -52,55 +74,79 @@ void test_leaf(const TriPacket* tris, int first, int cnt, Wave& w, Stats& st)
 	}
 }
 
-// mirrors traverse() of dg_kernels.hip
+// mirrors traverse() of dg_kernels.hip: near-first packet traversal with a wave-shared stack
 void traverse(const MeshDev& M, Wave& w, Stats& st)
 {
 	const BvhNode* nodes = M.nodes;
+	int stack[128];
+	int sp = 0;
+	int node = 0;
+	bool have = true; // `node` is valid and already known to be hit by some lane
+	float lbcur[64];
+	for (int k = 0; k < 64; ++k) lbcur[k] = 0.0f;
+	while (true)
 	{
-		int g = 0;
-		BvhNode nd = nodes[0];
-		while (nd.info >= 0)
+		if (!have)
 		{
-			st.descent_nodes++;
-			const int li = g + 1, ri = nd.info;
-			const BvhNode& l = nodes[li];
-			const BvhNode& r = nodes[ri];
-			int act = 0, pref = 0;
+			if (sp == 0)
+				break;
+			node = stack[--sp];
+			const BvhNode& nd = nodes[node];
+			st.node_visits++;
+			bool any = false;
 			for (int k = 0; k < 64; ++k)
 			{
-				const bool a = w.q[k].bestf >= 0.0f;
-				const float dl = box_lb2(l.lo, l.hi, w.q[k].fp);
-				const float dr = box_lb2(r.lo, r.hi, w.q[k].fp);
-				act += a;
-				pref += (a && dl <= dr);
+				lbcur[k] = node_lb2(nd.lo, nd.hi, nd.su, nd.slo, nd.shi, w.q[k].fp);
+				any = any || (lbcur[k] < w.q[k].bestf);
 			}
-			const bool go_left = 2 * pref >= act;
-			g = go_left ? li : ri;
-			nd = go_left ? l : r;
+			if (!any)
+				continue;
 		}
-		const unsigned code = ~(unsigned)nd.info;
-		test_leaf(M.tris, (int)(code >> 3), (int)(code & 7u) + 1, w, st);
-	}
-	int idx = 0;
-	while (idx < M.n_nodes)
-	{
-		const BvhNode& nd = nodes[idx];
-		st.node_visits++;
-		bool any = false;
-		for (int k = 0; k < 64; ++k)
-			any = any || (box_lb2(nd.lo, nd.hi, w.q[k].fp) < w.q[k].bestf);
-		if (!any)
-		{
-			idx = nd.skip;
-			continue;
-		}
+		const BvhNode& nd = nodes[node];
 		if (nd.info < 0)
 		{
 			st.leaf_visits++;
 			const unsigned code = ~(unsigned)nd.info;
-			test_leaf(M.tris, (int)(code >> 3), (int)(code & 7u) + 1, w, st);
+			test_leaf(M, (int)(code >> 3), (int)(code & 7u) + 1, lbcur, w, st);
+			have = false;
+			continue;
 		}
-		idx = idx + 1;
+		const int li = node + 1, ri = nd.info;
+		const BvhNode& l = nodes[li];
+		const BvhNode& r = nodes[ri];
+		st.node_visits += 2;
+		float lbl[64], lbr[64];
+		bool anyl = false, anyr = false;
+		int pref = 0, act = 0;
+		for (int k = 0; k < 64; ++k)
+		{
+			lbl[k] = node_lb2(l.lo, l.hi, l.su, l.slo, l.shi, w.q[k].fp);
+			lbr[k] = node_lb2(r.lo, r.hi, r.su, r.slo, r.shi, w.q[k].fp);
+			const bool hl = lbl[k] < w.q[k].bestf, hr = lbr[k] < w.q[k].bestf;
+			anyl = anyl || hl;
+			anyr = anyr || hr;
+			if (hl || hr)
+			{
+				act++;
+				pref += (lbl[k] <= lbr[k]);
+			}
+		}
+		if (anyl && anyr)
+		{
+			const bool left_first = 2 * pref >= act;
+			stack[sp++] = left_first ? ri : li;
+			node = left_first ? li : ri;
+			for (int k = 0; k < 64; ++k) lbcur[k] = left_first ? lbl[k] : lbr[k];
+			have = true;
+		}
+		else if (anyl || anyr)
+		{
+			node = anyl ? li : ri;
+			for (int k = 0; k < 64; ++k) lbcur[k] = anyl ? lbl[k] : lbr[k];
+			have = true;
+		}
+		else
+			have = false;
 	}
 }
 
@@ -126,6 +172,8 @@ void* emu_mesh_create(const double* verts, size_t nv, const uint32_t* tris, size
 	m->dev.nodes = m->B.nodes.data();
 	m->dev.tris = m->B.tris.data();
 	m->dev.pn = m->B.pn.data();
+	m->dev.slabs = m->B.slabs.data();
+	m->dev.mesh_l1 = m->B.mesh_l1;
 	m->dev.n_nodes = (int32_t)m->B.nodes.size();
 	m->dev.n_tris = (int32_t)m->B.tris.size();
 	for (int d = 0; d < 3; ++d)
@@ -205,7 +253,7 @@ int emu_mesh_check(void* h, const double* verts, const uint32_t* tris)
 // mode 0: flat range [a0, a1) -> out[l - a0];  mode 1: shard (rank = a0, nranks = a1) -> packed
 int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const uint32_t res[3], int invert, int mode,
 					 uint64_t a0, uint64_t a1, const uint8_t* mask, double* out, uint8_t* written /*nullable*/,
-					 uint64_t* stats /*5, nullable*/)
+					 uint64_t* stats /*6, nullable*/)
 {
 	auto m = static_cast<HostMesh*>(h);
 	SampleParams P;
@@ -243,7 +291,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 				sample[l] = ln[l].valid && (!mask || mask[ln[l].out_idx] != 0);
 				double x[3];
 				node_position(ln[l].cls, ln[l].a, ln[l].b, ln[l].s, P.dmin, P.cell, x);
-				init_query(P.mesh.origin, sample[l], x[0], x[1], x[2], w.q[l]);
+				init_query(P.mesh.origin, P.mesh.mesh_l1, sample[l], x[0], x[1], x[2], w.q[l]);
 				any = any || sample[l];
 			}
 			ls.bricks++;
@@ -274,6 +322,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.leaf_visits += ls.leaf_visits;
 			st.tri_tests += ls.tri_tests;
 			st.descent_nodes += ls.descent_nodes;
+			st.slab_tests += ls.slab_tests;
+			st.lane_interest += ls.lane_interest;
 		}
 	}
 	if (stats)
@@ -283,6 +333,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		stats[2] = st.leaf_visits;
 		stats[3] = st.tri_tests;
 		stats[4] = st.descent_nodes;
+		stats[5] = st.slab_tests;
+		stats[6] = st.lane_interest;
 	}
 	return err;
 }
@@ -302,7 +354,7 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 			const uint64_t gid = (uint64_t)wv * 64 + l;
 			const bool valid = gid < n;
 			const uint64_t g = valid ? gid : n - 1;
-			init_query(m->dev.origin, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
+			init_query(m->dev.origin, m->dev.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
 		}
 		traverse(m->dev, w, st);
 		for (int l = 0; l < 64; ++l)
