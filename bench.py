@@ -130,7 +130,7 @@ def main():
     if world > 1:
         count, stride = dg.shard_layout(grid, rank, world)
         gathered = torch.empty(world * stride, dtype=torch.float64, device="cuda")
-        mine = gathered[rank * stride:(rank + 1) * stride]
+        mine = torch.zeros(stride, dtype=torch.float64, device="cuda")   # this rank's packed shard (+ padding)
         launch_nodes = count
     else:
         launch_nodes = n_nodes

@@ -1,0 +1,675 @@
+// CubicLagrangeDiscreteGrid -- host side of the drop-in (reference:
+// discregrid/src/cubic_lagrange_discrete_grid.cpp).  The node-sampling loop of addFunction
+// (:806-831) for mesh SDFs and the batched interpolate run on the GPU through
+// include/discregrid_hip.h; file format (:678-778), reduceField (:1065-1174), the scalar
+// evaluator (:901-1063) and the generic-callback sampling loop are host code.
+#include <Discregrid/cubic_lagrange_discrete_grid.hpp>
+#include <Discregrid/geometry/TriangleMeshDistance.h>
+#include <Discregrid/utility/serialize.hpp>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+#include "discregrid_hip.h"
+#include "dg_geom.h"
+
+namespace Discregrid
+{
+
+namespace
+{
+const double kNoValue = std::numeric_limits<double>::max();
+const unsigned int kNoCell = std::numeric_limits<unsigned int>::max();
+
+struct ClassLayout
+{
+	uint32_t D[4][3];
+	uint64_t off[5];
+};
+ClassLayout class_layout(std::array<unsigned int, 3> const& res)
+{
+	ClassLayout L;
+	uint64_t o = 0;
+	const uint32_t r[3] = {res[0], res[1], res[2]};
+	for (int c = 0; c < 4; ++c)
+	{
+		dg::class_dims(c, r, L.D[c]);
+		L.off[c] = o;
+		o += (uint64_t)L.D[c][0] * L.D[c][1] * L.D[c][2];
+	}
+	L.off[4] = o;
+	return L;
+}
+
+dg_grid_desc make_desc(Eigen::AlignedBox3d const& dom, std::array<unsigned int, 3> const& res,
+					   Eigen::Vector3d const& cell, Eigen::Vector3d const& inv)
+{
+	dg_grid_desc g;
+	std::memset(&g, 0, sizeof(g));
+	for (int d = 0; d < 3; ++d)
+	{
+		g.domain_min[d] = dom.min()[d];
+		g.domain_max[d] = dom.max()[d];
+		g.resolution[d] = res[d];
+		g.cell_size[d] = cell[d];
+		g.inv_cell_size[d] = inv[d];
+	}
+	return g;
+}
+
+// Morton key of the reference's zValue()/morton_lut() (cubic_lagrange_discrete_grid.cpp:583-601,
+// src/data/z_sort_table.hpp:119-134).  The reference shifts its partial result by 48 and then by
+// 24 bits, which pushes the contribution of the top byte out of the 64-bit word: only the low
+// 16 bits of each biased coordinate end up in the key.  Reproduced as is (the node order of
+// reduced fields, and with it the .cdm files, depend on it).
+inline uint64_t spread3(uint32_t byte)
+{
+	uint64_t r = 0;
+	for (int b = 0; b < 8; ++b)
+		r |= (uint64_t)((byte >> b) & 1u) << (3 * b);
+	return r;
+}
+inline uint64_t z_value(const double x[3], double inv_cell)
+{
+	uint32_t p[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		int key = (x[d] >= 0.0) ? static_cast<int>(inv_cell * x[d]) : static_cast<int>(inv_cell * x[d]) - 1;
+		p[d] = static_cast<uint32_t>(static_cast<int64_t>(key) - (std::numeric_limits<int>::lowest() + 1));
+	}
+	auto level = [&](int shift) {
+		return spread3((p[0] >> shift) & 0xFFu) | (spread3((p[1] >> shift) & 0xFFu) << 1) |
+			   (spread3((p[2] >> shift) & 0xFFu) << 2);
+	};
+	uint64_t a = level(16);
+	a = (a << 48) | level(8);
+	a = (a << 24) | level(0);
+	return a;
+}
+} // namespace
+
+// device-side mirrors of the fields, created lazily by the batched interpolate
+struct CubicLagrangeDiscreteGrid::DeviceCache
+{
+	std::vector<dg_field*> fields;
+	~DeviceCache()
+	{
+		for (auto f : fields)
+			dg_field_destroy(f);
+	}
+};
+
+CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(std::string const& filename) : m_dev(new DeviceCache)
+{
+	load(filename);
+}
+
+CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(Eigen::AlignedBox3d const& domain,
+													 std::array<unsigned int, 3> const& resolution)
+	: DiscreteGrid(domain, resolution), m_dev(new DeviceCache)
+{
+}
+
+CubicLagrangeDiscreteGrid::~CubicLagrangeDiscreteGrid() = default;
+
+unsigned int CubicLagrangeDiscreteGrid::nNodesFull() const
+{
+	return static_cast<unsigned int>(class_layout(m_resolution).off[4]);
+}
+
+// cubic_lagrange_discrete_grid.cpp:604-665 through the class decomposition of dg_geom.h
+Eigen::Vector3d CubicLagrangeDiscreteGrid::indexToNodePosition(unsigned int l) const
+{
+	const ClassLayout L = class_layout(m_resolution);
+	int c = 0;
+	while (c < 3 && l >= L.off[c + 1])
+		++c;
+	const uint64_t lc = l - L.off[c];
+	const uint32_t a = (uint32_t)(lc % L.D[c][0]);
+	const uint32_t b = (uint32_t)((lc / L.D[c][0]) % L.D[c][1]);
+	const uint32_t s = (uint32_t)(lc / ((uint64_t)L.D[c][0] * L.D[c][1]));
+	const double dmin[3] = {m_domain.min()[0], m_domain.min()[1], m_domain.min()[2]};
+	const double cell[3] = {m_cell_size[0], m_cell_size[1], m_cell_size[2]};
+	double x[3];
+	dg::node_position(c, a, b, s, dmin, cell, x);
+	return Eigen::Vector3d(x[0], x[1], x[2]);
+}
+
+void CubicLagrangeDiscreteGrid::cellRow(unsigned int field_id, unsigned int row, unsigned int out[32]) const
+{
+	if (!m_cells[field_id].empty())
+	{
+		std::memcpy(out, m_cells[field_id][row].data(), 32 * sizeof(unsigned int));
+		return;
+	}
+	const unsigned int n01 = m_resolution[0] * m_resolution[1];
+	const unsigned int k = row / n01, r = row % n01;
+	const uint32_t res[3] = {m_resolution[0], m_resolution[1], m_resolution[2]};
+	dg::cell_node_indices(r % m_resolution[0], r / m_resolution[0], k, res, out);
+}
+
+void CubicLagrangeDiscreteGrid::materializeCells(unsigned int f)
+{
+	if (!m_cells[f].empty() || m_n_cells == 0)
+		return;
+	m_cells[f].resize(m_n_cells);
+	m_cell_map[f].resize(m_n_cells);
+#pragma omp parallel for schedule(static)
+	for (long long l = 0; l < (long long)m_n_cells; ++l)
+	{
+		const unsigned int n01 = m_resolution[0] * m_resolution[1];
+		const unsigned int k = (unsigned int)l / n01, r = (unsigned int)l % n01;
+		const uint32_t res[3] = {m_resolution[0], m_resolution[1], m_resolution[2]};
+		dg::cell_node_indices(r % m_resolution[0], r / m_resolution[0], k, res, m_cells[f][l].data());
+		m_cell_map[f][l] = (unsigned int)l;
+	}
+}
+
+void CubicLagrangeDiscreteGrid::invalidateDevice(unsigned int f) const
+{
+	if (m_dev && f < m_dev->fields.size() && m_dev->fields[f])
+	{
+		dg_field_destroy(m_dev->fields[f]);
+		m_dev->fields[f] = nullptr;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// addFunction
+// ---------------------------------------------------------------------------------------------
+unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& func, bool verbose,
+													SamplePredicate const& pred)
+{
+	using clock = std::chrono::high_resolution_clock;
+	const auto t_begin = clock::now();
+	const unsigned int n_nodes = nNodesFull();
+
+	m_nodes.push_back({});
+	auto& coeffs = m_nodes.back();
+	coeffs.resize(n_nodes);
+	m_cells.push_back({});    // implicit (closed form) until a reduction needs the table
+	m_cell_map.push_back({}); // implicit identity
+
+	const auto t_sample = clock::now();
+	MeshSDF const* sdf = func.target<MeshSDF>();
+	m_last_used_gpu = false;
+	if (sdf != nullptr && sdf->distance != nullptr)
+	{
+		// GPU path.  The predicate is opaque host code: evaluate it into a byte mask first.
+		std::vector<uint8_t> mask;
+		if (pred)
+		{
+			mask.resize(n_nodes);
+#pragma omp parallel for schedule(static)
+			for (long long l = 0; l < (long long)n_nodes; ++l)
+				mask[l] = pred(indexToNodePosition((unsigned int)l)) ? 1 : 0;
+		}
+		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+		const dg_mesh* mesh = static_cast<const dg_mesh*>(sdf->distance->deviceMesh());
+		if (mesh == nullptr)
+		{
+			std::cout << "DistanceTriangleMesh error: not constructed." << std::endl;
+			throw std::runtime_error("DistanceTriangleMesh error: not constructed.");
+		}
+		if (dg_sdf_sample_nodes(mesh, &g, sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr,
+								coeffs.data()) != DG_OK)
+			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addFunction (GPU): ") + dg_last_error());
+		m_last_used_gpu = true;
+		if (verbose)
+			std::cout << "\r"
+					  << "Construction " << std::setw(20) << 100.0 << "%";
+	}
+	else
+	{
+		// Arbitrary callable: can only run on the host (same loop as the reference, :806-831,
+		// with a dynamic schedule because the cost per node is very uneven).
+		std::atomic_uint counter(0u);
+		auto t0 = clock::now();
+#pragma omp parallel for schedule(dynamic, 256)
+		for (long long l = 0; l < (long long)n_nodes; ++l)
+		{
+			const Eigen::Vector3d x = indexToNodePosition((unsigned int)l);
+			coeffs[l] = (!pred || pred(x)) ? func(x) : kNoValue;
+			if (verbose)
+			{
+				const unsigned int done = ++counter;
+				if ((done & 0xFFFu) == 0u || done == n_nodes)
+				{
+#pragma omp critical(discregrid_progress)
+					{
+						if (done == n_nodes ||
+							std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count() > 1000)
+						{
+							t0 = clock::now();
+							std::cout << "\r"
+									  << "Construction " << std::setw(20)
+									  << 100.0 * static_cast<double>(done) / static_cast<double>(n_nodes) << "%"
+									  << std::flush;
+						}
+					}
+				}
+			}
+		}
+	}
+	const auto t_end = clock::now();
+	m_last_sampling_s = std::chrono::duration<double>(t_end - t_sample).count();
+	m_last_total_s = std::chrono::duration<double>(t_end - t_begin).count();
+	if (verbose)
+		std::cout << "\rConstruction took " << std::setw(15)
+				  << static_cast<double>(std::chrono::duration_cast<std::chrono::milliseconds>(t_end - t_begin).count()) /
+						 1000.0
+				  << "s" << std::endl;
+	if (m_dev->fields.size() < m_nodes.size())
+		m_dev->fields.resize(m_nodes.size(), nullptr);
+	return static_cast<unsigned int>(m_n_fields++);
+}
+
+// ---------------------------------------------------------------------------------------------
+// evaluation
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+dg::FieldDev host_field(Eigen::AlignedBox3d const& dom, std::array<unsigned int, 3> const& res,
+						Eigen::Vector3d const& cell, Eigen::Vector3d const& inv, std::vector<double> const& coeffs,
+						std::vector<std::array<unsigned int, 32>> const& cells, std::vector<unsigned int> const& map)
+{
+	dg::FieldDev F;
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = dom.min()[d];
+		F.dmax[d] = dom.max()[d];
+		F.cell[d] = cell[d];
+		F.inv_cell[d] = inv[d];
+		F.res[d] = res[d];
+	}
+	F.coeffs = coeffs.data();
+	F.cells = cells.empty() ? nullptr : cells[0].data();
+	F.cell_map = map.empty() ? nullptr : map.data();
+	F.cell_major = nullptr;
+	return F;
+}
+} // namespace
+
+// Single point, on the host (:977-1063).  Same arithmetic, in the same order, as the GPU kernel:
+// both instantiate dg::interpolate_point.
+double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vector3d const& x,
+											  Eigen::Vector3d* gradient) const
+{
+	const dg::FieldDev F = host_field(m_domain, m_resolution, m_cell_size, m_inv_cell_size, m_nodes[field_id],
+									  m_cells[field_id], m_cell_map[field_id]);
+	const double p[3] = {x[0], x[1], x[2]};
+	double g[3];
+	if (!gradient)
+		return dg::interpolate_point<false>(F, p, g);
+	const double phi = dg::interpolate_point<true>(F, p, g);
+	// the reference leaves *gradient untouched when x is outside the domain or in a removed cell
+	// (:981-994) and zeroes it when a coefficient is missing (:1050-1054); writing zero in all
+	// three cases is a superset of that behaviour
+	(*gradient)[0] = g[0];
+	(*gradient)[1] = g[1];
+	(*gradient)[2] = g[2];
+	return phi;
+}
+
+void CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, double const* xyz, std::size_t n, double* phi,
+											double* grad) const
+{
+	if (field_id >= m_nodes.size())
+		throw std::out_of_range("CubicLagrangeDiscreteGrid::interpolate: no such field");
+	if (m_dev->fields.size() < m_nodes.size())
+		m_dev->fields.resize(m_nodes.size(), nullptr);
+	dg_field*& f = m_dev->fields[field_id];
+	if (f == nullptr)
+	{
+		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+		auto const& cells = m_cells[field_id];
+		auto const& map = m_cell_map[field_id];
+		static_assert(sizeof(unsigned int) == sizeof(uint32_t), "unsigned int must be 32 bits");
+		if (dg_field_create(&g, m_nodes[field_id].data(), m_nodes[field_id].size(),
+							cells.empty() ? nullptr : reinterpret_cast<const uint32_t*>(cells[0].data()), cells.size(),
+							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
+			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::interpolate (GPU): ") + dg_last_error());
+	}
+	if (dg_interpolate_batch(f, xyz, n, phi, grad) != DG_OK)
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::interpolate (GPU): ") + dg_last_error());
+}
+
+bool CubicLagrangeDiscreteGrid::determineShapeFunctions(unsigned int field_id, Eigen::Vector3d const& x,
+														std::array<unsigned int, 32>& cell, Eigen::Vector3d& c0,
+														Eigen::Matrix<double, 32, 1>& N,
+														Eigen::Matrix<double, 32, 3>* dN) const
+{
+	for (int d = 0; d < 3; ++d)
+		if (!(m_domain.min()[d] <= x[d] && x[d] <= m_domain.max()[d]))
+			return false;
+	unsigned int mi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		mi[d] = static_cast<unsigned int>((x[d] - m_domain.min()[d]) * m_inv_cell_size[d]);
+		if (mi[d] >= m_resolution[d])
+			mi[d] = m_resolution[d] - 1;
+	}
+	const unsigned int ci = multiToSingleIndex({{mi[0], mi[1], mi[2]}});
+	const unsigned int cm = m_cell_map[field_id].empty() ? ci : m_cell_map[field_id][ci];
+	if (cm == kNoCell)
+		return false;
+	double xi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		const double lo = m_domain.min()[d] + static_cast<double>(mi[d]) * m_cell_size[d];
+		const double hi = lo + m_cell_size[d];
+		const double den = hi - lo;
+		c0[d] = 2.0 / den;
+		const double c1 = (hi + lo) / den;
+		xi[d] = c0[d] * x[d] - c1;
+	}
+	cellRow(field_id, cm, cell.data());
+	double n[32], dx[32], dy[32], dz[32];
+	if (dN)
+	{
+		dg::shape_functions<true>(xi[0], xi[1], xi[2], n, dx, dy, dz);
+		for (int j = 0; j < 32; ++j)
+		{
+			(*dN)(j, 0) = dx[j];
+			(*dN)(j, 1) = dy[j];
+			(*dN)(j, 2) = dz[j];
+		}
+	}
+	else
+		dg::shape_functions<false>(xi[0], xi[1], xi[2], n, dx, dy, dz);
+	for (int j = 0; j < 32; ++j)
+		N[j] = n[j];
+	return true;
+}
+
+double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vector3d const& /*xi*/,
+											  const std::array<unsigned int, 32>& cell, const Eigen::Vector3d& c0,
+											  const Eigen::Matrix<double, 32, 1>& N, Eigen::Vector3d* gradient,
+											  Eigen::Matrix<double, 32, 3>* dN) const
+{
+	auto const& coeffs = m_nodes[field_id];
+	double phi = 0.0;
+	if (!gradient)
+	{
+		for (unsigned int j = 0; j < 32u; ++j)
+		{
+			const double c = coeffs[cell[j]];
+			if (c == kNoValue)
+				return kNoValue;
+			phi += c * N[j];
+		}
+		return phi;
+	}
+	double g[3] = {0.0, 0.0, 0.0};
+	for (unsigned int j = 0; j < 32u; ++j)
+	{
+		const double c = coeffs[cell[j]];
+		if (c == kNoValue)
+		{
+			gradient->setZero();
+			return kNoValue;
+		}
+		phi += c * N[j];
+		g[0] += c * (*dN)(j, 0);
+		g[1] += c * (*dN)(j, 1);
+		g[2] += c * (*dN)(j, 2);
+	}
+	for (int d = 0; d < 3; ++d)
+		(*gradient)[d] = g[d] * c0[d];
+	return phi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reduceField (:1065-1174)
+// ---------------------------------------------------------------------------------------------
+void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pred)
+{
+	materializeCells(field_id);
+	invalidateDevice(field_id);
+	auto& coeffs = m_nodes[field_id];
+	auto& cells = m_cells[field_id];
+	auto& cell_map = m_cell_map[field_id];
+	const std::size_t n = coeffs.size();
+
+	// nodes that satisfy the predicate, and the Morton key of every node position
+	std::vector<char> keep(n);
+	std::vector<uint64_t> z(n);
+	const double zscale = 4.0 * std::min(std::min(m_inv_cell_size[0], m_inv_cell_size[1]), m_inv_cell_size[2]);
+	for (std::size_t l = 0; l < n; ++l)
+	{
+		const Eigen::Vector3d x = indexToNodePosition((unsigned int)l);
+		keep[l] = pred(x, coeffs[l]) && coeffs[l] != kNoValue;
+		const double p[3] = {x[0], x[1], x[2]};
+		z[l] = z_value(p, zscale);
+	}
+
+	// keep a cell if any of its 32 nodes is kept
+	const std::vector<std::array<unsigned int, 32>> old_cells = cells;
+	cells.clear();
+	cell_map.assign(m_n_cells, 0u);
+	std::iota(cell_map.begin(), cell_map.end(), 0u);
+	for (std::size_t i = 0; i < old_cells.size(); ++i)
+	{
+		bool any = false;
+		for (unsigned int v : old_cells[i])
+			any = any || keep[v];
+		if (any)
+		{
+			cells.push_back(old_cells[i]);
+			cell_map[i] = static_cast<unsigned int>(cells.size() - 1);
+		}
+		else
+			cell_map[i] = kNoCell;
+	}
+
+	// nodes referenced by a surviving cell stay; the others are removed by moving the current
+	// last node into the hole, scanning from the back (:1131-1150) -- simulated on a permutation
+	std::vector<char> used(n, 0);
+	for (auto const& cell : cells)
+		for (unsigned int v : cell)
+			used[v] = 1;
+	std::vector<unsigned int> at(n); // at[pos] = original node stored at pos
+	std::iota(at.begin(), at.end(), 0u);
+	long long last = (long long)n - 1;
+	for (long long i = (long long)n - 1; i >= 0; --i)
+		if (!used[i])
+		{
+			std::swap(at[i], at[last]);
+			--last;
+		}
+	const std::size_t m = (std::size_t)(last + 1);
+
+	// Morton sort of the survivors (std::sort as in the reference; keys are distinct for any
+	// lattice this class can represent, so the order is unique)
+	std::vector<unsigned int> order(m);
+	std::iota(order.begin(), order.end(), 0u);
+	std::sort(order.begin(), order.end(), [&](unsigned int a, unsigned int b) { return z[at[a]] < z[at[b]]; });
+
+	std::vector<unsigned int> new_id(n, kNoCell);
+	std::vector<double> out(m);
+	for (std::size_t i = 0; i < m; ++i)
+	{
+		out[i] = coeffs[at[order[i]]];
+		new_id[at[order[i]]] = (unsigned int)i;
+	}
+	for (auto& cell : cells)
+		for (auto& v : cell)
+			v = new_id[v];
+	coeffs.swap(out);
+}
+
+void CubicLagrangeDiscreteGrid::forEachCell(
+	unsigned int /*field_id*/, std::function<void(unsigned int, Eigen::AlignedBox3d const&, unsigned int)> const& cb) const
+{
+	const unsigned int n = m_resolution[0] * m_resolution[1] * m_resolution[2];
+	for (unsigned int i = 0; i < n; ++i)
+		cb(i, subdomain(i), 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// save / load (:678-778): packed little-endian, no magic:
+//   domain 6 f64 | resolution 3 u32 | cell_size 3 f64 | inv_cell_size 3 f64 | n_cells u64 | n_fields u64 |
+//   u64 F { u64 n ; n f64 } | u64 F { u64 n ; n x 32 u32 } | u64 F { u64 n ; n u32 }
+// Written with bulk I/O; implicit cell tables are generated on the fly.
+// ---------------------------------------------------------------------------------------------
+void CubicLagrangeDiscreteGrid::save(std::string const& filename) const
+{
+	std::ofstream out(filename, std::ios::binary);
+	std::streambuf& b = *out.rdbuf();
+	for (int d = 0; d < 3; ++d)
+		serialize::write(b, m_domain.min()[d]);
+	for (int d = 0; d < 3; ++d)
+		serialize::write(b, m_domain.max()[d]);
+	serialize::write(b, m_resolution);
+	for (int d = 0; d < 3; ++d)
+		serialize::write(b, m_cell_size[d]);
+	for (int d = 0; d < 3; ++d)
+		serialize::write(b, m_inv_cell_size[d]);
+	serialize::write(b, m_n_cells);
+	serialize::write(b, m_n_fields);
+
+	serialize::write(b, m_nodes.size());
+	for (auto const& nodes : m_nodes)
+	{
+		serialize::write(b, nodes.size());
+		b.sputn(reinterpret_cast<const char*>(nodes.data()), (std::streamsize)(nodes.size() * sizeof(double)));
+	}
+	serialize::write(b, m_cells.size());
+	for (std::size_t f = 0; f < m_cells.size(); ++f)
+	{
+		if (!m_cells[f].empty() || m_n_cells == 0 || !m_cell_map[f].empty())
+		{
+			serialize::write(b, m_cells[f].size());
+			if (!m_cells[f].empty())
+				b.sputn(reinterpret_cast<const char*>(m_cells[f][0].data()),
+						(std::streamsize)(m_cells[f].size() * 32 * sizeof(unsigned int)));
+			continue;
+		}
+		serialize::write(b, m_n_cells);
+		std::vector<unsigned int> chunk;
+		const std::size_t step = 1u << 16;
+		for (std::size_t l0 = 0; l0 < m_n_cells; l0 += step)
+		{
+			const std::size_t l1 = std::min(m_n_cells, l0 + step);
+			chunk.resize((l1 - l0) * 32);
+#pragma omp parallel for schedule(static)
+			for (long long l = (long long)l0; l < (long long)l1; ++l)
+				cellRow((unsigned int)f, (unsigned int)l, &chunk[(l - l0) * 32]);
+			b.sputn(reinterpret_cast<const char*>(chunk.data()), (std::streamsize)(chunk.size() * sizeof(unsigned int)));
+		}
+	}
+	serialize::write(b, m_cell_map.size());
+	for (std::size_t f = 0; f < m_cell_map.size(); ++f)
+	{
+		if (!m_cell_map[f].empty() || m_n_cells == 0)
+		{
+			serialize::write(b, m_cell_map[f].size());
+			b.sputn(reinterpret_cast<const char*>(m_cell_map[f].data()),
+					(std::streamsize)(m_cell_map[f].size() * sizeof(unsigned int)));
+			continue;
+		}
+		serialize::write(b, m_n_cells);
+		std::vector<unsigned int> iota(std::min<std::size_t>(m_n_cells, 1u << 20));
+		for (std::size_t l0 = 0; l0 < m_n_cells; l0 += iota.size())
+		{
+			const std::size_t cnt = std::min(iota.size(), m_n_cells - l0);
+			for (std::size_t i = 0; i < cnt; ++i)
+				iota[i] = (unsigned int)(l0 + i);
+			b.sputn(reinterpret_cast<const char*>(iota.data()), (std::streamsize)(cnt * sizeof(unsigned int)));
+		}
+	}
+	out.close();
+}
+
+void CubicLagrangeDiscreteGrid::load(std::string const& filename)
+{
+	std::ifstream in(filename, std::ios::binary);
+	if (!in.good())
+	{
+		std::cerr << "ERROR: Discrete grid can not be loaded. Input file does not exist!" << std::endl;
+		return;
+	}
+	std::streambuf& b = *in.rdbuf();
+	Eigen::Vector3d lo, hi;
+	for (int d = 0; d < 3; ++d)
+		serialize::read(b, lo[d]);
+	for (int d = 0; d < 3; ++d)
+		serialize::read(b, hi[d]);
+	m_domain = Eigen::AlignedBox3d(lo, hi);
+	serialize::read(b, m_resolution);
+	for (int d = 0; d < 3; ++d)
+		serialize::read(b, m_cell_size[d]);
+	for (int d = 0; d < 3; ++d)
+		serialize::read(b, m_inv_cell_size[d]);
+	serialize::read(b, m_n_cells);
+	serialize::read(b, m_n_fields);
+
+	std::size_t nf = 0;
+	serialize::read(b, nf);
+	m_nodes.assign(nf, {});
+	for (auto& nodes : m_nodes)
+	{
+		std::size_t n = 0;
+		serialize::read(b, n);
+		nodes.resize(n);
+		b.sgetn(reinterpret_cast<char*>(nodes.data()), (std::streamsize)(n * sizeof(double)));
+	}
+	serialize::read(b, nf);
+	m_cells.assign(nf, {});
+	for (auto& cells : m_cells)
+	{
+		std::size_t n = 0;
+		serialize::read(b, n);
+		cells.resize(n);
+		if (n)
+			b.sgetn(reinterpret_cast<char*>(cells[0].data()), (std::streamsize)(n * 32 * sizeof(unsigned int)));
+	}
+	serialize::read(b, nf);
+	m_cell_map.assign(nf, {});
+	for (auto& map : m_cell_map)
+	{
+		std::size_t n = 0;
+		serialize::read(b, n);
+		map.resize(n);
+		b.sgetn(reinterpret_cast<char*>(map.data()), (std::streamsize)(n * sizeof(unsigned int)));
+	}
+	in.close();
+
+	// A field whose table is the identity/closed-form one goes back to the implicit form (saves
+	// 132 bytes per cell of host memory and lets the GPU evaluator compute the indices).
+	const unsigned int full = nNodesFull();
+	for (std::size_t f = 0; f < m_nodes.size() && f < m_cells.size() && f < m_cell_map.size(); ++f)
+	{
+		if (m_nodes[f].size() != full || m_cells[f].size() != m_n_cells || m_cell_map[f].size() != m_n_cells)
+			continue;
+		bool implicit = true;
+		unsigned int row[32];
+		const uint32_t res[3] = {m_resolution[0], m_resolution[1], m_resolution[2]};
+		for (std::size_t l = 0; l < m_n_cells && implicit; ++l)
+		{
+			const unsigned int n01 = m_resolution[0] * m_resolution[1];
+			const unsigned int k = (unsigned int)l / n01, r = (unsigned int)l % n01;
+			dg::cell_node_indices(r % m_resolution[0], r / m_resolution[0], k, res, row);
+			implicit = m_cell_map[f][l] == (unsigned int)l &&
+					   std::memcmp(row, m_cells[f][l].data(), sizeof(row)) == 0;
+		}
+		if (implicit)
+		{
+			std::vector<std::array<unsigned int, 32>>().swap(m_cells[f]);
+			std::vector<unsigned int>().swap(m_cell_map[f]);
+		}
+	}
+	m_dev.reset(new DeviceCache);
+	m_dev->fields.resize(m_nodes.size(), nullptr);
+}
+
+} // namespace Discregrid

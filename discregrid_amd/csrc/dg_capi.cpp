@@ -34,7 +34,9 @@ struct dg_field
 {
 	dg::FieldDev dev;
 	void* owned[3] = {nullptr, nullptr, nullptr};
+	void* d_cell_major = nullptr;
 	uint64_t n_coeffs = 0;
+	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)
 	int device = -1;
 };
 
@@ -460,7 +462,9 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 	f->dev.coeffs = d_coeffs;
 	f->dev.cells = d_cells;
 	f->dev.cell_map = d_cell_map;
+	f->dev.cell_major = nullptr;
 	f->n_coeffs = n_coeffs;
+	f->n_rows = d_cells ? n_cell_rows : dg_grid_n_cells(grid);
 	(void)hipGetDevice(&f->device);
 	*out = f;
 	return DG_OK;
@@ -517,7 +521,47 @@ void dg_field_destroy(dg_field* f)
 	for (void* p : f->owned)
 		if (p)
 			(void)hipFree(p);
+	if (f->d_cell_major)
+		(void)hipFree(f->d_cell_major);
 	delete f;
+}
+
+dg_status dg_field_build_cell_major(dg_field* field, void* stream)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (field->d_cell_major)
+		return DG_OK;
+	if (field->n_rows == 0)
+		return DG_OK;
+	void* p = nullptr;
+	hipError_t e = hipMalloc(&p, field->n_rows * 32 * sizeof(double));
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "cell-major allocation of %llu bytes: %s",
+					(unsigned long long)(field->n_rows * 256), hipGetErrorString(e));
+	e = dg::launch_expand_cells(field->dev, field->n_rows, static_cast<double*>(p), static_cast<hipStream_t>(stream));
+	if (e != hipSuccess)
+	{
+		(void)hipFree(p);
+		return fail(DG_ERR_HIP, "k_expand_cells: %s", hipGetErrorString(e));
+	}
+	field->d_cell_major = p;
+	field->dev.cell_major = static_cast<const double*>(p);
+	return DG_OK;
+}
+
+dg_status dg_field_drop_cell_major(dg_field* field)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (field->d_cell_major)
+	{
+		DG_HIP(hipDeviceSynchronize());
+		(void)hipFree(field->d_cell_major);
+		field->d_cell_major = nullptr;
+		field->dev.cell_major = nullptr;
+	}
+	return DG_OK;
 }
 
 dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,

@@ -608,4 +608,116 @@ DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t 
 		out[m + 1] = out[m] + 1;
 }
 
+// ---- K2 per-query body -------------------------------------------------------------------------------
+// Host or device arrays, same code (the C++ host API evaluates single points with it).
+struct FieldDev
+{
+	double dmin[3], dmax[3];
+	double cell[3], inv_cell[3];
+	uint32_t res[3];
+	const double* coeffs;
+	const uint32_t* cells;    // nullable => closed-form rows
+	const uint32_t* cell_map; // nullable => identity
+	// Optional cell-major copy of the field: 32 doubles (256 B, 2 cache lines) per cell row, in
+	// the row's node order.  Trades 4.6x the memory (288 GB of HBM3E is the point of this chip)
+	// for a gather-free evaluator: one query reads 256 contiguous bytes instead of 16 scattered
+	// 16-byte segments in 16 different lines.
+	const double* cell_major;
+};
+
+// Per-query body of K2 = CubicLagrangeDiscreteGrid::interpolate(field, x, gradient*)
+// (discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063).  The 32-term sum runs in j order
+// (parity), the 32 coefficients are fetched as 16 adjacent pairs for unreduced fields.  Returns
+// DBL_MAX ("no value") outside the domain, in removed cells, or if a coefficient is DBL_MAX;
+// the gradient is zero in those cases.
+template <bool GRAD>
+DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
+{
+	const double NOVAL = 1.7976931348623157e308;
+	g[0] = g[1] = g[2] = 0.0;
+	for (int d = 0; d < 3; ++d)
+		if (!((F.dmin[d] <= x[d]) && (x[d] <= F.dmax[d]))) // AlignedBox::contains, inclusive (:981)
+			return NOVAL;
+	uint32_t mi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		mi[d] = (uint32_t)((x[d] - F.dmin[d]) * F.inv_cell[d]); // :984
+		if (mi[d] >= F.res[d])
+			mi[d] = F.res[d] - 1;
+	}
+	const uint32_t ci = F.res[1] * F.res[0] * mi[2] + F.res[0] * mi[1] + mi[0];
+	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
+	if (cm == 0xffffffffu)
+		return NOVAL;
+	double c0[3], xi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		const double lo = F.dmin[d] + (double)mi[d] * F.cell[d]; // subdomain(), discrete_grid.cpp:26-32
+		const double hi = lo + F.cell[d];
+		const double den = hi - lo; // :1000
+		c0[d] = 2.0 / den;
+		const double c1 = (hi + lo) / den;
+		xi[d] = c0[d] * x[d] - c1;
+	}
+	double cf[32];
+	if (F.cell_major)
+	{
+		const double* row = F.cell_major + 32 * (size_t)cm;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int j = 0; j < 32; ++j)
+			cf[j] = row[j];
+	}
+	else if (F.cells)
+	{
+		const uint32_t* row = F.cells + 32 * (size_t)cm;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int j = 0; j < 32; ++j)
+			cf[j] = F.coeffs[row[j]];
+	}
+	else
+	{
+		uint32_t idx[32];
+		cell_node_indices(mi[0], mi[1], mi[2], F.res, idx);
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int m = 0; m < 32; m += 2)
+		{
+			cf[m] = F.coeffs[idx[m]]; // adjacent pair: one 16-byte segment
+			cf[m + 1] = F.coeffs[idx[m] + 1];
+		}
+	}
+	double N[32], dNx[32], dNy[32], dNz[32];
+	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
+	bool ok = true;
+	double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 32; ++j)
+	{
+		ok = ok && (cf[j] != NOVAL);
+		phi += cf[j] * N[j];
+		if (GRAD)
+		{
+			gx += cf[j] * dNx[j];
+			gy += cf[j] * dNy[j];
+			gz += cf[j] * dNz[j];
+		}
+	}
+	if (!ok)
+		return NOVAL;
+	if (GRAD)
+	{
+		g[0] = gx * c0[0];
+		g[1] = gy * c0[1];
+		g[2] = gz * c0[2];
+	}
+	return phi;
+}
+
 } // namespace dg

@@ -328,7 +328,40 @@ __global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const dou
 	}
 }
 
+// Builds the cell-major copy of a field (FieldDev::cell_major): one thread per cell row.
+__global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t n_rows, double* __restrict__ out)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= n_rows)
+		return;
+	uint32_t idx[32];
+	if (F.cells)
+	{
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			idx[j] = F.cells[32 * row + j];
+	}
+	else
+	{
+		const uint32_t n01 = F.res[0] * F.res[1];
+		const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+		cell_node_indices(r % F.res[0], r / F.res[0], k, F.res, idx);
+	}
+	double* o = out + 32 * row;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		o[j] = F.coeffs[idx[j]];
+}
+
 } // namespace
+
+hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_expand_cells, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, d_out);
+	return hipGetLastError();
+}
 
 hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
 {

@@ -148,6 +148,15 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 								 dg_field** out);
 void dg_field_destroy(dg_field* field);
 
+/* Optional: builds (once, asynchronously on `stream`) a cell-major device copy of the field --
+ * 32 doubles = 256 contiguous bytes per cell row -- that dg_interpolate_batch* then reads
+ * instead of gathering 16 scattered 16-byte segments per query.  Costs 256 bytes per cell of
+ * device memory (4.3 GB at 256^3); results are bit-identical.  No reference counterpart: the
+ * reference gathers through m_cells (cubic_lagrange_discrete_grid.cpp:1005-1019).  The
+ * coefficient array must not change afterwards (drop and rebuild if it does). */
+dg_status dg_field_build_cell_major(dg_field* field, void* stream);
+dg_status dg_field_drop_cell_major(dg_field* field);
+
 /* phi[q] = interpolate(field, x_q [, &grad_q]); DG_NO_VALUE outside the domain, in removed
  * cells or when a coefficient is DG_NO_VALUE (grad_q is then zero).  grad may be NULL. */
 dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad);

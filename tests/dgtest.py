@@ -127,6 +127,38 @@ def bunny_mesh():
     return z["V"].astype(np.float64), z["F"].astype(np.uint32)
 
 
+def write_obj(path, V, F):
+    with open(path, "w") as f:
+        for v in V:
+            f.write("v %s %s %s\n" % tuple(repr(float(x)) for x in v))
+        for t in F:
+            f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in t))
+
+
+def read_cdf(path):
+    """Parses the reference's .cdf/.cdm layout (cubic_lagrange_discrete_grid.cpp:678-719)."""
+    b = open(path, "rb").read()
+    o = 0
+
+    def take(dtype, n):
+        nonlocal o
+        a = np.frombuffer(b, dtype=dtype, count=n, offset=o)
+        o += a.nbytes
+        return a
+
+    out = {"domain": take(np.float64, 6).copy(), "res": take(np.uint32, 3).copy(), "cell": take(np.float64, 3).copy(),
+           "inv_cell": take(np.float64, 3).copy(), "n_cells": int(take(np.uint64, 1)[0]),
+           "n_fields": int(take(np.uint64, 1)[0])}
+    nf = int(take(np.uint64, 1)[0])
+    out["nodes"] = [take(np.float64, int(take(np.uint64, 1)[0])).copy() for _ in range(nf)]
+    nf = int(take(np.uint64, 1)[0])
+    out["cells"] = [take(np.uint32, 32 * int(take(np.uint64, 1)[0])).reshape(-1, 32).copy() for _ in range(nf)]
+    nf = int(take(np.uint64, 1)[0])
+    out["cell_map"] = [take(np.uint32, int(take(np.uint64, 1)[0])).copy() for _ in range(nf)]
+    assert o == len(b), "trailing bytes in %s" % path
+    return out
+
+
 def n_nodes(res):
     nx, ny, nz = (int(r) for r in res)
     nv = (nx + 1) * (ny + 1) * (nz + 1)

@@ -408,6 +408,7 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	F.coeffs = coeffs;
 	F.cells = cells;
 	F.cell_map = cell_map;
+	F.cell_major = nullptr;
 #pragma omp parallel for schedule(static)
 	for (long long q = 0; q < (long long)n; ++q)
 	{

@@ -97,6 +97,18 @@ def main():
     out["bunny128_domain"] = dom
     out["bunny128_lattice_idx"] = idx
     out["bunny128_lattice_sd"] = np.array([g.sample_nodes(int(l), int(l) + 1)[0] for l in idx])
+    # reduceField golden (cubic_lagrange_discrete_grid.cpp:1065-1174): box.cdf reduced with |v| < 0.25
+    g = T.RefGrid(path=os.path.join(HERE, "box.cdf"))
+    g.reduce_abs_lt(0, 0.25)
+    g.save(os.path.join(HERE, "box_reduced_0p25.cdf"))
+    # and a bigger, Morton-sorted one: torus 9x14x6, |v| < 0.08
+    V, F = T.torus()
+    dom = T.ref_default_domain(V)
+    g = T.RefGrid(V, F, dom, [9, 14, 6])
+    g.add_sdf()
+    g.save(os.path.join(HERE, "torus_9_14_6.cdf"))
+    g.reduce_abs_lt(0, 0.08)
+    g.save(os.path.join(HERE, "torus_9_14_6_reduced_0p08.cdf"))
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_vectors.npz"))
 

@@ -130,6 +130,14 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(grad[inside], golden[name + "_grad"][inside])
     assert (grad[~inside] == 0).all()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    # cell-major device copy: bit-identical results
+    f.build_cell_major()
+    phi2, grad2 = f.interpolate(P, grad=True)
+    np.testing.assert_array_equal(phi2, phi)
+    np.testing.assert_array_equal(grad2, grad)
+    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    f.drop_cell_major()
+    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     # table mode, removed cells, DBL_MAX coefficients
     cells = T.oracle_cell_table(res)
     cmap = np.arange(len(cells), dtype=np.uint32)
@@ -138,10 +146,15 @@ def test_interpolate_vs_golden(dg, golden, name):
     cmap2[::3] = 0xFFFFFFFF
     c2 = coeffs.copy()
     c2[::7] = DBL_MAX
-    a, ga = dg.Field(g, c2, cells, cmap2).interpolate(P, grad=True)
+    f2 = dg.Field(g, c2, cells, cmap2)
+    a, ga = f2.interpolate(P, grad=True)
     b, gb = T.oracle_interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap2)
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ga[b != DBL_MAX], gb[b != DBL_MAX])
+    f2.build_cell_major()
+    a2, ga2 = f2.interpolate(P, grad=True)
+    np.testing.assert_array_equal(a2, a)
+    np.testing.assert_array_equal(ga2, ga)
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 8])

@@ -1,0 +1,125 @@
+"""The Discregrid-compatible C++ host API (discregrid_amd/cpp): file format, scalar evaluator,
+generic-callback addFunction, reduceField -- against the reference's golden files and the
+oracle.  CPU only (the GPU-backed parts are in test_gpu_host_api.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import dgtest as T
+
+DBL_MAX = np.finfo(np.float64).max
+CPP = os.path.join(T.ROOT, "discregrid_amd", "cpp")
+DRIVER = os.path.join(CPP, "build", "host_api_driver")
+
+
+@pytest.fixture(scope="module")
+def driver():
+    from discregrid_amd.build import build
+    build()
+    subprocess.check_call(["make", "-s", "-C", CPP])
+    return DRIVER
+
+
+def run(driver, *args):
+    subprocess.check_call([driver] + [str(a) for a in args])
+
+
+def read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("name", ["box.cdf", "box_reduced_0p25.cdf", "torus_9_14_6.cdf", "torus_9_14_6_reduced_0p08.cdf"])
+def test_load_save_roundtrip_is_byte_identical(driver, tmp_path, name):
+    """Loads files written by the reference (unreduced and reduced) and writes them back."""
+    src = os.path.join(T.GOLDEN, name)
+    out = str(tmp_path / "rt.cdf")
+    run(driver, "roundtrip", src, out)
+    assert read(out) == read(src)
+
+
+def test_generic_callback_addfunction(driver, tmp_path):
+    """addFunction with an arbitrary host callable (+ SamplePredicate) == reference semantics."""
+    out = str(tmp_path / "poly.cdf")
+    run(driver, "poly", out)
+    dom = np.array([-1.0, -0.5, 0.0, 1.5, 0.75, 2.0])
+    res = [3, 4, 2]
+    p = T.oracle_node_positions(dom, res)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    f0 = 1 + x - 2 * y + 0.5 * z + x * y - y * z + x * x * z - 0.3 * y * y * y + 0.7 * x * y * z
+    f1 = np.where(x < 0.25, f0, DBL_MAX)
+    want = str(tmp_path / "want.cdf")
+    T.oracle_write_cdf(want, dom, res, [f0, f1])
+    got = T.read_cdf(out)
+    np.testing.assert_array_equal(got["nodes"][0], f0)
+    np.testing.assert_array_equal(got["nodes"][1], f1)
+    assert read(out) == read(want)
+
+
+@pytest.mark.parametrize("src,bound,golden", [("box.cdf", 0.25, "box_reduced_0p25.cdf"),
+                                               ("torus_9_14_6.cdf", 0.08, "torus_9_14_6_reduced_0p08.cdf")])
+def test_reduce_field_matches_reference_file(driver, tmp_path, src, bound, golden):
+    """reduceField (cell drop, node compaction, Morton re-sort, renumbering) reproduces the
+    file the reference writes, byte for byte."""
+    out = str(tmp_path / "red.cdf")
+    run(driver, "reduce", os.path.join(T.GOLDEN, src), bound, out)
+    assert read(out) == read(os.path.join(T.GOLDEN, golden))
+    g = T.read_cdf(out)
+    assert len(g["nodes"][0]) < T.n_nodes(g["res"]) and (g["cell_map"][0] == 0xFFFFFFFF).any()
+
+
+@pytest.mark.skipif(not T.ref_available(), reason="oracle/_ref not built")
+def test_reduce_field_against_live_reference(driver, tmp_path):
+    V, F = T.icosphere(8)
+    dom = T.ref_default_domain(V)
+    g = T.RefGrid(V, F, dom, [11, 9, 10])
+    g.add_sdf()
+    src = str(tmp_path / "src.cdf")
+    g.save(src)
+    g.reduce_abs_lt(0, 0.11)
+    want = str(tmp_path / "want.cdf")
+    g.save(want)
+    out = str(tmp_path / "got.cdf")
+    run(driver, "reduce", src, 0.11, out)
+    assert read(out) == read(want)
+
+
+@pytest.mark.parametrize("name", ["torus_9_14_6.cdf", "torus_9_14_6_reduced_0p08.cdf", "box_reduced_0p25.cdf"])
+@pytest.mark.parametrize("mode", ["eval", "evalsplit"])
+def test_scalar_interpolate(driver, tmp_path, name, mode):
+    """interpolate(field, x, grad*) and the determineShapeFunctions / split-interpolate pair on
+    unreduced (implicit table) and reduced (explicit table) fields vs the oracle."""
+    src = os.path.join(T.GOLDEN, name)
+    g = T.read_cdf(src)
+    dom = g["domain"]
+    ext = dom[3:] - dom[:3]
+    rng = np.random.default_rng(21)
+    P = rng.uniform(dom[:3] - 0.05 * ext, dom[3:] + 0.05 * ext, size=(3000, 3))
+    P[:4] = dom[3:]
+    P[4:8] = dom[:3]
+    pts = str(tmp_path / "pts.bin")
+    P.tofile(pts)
+    out = str(tmp_path / "out.bin")
+    run(driver, mode, src, pts, out)
+    got = np.fromfile(out).reshape(-1, 5)
+    phi, grad = T.oracle_interpolate(dom, g["res"], g["nodes"][0], P, grad=True, cells=g["cells"][0],
+                                     cell_map=g["cell_map"][0])
+    np.testing.assert_array_equal(got[:, 0], phi)
+    np.testing.assert_array_equal(got[:, 1], phi)
+    ok = phi != DBL_MAX
+    assert ok.any() and (~ok).any()
+    np.testing.assert_array_equal(got[ok, 2:], grad[ok])
+    assert (got[~ok, 2:] == 0).all()
+
+
+def test_headers_compile_standalone(tmp_path):
+    """Every public header is self-contained (compiles on its own against the Eigen stand-in)."""
+    inc = os.path.join(CPP, "include")
+    for h in ("Discregrid/All", "Discregrid/discrete_grid.hpp", "Discregrid/cubic_lagrange_discrete_grid.hpp",
+              "Discregrid/geometry/TriangleMeshDistance.h", "Discregrid/mesh/triangle_mesh.hpp"):
+        src = tmp_path / "t.cpp"
+        src.write_text("#include <%s>\nint main() { return 0; }\n" % h)
+        subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + inc,
+                               "-I" + os.path.join(T.ROOT, "oracle", "eigen_shim"), str(src)])
