@@ -30,16 +30,22 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP/C++ source for gfx950 and link the shared library."""
-    if not force and not _stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile every HIP/C++ source for gfx950 and link the shared library.  `defines`/`out`
+    build an experiment variant (e.g. defines=("-DDG_TRI_BOX=0",), out=".../libdg_x.so")."""
+    if out is None and not force and not _stale():
         return OUT
-    objdir = os.path.join(HERE, "build")
+    if out is not None:
+        return _build(verbose, tuple(defines), os.path.join(HERE, "build", os.path.basename(out) + ".d"), out)
+    return _build(verbose, tuple(defines), os.path.join(HERE, "build"), OUT)
+
+
+def _build(verbose, defines, objdir, target):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in SOURCES_HIP:
         obj = os.path.join(objdir, src + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))
@@ -47,17 +53,17 @@ def build(force=False, verbose=False):
         objs.append(obj)
     for src in SOURCES_CXX:
         obj = os.path.join(objdir, src + ".o")
-        cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", *COMMON, "-I" + os.path.join(ROCM, "include"), "-c",
+        cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", *COMMON, *defines, "-I" + os.path.join(ROCM, "include"), "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", target]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return target
 
 
 if __name__ == "__main__":

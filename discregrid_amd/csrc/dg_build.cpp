@@ -181,7 +181,7 @@ struct Builder
 			const uint32_t first = (uint32_t)order.size();
 			for (size_t i = b; i < e; ++i)
 				order.push_back(prims[i].tri);
-			nodes[me].info = ~(int32_t)((first << 3) | (uint32_t)(e - b - 1));
+			nodes[me].info = ~(int32_t)((first << kLeafBits) | (uint32_t)(e - b - 1));
 			nodes[me].skip = (int32_t)nodes.size();
 			return;
 		}
@@ -222,9 +222,9 @@ struct Builder
 bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles, int max_leaf,
 				MeshBuild& out)
 {
-	if (!verts || !tris || n_triangles == 0 || n_vertices == 0 || n_triangles >= (1u << 28))
+	if (!verts || !tris || n_triangles == 0 || n_vertices == 0 || n_triangles >= (1u << 27))
 		return false;
-	max_leaf = std::max(1, std::min(8, max_leaf));
+	max_leaf = std::max(1, std::min(kMaxLeaf, max_leaf));
 	for (size_t i = 0; i < 3 * n_triangles; ++i)
 		if (tris[i] >= n_vertices)
 			return false;
@@ -295,7 +295,13 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	{
 		sl.u[0] = sl.u[1] = sl.u[2] = 0.0f; // u = 0: lower bound 0, never prunes (padding, degenerate triangles)
 		sl.lo = sl.hi = 0.0f;
-		sl.pad_[0] = sl.pad_[1] = sl.pad_[2] = 0.0f;
+		sl.pad_ = 0.0f;
+		for (int d = 0; d < 3; ++d)
+		{
+			// padding entries: an empty box far away is never "hit" but is never used either
+			sl.blo[d] = 0.0f;
+			sl.bhi[d] = 0.0f;
+		}
 	}
 	for (size_t k = 0; k < n_triangles; ++k)
 	{
@@ -306,6 +312,14 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 			const D3 n = cross3(sub(b, a), sub(c, a));
 			const double len = std::sqrt(dot3(n, n));
 			TriSlab& sl = out.slabs[k];
+			for (int d = 0; d < 3; ++d)
+			{
+				const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z}, cv[3] = {c.x, c.y, c.z};
+				const double lo = std::min(av[d], std::min(bv[d], cv[d])) - out.origin[d];
+				const double hi = std::max(av[d], std::max(bv[d], cv[d])) - out.origin[d];
+				sl.blo[d] = std::nextafterf(round_down(lo), -std::numeric_limits<float>::infinity());
+				sl.bhi[d] = std::nextafterf(round_up(hi), std::numeric_limits<float>::infinity());
+			}
 			if (len > 0 && std::isfinite(len))
 			{
 				const double sc = (1.0 - 1.0e-6) / len;

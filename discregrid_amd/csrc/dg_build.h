@@ -18,7 +18,7 @@ struct MeshBuild
 {
 	std::vector<BvhNode> nodes;    // depth-first, skip pointers
 	std::vector<TriPacket> tris;   // leaf order
-	std::vector<TriSlab> slabs;    // leaf order, padded by 4 entries (leaves are read 4 at a time)
+	std::vector<TriSlab> slabs;    // leaf order, padded by 4 entries (leaves are read in groups of 4)
 	std::vector<double> pn;        // kPnSlots * 3 doubles per triangle, leaf order
 	double origin[3];              // boxes are relative to this point
 	float mesh_l1 = 0;             // max over vertices of |v - origin|_1, rounded up
@@ -27,7 +27,7 @@ struct MeshBuild
 	uint64_t n_vertices = 0, n_triangles = 0;
 };
 
-// max_leaf: triangles per leaf (1..8).  Returns false on invalid input (no triangles, index
+// max_leaf: triangles per leaf (1..16).  Returns false on invalid input (no triangles, index
 // out of range).
 bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles, int max_leaf,
 				MeshBuild& out);

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -170,7 +171,10 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 
 	auto t0 = std::chrono::high_resolution_clock::now();
 	dg::MeshBuild B;
-	if (!dg::build_mesh(verts, n_vertices, tris, n_triangles, 4, B))
+	int max_leaf = 8; // measured optimum on MI355X (profiles/r01_k1_ab.txt): fewer, fatter leaves = fewer dependent node steps
+	if (const char* e = std::getenv("DG_MAX_LEAF")) // tuning knob (1..16)
+		max_leaf = std::max(1, std::min(dg::kMaxLeaf, std::atoi(e)));
+	if (!dg::build_mesh(verts, n_vertices, tris, n_triangles, max_leaf, B))
 		return fail(DG_ERR_INVALID, "invalid mesh (vertex index out of range or too many triangles)");
 	auto t1 = std::chrono::high_resolution_clock::now();
 

@@ -34,12 +34,14 @@ struct alignas(64) BvhNode
 	float lo[3];
 	float hi[3];
 	int32_t skip;
-	int32_t info; // >= 0: index of the right child (left child = idx + 1);  < 0: leaf, ~info = (first << 3) | (count - 1)
+	int32_t info; // >= 0: index of the right child (left child = idx + 1);  < 0: leaf, ~info = (first << kLeafBits) | (count - 1), count <= 16
 	float su[3];  // slab direction, |su| <= 1 (0 = no slab)
 	float slo, shi;
 	float pad_[3];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static const int kLeafBits = 4;      // leaf triangle count - 1 in the low bits of ~info
+static const int kMaxLeaf = 16;
 
 // One triangle packet = 128 bytes, in BVH leaf order.  The point-independent terms of the
 // Eberly test are precomputed on the host WITH THE REFERENCE'S OWN OPERATIONS (same inputs,
@@ -59,18 +61,22 @@ struct alignas(128) TriPacket
 };
 static_assert(sizeof(TriPacket) == 128, "TriPacket must be 128 bytes");
 
-// One slab per triangle = 32 bytes, leaf order: a float direction u (|u| <= 1, ~ the face normal)
+// One bound record per triangle = 48 bytes, leaf order: a float direction u (|u| <= 1, ~ the face normal)
 // and the interval [lo, hi] of u.(x - origin) over the triangle's vertices, rounded outward.
 // For ANY |u| <= 1:  dist(p, triangle) >= max(u.p - hi, lo - u.p, 0)  -- a one-direction k-DOP
 // that is tight exactly where boxes are loose (queries on the concave side of a curved surface
 // see dozens of nearly equidistant facets whose AABBs all overlap the search sphere).
-struct alignas(32) TriSlab
+// The record also carries the triangle's own axis-aligned box (leaves hold up to 4 triangles;
+// the leaf box is much looser than each triangle's).
+struct alignas(16) TriSlab
 {
 	float u[3];
 	float lo, hi;
-	float pad_[3];
+	float blo[3];
+	float bhi[3];
+	float pad_;
 };
-static_assert(sizeof(TriSlab) == 32, "TriSlab must be 32 bytes");
+static_assert(sizeof(TriSlab) == 48, "TriSlab must be 48 bytes");
 
 // Pseudonormals, 8 slots of 3 doubles per triangle (leaf order), slot = nearest entity:
 // 0..2 vertex normals of v0,v1,v2; 3..5 edge normals E01,E12,E02; 6 face normal; 7 unused.

@@ -10,6 +10,10 @@ namespace dg
 
 static const int kMaxRanks = 16;   // shard table size
 static const int kSlabPlanes = 4;  // planes per slab == brick depth
+#ifndef DG_WAVES_PER_BLOCK
+#define DG_WAVES_PER_BLOCK 1
+#endif
+static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 
 struct MeshDev
 {
@@ -45,7 +49,7 @@ struct SampleParams
 	double cell[3];
 	ClassDesc cls[4];
 	uint64_t total_bricks;
-	uint32_t n_blocks;       // ceil(total_bricks / 4)
+	uint32_t n_blocks;       // ceil(total_bricks / kWavesPerBlock)
 	uint32_t blocks_per_xcd; // ceil(n_blocks / 8)
 	int32_t shard_rank, shard_n; // shard_n == 1: identity plane map
 	int32_t invert;

@@ -30,6 +30,10 @@
 #include <stdint.h>
 #include "dg_kernels.h"
 
+#ifndef DG_TRI_BOX
+#define DG_TRI_BOX 1 // per-triangle box in the leaf pre-test (in addition to the slab)
+#endif
+
 namespace dg
 {
 namespace
@@ -82,43 +86,67 @@ __device__ __forceinline__ SNode load_node(const BvhNode* nodes, int idx)
 	return n;
 }
 
-// Leaf of `cnt` <= 4 triangles starting at packet `first` (wave-uniform arguments).  A triangle
-// gets the full double-precision test only if some lane's float lower bound -- the larger of
-// the leaf box bound and the triangle's own slab bound -- is below that lane's running best.
+// Leaf of `cnt` <= 16 triangles starting at packet `first` (wave-uniform arguments), handled in
+// groups of 4.  A triangle gets the full double-precision test only if some lane's float lower
+// bound -- the largest of the leaf bound, the triangle's own slab and (DG_TRI_BOX) the
+// triangle's own box -- is below that lane's running best.
 __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
 {
-	// the 4 slabs of the leaf in two scalar loads (the array is padded, cnt < 4 reads neighbours)
-	const char* sbase = (const char*)(M.slabs + first);
-	const v16i s0 = sload16(sbase);
-	const v16i s1 = sload16(sbase + 64);
-	unsigned want = 0;
+	for (int g0 = 0; g0 < cnt; g0 += 4)
+	{
+		const int gfirst = first + g0;
+		const int gcnt = (cnt - g0) < 4 ? (cnt - g0) : 4;
+		// the 4 bound records of the group (4 x 48 B) in three scalar loads (the array is padded:
+		// a group with fewer than 4 triangles reads its neighbours' records and ignores them)
+		const char* sbase = (const char*)(M.slabs + gfirst);
+		const v16i s0 = sload16(sbase);
+		const v16i s1 = sload16(sbase + 64);
+		const v16i s2 = sload16(sbase + 128);
+		int rec[48];
 #pragma unroll
-	for (int t = 0; t < 4; ++t)
-	{
-		const v16i& sv = (t < 2) ? s0 : s1;
-		const int o = (t & 1) * 8;
-		const float lb = slab_lb2(__int_as_float(sv[o + 0]), __int_as_float(sv[o + 1]), __int_as_float(sv[o + 2]),
-								  __int_as_float(sv[o + 3]), __int_as_float(sv[o + 4]), q.fp);
-		const bool hit = fmax2(lb, leaf_lb2) < q.bestf;
-		if (t < cnt && __ballot(hit) != 0ull)
-			want |= 1u << t;
-	}
-	for (int t = 0; t < cnt; ++t)
-	{
-		if (!((want >> t) & 1u))
-			continue;
-		const char* base = (const char*)(M.tris + first + t);
-		const v16i a = sload16(base);
-		const v16i b = sload16(base + 64);
-		const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
-		const double e0x = pack_double(a[6], a[7]), e0y = pack_double(a[8], a[9]), e0z = pack_double(a[10], a[11]);
-		const double e1x = pack_double(a[12], a[13]), e1y = pack_double(a[14], a[15]), e1z = pack_double(b[0], b[1]);
-		const double a00 = pack_double(b[2], b[3]), a01 = pack_double(b[4], b[5]), a11 = pack_double(b[6], b[7]);
-		const double det = pack_double(b[8], b[9]), inv_det = pack_double(b[10], b[11]);
-		const double denom = pack_double(b[12], b[13]);
-		const Hit h = tri_closest<false>(v0x, v0y, v0z, e0x, e0y, e0z, e1x, e1y, e1z, a00, a01, a11, det, inv_det,
-										 denom, q.px, q.py, q.pz);
-		offer(q, h.d2, first + t);
+		for (int i = 0; i < 16; ++i)
+		{
+			rec[i] = s0[i];
+			rec[16 + i] = s1[i];
+			rec[32 + i] = s2[i];
+		}
+		unsigned want = 0;
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+		{
+			const int o = 12 * t;
+			const float slab = slab_lb2(__int_as_float(rec[o + 0]), __int_as_float(rec[o + 1]),
+										__int_as_float(rec[o + 2]), __int_as_float(rec[o + 3]),
+										__int_as_float(rec[o + 4]), q.fp);
+#if DG_TRI_BOX
+			const float blo[3] = {__int_as_float(rec[o + 5]), __int_as_float(rec[o + 6]), __int_as_float(rec[o + 7])};
+			const float bhi[3] = {__int_as_float(rec[o + 8]), __int_as_float(rec[o + 9]), __int_as_float(rec[o + 10])};
+			const float lb = fmax2(slab, box_lb2(blo, bhi, q.fp));
+#else
+			const float lb = slab;
+#endif
+			const bool hit = fmax2(lb, leaf_lb2) < q.bestf;
+			if (t < gcnt && __ballot(hit) != 0ull)
+				want |= 1u << t;
+		}
+		for (int t = 0; t < gcnt; ++t)
+		{
+			if (!((want >> t) & 1u))
+				continue;
+			const char* base = (const char*)(M.tris + gfirst + t);
+			const v16i a = sload16(base);
+			const v16i b = sload16(base + 64);
+			const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
+			const double e0x = pack_double(a[6], a[7]), e0y = pack_double(a[8], a[9]), e0z = pack_double(a[10], a[11]);
+			const double e1x = pack_double(a[12], a[13]), e1y = pack_double(a[14], a[15]),
+						 e1z = pack_double(b[0], b[1]);
+			const double a00 = pack_double(b[2], b[3]), a01 = pack_double(b[4], b[5]), a11 = pack_double(b[6], b[7]);
+			const double det = pack_double(b[8], b[9]), inv_det = pack_double(b[10], b[11]);
+			const double denom = pack_double(b[12], b[13]);
+			const Hit h = tri_closest<false>(v0x, v0y, v0z, e0x, e0y, e0z, e1x, e1y, e1z, a00, a01, a11, det, inv_det,
+											 denom, q.px, q.py, q.pz);
+			offer(q, h.d2, gfirst + t);
+		}
 	}
 }
 
@@ -157,7 +185,7 @@ __device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q)
 		if (nd.info < 0)
 		{
 			const unsigned code = ~(unsigned)nd.info;
-			test_leaf(M, (int)(code >> 3), (int)(code & 7u) + 1, lbcur, q);
+			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
 			have = false;
 			continue;
 		}
@@ -204,7 +232,7 @@ __device__ __forceinline__ LaneResult finish(const MeshDev& M, const LaneQuery& 
 // ------------------------------------------------------------------------------------------------
 // K1: one wave per 4x4x4 brick of one node class.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample_nodes(const SampleParams P)
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_sample_nodes(const SampleParams P)
 {
 	// XCD-aware remap: hardware deals blockIdx round-robin over the 8 XCDs; give XCD x the
 	// contiguous chunk [x*blocks_per_xcd, (x+1)*blocks_per_xcd) of logical blocks.
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(256) void k_sample_nodes(const SampleParams P)
 		return;
 	const int wave = uniform((int)(threadIdx.x >> 6));
 	const int lane = (int)(threadIdx.x & 63u);
-	const uint64_t brick = (uint64_t)blk * 4u + (uint64_t)wave;
+	const uint64_t brick = (uint64_t)blk * (uint64_t)kWavesPerBlock + (uint64_t)wave;
 	if (brick >= P.total_bricks)
 		return;
 
@@ -368,7 +396,7 @@ hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
 	if (p.total_bricks == 0)
 		return hipSuccess;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
-	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(256), 0, stream, p);
+	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(64 * kWavesPerBlock), 0, stream, p);
 	return hipGetLastError();
 }
 

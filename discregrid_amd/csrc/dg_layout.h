@@ -67,7 +67,7 @@ inline void finish_bricks(SampleParams& P)
 		prefix += (uint64_t)C.nb0 * C.nb1 * C.nbq;
 	}
 	P.total_bricks = prefix;
-	P.n_blocks = (uint32_t)((prefix + 3) / 4);
+	P.n_blocks = (uint32_t)((prefix + kWavesPerBlock - 1) / kWavesPerBlock);
 	P.blocks_per_xcd = (P.n_blocks + 7) / 8;
 }
 

@@ -18,6 +18,10 @@
 #include "../../discregrid_amd/csrc/dg_kernels.h"
 #include "../../discregrid_amd/csrc/dg_layout.h"
 
+#ifndef DG_TRI_BOX
+#define DG_TRI_BOX 1
+#endif
+
 using namespace dg;
 
 namespace
@@ -25,7 +29,7 @@ namespace
 
 struct Stats
 {
-	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0;
+	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0, useful_tests = 0, leaf_groups = 0;
 };
 
 struct HostSqrt
@@ -40,36 +44,48 @@ struct Wave
 
 void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane or null*/, Wave& w, Stats& st)
 {
-	unsigned want = 0;
-	for (int t = 0; t < 4; ++t)
+	for (int g0 = 0; g0 < cnt; g0 += 4)
 	{
-		const TriSlab& sl = M.slabs[first + t];
-		bool any = false;
-		int n_int = 0;
-		for (int l = 0; l < 64; ++l)
+		const int gfirst = first + g0;
+		const int gcnt = (cnt - g0) < 4 ? (cnt - g0) : 4;
+		unsigned want = 0;
+		st.leaf_groups++;
+		for (int t = 0; t < 4; ++t)
 		{
-			const float lb = slab_lb2(sl.u[0], sl.u[1], sl.u[2], sl.lo, sl.hi, w.q[l].fp);
-			const bool hit = (fmax2(lb, leaf_lb2 ? leaf_lb2[l] : 0.0f) < w.q[l].bestf);
-			any = any || hit;
-			n_int += hit;
+			const TriSlab& sl = M.slabs[gfirst + t];
+			bool any = false;
+			int n_int = 0;
+			for (int l = 0; l < 64; ++l)
+			{
+				float lb = slab_lb2(sl.u[0], sl.u[1], sl.u[2], sl.lo, sl.hi, w.q[l].fp);
+#if DG_TRI_BOX
+				lb = fmax2(lb, box_lb2(sl.blo, sl.bhi, w.q[l].fp));
+#endif
+				const bool hit = (fmax2(lb, leaf_lb2 ? leaf_lb2[l] : 0.0f) < w.q[l].bestf);
+				any = any || hit;
+				n_int += hit;
+			}
+			if (t < gcnt && any)
+			{
+				want |= 1u << t;
+				st.lane_interest += n_int;
+			}
 		}
-		if (t < cnt && any)
+		for (int t = 0; t < gcnt; ++t)
 		{
-			want |= 1u << t;
-			st.lane_interest += n_int;
-		}
-	}
-	for (int t = 0; t < cnt; ++t)
-	{
-		st.slab_tests++;
-		if (!((want >> t) & 1u))
-			continue;
-		st.tri_tests++;
-		const TriPacket& T = M.tris[first + t];
-		for (int l = 0; l < 64; ++l)
-		{
-			const Hit h = tri_closest<false>(T, w.q[l].px, w.q[l].py, w.q[l].pz);
-			offer(w.q[l], h.d2, first + t);
+			st.slab_tests++;
+			if (!((want >> t) & 1u))
+				continue;
+			st.tri_tests++;
+			const TriPacket& T = M.tris[gfirst + t];
+			bool useful = false;
+			for (int l = 0; l < 64; ++l)
+			{
+				const Hit h = tri_closest<false>(T, w.q[l].px, w.q[l].py, w.q[l].pz);
+				useful = useful || (h.d2 < w.q[l].best_d2);
+				offer(w.q[l], h.d2, gfirst + t);
+			}
+			st.useful_tests += useful;
 		}
 	}
 }
@@ -107,7 +123,7 @@ void traverse(const MeshDev& M, Wave& w, Stats& st)
 		{
 			st.leaf_visits++;
 			const unsigned code = ~(unsigned)nd.info;
-			test_leaf(M, (int)(code >> 3), (int)(code & 7u) + 1, lbcur, w, st);
+			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
 			have = false;
 			continue;
 		}
@@ -219,7 +235,7 @@ int emu_mesh_check(void* h, const double* verts, const uint32_t* tris)
 			if (N[i].skip != (int)i + 1)
 				return 4;
 			const unsigned code = ~(unsigned)N[i].info;
-			for (unsigned t = code >> 3; t <= (code >> 3) + (code & 7u); ++t)
+			for (unsigned t = code >> kLeafBits; t <= (code >> kLeafBits) + (code & (unsigned)(kMaxLeaf - 1)); ++t)
 			{
 				if (t >= seen.size())
 					return 5;
@@ -276,9 +292,9 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		if (within >= P.blocks_per_xcd || blk >= P.n_blocks)
 			continue;
 		Stats ls;
-		for (int wave = 0; wave < 4; ++wave)
+		for (int wave = 0; wave < kWavesPerBlock; ++wave)
 		{
-			const uint64_t brick = (uint64_t)blk * 4u + (uint64_t)wave;
+			const uint64_t brick = (uint64_t)blk * (uint64_t)kWavesPerBlock + (uint64_t)wave;
 			if (brick >= P.total_bricks)
 				continue;
 			Wave w;
@@ -324,6 +340,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.descent_nodes += ls.descent_nodes;
 			st.slab_tests += ls.slab_tests;
 			st.lane_interest += ls.lane_interest;
+			st.useful_tests += ls.useful_tests;
+			st.leaf_groups += ls.leaf_groups;
 		}
 	}
 	if (stats)
@@ -335,6 +353,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		stats[4] = st.descent_nodes;
 		stats[5] = st.slab_tests;
 		stats[6] = st.lane_interest;
+		stats[7] = st.useful_tests;
+		stats[8] = st.leaf_groups;
 	}
 	return err;
 }

@@ -17,7 +17,7 @@ MESHES = {"box": T.box_mesh, "ico8": lambda: T.icosphere(8), "torus": T.torus, "
 @pytest.mark.parametrize("name", list(MESHES))
 def test_bvh_structure_and_pseudonormals(name):
     V, F = MESHES[name]()
-    for leaf in (1, 4, 8):
+    for leaf in (1, 4, 8, 16):
         em = emu.EmuMesh(V, F, max_leaf=leaf)
         assert em.check() == 0
     em = emu.EmuMesh(V, F)
