@@ -78,6 +78,9 @@ SYMBOLS = {
     "dg_interpolate_batch": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _dp]),
     "dg_interpolate_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
+    "dg_density_map_nodes": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _u8p, _dp]),
+    "dg_density_map_nodes_device": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_last_kernel_ms": (C.c_double, []),
 }
 
@@ -258,6 +261,21 @@ class Field:
         _check(self._lib.dg_interpolate_batch(self.handle, P.ctypes.data_as(_dp), len(P), phi.ctypes.data_as(_dp),
                                               None if g is None else g.ctypes.data_as(_dp)))
         return (phi, g) if grad else phi
+
+    def density_map_nodes(self, n_nodes_total, support_radius, rho0, band_predicate=True, begin=0, end=None,
+                          mask=None):
+        """K3: the GenerateDensityMap node function on this SDF field's own lattice."""
+        if end is None:
+            end = n_nodes_total
+        out = np.empty(end - begin)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _check(self._lib.dg_density_map_nodes(self.handle, support_radius, rho0, int(band_predicate), begin, end,
+                                              None if m is None else m.ctypes.data_as(_u8p), out.ctypes.data_as(_dp)))
+        return out
+
+    def density_map_nodes_device(self, support_radius, rho0, band_predicate, begin, end, d_out, d_mask=0, stream=0):
+        _check(self._lib.dg_density_map_nodes_device(self.handle, support_radius, rho0, int(band_predicate), begin, end,
+                                                     C.c_void_p(d_mask), C.c_void_p(d_out), C.c_void_p(stream)))
 
     def interpolate_device(self, d_xyz, n, d_phi, d_grad=0, stream=0):
         _check(self._lib.dg_interpolate_batch_device(self.handle, C.c_void_p(d_xyz), n, C.c_void_p(d_phi),

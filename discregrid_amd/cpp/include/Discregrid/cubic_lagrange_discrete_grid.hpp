@@ -65,6 +65,15 @@ public:
 	void interpolate(unsigned int field_id, double const* xyz, std::size_t n, double* phi,
 					 double* grad = nullptr) const;
 
+	// The SPH boundary density map of the reference's GenerateDensityMap tool
+	// (cmd/generate_density_map/main.cpp:83-133) as ONE call, evaluated on the GPU: appends the
+	// field  rho0 * integral_{[-h,h]^3} gamma(x + xi) W(xi) dxi  (gamma from field `sdf_field`, W the
+	// cubic spline kernel of support radius h, 16^3 Gauss points) sampled on this grid's lattice.
+	// band_predicate applies the tool's node predicate (nodes outside the band around the surface
+	// get DBL_MAX); pass false for the tool's --no-reduction behaviour.  Returns the new field id.
+	unsigned int addDensityMap(unsigned int sdf_field, double support_radius, double rho0, bool band_predicate = true,
+							   bool verbose = false);
+
 	std::size_t nFields() const { return m_n_fields; }
 	std::vector<double> const& nodeData(unsigned int field_id) const { return m_nodes[field_id]; }
 	// Seconds spent in the last addFunction call (whole call) and in its node-sampling stage.

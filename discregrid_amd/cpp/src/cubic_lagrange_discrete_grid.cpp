@@ -273,6 +273,44 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 	return static_cast<unsigned int>(m_n_fields++);
 }
 
+unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, double support_radius, double rho0,
+													  bool band_predicate, bool verbose)
+{
+	using clock = std::chrono::high_resolution_clock;
+	const auto t0 = clock::now();
+	if (sdf_field >= m_nodes.size())
+		throw std::out_of_range("CubicLagrangeDiscreteGrid::addDensityMap: no such field");
+	const unsigned int n_nodes = nNodesFull();
+	if (m_dev->fields.size() < m_nodes.size())
+		m_dev->fields.resize(m_nodes.size(), nullptr);
+	dg_field*& f = m_dev->fields[sdf_field];
+	if (f == nullptr)
+	{
+		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+		auto const& cells = m_cells[sdf_field];
+		auto const& map = m_cell_map[sdf_field];
+		if (dg_field_create(&g, m_nodes[sdf_field].data(), m_nodes[sdf_field].size(),
+							cells.empty() ? nullptr : reinterpret_cast<const uint32_t*>(cells[0].data()), cells.size(),
+							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
+			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
+	}
+	std::vector<double> coeffs(n_nodes);
+	if (dg_density_map_nodes(f, support_radius, rho0, band_predicate ? 1 : 0, 0, n_nodes, nullptr, coeffs.data()) != DG_OK)
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
+	m_nodes.push_back(std::move(coeffs));
+	m_cells.push_back({});
+	m_cell_map.push_back({});
+	m_dev->fields.resize(m_nodes.size(), nullptr);
+	m_last_used_gpu = true;
+	const auto t1 = clock::now();
+	m_last_total_s = m_last_sampling_s = std::chrono::duration<double>(t1 - t0).count();
+	if (verbose)
+		std::cout << "\rConstruction took " << std::setw(15)
+				  << static_cast<double>(std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count()) / 1000.0
+				  << "s" << std::endl;
+	return static_cast<unsigned int>(m_n_fields++);
+}
+
 // ---------------------------------------------------------------------------------------------
 // evaluation
 // ---------------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include <cmath>
+
 #include "dg_build.h"
 #include "dg_kernels.h"
 #include "dg_layout.h"
@@ -36,6 +38,11 @@ struct dg_field
 	dg::FieldDev dev;
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
+	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
+	double wtab_h = -1.0;
+	void* d_ws = nullptr;      // K3 workspace: compaction list + counter
+	uint64_t ws_nodes = 0;
+	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
 	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)
 	int device = -1;
@@ -467,6 +474,7 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 	f->dev.cells = d_cells;
 	f->dev.cell_map = d_cell_map;
 	f->dev.cell_major = nullptr;
+	f->grid = *grid;
 	f->n_coeffs = n_coeffs;
 	f->n_rows = d_cells ? n_cell_rows : dg_grid_n_cells(grid);
 	(void)hipGetDevice(&f->device);
@@ -527,6 +535,10 @@ void dg_field_destroy(dg_field* f)
 			(void)hipFree(p);
 	if (f->d_cell_major)
 		(void)hipFree(f->d_cell_major);
+	if (f->d_wtab)
+		(void)hipFree(f->d_wtab);
+	if (f->d_ws)
+		(void)hipFree(f->d_ws);
 	delete f;
 }
 
@@ -565,6 +577,102 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 		field->d_cell_major = nullptr;
 		field->dev.cell_major = nullptr;
 	}
+	return DG_OK;
+}
+
+// ---- K3 ---------------------------------------------------------------------------------------------------
+dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
+									  double* d_out, void* stream)
+{
+	if (!sdf || !d_out)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!(support_radius > 0.0))
+		return fail(DG_ERR_INVALID, "support radius must be positive");
+	const uint64_t total = dg_grid_n_nodes(&sdf->grid);
+	if (node_begin > node_end || node_end > total)
+		return fail(DG_ERR_INVALID, "node range outside the lattice");
+	if (node_begin == node_end)
+		return DG_OK;
+	const uint64_t n = node_end - node_begin;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	dg::DensityParams P;
+	std::vector<double> w;
+	dg::init_density_params(P, support_radius, rho0, sdf->grid.cell_size, band_predicate, w);
+	if (sdf->wtab_h != support_radius)
+	{
+		if (!sdf->d_wtab)
+			DG_HIP(hipMalloc(&sdf->d_wtab, 4096 * sizeof(double)));
+		DG_HIP(hipMemcpy(sdf->d_wtab, w.data(), 4096 * sizeof(double), hipMemcpyHostToDevice));
+		sdf->wtab_h = support_radius;
+	}
+	P.wtab = static_cast<const double*>(sdf->d_wtab);
+	if (sdf->ws_nodes < n)
+	{
+		if (sdf->d_ws)
+		{
+			DG_HIP(hipDeviceSynchronize());
+			(void)hipFree(sdf->d_ws);
+			sdf->d_ws = nullptr;
+			sdf->ws_nodes = 0;
+		}
+		DG_HIP(hipMalloc(&sdf->d_ws, (n + 4) * sizeof(uint32_t)));
+		sdf->ws_nodes = n;
+	}
+	uint32_t* counter = static_cast<uint32_t*>(sdf->d_ws);
+	uint32_t* list = counter + 4;
+	DG_HIP(dg::launch_density_map(sdf->dev, P, node_begin, node_end, d_pred_mask, d_out, list, counter, st));
+	return DG_OK;
+}
+
+dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+							   uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out)
+{
+	if (!sdf || !out)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (node_begin > node_end)
+		return fail(DG_ERR_INVALID, "node_begin > node_end");
+	const uint64_t n = node_end - node_begin;
+	if (n == 0)
+		return DG_OK;
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	double* d_out = nullptr;
+	uint8_t* d_mask = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	dg_status st = DG_OK;
+	hipError_t e = hipMalloc((void**)&d_out, n * sizeof(double));
+	if (e == hipSuccess && pred_mask)
+	{
+		e = hipMalloc((void**)&d_mask, n);
+		if (e == hipSuccess) e = hipMemcpy(d_mask, pred_mask, n, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+	if (e == hipSuccess)
+	{
+		st = dg_density_map_nodes_device(sdf, support_radius, rho0, band_predicate, node_begin, node_end, d_mask, d_out,
+										 nullptr);
+		if (st == DG_OK)
+		{
+			e = hipEventRecord(e1, nullptr);
+			if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost);
+			float ms = -1.f;
+			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+				g_last_ms = ms;
+		}
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (d_out) (void)hipFree(d_out);
+	if (d_mask) (void)hipFree(d_mask);
+	if (st != DG_OK)
+		return st;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_density_map_nodes: %s",
+					hipGetErrorString(e));
 	return DG_OK;
 }
 

@@ -15,8 +15,10 @@
 
 #if defined(__HIP__)
 #define DG_HD __host__ __device__ __attribute__((always_inline)) inline
+#define DG_NOUNROLL _Pragma("nounroll")
 #else
 #define DG_HD inline
+#define DG_NOUNROLL
 #endif
 
 namespace dg
@@ -724,6 +726,135 @@ DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3]
 		g[2] = gz * c0[2];
 	}
 	return phi;
+}
+
+// ---- K3: SPH boundary density map (GenerateDensityMap) ------------------------------------------------
+// Restates cmd/generate_density_map/main.cpp:86-112 (gamma, density_func), :119-133 (node
+// predicate), sph_kernel.hpp:11-42 (CubicKernel::W) and gauss_quadrature.cpp:5927-5960 (the
+// 16^3-point tensor Gauss-Legendre rule for p = 30), with the reference's operation order:
+// the 4096-term sum runs i, j, k sequentially per node.
+struct DensityParams
+{
+	double h;           // kernel support radius ("ar")
+	double rho0;
+	double c0prod;      // (0.5*diag).prod() = h*(h*h)
+	double cell_diag;   // cellSize().norm(), Eigen association x^2 + (y^2 + z^2)
+	int band_predicate; // apply the node predicate of main.cpp:119-133
+	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
+	double w[16];       // weights
+	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
+};
+
+// CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector
+DG_HD double cubic_kernel_k(double radius)
+{
+	const double pi = 3.14159265358979323846; // M_PI
+	const double h3 = radius * radius * radius;
+	return 8.0 / (pi * h3);
+}
+template <class Sqrt>
+DG_HD double cubic_kernel_W(double rx, double ry, double rz, double radius, double k, Sqrt sqrt_fn)
+{
+	double res = 0.0;
+	const double rl = sqrt_fn(rx * rx + (ry * ry + rz * rz));
+	const double q = rl / radius;
+	if (q <= 1.0)
+	{
+		if (q <= 0.5)
+		{
+			const double q2 = q * q;
+			const double q3 = q2 * q;
+			res = k * (6.0 * q3 - 6.0 * q2 + 1.0);
+		}
+		else
+		{
+			const double omq = 1.0 - q;
+			res = k * (2.0 * omq * omq * omq);
+		}
+	}
+	return res;
+}
+
+// Stage 1 (cheap): node predicate (main.cpp:119-133) and the early-out of density_func (:98-102).
+// Returns true if the node needs the quadrature; otherwise *value is the final field value
+// (DBL_MAX for predicate-rejected nodes, 0.0 for nodes farther than 2h from the surface).
+DG_HD bool density_prefilter(const FieldDev& F, const DensityParams& P, const double x[3], double* value)
+{
+	const double NOVAL = 1.7976931348623157e308;
+	double g[3];
+	if (P.band_predicate)
+	{
+		double xc[3];
+		for (int d = 0; d < 3; ++d) // x.cwiseMax(domain.min()).cwiseMin(domain.max())
+		{
+			const double a = x[d] < F.dmin[d] ? F.dmin[d] : x[d];
+			xc[d] = a < F.dmax[d] ? a : F.dmax[d];
+		}
+		const double dist = interpolate_point<false>(F, xc, g);
+		if (dist == NOVAL || !(-6.0 * P.h < dist + P.cell_diag && dist - P.cell_diag < 2.0 * P.h))
+		{
+			*value = NOVAL;
+			return false;
+		}
+	}
+	const double dist = interpolate_point<false>(F, x, g);
+	if (dist > 2.0 * P.h)
+	{
+		*value = 0.0;
+		return false;
+	}
+	return true;
+}
+
+// Stage 2: rho0 * integral over [-h,h]^3 of gamma(x + xi) W(xi), 16^3 Gauss points, summed in
+// the reference's i, j, k order (gauss_quadrature.cpp:5941-5958).
+DG_HD double density_integral(const FieldDev& F, const DensityParams& P, const double x[3])
+{
+	double g[3];
+	double res = 0.0;
+	DG_NOUNROLL
+	for (int i = 0; i < 16; ++i)
+	{
+		const double wi = P.w[i];
+		DG_NOUNROLL
+		for (int j = 0; j < 16; ++j)
+		{
+			const double wij = wi * P.w[j];
+			DG_NOUNROLL
+			for (int k = 0; k < 16; ++k)
+			{
+				const double wijk = wij * P.w[k];
+				const double y[3] = {x[0] + P.xi[i], x[1] + P.xi[j], x[2] + P.xi[k]};
+				const double d = interpolate_point<false>(F, y, g);
+				const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
+				res += wijk * (gamma * P.wtab[(i * 16 + j) * 16 + k]);
+			}
+		}
+	}
+	res *= P.c0prod;
+	return P.rho0 * res;
+}
+
+// flat node index -> position (the inverse of the class decomposition; used where nodes are
+// addressed individually rather than as bricks)
+DG_HD void node_position_flat(uint64_t l, const uint32_t res[3], const double dmin[3], const double cell[3], double x[3])
+{
+	uint32_t D[3];
+	int c = 0;
+	uint64_t off = 0;
+	for (; c < 4; ++c)
+	{
+		class_dims(c, res, D);
+		const uint64_t size = (uint64_t)D[0] * D[1] * D[2];
+		if (l < off + size || c == 3)
+			break;
+		off += size;
+	}
+	const uint64_t lc = l - off;
+	const uint32_t a = (uint32_t)(lc % D[0]);
+	const uint32_t b = (uint32_t)((lc / D[0]) % D[1]);
+	const uint32_t s = (uint32_t)(lc / ((uint64_t)D[0] * D[1]));
+	node_position(c, a, b, s, dmin, cell, x);
 }
 
 } // namespace dg

@@ -381,7 +381,74 @@ __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t
 		o[j] = F.coeffs[idx[j]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3: SPH boundary density map.  Pass 1 classifies every node (predicate / early-out) and
+// compacts the ones that need the 4096-point quadrature; pass 2 integrates them, one thread
+// per node (the sum must run i, j, k sequentially per node for parity; parallelism = nodes).
+// The loop indices are wave-uniform, so the weights and the W table come through scalar loads;
+// every step is one full interpolate() of the SDF at x + xi.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_density_classify(const FieldDev F, const DensityParams P, uint64_t begin,
+														   uint64_t end, const uint8_t* __restrict__ mask,
+														   double* __restrict__ out, uint32_t* __restrict__ list,
+														   uint32_t* __restrict__ counter)
+{
+	const uint64_t l = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (l >= end)
+		return;
+	if (mask != nullptr && mask[l - begin] == 0)
+	{
+		out[l - begin] = 1.7976931348623157e308;
+		return;
+	}
+	double x[3];
+	node_position_flat(l, F.res, F.dmin, F.cell, x);
+	double v;
+	if (density_prefilter(F, P, x, &v))
+		list[atomicAdd(counter, 1u)] = (uint32_t)(l - begin);
+	else
+		out[l - begin] = v;
+}
+
+__global__ __launch_bounds__(256) void k_density_integrate(const FieldDev F, const DensityParams P, uint64_t begin,
+															const uint32_t* __restrict__ list,
+															const uint32_t* __restrict__ counter, double* __restrict__ out)
+{
+	const uint32_t n = *counter;
+	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+	{
+		const uint32_t rel = list[t];
+		double x[3];
+		node_position_flat(begin + rel, F.res, F.dmin, F.cell, x);
+		out[rel] = density_integral(F, P, x);
+	}
+}
+
 } // namespace
+
+hipError_t launch_density_map(const FieldDev& f, const DensityParams& p, uint64_t begin, uint64_t end,
+							  const uint8_t* d_mask, double* d_out, uint32_t* d_list, uint32_t* d_counter,
+							  hipStream_t stream)
+{
+	if (end <= begin)
+		return hipSuccess;
+	const uint64_t n = end - begin;
+	hipError_t e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), stream);
+	if (e != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(k_density_classify, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, f, p, begin, end,
+					   d_mask, d_out, d_list, d_counter);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return e;
+	// grid-stride over the compacted list: enough blocks to fill the chip, the count stays on the device
+	uint64_t blocks = (n + 255) / 256;
+	if (blocks > 256ull * 16ull)
+		blocks = 256ull * 16ull;
+	hipLaunchKernelGGL(k_density_integrate, dim3((uint32_t)blocks), dim3(256), 0, stream, f, p, begin, d_list, d_counter,
+					   d_out);
+	return hipGetLastError();
+}
 
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream)
 {

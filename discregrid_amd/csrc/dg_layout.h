@@ -4,7 +4,10 @@
 // (dg_capi.cpp) and the wave emulator of the CPU tests.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <vector>
+#include "dg_gauss16.h"
 #include "dg_kernels.h"
 
 namespace dg
@@ -164,6 +167,34 @@ inline void layout_unpack(UnpackParams& U, const uint32_t res[3], int nranks)
 		}
 	}
 	U.nranks = nranks;
+}
+
+// K3 launch constants: quadrature offsets/weights and the table of kernel values W(xi) for
+// support radius h (host arithmetic, same operations as the reference performs per call).
+inline void init_density_params(DensityParams& P, double h, double rho0, const double cell_size[3], int band,
+								std::vector<double>& wtab_host)
+{
+	struct HostSqrt
+	{
+		double operator()(double x) const { return std::sqrt(x); }
+	};
+	P.h = h;
+	P.rho0 = rho0;
+	P.c0prod = h * (h * h);
+	P.cell_diag = std::sqrt(cell_size[0] * cell_size[0] + (cell_size[1] * cell_size[1] + cell_size[2] * cell_size[2]));
+	P.band_predicate = band ? 1 : 0;
+	for (int i = 0; i < 16; ++i)
+	{
+		P.xi[i] = h * kGaussX[i] + 0.0; // c0 * abscissa + c1 with c0 = 0.5 * (h - (-h)) = h, c1 = 0.5 * (-h + h) = 0
+		P.w[i] = kGaussW[i];
+	}
+	const double k = cubic_kernel_k(h);
+	wtab_host.resize(4096);
+	for (int i = 0; i < 16; ++i)
+		for (int j = 0; j < 16; ++j)
+			for (int kk = 0; kk < 16; ++kk)
+				wtab_host[(i * 16 + j) * 16 + kk] = cubic_kernel_W(P.xi[i], P.xi[j], P.xi[kk], h, k, HostSqrt());
+	P.wtab = nullptr;
 }
 
 // the source index k_unpack_shards reads for global node l (host mirror, used by tests)

@@ -163,6 +163,20 @@ dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_
 dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
 									  double* d_grad, void* stream);
 
+/* ---- K3: SPH boundary density map (next row of the path: GenerateDensityMap) ------------------ */
+/* out[l - node_begin] = density_func(indexToNodePosition(l)) of cmd/generate_density_map/main.cpp:96-112
+ * evaluated on the lattice of `sdf`'s own grid: rho0 * integral over [-h,h]^3 of gamma(x + xi) W(xi),
+ * gamma from the SDF field (:86-93), W the cubic spline kernel (sph_kernel.hpp:22-42), 16^3-point
+ * Gauss-Legendre rule summed in the reference's order (gauss_quadrature.cpp:5927-5960), 0 where the
+ * node is farther than 2h from the surface.  band_predicate != 0 additionally applies the node
+ * predicate of main.cpp:119-133 (DG_NO_VALUE outside the band -6h < phi + cell_diag, phi - cell_diag < 2h);
+ * pred_mask (nullable, indexed l - node_begin) works as in dg_sdf_sample_nodes. */
+dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+							   uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out);
+dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
+									  double* d_out, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* Device time (HIP events on the launch stream) of the most recent K1 / K2 kernel launch issued
  * by this thread through the HOST entry points, in milliseconds; <0 if none. */

@@ -766,6 +766,84 @@ double interpolate_one(const Grid& g, const double* coeffs, const unsigned* cell
 	return phi;
 }
 
+// ----------------------------------------------------------------------------------
+// Density map node function (cmd/generate_density_map): CubicKernel::W sph_kernel.hpp:22-42
+// (r.norm() with Eigen's 3-vector association), gamma main.cpp:86-93, density_func :96-112,
+// tensor Gauss-Legendre rule gauss_quadrature.cpp:5927-5960, node predicate main.cpp:119-133.
+// ----------------------------------------------------------------------------------
+struct Density
+{
+	double h, rho0, k, cell_diag;
+	int band;
+	const double* gx; // 16 abscissae (ascending) and weights of the reference's p = 30 rule
+	const double* gw;
+	double W(const double r[3]) const
+	{
+		double res = 0.0;
+		const double rl = std::sqrt(r[0] * r[0] + (r[1] * r[1] + r[2] * r[2]));
+		const double q = rl / h;
+		if (q <= 1.0)
+		{
+			if (q <= 0.5)
+			{
+				const double q2 = q * q, q3 = q2 * q;
+				res = k * (6.0 * q3 - 6.0 * q2 + 1.0);
+			}
+			else
+			{
+				const double m = 1.0 - q;
+				res = k * (2.0 * m * m * m);
+			}
+		}
+		return res;
+	}
+};
+
+double density_node(const Grid& g, const double* coeffs, const unsigned* cells, const unsigned* map, const Density& D,
+					const double x[3])
+{
+	if (D.band) // main.cpp:119-133
+	{
+		double xc[3];
+		for (int d = 0; d < 3; ++d)
+			xc[d] = std::min(std::max(x[d], g.dmin[d]), g.dmax[d]);
+		const double dist = interpolate_one(g, coeffs, cells, map, xc, nullptr);
+		if (dist == kNoValue)
+			return kNoValue;
+		if (!(-6.0 * D.h < dist + D.cell_diag && dist - D.cell_diag < 2.0 * D.h))
+			return kNoValue;
+	}
+	const double dist = interpolate_one(g, coeffs, cells, map, x, nullptr);
+	if (dist > 2.0 * D.h)
+		return 0.0;
+	const double c0 = 0.5 * (D.h - (-D.h));   // 0.5 * diagonal
+	const double c1 = 0.5 * (-D.h + D.h);     // 0.5 * (min + max)
+	double res = 0.0;
+	double xi[3];
+	for (int i = 0; i < 16; ++i)
+	{
+		const double wi = D.gw[i];
+		xi[0] = D.gx[i];
+		for (int j = 0; j < 16; ++j)
+		{
+			const double wij = wi * D.gw[j];
+			xi[1] = D.gx[j];
+			for (int k = 0; k < 16; ++k)
+			{
+				const double wijk = wij * D.gw[k];
+				xi[2] = D.gx[k];
+				const double r[3] = {c0 * xi[0] + c1, c0 * xi[1] + c1, c0 * xi[2] + c1};
+				const double y[3] = {x[0] + r[0], x[1] + r[1], x[2] + r[2]};
+				const double d = interpolate_one(g, coeffs, cells, map, y, nullptr);
+				const double gamma = (d > D.h) ? 0.0 : 1.0 - d / D.h;
+				res += wijk * (gamma * D.W(r));
+			}
+		}
+	}
+	res *= c0 * (c0 * c0); // Eigen prod() of a 3-vector
+	return D.rho0 * res;
+}
+
 template <class T>
 void put(std::vector<unsigned char>& b, const T& v)
 {
@@ -1014,6 +1092,33 @@ double dgo_interpolate(const double domain[6], const unsigned res[3], const doub
 #pragma omp parallel for schedule(static)
 	for (long long q = 0; q < (long long)n; ++q)
 		phi[q] = interpolate_one(g, coeffs, cells, cell_map, xyz + 3 * q, grad ? grad + 3 * q : nullptr);
+	auto t1 = std::chrono::high_resolution_clock::now();
+	return std::chrono::duration<double>(t1 - t0).count();
+}
+
+double dgo_density_map_nodes(const double domain[6], const unsigned res[3], const double* coeffs, const unsigned* cells,
+							 const unsigned* cell_map, double h, double rho0, int band, const double* gx, const double* gw,
+							 unsigned begin, unsigned end, double* out)
+{
+	Grid g;
+	g.init(domain, res);
+	Density D;
+	D.h = h;
+	D.rho0 = rho0;
+	D.band = band;
+	D.gx = gx;
+	D.gw = gw;
+	const double pi = 3.14159265358979323846;
+	D.k = 8.0 / (pi * (h * h * h)); // sph_kernel.hpp:14-17
+	D.cell_diag = std::sqrt(g.cell[0] * g.cell[0] + (g.cell[1] * g.cell[1] + g.cell[2] * g.cell[2]));
+	auto t0 = std::chrono::high_resolution_clock::now();
+#pragma omp parallel for schedule(dynamic, 16)
+	for (long long l = begin; l < (long long)end; ++l)
+	{
+		double x[3];
+		g.node_position((unsigned)l, x);
+		out[l - begin] = density_node(g, coeffs, cells, cell_map, D, x);
+	}
 	auto t1 = std::chrono::high_resolution_clock::now();
 	return std::chrono::duration<double>(t1 - t0).count();
 }

@@ -43,6 +43,10 @@
 #undef private
 #undef protected
 
+// the density-map tool's helpers (cmd/generate_density_map): header-only kernel + quadrature
+#include "sph_kernel.hpp"
+#include "gauss_quadrature.hpp"
+
 using namespace Discregrid;
 
 namespace
@@ -233,6 +237,56 @@ void ref_grid_reduce_abs_lt(void* h, unsigned field, double bound)
 {
 	static_cast<RefGrid*>(h)->grid->reduceField(
 		field, [bound](Eigen::Vector3d const&, double v) { return std::abs(v) < bound; });
+}
+
+// GenerateDensityMap's addFunction call (cmd/generate_density_map/main.cpp:83-133) on the grid's
+// field 0: the lambdas below are the tool's own, re-typed around the reference's CubicKernel,
+// GaussQuadrature and DiscreteGrid::interpolate.  Returns the wall time of addFunction.
+double ref_grid_add_density_map(void* hh, double h, double rho0, int no_reduction)
+{
+	auto* sdf = static_cast<RefGrid*>(hh)->grid.get();
+	auto sph_kernel = CubicKernel{};
+	sph_kernel.setRadius(h);
+	auto gamma = [&](Eigen::Vector3d const& x) {
+		auto ar = sph_kernel.getRadius();
+		auto dist = sdf->interpolate(0u, x);
+		if (dist > ar)
+			return 0.0;
+		return 1.0 - dist / ar;
+	};
+	auto int_domain = Eigen::AlignedBox3d(Eigen::Vector3d::Constant(-h), Eigen::Vector3d::Constant(h));
+	auto density_func = [&](Eigen::Vector3d const& x) {
+		auto dist = sdf->interpolate(0u, x);
+		if (dist > 2.0 * sph_kernel.getRadius())
+			return 0.0;
+		auto integrand = [&sph_kernel, &gamma, &x](Eigen::Vector3d const& xi) {
+			auto res = gamma(x + xi) * sph_kernel.W(xi);
+			return res;
+		};
+		auto res = GaussQuadrature::integrate(integrand, int_domain, 30);
+		return rho0 * res;
+	};
+	auto cell_diag = sdf->cellSize().norm();
+	auto t0 = std::chrono::high_resolution_clock::now();
+	sdf->addFunction(density_func, false, [&](Eigen::Vector3d const& x_) {
+		if (no_reduction)
+			return true;
+		auto x = x_.cwiseMax(sdf->domain().min()).cwiseMin(sdf->domain().max());
+		auto dist = sdf->interpolate(0u, x);
+		if (dist == std::numeric_limits<double>::max())
+			return false;
+		return -6.0 * h < dist + cell_diag && dist - cell_diag < 2.0 * h;
+	});
+	auto t1 = std::chrono::high_resolution_clock::now();
+	return std::chrono::duration<double>(t1 - t0).count();
+}
+// the two reduceField calls of main.cpp:135-147
+void ref_grid_reduce_density(void* hh, double h, double rho0)
+{
+	auto* sdf = static_cast<RefGrid*>(hh)->grid.get();
+	auto cell_diag = sdf->cellSize().norm();
+	sdf->reduceField(0u, [&](const Eigen::Vector3d&, double v) { return -6.0 * h < v + cell_diag && v - cell_diag < 2.0 * h; });
+	sdf->reduceField(1u, [&](const Eigen::Vector3d&, double v) { return 0.0 <= v && v <= 3.0 * rho0; });
 }
 
 // TriangleMeshDistance::signed_distance for a batch of points

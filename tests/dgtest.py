@@ -213,6 +213,9 @@ def oracle_lib():
         L.dgo_shape_functions.argtypes = [c_dp, C.c_size_t, c_dp, c_dp]
         L.dgo_interpolate.restype = C.c_double
         L.dgo_interpolate.argtypes = [c_dp, c_up, c_dp, c_up, c_up, c_dp, C.c_size_t, c_dp, c_dp]
+        L.dgo_density_map_nodes.restype = C.c_double
+        L.dgo_density_map_nodes.argtypes = [c_dp, c_up, c_dp, c_up, c_up, C.c_double, C.c_double, C.c_int, c_dp, c_dp,
+                                            C.c_uint, C.c_uint, c_dp]
         L.dgo_write_cdf.restype = C.c_size_t
         L.dgo_write_cdf.argtypes = [C.c_char_p, c_dp, c_up, C.POINTER(c_dp), C.c_size_t]
         _oracle = L
@@ -322,6 +325,44 @@ def oracle_interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=
     return (phi, g) if grad else phi
 
 
+def gauss_rule_p30():
+    """The reference's 16-point rule (table row p = 30 of gauss_quadrature.cpp, which lives in an
+    unnamed namespace and cannot be linked): parsed from the reference source by make_golden.py and
+    stored in the golden fixture."""
+    z = np.load(os.path.join(GOLDEN, "ref_vectors.npz"))
+    return z["gauss16_x"], z["gauss16_w"]
+
+
+def parse_reference_gauss_rule(p=30):
+    import re
+    src = open(os.path.join(REF_ROOT, "cmd", "generate_density_map", "gauss_quadrature.cpp")).read()
+    a = src.index("gaussian_abscissae_1[101][51]")
+    b = src.index("gaussian_weights_1[101][51]")
+
+    def row(s):
+        i = s.index("// p = %d\n" % p)
+        return np.array([float(v) for v in re.findall(r"[-+]?\d+\.\d+", s[i:s.index("}", i)])])
+    return row(src[a:b]), row(src[b:])
+
+
+def oracle_density_map(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, cells=None, cell_map=None):
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    if end is None:
+        end = n_nodes(res)
+    gx, gw = gauss_rule_p30()
+    gx, gw = np.ascontiguousarray(gx), np.ascontiguousarray(gw)
+    out = np.empty(end - begin)
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell_map = np.ascontiguousarray(cell_map, dtype=np.uint32)
+    secs = oracle_lib().dgo_density_map_nodes(dp(domain), up(res), dp(coeffs), up(cells), up(cell_map), h, rho0,
+                                              int(band), dp(gx), dp(gw), begin, end, dp(out))
+    oracle_density_map.last_seconds = secs
+    return out
+
+
 def oracle_write_cdf(path, domain, res, fields):
     domain = np.ascontiguousarray(domain, dtype=np.float64)
     res = np.ascontiguousarray(res, dtype=np.uint32)
@@ -372,6 +413,9 @@ def ref_lib():
         L.ref_grid_interpolate.argtypes = [C.c_void_p, C.c_uint, c_dp, C.c_size_t, c_dp, c_dp]
         L.ref_grid_reduce_abs_lt.argtypes = [C.c_void_p, C.c_uint, C.c_double]
         L.ref_signed_distance.argtypes = [C.c_void_p, c_dp, C.c_size_t, c_dp, c_ip, c_ip, c_dp]
+        L.ref_grid_add_density_map.restype = C.c_double
+        L.ref_grid_add_density_map.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.ref_grid_reduce_density.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ref_md_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 3
         L.ref_md_get.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_ip]
         _ref = L
@@ -458,6 +502,12 @@ class RefGrid:
         g = np.empty((len(P), 3)) if grad else None
         self.last_seconds = self.L.ref_grid_interpolate(self.h, f, dp(P), len(P), dp(phi), dp(g))
         return (phi, g) if grad else phi
+
+    def add_density_map(self, h, rho0, no_reduction=False):
+        return self.L.ref_grid_add_density_map(self.h, h, rho0, int(no_reduction))
+
+    def reduce_density(self, h, rho0):
+        self.L.ref_grid_reduce_density(self.h, h, rho0)
 
     def reduce_abs_lt(self, f, bound):
         self.L.ref_grid_reduce_abs_lt(self.h, f, float(bound))

@@ -35,6 +35,8 @@ def lib():
         L.emu_shard_count.restype = C.c_uint64
         L.emu_shard_count.argtypes = [T.c_up, C.c_int, C.c_int]
         L.emu_unpack.argtypes = [T.c_up, C.c_int, T.c_dp, C.c_uint64, T.c_dp]
+        L.emu_density_map.argtypes = [T.c_dp, T.c_dp, T.c_dp, T.c_up, T.c_dp, T.c_up, T.c_up, C.c_double, C.c_double,
+                                      C.c_int, C.c_uint64, C.c_uint64, T.c_dp]
         L.emu_interpolate.argtypes = [T.c_dp, T.c_dp, T.c_dp, T.c_up, T.c_dp, T.c_up, T.c_up, T.c_dp, C.c_uint64,
                                       T.c_dp, T.c_dp]
         _lib = L
@@ -113,6 +115,24 @@ class EmuMesh:
         near = np.empty((n, 3))
         self.L.emu_signed_distance(self.h, T.dp(P), n, T.dp(d), T.ip(tri), T.ip(ent), T.dp(near))
         return (d, tri, ent, near) if full else d
+
+
+def density_map(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, cells=None, cell_map=None):
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    cell = np.empty(3)
+    inv = np.empty(3)
+    T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    if end is None:
+        end = T.n_nodes(res)
+    out = np.empty(end - begin)
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell_map = np.ascontiguousarray(cell_map, dtype=np.uint32)
+    lib().emu_density_map(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), T.up(cells), T.up(cell_map),
+                          h, rho0, int(band), begin, end, T.dp(out))
+    return out
 
 
 def unpack(res, nranks, gathered, stride):

@@ -440,4 +440,35 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	}
 }
 
+// K3 on the host: the product's density_prefilter / density_integral and launch constants
+void emu_density_map(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
+					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, double h, double rho0, int band,
+					 uint64_t begin, uint64_t end, double* out)
+{
+	FieldDev F;
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = domain[d];
+		F.dmax[d] = domain[3 + d];
+		F.cell[d] = cell[d];
+		F.inv_cell[d] = inv_cell[d];
+		F.res[d] = res[d];
+	}
+	F.coeffs = coeffs;
+	F.cells = cells;
+	F.cell_map = cell_map;
+	F.cell_major = nullptr;
+	DensityParams P;
+	std::vector<double> w;
+	init_density_params(P, h, rho0, cell, band, w);
+	P.wtab = w.data();
+#pragma omp parallel for schedule(dynamic, 16)
+	for (long long l = (long long)begin; l < (long long)end; ++l)
+	{
+		double x[3], v;
+		node_position_flat((uint64_t)l, F.res, F.dmin, F.cell, x);
+		out[l - begin] = density_prefilter(F, P, x, &v) ? density_integral(F, P, x) : v;
+	}
+}
+
 } // extern "C"

@@ -109,6 +109,30 @@ def main():
     g.save(os.path.join(HERE, "torus_9_14_6.cdf"))
     g.reduce_abs_lt(0, 0.08)
     g.save(os.path.join(HERE, "torus_9_14_6_reduced_0p08.cdf"))
+    # density map (cmd/generate_density_map): torus SDF 9x14x6, h = 0.15, rho0 = 1000
+    gx, gw = T.parse_reference_gauss_rule(30)
+    assert len(gx) == 16 and len(gw) == 16
+    out["gauss16_x"], out["gauss16_w"] = gx, gw
+    g = T.RefGrid(path=os.path.join(HERE, "torus_9_14_6.cdf"))
+    secs = g.add_density_map(0.15, 1000.0)
+    print("density map (reference): %.1f s" % secs)
+    out["torus_density_h015"] = g.nodes(1)
+    g.save(os.path.join(HERE, "torus_9_14_6_density.cdm"))         # = GenerateDensityMap --no-reduction
+    g.reduce_density(0.15, 1000.0)
+    g.save(os.path.join(HERE, "torus_9_14_6_density_reduced.cdm")) # = GenerateDensityMap
+    # finer lattice where the node predicate and both reductions actually remove something
+    V, F = T.torus()
+    dom = T.ref_default_domain(V)
+    g = T.RefGrid(V, F, dom, [16, 16, 6])
+    g.add_sdf()
+    g.save(os.path.join(HERE, "torus_16_16_6.cdf"))
+    g.add_density_map(0.1, 1000.0)
+    out["torus16_density_h01"] = g.nodes(1)
+    g.reduce_density(0.1, 1000.0)
+    g.save(os.path.join(HERE, "torus_16_16_6_density_reduced.cdm"))
+    g2 = T.RefGrid(path=os.path.join(HERE, "torus_9_14_6.cdf"))
+    g2.add_density_map(0.15, 1000.0, no_reduction=True)
+    out["torus_density_h015_nopred"] = g2.nodes(1)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "ref_vectors.npz"))
 

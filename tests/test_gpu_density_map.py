@@ -1,0 +1,91 @@
+"""K3 on the GPU through the C ABI and through the GenerateDensityMap tool, against the
+reference's outputs (golden) and the oracle."""
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+import dgtest as T
+
+pytestmark = pytest.mark.gpu
+DBL_MAX = np.finfo(np.float64).max
+BUILD = os.path.join(T.ROOT, "discregrid_amd", "cpp", "build")
+
+
+@pytest.fixture(scope="module")
+def dg():
+    import discregrid_amd
+    discregrid_amd.load_library()
+    assert discregrid_amd.device_count() >= 1
+    return discregrid_amd
+
+
+@pytest.mark.parametrize("name,res,h,key", [("torus_9_14_6.cdf", [9, 14, 6], 0.15, "torus_density_h015"),
+                                             ("torus_16_16_6.cdf", [16, 16, 6], 0.1, "torus16_density_h01")])
+def test_density_map_vs_reference_golden(dg, golden, name, res, h, key):
+    g = T.read_cdf(os.path.join(T.GOLDEN, name))
+    grid = dg.grid_desc(g["domain"][:3], g["domain"][3:], res)
+    f = dg.Field(grid, g["nodes"][0])
+    n = dg.n_nodes(grid)
+    got = f.density_map_nodes(n, h, 1000.0, True)
+    want = golden[key]
+    rel = T.rel_err(got, want)
+    print("%s: max rel err %.3e, %d / %d not bit-equal, K3 %.2f ms" % (key, rel, int((got != want).sum()), n,
+                                                                       dg.last_kernel_ms()))
+    assert rel <= 1e-10
+    np.testing.assert_array_equal(got, want)
+    # ranges, mask, cell-major layout, no predicate
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 777, 2500), want[777:2500])
+    mask = (np.arange(n) % 3 != 0).astype(np.uint8)
+    m = f.density_map_nodes(n, h, 1000.0, True, mask=mask)
+    np.testing.assert_array_equal(m[mask == 1], want[mask == 1])
+    assert (m[mask == 0] == DBL_MAX).all()
+    f.build_cell_major()
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
+    if key == "torus_density_h015":
+        np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False), golden["torus_density_h015_nopred"])
+
+
+def test_generate_density_map_cli(tmp_path):
+    """GenerateDensityMap on the golden SDF files == the files the reference's tool flow writes
+    (addFunction with predicate, both reduceField calls, save), byte for byte."""
+    exe = os.path.join(BUILD, "GenerateDensityMap")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(BUILD)])
+    out = str(tmp_path / "a.cdm")
+    subprocess.check_call([exe, "-s", "0.1", "-r", "1000", "-o", out, os.path.join(T.GOLDEN, "torus_16_16_6.cdf")],
+                          stdout=subprocess.DEVNULL)
+    assert open(out, "rb").read() == open(os.path.join(T.GOLDEN, "torus_16_16_6_density_reduced.cdm"), "rb").read()
+    out2 = str(tmp_path / "b.cdm")
+    subprocess.check_call([exe, "--smoothing_length=0.15", "--no-reduction", "--output", out2,
+                           os.path.join(T.GOLDEN, "torus_9_14_6.cdf")], stdout=subprocess.DEVNULL)
+    got = T.read_cdf(out2)
+    want = T.read_cdf(os.path.join(T.GOLDEN, "torus_9_14_6_density.cdm"))
+    # the golden was produced WITH the predicate (which rejects nothing on this coarse lattice)
+    np.testing.assert_array_equal(got["nodes"][1], want["nodes"][1])
+    assert open(out2, "rb").read() == open(os.path.join(T.GOLDEN, "torus_9_14_6_density.cdm"), "rb").read()
+
+
+def test_density_map_bigger_lattice_vs_oracle(dg):
+    """Icosphere SDF at 40^3 (GPU-generated), density map with the tool's defaults (h = 0.1):
+    random node sample against the oracle; timing printed."""
+    V, F = T.icosphere(12)
+    dom = T.oracle_default_domain(V)
+    res = [40, 40, 40]
+    grid = dg.grid_desc(dom[:3], dom[3:], res)
+    sdf = dg.Mesh(V, F).sample_nodes(grid)
+    f = dg.Field(grid, sdf)
+    n = dg.n_nodes(grid)
+    t0 = time.time()
+    got = f.density_map_nodes(n, 0.1, 1000.0, True)
+    dt = time.time() - t0
+    active = int(((got != DBL_MAX) & (got != 0)).sum())
+    print("density map 40^3: %d nodes, %d integrated, K3 %.1f ms (%.2f G interpolations/s), wall %.2f s"
+          % (n, active, dg.last_kernel_ms(), active * 4097 / dg.last_kernel_ms() / 1e6, dt))
+    rng = np.random.default_rng(3)
+    for b in rng.integers(0, n - 64, size=12):
+        want = T.oracle_density_map(dom, res, sdf, 0.1, 1000.0, True, int(b), int(b) + 64)
+        np.testing.assert_array_equal(got[b:b + 64], want)
+    assert active > 20000
