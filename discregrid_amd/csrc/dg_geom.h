@@ -338,19 +338,23 @@ DG_HD FPoint make_fpoint(double rx, double ry, double rz, float mesh_l1)
 	f.hi[2] = z + e;
 	return f;
 }
-DG_HD float fmax2(float a, float b) { return a > b ? a : b; }
+// The bound arithmetic only prunes, so it may use fused multiply-adds (smaller rounding error,
+// fewer VALU instructions) and the hardware max (v_max_f32 / v_max3_f32; a NaN operand yields
+// the other operand, i.e. bound 0 = never prune).
+DG_HD float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
+DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 DG_HD float box_lb2(const float blo[3], const float bhi[3], const FPoint& p)
 {
-	const float dx = fmax2(fmax2(blo[0] - p.hi[0], p.lo[0] - bhi[0]), 0.0f);
-	const float dy = fmax2(fmax2(blo[1] - p.hi[1], p.lo[1] - bhi[1]), 0.0f);
-	const float dz = fmax2(fmax2(blo[2] - p.hi[2], p.lo[2] - bhi[2]), 0.0f);
-	return dx * dx + dy * dy + dz * dz;
+	const float dx = fmax3(blo[0] - p.hi[0], p.lo[0] - bhi[0], 0.0f);
+	const float dy = fmax3(blo[1] - p.hi[1], p.lo[1] - bhi[1], 0.0f);
+	const float dz = fmax3(blo[2] - p.hi[2], p.lo[2] - bhi[2], 0.0f);
+	return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 // squared slab lower bound (see TriSlab)
 DG_HD float slab_lb2(float ux, float uy, float uz, float lo, float hi, const FPoint& p)
 {
-	const float t = ux * p.x[0] + uy * p.x[1] + uz * p.x[2];
-	const float d = fmax2(fmax2(t - p.es - hi, lo - t - p.es), 0.0f);
+	const float t = __builtin_fmaf(ux, p.x[0], __builtin_fmaf(uy, p.x[1], uz * p.x[2]));
+	const float d = fmax3(t - p.es - hi, lo - t - p.es, 0.0f);
 	return d * d;
 }
 // node bound = max(box bound, slab bound)
