@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <unordered_map>
@@ -108,82 +109,113 @@ struct Prim
 	uint32_t tri;
 };
 
+// box + slab of a set of primitives, float, relative to origin, rounded outward
+struct Bounds
+{
+	float lo[3], hi[3], u[3], slo, shi;
+};
+
+inline float down(double v) { return std::nextafterf(round_down(v), -std::numeric_limits<float>::infinity()); }
+inline float up(double v) { return std::nextafterf(round_up(v), std::numeric_limits<float>::infinity()); }
+
+Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
+{
+	Bounds B;
+	double lo[3], hi[3], m[3] = {0, 0, 0};
+	for (int d = 0; d < 3; ++d)
+	{
+		lo[d] = std::numeric_limits<double>::max();
+		hi[d] = std::numeric_limits<double>::lowest();
+	}
+	for (size_t i = 0; i < n; ++i)
+		for (int d = 0; d < 3; ++d)
+		{
+			lo[d] = std::min(lo[d], p[i].lo[d]);
+			hi[d] = std::max(hi[d], p[i].hi[d]);
+			m[d] += p[i].an[d];
+		}
+	for (int d = 0; d < 3; ++d)
+	{
+		// two ulps outward: the subtraction of the origin rounds as well
+		B.lo[d] = down(lo[d] - origin[d]);
+		B.hi[d] = up(hi[d] - origin[d]);
+	}
+	// slab along the area-weighted mean normal, shrunk by 1e-6 so that |u| <= 1 after rounding
+	const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+	B.u[0] = B.u[1] = B.u[2] = 0.0f; // u = 0: lower bound 0, never prunes (degenerate / cancelling normals)
+	B.slo = B.shi = 0.0f;
+	if (len > 0 && std::isfinite(len))
+	{
+		const double sc = (1.0 - 1.0e-6) / len;
+		for (int d = 0; d < 3; ++d)
+			B.u[d] = (float)(m[d] * sc);
+		double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+			{
+				const double pr = (double)B.u[0] * (p[i].v[k][0] - origin[0]) + (double)B.u[1] * (p[i].v[k][1] - origin[1]) +
+								  (double)B.u[2] * (p[i].v[k][2] - origin[2]);
+				plo = std::min(plo, pr);
+				phi = std::max(phi, pr);
+			}
+		B.slo = down(plo);
+		B.shi = up(phi);
+	}
+	return B;
+}
+
+void put_side(PairRec& r, int side, const Bounds& B)
+{
+	for (int d = 0; d < 3; ++d)
+	{
+		r.f[d][side] = B.lo[d];
+		r.f[3 + d][side] = B.hi[d];
+		r.f[6 + d][side] = B.u[d];
+	}
+	r.f[9][side] = B.slo;
+	r.f[10][side] = B.shi;
+}
+// a side that can never be hit: empty box (distance = inf)
+void put_empty(PairRec& r, int side)
+{
+	for (int d = 0; d < 3; ++d)
+	{
+		r.f[d][side] = std::numeric_limits<float>::max();
+		r.f[3 + d][side] = -std::numeric_limits<float>::max();
+		r.f[6 + d][side] = 0.0f;
+	}
+	r.f[9][side] = r.f[10][side] = 0.0f;
+}
+void clear_rec(PairRec& r)
+{
+	std::memset(&r, 0, sizeof(r));
+	put_empty(r, 0);
+	put_empty(r, 1);
+}
+
 struct Builder
 {
 	std::vector<Prim> prims;
-	std::vector<BvhNode> nodes;
-	std::vector<uint32_t> order; // leaf order -> caller triangle index
+	std::vector<PairRec> pairs;
+	std::vector<int64_t> order; // position (leaf order, padded to even per leaf) -> prim index or -1
 	const double* origin;
 	int max_leaf;
 	uint32_t depth = 0;
 
-	void emit_box(BvhNode& n, size_t b, size_t e)
-	{
-		double lo[3], hi[3];
-		for (int d = 0; d < 3; ++d)
-		{
-			lo[d] = std::numeric_limits<double>::max();
-			hi[d] = std::numeric_limits<double>::lowest();
-		}
-		for (size_t i = b; i < e; ++i)
-			for (int d = 0; d < 3; ++d)
-			{
-				lo[d] = std::min(lo[d], prims[i].lo[d]);
-				hi[d] = std::max(hi[d], prims[i].hi[d]);
-			}
-		for (int d = 0; d < 3; ++d)
-		{
-			n.lo[d] = round_down(lo[d] - origin[d]);
-			n.hi[d] = round_up(hi[d] - origin[d]);
-			// one more ulp outward: the subtraction above rounds too
-			n.lo[d] = std::nextafterf(n.lo[d], -std::numeric_limits<float>::infinity());
-			n.hi[d] = std::nextafterf(n.hi[d], std::numeric_limits<float>::infinity());
-		}
-		// slab along the area-weighted mean normal of the subtree
-		double m[3] = {0, 0, 0};
-		for (size_t i = b; i < e; ++i)
-			for (int d = 0; d < 3; ++d)
-				m[d] += prims[i].an[d];
-		const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-		n.su[0] = n.su[1] = n.su[2] = 0.0f;
-		n.slo = n.shi = 0.0f;
-		n.pad_[0] = n.pad_[1] = n.pad_[2] = 0.0f;
-		if (len > 0 && std::isfinite(len))
-		{
-			const double sc = (1.0 - 1.0e-6) / len;
-			for (int d = 0; d < 3; ++d)
-				n.su[d] = (float)(m[d] * sc);
-			double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
-			for (size_t i = b; i < e; ++i)
-				for (int k = 0; k < 3; ++k)
-				{
-					const double pr = (double)n.su[0] * (prims[i].v[k][0] - origin[0]) +
-									  (double)n.su[1] * (prims[i].v[k][1] - origin[1]) +
-									  (double)n.su[2] * (prims[i].v[k][2] - origin[2]);
-					plo = std::min(plo, pr);
-					phi = std::max(phi, pr);
-				}
-			n.slo = std::nextafterf(round_down(plo), -std::numeric_limits<float>::infinity());
-			n.shi = std::nextafterf(round_up(phi), std::numeric_limits<float>::infinity());
-		}
-	}
-
-	// Depth-first emission.  Split: object median along the largest extent of the centroid
-	// bounds (balanced tree, depth = ceil(log2(n / max_leaf))).
-	void build(size_t b, size_t e, uint32_t level)
+	// Returns the info word of the subtree over prims [b, e).  Split: object median along the
+	// largest extent of the centroid bounds (balanced tree, depth = ceil(log2(n / max_leaf))).
+	int32_t build(size_t b, size_t e, uint32_t level)
 	{
 		depth = std::max(depth, level);
-		const size_t me = nodes.size();
-		nodes.push_back(BvhNode());
-		emit_box(nodes[me], b, e);
 		if (e - b <= (size_t)max_leaf)
 		{
 			const uint32_t first = (uint32_t)order.size();
 			for (size_t i = b; i < e; ++i)
-				order.push_back(prims[i].tri);
-			nodes[me].info = ~(int32_t)((first << kLeafBits) | (uint32_t)(e - b - 1));
-			nodes[me].skip = (int32_t)nodes.size();
-			return;
+				order.push_back((int64_t)i);
+			if ((e - b) & 1u)
+				order.push_back(-1); // padding slot: leaves start at even positions
+			const uint32_t positions = (uint32_t)order.size() - first;
+			return ~(int32_t)((first << kLeafBits) | (positions - 1));
 		}
 		double clo[3], chi[3];
 		for (int d = 0; d < 3; ++d)
@@ -201,7 +233,7 @@ struct Builder
 		for (int d = 1; d < 3; ++d)
 			if (chi[d] - clo[d] > chi[axis] - clo[axis])
 				axis = d;
-		// keep leaves full: left half gets a multiple of max_leaf when possible
+		// keep leaves full: the left half gets a multiple of max_leaf when possible
 		size_t half = (e - b) / 2;
 		if ((e - b) > (size_t)(2 * max_leaf))
 			half = ((half + max_leaf - 1) / max_leaf) * max_leaf;
@@ -210,10 +242,16 @@ struct Builder
 						 [axis](const Prim& p, const Prim& q) {
 							 return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.tri < q.tri);
 						 });
-		build(b, mid, level + 1);
-		nodes[me].info = (int32_t)nodes.size(); // right child
-		build(mid, e, level + 1);
-		nodes[me].skip = (int32_t)nodes.size();
+		const size_t rec = pairs.size();
+		pairs.emplace_back();
+		clear_rec(pairs[rec]);
+		const int32_t il = build(b, mid, level + 1);
+		const int32_t ir = build(mid, e, level + 1);
+		put_side(pairs[rec], 0, bounds_of(&prims[b], mid - b, origin));
+		put_side(pairs[rec], 1, bounds_of(&prims[mid], e - mid, origin));
+		pairs[rec].info[0] = il;
+		pairs[rec].info[1] = ir;
+		return (int32_t)rec;
 	}
 };
 
@@ -275,71 +313,39 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	for (int d = 0; d < 3; ++d)
 		out.origin[d] = 0.5 * (lo[d] + hi[d]);
 	B.origin = out.origin;
-	B.nodes.reserve(2 * n_triangles / max_leaf + 16);
-	B.order.reserve(n_triangles);
-	B.build(0, n_triangles, 0);
+	B.pairs.reserve(2 * n_triangles / max_leaf + 16);
+	B.order.reserve(n_triangles + n_triangles / 2 + 2);
+	out.root_info = B.build(0, n_triangles, 0);
 
-	out.nodes.swap(B.nodes);
+	out.pairs.swap(B.pairs);
 	out.depth = B.depth;
 	out.n_vertices = n_vertices;
 	out.n_triangles = n_triangles;
-	out.tris.resize(n_triangles);
-	out.pn.assign(n_triangles * kPnSlots * 3, 0.0);
+	const size_t npos = B.order.size(); // even
+	out.tris.resize(npos);
+	out.pn.assign(npos * kPnSlots * 3, 0.0);
+	out.tri_pairs.resize(npos / 2);
+	for (auto& r : out.tri_pairs)
+		clear_rec(r);
 	double l1 = 0.0;
 	for (size_t i = 0; i < n_vertices; ++i)
 		l1 = std::max(l1, std::fabs(V[i].x - out.origin[0]) + std::fabs(V[i].y - out.origin[1]) +
 							  std::fabs(V[i].z - out.origin[2]));
 	out.mesh_l1 = std::nextafterf(round_up(l1), std::numeric_limits<float>::infinity());
-	out.slabs.assign(n_triangles + 4, TriSlab());
-	for (auto& sl : out.slabs)
+	for (size_t k = 0; k < npos; ++k)
 	{
-		sl.u[0] = sl.u[1] = sl.u[2] = 0.0f; // u = 0: lower bound 0, never prunes (padding, degenerate triangles)
-		sl.lo = sl.hi = 0.0f;
-		sl.pad_ = 0.0f;
-		for (int d = 0; d < 3; ++d)
+		if (B.order[k] < 0)
 		{
-			// padding entries: an empty box far away is never "hit" but is never used either
-			sl.blo[d] = 0.0f;
-			sl.bhi[d] = 0.0f;
+			// padding slot: a copy of its left neighbour's packet that no bound test can select
+			out.tris[k] = out.tris[k - 1];
+			out.tris[k].tri_id = -1;
+			continue;
 		}
-	}
-	for (size_t k = 0; k < n_triangles; ++k)
-	{
-		const uint32_t t = B.order[k];
-		{
-			// slab direction: the face normal shrunk by 1e-6 so that |u| <= 1 after rounding to float
-			const D3 a = V[tris[3 * t]], b = V[tris[3 * t + 1]], c = V[tris[3 * t + 2]];
-			const D3 n = cross3(sub(b, a), sub(c, a));
-			const double len = std::sqrt(dot3(n, n));
-			TriSlab& sl = out.slabs[k];
-			for (int d = 0; d < 3; ++d)
-			{
-				const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z}, cv[3] = {c.x, c.y, c.z};
-				const double lo = std::min(av[d], std::min(bv[d], cv[d])) - out.origin[d];
-				const double hi = std::max(av[d], std::max(bv[d], cv[d])) - out.origin[d];
-				sl.blo[d] = std::nextafterf(round_down(lo), -std::numeric_limits<float>::infinity());
-				sl.bhi[d] = std::nextafterf(round_up(hi), std::numeric_limits<float>::infinity());
-			}
-			if (len > 0 && std::isfinite(len))
-			{
-				const double sc = (1.0 - 1.0e-6) / len;
-				sl.u[0] = (float)(n.x * sc);
-				sl.u[1] = (float)(n.y * sc);
-				sl.u[2] = (float)(n.z * sc);
-				double lo = std::numeric_limits<double>::max(), hi = std::numeric_limits<double>::lowest();
-				for (const D3& v : {a, b, c})
-				{
-					const double pr = (double)sl.u[0] * (v.x - out.origin[0]) + (double)sl.u[1] * (v.y - out.origin[1]) +
-									  (double)sl.u[2] * (v.z - out.origin[2]);
-					lo = std::min(lo, pr);
-					hi = std::max(hi, pr);
-				}
-				sl.lo = std::nextafterf(round_down(lo), -std::numeric_limits<float>::infinity());
-				sl.hi = std::nextafterf(round_up(hi), std::numeric_limits<float>::infinity());
-			}
-		}
+		const Prim& P = B.prims[(size_t)B.order[k]];
+		const uint32_t t = P.tri;
 		make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
 					out.tris[k]);
+		put_side(out.tri_pairs[k / 2], (int)(k & 1), bounds_of(&P, 1, out.origin));
 		for (int s = 0; s < kPnSlots; ++s)
 		{
 			out.pn[(k * kPnSlots + s) * 3 + 0] = pn[t * kPnSlots + s].x;

@@ -3,7 +3,7 @@
 //     (discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:359-420) -- the sign of the
 //     distance depends on them bit for bit;
 //   * triangle packets (dg_geom.h) in BVH leaf order;
-//   * a flattened AABB BVH of this library's own design (the reference's bounding-sphere tree
+//   * a flattened BVH of this library's own design, stored as sibling-pair records (the reference's bounding-sphere tree
 //     is not reproduced: traversal order and bounding volumes only prune).
 #pragma once
 #include <cstddef>
@@ -16,14 +16,15 @@ namespace dg
 
 struct MeshBuild
 {
-	std::vector<BvhNode> nodes;    // depth-first, skip pointers
-	std::vector<TriPacket> tris;   // leaf order
-	std::vector<TriSlab> slabs;    // leaf order, padded by 4 entries (leaves are read in groups of 4)
-	std::vector<double> pn;        // kPnSlots * 3 doubles per triangle, leaf order
-	double origin[3];              // boxes are relative to this point
-	float mesh_l1 = 0;             // max over vertices of |v - origin|_1, rounded up
+	std::vector<PairRec> pairs;     // node pairs; an inner node's record holds its two children
+	std::vector<PairRec> tri_pairs; // triangle bound pairs: position t -> tri_pairs[t / 2], side t & 1
+	std::vector<TriPacket> tris;    // one per position (leaf order; padding slots have tri_id = -1)
+	std::vector<double> pn;         // kPnSlots * 3 doubles per position
+	int32_t root_info = 0;          // info word of the root (dg_geom.h)
+	double origin[3];               // bounds are relative to this point
+	float mesh_l1 = 0;              // max over vertices of |v - origin|_1, rounded up
 	uint32_t depth = 0;
-	uint32_t not_watertight = 0;   // bit0 single edge, bit1 edge shared by > 2 faces
+	uint32_t not_watertight = 0;    // bit0 single edge, bit1 edge shared by > 2 faces
 	uint64_t n_vertices = 0, n_triangles = 0;
 };
 

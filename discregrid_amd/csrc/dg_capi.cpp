@@ -25,9 +25,9 @@
 struct dg_mesh
 {
 	dg::MeshDev dev;
-	void* d_nodes = nullptr;
+	void* d_pairs = nullptr;
+	void* d_tri_pairs = nullptr;
 	void* d_tris = nullptr;
-	void* d_slabs = nullptr;
 	void* d_pn = nullptr;
 	int device = -1;
 	dg_mesh_info info;
@@ -189,17 +189,17 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	if (!m)
 		return fail(DG_ERR_ALLOC, "host allocation failed");
 	std::memset(&m->info, 0, sizeof(m->info));
-	const size_t nb = B.nodes.size() * sizeof(dg::BvhNode);
+	const size_t nb = B.pairs.size() * sizeof(dg::PairRec);
+	const size_t sb = B.tri_pairs.size() * sizeof(dg::PairRec);
 	const size_t tb = B.tris.size() * sizeof(dg::TriPacket);
 	const size_t pb = B.pn.size() * sizeof(double);
-	const size_t sb = B.slabs.size() * sizeof(dg::TriSlab);
 	hipError_t e = hipGetDevice(&m->device);
-	if (e == hipSuccess) e = hipMalloc(&m->d_nodes, nb);
+	if (e == hipSuccess) e = hipMalloc(&m->d_pairs, std::max<size_t>(nb, 128));
+	if (e == hipSuccess) e = hipMalloc(&m->d_tri_pairs, sb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_tris, tb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_pn, pb);
-	if (e == hipSuccess) e = hipMalloc(&m->d_slabs, sb);
-	if (e == hipSuccess) e = hipMemcpy(m->d_slabs, B.slabs.data(), sb, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(m->d_nodes, B.nodes.data(), nb, hipMemcpyHostToDevice);
+	if (e == hipSuccess && nb) e = hipMemcpy(m->d_pairs, B.pairs.data(), nb, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(m->d_tri_pairs, B.tri_pairs.data(), sb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_tris, B.tris.data(), tb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_pn, B.pn.data(), pb, hipMemcpyHostToDevice);
 	if (e != hipSuccess)
@@ -208,19 +208,21 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "mesh upload failed: %s",
 					hipGetErrorString(e));
 	}
-	m->dev.nodes = static_cast<const dg::BvhNode*>(m->d_nodes);
+	m->dev.pairs = static_cast<const dg::PairRec*>(m->d_pairs);
+	m->dev.tri_pairs = static_cast<const dg::PairRec*>(m->d_tri_pairs);
 	m->dev.tris = static_cast<const dg::TriPacket*>(m->d_tris);
 	m->dev.pn = static_cast<const double*>(m->d_pn);
-	m->dev.slabs = static_cast<const dg::TriSlab*>(m->d_slabs);
-	m->dev.mesh_l1 = B.mesh_l1;
-	m->dev.pad_ = 0.0f;
-	m->dev.n_nodes = (int32_t)B.nodes.size();
-	m->dev.n_tris = (int32_t)B.tris.size();
+	m->dev.root_info = B.root_info;
+	m->dev.n_positions = (int32_t)B.tris.size();
+	m->dev.stack_levels = (int32_t)std::min<uint32_t>(B.depth + 1, dg::kStackDepth);
+	m->dev.pad0_ = 0;
 	for (int d = 0; d < 3; ++d)
 		m->dev.origin[d] = B.origin[d];
+	m->dev.mesh_l1 = B.mesh_l1;
+	m->dev.pad_ = 0.0f;
 	m->info.n_vertices = n_vertices;
 	m->info.n_triangles = n_triangles;
-	m->info.n_bvh_nodes = B.nodes.size();
+	m->info.n_bvh_nodes = 2 * B.pairs.size() + 1;
 	m->info.bvh_depth = B.depth;
 	m->info.not_watertight = B.not_watertight;
 	m->info.device_bytes = nb + tb + pb + sb;
@@ -241,10 +243,10 @@ void dg_mesh_destroy(dg_mesh* m)
 {
 	if (!m)
 		return;
-	if (m->d_nodes) (void)hipFree(m->d_nodes);
+	if (m->d_pairs) (void)hipFree(m->d_pairs);
+	if (m->d_tri_pairs) (void)hipFree(m->d_tri_pairs);
 	if (m->d_tris) (void)hipFree(m->d_tris);
 	if (m->d_pn) (void)hipFree(m->d_pn);
-	if (m->d_slabs) (void)hipFree(m->d_slabs);
 	delete m;
 }
 

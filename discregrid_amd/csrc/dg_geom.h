@@ -25,24 +25,30 @@ namespace dg
 {
 
 // ---- data layouts (shared by host builder and device kernels) ------------------------------
-// One BVH node = 64 bytes = one s_load_dwordx16.  Bounds are float, relative to the mesh origin,
-// rounded OUTWARD: they are only ever used to prune, so their arithmetic is free.  A node
-// carries an axis-aligned box AND one slab (see TriSlab) along the area-weighted mean normal of
-// its subtree: a smooth surface patch is thin along its normal however it is oriented, which
-// the box cannot express.  Nodes are stored in depth-first order; `skip` is the index of the
-// next node when the subtree is pruned (stackless traversal: next = hit ? idx + 1 : skip).
-struct alignas(64) BvhNode
+// Bounds come in PAIRS: one 128-byte record holds the bounds of two sibling BVH nodes (or of two
+// neighbouring triangles of a leaf), interleaved field by field, so that (a) one scalar load
+// fetches both and (b) the wave tests both with packed two-wide float instructions
+// (v_pk_add/mul/fma_f32) -- the kernel is VALU-issue bound, every packed instruction saved is
+// time saved.  All bounds are float, relative to the mesh origin, rounded OUTWARD: they are only
+// ever used to prune, so their arithmetic is free.  Each item has an axis-aligned box AND one
+// slab: a direction u (|u| <= 1; the area-weighted mean normal of the subtree / the triangle's
+// normal) with the interval [lo, hi] of u.(x - origin) over the item.  For ANY |u| <= 1:
+//     dist(p, item) >= max(u.p - hi, lo - u.p, 0)
+// -- a one-direction k-DOP that is tight exactly where boxes are loose: a smooth surface patch is
+// thin along its normal however it is oriented, and a query on the concave side of a curved
+// surface sees dozens of nearly equidistant facets whose boxes all overlap the search sphere.
+struct alignas(128) PairRec
 {
-	float lo[3];
-	float hi[3];
-	int32_t skip;
-	int32_t info; // >= 0: index of the right child (left child = idx + 1);  < 0: leaf, ~info = (first << kLeafBits) | (count - 1), count <= 16
-	float su[3];  // slab direction, |su| <= 1 (0 = no slab)
-	float slo, shi;
-	float pad_[3];
+	float f[11][2];  // [k][side], k: 0..2 box lo xyz, 3..5 box hi xyz, 6..8 slab direction, 9 slab lo, 10 slab hi
+	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
+	float pad_[8];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-static const int kLeafBits = 4;      // leaf triangle count - 1 in the low bits of ~info
+static_assert(sizeof(PairRec) == 128, "PairRec must be 128 bytes");
+// info word of a subtree:  >= 0: index of the PairRec holding its two children;
+//                          <  0: leaf, ~info = (first_position << kLeafBits) | (positions - 1),
+// where positions (<= 16, even) counts triangle slots in leaf order including one padding slot
+// for leaves with an odd triangle count (padding slots have empty bounds and are never tested).
+static const int kLeafBits = 4;
 static const int kMaxLeaf = 16;
 
 // One triangle packet = 128 bytes, in BVH leaf order.  The point-independent terms of the
@@ -62,23 +68,6 @@ struct alignas(128) TriPacket
 	int32_t pad_;
 };
 static_assert(sizeof(TriPacket) == 128, "TriPacket must be 128 bytes");
-
-// One bound record per triangle = 48 bytes, leaf order: a float direction u (|u| <= 1, ~ the face normal)
-// and the interval [lo, hi] of u.(x - origin) over the triangle's vertices, rounded outward.
-// For ANY |u| <= 1:  dist(p, triangle) >= max(u.p - hi, lo - u.p, 0)  -- a one-direction k-DOP
-// that is tight exactly where boxes are loose (queries on the concave side of a curved surface
-// see dozens of nearly equidistant facets whose AABBs all overlap the search sphere).
-// The record also carries the triangle's own axis-aligned box (leaves hold up to 4 triangles;
-// the leaf box is much looser than each triangle's).
-struct alignas(16) TriSlab
-{
-	float u[3];
-	float lo, hi;
-	float blo[3];
-	float bhi[3];
-	float pad_;
-};
-static_assert(sizeof(TriSlab) == 48, "TriSlab must be 48 bytes");
 
 // Pseudonormals, 8 slots of 3 doubles per triangle (leaf order), slot = nearest entity:
 // 0..2 vertex normals of v0,v1,v2; 3..5 edge normals E01,E12,E02; 6 face normal; 7 unused.
@@ -341,26 +330,47 @@ DG_HD FPoint make_fpoint(double rx, double ry, double rz, float mesh_l1)
 // The bound arithmetic only prunes, so it may use fused multiply-adds (smaller rounding error,
 // fewer VALU instructions) and the hardware max (v_max_f32 / v_max3_f32; a NaN operand yields
 // the other operand, i.e. bound 0 = never prune).
+#if defined(__clang__)
+typedef float f2 __attribute__((ext_vector_type(2))); // two-wide: v_pk_*_f32 on gfx950
+DG_HD f2 f2_make(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+DG_HD f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f2
+{
+	float x, y;
+};
+DG_HD f2 f2_make(float a, float b) { return f2{a, b}; }
+DG_HD f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+DG_HD f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+DG_HD f2 f2_fma(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
+DG_HD f2 f2_splat(float a) { return f2_make(a, a); }
 DG_HD float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-DG_HD float box_lb2(const float blo[3], const float bhi[3], const FPoint& p)
+
+// Squared lower bounds (box and slab combined) of BOTH items of a pair record for one query.
+// r = the record's 22 interleaved floats (PairRec::f).
+DG_HD f2 pair_lb2(const float* r, const FPoint& p)
 {
-	const float dx = fmax3(blo[0] - p.hi[0], p.lo[0] - bhi[0], 0.0f);
-	const float dy = fmax3(blo[1] - p.hi[1], p.lo[1] - bhi[1], 0.0f);
-	const float dz = fmax3(blo[2] - p.hi[2], p.lo[2] - bhi[2], 0.0f);
-	return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-// squared slab lower bound (see TriSlab)
-DG_HD float slab_lb2(float ux, float uy, float uz, float lo, float hi, const FPoint& p)
-{
-	const float t = __builtin_fmaf(ux, p.x[0], __builtin_fmaf(uy, p.x[1], uz * p.x[2]));
-	const float d = fmax3(t - p.es - hi, lo - t - p.es, 0.0f);
-	return d * d;
-}
-// node bound = max(box bound, slab bound)
-DG_HD float node_lb2(const float blo[3], const float bhi[3], const float su[3], float slo, float shi, const FPoint& p)
-{
-	return fmax2(box_lb2(blo, bhi, p), slab_lb2(su[0], su[1], su[2], slo, shi, p));
+	f2 acc = f2_splat(0.0f);
+	for (int d = 0; d < 3; ++d)
+	{
+		const f2 lo = f2_make(r[2 * d], r[2 * d + 1]);
+		const f2 hi = f2_make(r[6 + 2 * d], r[6 + 2 * d + 1]);
+		const f2 a = lo - f2_splat(p.hi[d]);
+		const f2 b = f2_splat(p.lo[d]) - hi;
+		const f2 m = f2_make(fmax3(a.x, b.x, 0.0f), fmax3(a.y, b.y, 0.0f));
+		acc = f2_fma(m, m, acc);
+	}
+	f2 t = f2_make(r[16], r[17]) * f2_splat(p.x[2]);
+	t = f2_fma(f2_make(r[14], r[15]), f2_splat(p.x[1]), t);
+	t = f2_fma(f2_make(r[12], r[13]), f2_splat(p.x[0]), t);
+	const f2 es = f2_splat(p.es);
+	const f2 q1 = t - es - f2_make(r[20], r[21]);
+	const f2 q2 = f2_make(r[18], r[19]) - t - es;
+	const f2 ds = f2_make(fmax3(q1.x, q2.x, 0.0f), fmax3(q1.y, q2.y, 0.0f));
+	const f2 s2 = ds * ds;
+	return f2_make(fmax2(acc.x, s2.x), fmax2(acc.y, s2.y));
 }
 // float upper bound of the running best d^2 (strictly above it unless it is 0 or inf)
 DG_HD float best_as_float(double d2)

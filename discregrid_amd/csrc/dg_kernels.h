@@ -17,16 +17,19 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 
 struct MeshDev
 {
-	const BvhNode* nodes;
-	const TriPacket* tris;
-	const TriSlab* slabs; // n_tris + 4 entries
-	const double* pn;
-	int32_t n_nodes;
-	int32_t n_tris;
+	const PairRec* pairs;     // node pairs (dg_geom.h)
+	const PairRec* tri_pairs; // triangle bound pairs, position t -> [t / 2] side t & 1
+	const TriPacket* tris;    // one per position
+	const double* pn;         // pseudonormals, kPnSlots x 3 per position
+	int32_t root_info;
+	int32_t n_positions;
+	int32_t stack_levels; // tree depth + 1 (<= kStackDepth): LDS bound-stack levels a traversal can need
+	int32_t pad0_;
 	double origin[3];
 	float mesh_l1;
 	float pad_;
 };
+static const int kStackDepth = 32; // >= tree depth; 2^32 leaves of >= 1 triangle is beyond the 2^27 triangle limit
 
 // One of the four node classes of the lattice as the K1 kernel sees it (see dg_geom.h
 // node_position() for the (a, b, s) coordinates).  The kernel walks "packed planes"

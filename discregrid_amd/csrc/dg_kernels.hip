@@ -14,9 +14,9 @@
 //     unit (s_load_dwordx8 / x16 into SGPRs) and broadcast to all lanes for free; lanes only
 //     differ in their query point and running best.  No per-lane stack, no divergent gathers
 //     in the loop.
-//   * Near-first traversal with one wave-shared stack held in a single VGPR (v_writelane /
-//     v_readlane), so the bound tightens after the first leaf; nodes carry a box AND a slab
-//     along the mean normal of their subtree, triangles a slab along their own normal.
+//   * Near-first traversal with one wave-shared stack (subtree ids in one VGPR, per-lane bounds
+//     parked in LDS); bounds = box AND slab along the (mean) normal, stored as sibling pairs and
+//     evaluated two at a time with packed float math.
 //   * Box tests in conservative float (they only prune); triangle tests in double with the
 //     reference's exact operation order (no FMA contraction) so d^2, the winning feature and
 //     the sign reproduce the reference bit for bit.
@@ -29,10 +29,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dg_kernels.h"
-
-#ifndef DG_TRI_BOX
-#define DG_TRI_BOX 1 // per-triangle box in the leaf pre-test (in addition to the slab)
-#endif
 
 namespace dg
 {
@@ -60,80 +56,48 @@ __device__ __forceinline__ double pack_double(int lo, int hi)
 	return __hiloint2double(hi, lo);
 }
 
-struct SNode
+// first 24 dwords of a pair record: 22 interleaved bound floats + the two info words
+struct SPair
 {
-	float lo[3], hi[3];
-	int skip, info;
-	float su[3], slo, shi;
+	float r[22];
+	int info0, info1;
 };
-__device__ __forceinline__ SNode load_node(const BvhNode* nodes, int idx)
+__device__ __forceinline__ SPair load_pair(const PairRec* base, int idx)
 {
-	const v16i v = sload16(nodes + idx);
-	SNode n;
-	n.su[0] = __int_as_float(v[8]);
-	n.su[1] = __int_as_float(v[9]);
-	n.su[2] = __int_as_float(v[10]);
-	n.slo = __int_as_float(v[11]);
-	n.shi = __int_as_float(v[12]);
-	n.lo[0] = __int_as_float(v[0]);
-	n.lo[1] = __int_as_float(v[1]);
-	n.lo[2] = __int_as_float(v[2]);
-	n.hi[0] = __int_as_float(v[3]);
-	n.hi[1] = __int_as_float(v[4]);
-	n.hi[2] = __int_as_float(v[5]);
-	n.skip = v[6];
-	n.info = v[7];
-	return n;
+	const char* p = (const char*)(base + idx);
+	const v16i a = sload16(p);
+	const v8i b = sload8(p + 64);
+	SPair s;
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		s.r[i] = __int_as_float(a[i]);
+#pragma unroll
+	for (int i = 0; i < 6; ++i)
+		s.r[16 + i] = __int_as_float(b[i]);
+	s.info0 = b[6];
+	s.info1 = b[7];
+	return s;
 }
 
-// Leaf of `cnt` <= 16 triangles starting at packet `first` (wave-uniform arguments), handled in
-// groups of 4.  A triangle gets the full double-precision test only if some lane's float lower
-// bound -- the largest of the leaf bound, the triangle's own slab and (DG_TRI_BOX) the
-// triangle's own box -- is below that lane's running best.
+// Leaf: `cnt` triangle positions (even, <= 16) starting at the even position `first`
+// (wave-uniform arguments), handled pair by pair.  A triangle gets the full double-precision
+// test only if some lane's float lower bound -- the larger of the leaf's bound and the
+// triangle's own box+slab bound -- is below that lane's running best.
 __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
 {
-	for (int g0 = 0; g0 < cnt; g0 += 4)
+	for (int g = 0; g < cnt; g += 2)
 	{
-		const int gfirst = first + g0;
-		const int gcnt = (cnt - g0) < 4 ? (cnt - g0) : 4;
-		// the 4 bound records of the group (4 x 48 B) in three scalar loads (the array is padded:
-		// a group with fewer than 4 triangles reads its neighbours' records and ignores them)
-		const char* sbase = (const char*)(M.slabs + gfirst);
-		const v16i s0 = sload16(sbase);
-		const v16i s1 = sload16(sbase + 64);
-		const v16i s2 = sload16(sbase + 128);
-		int rec[48];
+		const SPair pr = load_pair(M.tri_pairs, (first + g) >> 1);
+		const f2 lb = pair_lb2(pr.r, q.fp);
+		const bool w0 = __ballot(fmax2(lb.x, leaf_lb2) < q.bestf) != 0ull;
+		const bool w1 = __ballot(fmax2(lb.y, leaf_lb2) < q.bestf) != 0ull;
 #pragma unroll
-		for (int i = 0; i < 16; ++i)
+		for (int side = 0; side < 2; ++side)
 		{
-			rec[i] = s0[i];
-			rec[16 + i] = s1[i];
-			rec[32 + i] = s2[i];
-		}
-		unsigned want = 0;
-#pragma unroll
-		for (int t = 0; t < 4; ++t)
-		{
-			const int o = 12 * t;
-			const float slab = slab_lb2(__int_as_float(rec[o + 0]), __int_as_float(rec[o + 1]),
-										__int_as_float(rec[o + 2]), __int_as_float(rec[o + 3]),
-										__int_as_float(rec[o + 4]), q.fp);
-#if DG_TRI_BOX
-			const float blo[3] = {__int_as_float(rec[o + 5]), __int_as_float(rec[o + 6]), __int_as_float(rec[o + 7])};
-			const float bhi[3] = {__int_as_float(rec[o + 8]), __int_as_float(rec[o + 9]), __int_as_float(rec[o + 10])};
-			const float lb = fmax2(slab, box_lb2(blo, bhi, q.fp));
-#else
-			const float lb = slab;
-#endif
-			const bool hit = fmax2(lb, leaf_lb2) < q.bestf;
-			if (t < gcnt && __ballot(hit) != 0ull)
-				want |= 1u << t;
-		}
-		for (int t = 0; t < gcnt; ++t)
-		{
-			if (!((want >> t) & 1u))
+			if (!(side == 0 ? w0 : w1))
 				continue;
-			const char* base = (const char*)(M.tris + gfirst + t);
+			const int t = first + g + side;
+			const char* base = (const char*)(M.tris + t);
 			const v16i a = sload16(base);
 			const v16i b = sload16(base + 64);
 			const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
@@ -145,78 +109,78 @@ __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, 
 			const double denom = pack_double(b[12], b[13]);
 			const Hit h = tri_closest<false>(v0x, v0y, v0z, e0x, e0y, e0z, e1x, e1y, e1z, a00, a01, a11, det, inv_det,
 											 denom, q.px, q.py, q.pz);
-			offer(q, h.d2, gfirst + t);
+			offer(q, h.d2, t);
 		}
 	}
 }
 
 // Packet traversal, near-first.  On return every active lane holds the minimum squared distance
-// over all triangles (q.best_d2) and the packet index attaining it.
+// over all triangles (q.best_d2) and the position attaining it.
 //
-// The wave walks the tree with ONE shared stack that lives in a single VGPR (entry i in lane i,
-// pushed with a lane-select, popped with v_readlane under a wave-uniform stack pointer): no LDS, no
-// scratch.  At an inner node both children are fetched (2 x s_load_dwordx16) and bounded per
-// lane; a child is entered if ANY lane may still improve there, the child most lanes are
-// closer to first, the other one is pushed.  A popped node is re-tested against the (by then
-// tighter) running bests before its children are fetched.
-__device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q)
+// The wave walks the tree with ONE shared stack: the info word of a postponed subtree lives in
+// one VGPR (entry i in lane i, pushed with a lane select, popped with v_readlane under a
+// wave-uniform stack pointer); each lane's own lower bound for that subtree is parked in LDS
+// (one float per lane and level), so a popped entry is re-tested against the by then tighter
+// running bests with one compare -- no reload, no recomputation.  At an inner node ONE scalar
+// load fetches the bounds of both children, which are evaluated with packed two-wide float
+// math; a child is entered if ANY lane may still improve there, the child most lanes are
+// closer to first, the other one is pushed.
+__device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q, float* lds_lb /* [M.stack_levels][64] of this wave */)
 {
-	const BvhNode* nodes = M.nodes;
 	const int lane_id = (int)__lane_id();
-	int stackv = 0; // the stack: lane i holds entry i
+	int stackv = 0; // info words: lane i holds entry i
 	int sp = 0;     // wave-uniform
-	int node = 0;
-	SNode nd = load_node(nodes, 0);
-	float lbcur = 0.0f; // this lane's lower bound for `node`
-	bool have = true;   // `node`/`nd`/`lbcur` describe a node some lane still needs
+	int cur = M.root_info;
+	float lbcur = 0.0f; // this lane's lower bound for `cur`
 	while (true)
 	{
-		if (!have)
+		if (cur < 0)
 		{
-			if (sp == 0)
-				break;
-			--sp;
-			node = __builtin_amdgcn_readlane(stackv, sp);
-			nd = load_node(nodes, node);
-			lbcur = node_lb2(nd.lo, nd.hi, nd.su, nd.slo, nd.shi, q.fp);
-			if (__ballot(lbcur < q.bestf) == 0ull)
-				continue;
-		}
-		if (nd.info < 0)
-		{
-			const unsigned code = ~(unsigned)nd.info;
+			const unsigned code = ~(unsigned)cur;
 			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
-			have = false;
-			continue;
-		}
-		const int li = node + 1, ri = nd.info;
-		const SNode l = load_node(nodes, li);
-		const SNode r = load_node(nodes, ri);
-		const float lbl = node_lb2(l.lo, l.hi, l.su, l.slo, l.shi, q.fp);
-		const float lbr = node_lb2(r.lo, r.hi, r.su, r.slo, r.shi, q.fp);
-		const bool hl = lbl < q.bestf, hr = lbr < q.bestf;
-		const unsigned long long bl = __ballot(hl), br = __ballot(hr);
-		if (bl != 0ull && br != 0ull)
-		{
-			const unsigned long long pref = __ballot((hl || hr) && (lbl <= lbr));
-			const bool left_first = 2 * __popcll(pref) >= __popcll(bl | br);
-			stackv = (lane_id == sp) ? (left_first ? ri : li) : stackv; // v_writelane equivalent
-			++sp;
-			node = left_first ? li : ri;
-			nd = left_first ? l : r;
-			lbcur = left_first ? lbl : lbr;
-			have = true;
-		}
-		else if ((bl | br) != 0ull)
-		{
-			const bool left = bl != 0ull;
-			node = left ? li : ri;
-			nd = left ? l : r;
-			lbcur = left ? lbl : lbr;
-			have = true;
 		}
 		else
-			have = false;
+		{
+			const SPair pr = load_pair(M.pairs, cur);
+			const f2 lb = pair_lb2(pr.r, q.fp);
+			const bool hl = lb.x < q.bestf, hr = lb.y < q.bestf;
+			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
+			if ((bl | br) != 0ull)
+			{
+				bool left = bl != 0ull;
+				if (bl != 0ull && br != 0ull)
+				{
+					// both children are needed: the one most lanes are closer to first, the other is
+					// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
+					const unsigned long long pref = __ballot((hl || hr) && (lb.x <= lb.y));
+					left = 2 * __popcll(pref) >= __popcll(bl | br);
+					if (sp < M.stack_levels) // always true: one push per tree level at most
+					{
+						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
+						lds_lb[sp * 64 + lane_id] = left ? lb.y : lb.x;
+						++sp;
+					}
+				}
+				cur = left ? pr.info0 : pr.info1;
+				lbcur = left ? lb.x : lb.y;
+				continue;
+			}
+		}
+		// pop the next postponed subtree that some lane still needs
+		bool found = false;
+		while (sp > 0)
+		{
+			--sp;
+			lbcur = lds_lb[sp * 64 + lane_id];
+			if (__ballot(lbcur < q.bestf) != 0ull)
+			{
+				cur = __builtin_amdgcn_readlane(stackv, sp);
+				found = true;
+				break;
+			}
+		}
+		if (!found)
+			break;
 	}
 }
 
@@ -257,10 +221,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sample_nodes(const Samp
 	double x[3];
 	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
 
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [waves][stack_levels][64]
 	LaneQuery q;
 	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
 	if (__ballot(sample) != 0ull)
-		traverse(P.mesh, q);
+		traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64));
 
 	if (valid)
 	{
@@ -285,8 +250,9 @@ __global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const 
 	const bool valid = gid < n;
 	const uint64_t g = valid ? gid : (n - 1);
 	LaneQuery q;
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [4 waves][stack_levels][64]
 	init_query(M.origin, M.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
-	traverse(M, q);
+	traverse(M, q, lds_lb + (threadIdx.x >> 6) * (M.stack_levels * 64));
 	if (!valid)
 		return;
 	if (q.best_tri < 0)
@@ -463,7 +429,8 @@ hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
 	if (p.total_bricks == 0)
 		return hipSuccess;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
-	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(64 * kWavesPerBlock), 0, stream, p);
+	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
+	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
 	return hipGetLastError();
 }
 
@@ -473,7 +440,7 @@ hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_
 	if (n == 0)
 		return hipSuccess;
 	const uint32_t grid = (uint32_t)((n + 255) / 256);
-	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), 0, stream, m, d_xyz, n, d_dist, d_tri, d_entity,
+	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), (size_t)4 * m.stack_levels * 64 * sizeof(float), stream, m, d_xyz, n, d_dist, d_tri, d_entity,
 					   d_nearest);
 	return hipGetLastError();
 }

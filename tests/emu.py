@@ -85,14 +85,14 @@ class EmuMesh:
             end = T.n_nodes(res)
         out = np.full(end - begin, np.nan)
         written = np.zeros(end - begin, dtype=np.uint8)
-        st = np.zeros(9, dtype=np.uint64)
+        st = np.zeros(11, dtype=np.uint64)
         dmin = np.ascontiguousarray(domain[:3])
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self.L.emu_sample_nodes(self.h, T.dp(dmin), T.dp(cell), T.up(res), int(invert), 0, begin, end,
                                 None if m is None else m.ctypes.data_as(C.c_void_p), T.dp(out),
                                 written.ctypes.data_as(C.c_void_p), st.ctypes.data_as(T.c_u64p))
         self.written = written
-        self.stats = dict(zip(("bricks", "node_visits", "leaf_visits", "tri_tests", "descent_nodes", "slab_tests", "lane_interest", "useful_tests", "leaf_groups"), st.tolist()))
+        self.stats = dict(zip(("bricks", "node_visits", "leaf_visits", "tri_tests", "descent_nodes", "slab_tests", "lane_interest", "useful_tests", "leaf_groups", "pops", "stale_pops"), st.tolist()))
         return out
 
     def sample_shard(self, domain, res, rank, nranks, invert=False):

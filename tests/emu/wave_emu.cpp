@@ -18,9 +18,7 @@
 #include "../../discregrid_amd/csrc/dg_kernels.h"
 #include "../../discregrid_amd/csrc/dg_layout.h"
 
-#ifndef DG_TRI_BOX
-#define DG_TRI_BOX 1
-#endif
+
 
 using namespace dg;
 
@@ -29,7 +27,7 @@ namespace
 
 struct Stats
 {
-	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0, useful_tests = 0, leaf_groups = 0;
+	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0, useful_tests = 0, leaf_groups = 0, pops = 0, stale_pops = 0;
 };
 
 struct HostSqrt
@@ -42,127 +40,129 @@ struct Wave
 	LaneQuery q[64];
 };
 
-void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane or null*/, Wave& w, Stats& st)
+void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane*/, Wave& w, Stats& st)
 {
-	for (int g0 = 0; g0 < cnt; g0 += 4)
+	for (int g = 0; g < cnt; g += 2)
 	{
-		const int gfirst = first + g0;
-		const int gcnt = (cnt - g0) < 4 ? (cnt - g0) : 4;
-		unsigned want = 0;
+		const PairRec& pr = M.tri_pairs[(first + g) >> 1];
 		st.leaf_groups++;
-		for (int t = 0; t < 4; ++t)
+		bool want[2] = {false, false};
+		int n_int[2] = {0, 0};
+		for (int l = 0; l < 64; ++l)
 		{
-			const TriSlab& sl = M.slabs[gfirst + t];
-			bool any = false;
-			int n_int = 0;
-			for (int l = 0; l < 64; ++l)
-			{
-				float lb = slab_lb2(sl.u[0], sl.u[1], sl.u[2], sl.lo, sl.hi, w.q[l].fp);
-#if DG_TRI_BOX
-				lb = fmax2(lb, box_lb2(sl.blo, sl.bhi, w.q[l].fp));
-#endif
-				const bool hit = (fmax2(lb, leaf_lb2 ? leaf_lb2[l] : 0.0f) < w.q[l].bestf);
-				any = any || hit;
-				n_int += hit;
-			}
-			if (t < gcnt && any)
-			{
-				want |= 1u << t;
-				st.lane_interest += n_int;
-			}
+			const f2 lb = pair_lb2(&pr.f[0][0], w.q[l].fp);
+			const bool h0 = fmax2(lb.x, leaf_lb2[l]) < w.q[l].bestf;
+			const bool h1 = fmax2(lb.y, leaf_lb2[l]) < w.q[l].bestf;
+			want[0] = want[0] || h0;
+			want[1] = want[1] || h1;
+			n_int[0] += h0;
+			n_int[1] += h1;
 		}
-		for (int t = 0; t < gcnt; ++t)
+		for (int side = 0; side < 2; ++side)
 		{
 			st.slab_tests++;
-			if (!((want >> t) & 1u))
+			if (!want[side])
 				continue;
 			st.tri_tests++;
-			const TriPacket& T = M.tris[gfirst + t];
+			st.lane_interest += n_int[side];
+			const int t = first + g + side;
+			const TriPacket& T = M.tris[t];
 			bool useful = false;
 			for (int l = 0; l < 64; ++l)
 			{
 				const Hit h = tri_closest<false>(T, w.q[l].px, w.q[l].py, w.q[l].pz);
 				useful = useful || (h.d2 < w.q[l].best_d2);
-				offer(w.q[l], h.d2, gfirst + t);
+				offer(w.q[l], h.d2, t);
 			}
 			st.useful_tests += useful;
 		}
 	}
 }
 
-// mirrors traverse() of dg_kernels.hip: near-first packet traversal with a wave-shared stack
+// mirrors traverse() of dg_kernels.hip: near-first packet traversal, wave-shared stack of info
+// words, per-lane bounds of postponed subtrees parked per level
 void traverse(const MeshDev& M, Wave& w, Stats& st)
 {
-	const BvhNode* nodes = M.nodes;
-	int stack[128];
+	int stack_info[kStackDepth];
+	static thread_local float stack_lb[kStackDepth][64];
 	int sp = 0;
-	int node = 0;
-	bool have = true; // `node` is valid and already known to be hit by some lane
+	int cur = M.root_info;
 	float lbcur[64];
-	for (int k = 0; k < 64; ++k) lbcur[k] = 0.0f;
+	for (int k = 0; k < 64; ++k)
+		lbcur[k] = 0.0f;
 	while (true)
 	{
-		if (!have)
+		bool descended = false;
+		if (cur < 0)
 		{
-			if (sp == 0)
-				break;
-			node = stack[--sp];
-			const BvhNode& nd = nodes[node];
-			st.node_visits++;
+			st.leaf_visits++;
+			const unsigned code = ~(unsigned)cur;
+			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
+		}
+		else
+		{
+			const PairRec& pr = M.pairs[cur];
+			st.node_visits += 2;
+			float lbl[64], lbr[64];
+			bool anyl = false, anyr = false;
+			int pref = 0, act = 0;
+			for (int k = 0; k < 64; ++k)
+			{
+				const f2 lb = pair_lb2(&pr.f[0][0], w.q[k].fp);
+				lbl[k] = lb.x;
+				lbr[k] = lb.y;
+				const bool hl = lb.x < w.q[k].bestf, hr = lb.y < w.q[k].bestf;
+				anyl = anyl || hl;
+				anyr = anyr || hr;
+				if (hl || hr)
+				{
+					act++;
+					pref += (lb.x <= lb.y);
+				}
+			}
+			if (anyl || anyr)
+			{
+				bool left = anyl;
+				if (anyl && anyr)
+				{
+					left = 2 * pref >= act;
+					if (sp < M.stack_levels)
+					{
+						stack_info[sp] = left ? pr.info[1] : pr.info[0];
+						for (int k = 0; k < 64; ++k)
+							stack_lb[sp][k] = left ? lbr[k] : lbl[k];
+						++sp;
+					}
+				}
+				cur = left ? pr.info[0] : pr.info[1];
+				for (int k = 0; k < 64; ++k)
+					lbcur[k] = left ? lbl[k] : lbr[k];
+				descended = true;
+			}
+		}
+		if (descended)
+			continue;
+		bool found = false;
+		while (sp > 0)
+		{
+			--sp;
+			st.pops++;
 			bool any = false;
 			for (int k = 0; k < 64; ++k)
 			{
-				lbcur[k] = node_lb2(nd.lo, nd.hi, nd.su, nd.slo, nd.shi, w.q[k].fp);
+				lbcur[k] = stack_lb[sp][k];
 				any = any || (lbcur[k] < w.q[k].bestf);
 			}
-			if (!any)
-				continue;
-		}
-		const BvhNode& nd = nodes[node];
-		if (nd.info < 0)
-		{
-			st.leaf_visits++;
-			const unsigned code = ~(unsigned)nd.info;
-			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
-			have = false;
-			continue;
-		}
-		const int li = node + 1, ri = nd.info;
-		const BvhNode& l = nodes[li];
-		const BvhNode& r = nodes[ri];
-		st.node_visits += 2;
-		float lbl[64], lbr[64];
-		bool anyl = false, anyr = false;
-		int pref = 0, act = 0;
-		for (int k = 0; k < 64; ++k)
-		{
-			lbl[k] = node_lb2(l.lo, l.hi, l.su, l.slo, l.shi, w.q[k].fp);
-			lbr[k] = node_lb2(r.lo, r.hi, r.su, r.slo, r.shi, w.q[k].fp);
-			const bool hl = lbl[k] < w.q[k].bestf, hr = lbr[k] < w.q[k].bestf;
-			anyl = anyl || hl;
-			anyr = anyr || hr;
-			if (hl || hr)
+			if (any)
 			{
-				act++;
-				pref += (lbl[k] <= lbr[k]);
+				cur = stack_info[sp];
+				found = true;
+				break;
 			}
+			st.stale_pops++;
 		}
-		if (anyl && anyr)
-		{
-			const bool left_first = 2 * pref >= act;
-			stack[sp++] = left_first ? ri : li;
-			node = left_first ? li : ri;
-			for (int k = 0; k < 64; ++k) lbcur[k] = left_first ? lbl[k] : lbr[k];
-			have = true;
-		}
-		else if (anyl || anyr)
-		{
-			node = anyl ? li : ri;
-			for (int k = 0; k < 64; ++k) lbcur[k] = anyl ? lbl[k] : lbr[k];
-			have = true;
-		}
-		else
-			have = false;
+		if (!found)
+			break;
 	}
 }
 
@@ -185,13 +185,14 @@ void* emu_mesh_create(const double* verts, size_t nv, const uint32_t* tris, size
 		delete m;
 		return nullptr;
 	}
-	m->dev.nodes = m->B.nodes.data();
+	m->dev.pairs = m->B.pairs.data();
+	m->dev.tri_pairs = m->B.tri_pairs.data();
 	m->dev.tris = m->B.tris.data();
 	m->dev.pn = m->B.pn.data();
-	m->dev.slabs = m->B.slabs.data();
 	m->dev.mesh_l1 = m->B.mesh_l1;
-	m->dev.n_nodes = (int32_t)m->B.nodes.size();
-	m->dev.n_tris = (int32_t)m->B.tris.size();
+	m->dev.root_info = m->B.root_info;
+	m->dev.n_positions = (int32_t)m->B.tris.size();
+	m->dev.stack_levels = (int32_t)std::min<uint32_t>(m->B.depth + 1, kStackDepth);
 	for (int d = 0; d < 3; ++d)
 		m->dev.origin[d] = m->B.origin[d];
 	return m;
@@ -200,7 +201,7 @@ void emu_mesh_free(void* h) { delete static_cast<HostMesh*>(h); }
 void emu_mesh_info(void* h, uint64_t* n_nodes, uint32_t* depth, uint32_t* flags)
 {
 	auto m = static_cast<HostMesh*>(h);
-	*n_nodes = m->B.nodes.size();
+	*n_nodes = 2 * m->B.pairs.size() + 1;
 	*depth = m->B.depth;
 	*flags = m->B.not_watertight;
 }
@@ -209,67 +210,98 @@ void emu_mesh_pseudonormals(void* h, double* pn)
 {
 	auto m = static_cast<HostMesh*>(h);
 	for (size_t k = 0; k < m->B.tris.size(); ++k)
-		std::memcpy(pn + (size_t)m->B.tris[k].tri_id * kPnSlots * 3, m->B.pn.data() + k * kPnSlots * 3,
-					kPnSlots * 3 * sizeof(double));
+		if (m->B.tris[k].tri_id >= 0)
+			std::memcpy(pn + (size_t)m->B.tris[k].tri_id * kPnSlots * 3, m->B.pn.data() + k * kPnSlots * 3,
+						kPnSlots * 3 * sizeof(double));
 }
-// structural self-check of the flattened BVH: every triangle in exactly one leaf, boxes
-// contain their triangles (with the float rounding), skip pointers consistent
-int emu_mesh_check(void* h, const double* verts, const uint32_t* tris)
+// structural self-check of the pair BVH: every triangle in exactly one leaf slot, every bound of
+// every ancestor contains the triangle (float rounding included), padding slots unreachable
+static int check_subtree(const HostMesh* m, int32_t info, const double* verts, const uint32_t* tris,
+						 std::vector<int>& seen, std::vector<const float*>& anc /* ancestor bounds: rec ptr + side */,
+						 std::vector<int>& anc_side, int depth)
 {
-	auto m = static_cast<HostMesh*>(h);
-	const auto& N = m->B.nodes;
-	std::vector<int> seen(m->B.tris.size(), 0);
-	for (size_t i = 0; i < N.size(); ++i)
+	if (depth > kStackDepth)
+		return 9;
+	if (info < 0)
 	{
-		if (N[i].skip <= (int)i || N[i].skip > (int)N.size())
-			return 1;
-		if (N[i].info >= 0)
+		const unsigned code = ~(unsigned)info;
+		const unsigned first = code >> kLeafBits, cnt = (code & (unsigned)(kMaxLeaf - 1)) + 1;
+		if ((first & 1u) || (cnt & 1u) || first + cnt > m->B.tris.size())
+			return 5;
+		for (unsigned t = first; t < first + cnt; ++t)
 		{
-			if (N[i].info <= (int)i + 1 || N[i].info >= N[i].skip)
-				return 2;
-			if (N[i + 1].skip != N[i].info || N[N[i].info].skip != N[i].skip)
-				return 3;
-		}
-		else
-		{
-			if (N[i].skip != (int)i + 1)
-				return 4;
-			const unsigned code = ~(unsigned)N[i].info;
-			for (unsigned t = code >> kLeafBits; t <= (code >> kLeafBits) + (code & (unsigned)(kMaxLeaf - 1)); ++t)
+			const int id = m->B.tris[t].tri_id;
+			const PairRec& tp = m->B.tri_pairs[t >> 1];
+			if (id < 0)
 			{
-				if (t >= seen.size())
-					return 5;
-				seen[t]++;
-				const uint32_t id = (uint32_t)m->B.tris[t].tri_id;
+				if (!(tp.f[0][t & 1] > tp.f[3][t & 1])) // padding must have an empty box
+					return 10;
+				continue;
+			}
+			seen[id]++;
+			std::vector<const float*> all = anc;
+			std::vector<int> sides = anc_side;
+			all.push_back(&tp.f[0][0]);
+			sides.push_back((int)(t & 1));
+			for (size_t a = 0; a < all.size(); ++a)
+			{
+				const float* r = all[a];
+				const int sd = sides[a];
 				for (int k = 0; k < 3; ++k)
+				{
+					double pr = 0;
 					for (int d = 0; d < 3; ++d)
 					{
 						const double v = verts[3 * tris[3 * id + k] + d] - m->B.origin[d];
-						// every ancestor must contain it too: checked through the leaf's own box
-						// being inside its ancestors (below)
-						if (!((double)N[i].lo[d] <= v && v <= (double)N[i].hi[d]))
+						if (!((double)r[2 * d + sd] <= v && v <= (double)r[6 + 2 * d + sd]))
 							return 6;
+						pr += (double)r[12 + 2 * d + sd] * v;
 					}
+					const double ulen = std::sqrt((double)r[12 + sd] * r[12 + sd] + (double)r[14 + sd] * r[14 + sd] +
+												  (double)r[16 + sd] * r[16 + sd]);
+					if (ulen > 1.0)
+						return 11;
+					if (ulen > 0 && !((double)r[18 + sd] <= pr + 1e-12 && pr - 1e-12 <= (double)r[20 + sd]))
+						return 12;
+				}
 			}
 		}
+		return 0;
 	}
+	if ((size_t)info >= m->B.pairs.size())
+		return 2;
+	const PairRec& pr = m->B.pairs[info];
+	for (int sd = 0; sd < 2; ++sd)
+	{
+		anc.push_back(&pr.f[0][0]);
+		anc_side.push_back(sd);
+		const int e = check_subtree(m, pr.info[sd], verts, tris, seen, anc, anc_side, depth + 1);
+		anc.pop_back();
+		anc_side.pop_back();
+		if (e)
+			return e;
+	}
+	return 0;
+}
+int emu_mesh_check(void* h, const double* verts, const uint32_t* tris)
+{
+	auto m = static_cast<HostMesh*>(h);
+	std::vector<int> seen(m->B.n_triangles, 0);
+	std::vector<const float*> anc;
+	std::vector<int> anc_side;
+	const int e = check_subtree(m, m->B.root_info, verts, tris, seen, anc, anc_side, 0);
+	if (e)
+		return e;
 	for (int s : seen)
 		if (s != 1)
 			return 7;
-	// child boxes inside parent boxes
-	for (size_t i = 0; i < N.size(); ++i)
-		if (N[i].info >= 0)
-			for (int ch : {(int)i + 1, N[i].info})
-				for (int d = 0; d < 3; ++d)
-					if (N[ch].lo[d] < N[i].lo[d] || N[ch].hi[d] > N[i].hi[d])
-						return 8;
 	return 0;
 }
 
 // mode 0: flat range [a0, a1) -> out[l - a0];  mode 1: shard (rank = a0, nranks = a1) -> packed
 int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const uint32_t res[3], int invert, int mode,
 					 uint64_t a0, uint64_t a1, const uint8_t* mask, double* out, uint8_t* written /*nullable*/,
-					 uint64_t* stats /*6, nullable*/)
+					 uint64_t* stats /*11, nullable*/)
 {
 	auto m = static_cast<HostMesh*>(h);
 	SampleParams P;
@@ -342,6 +374,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.lane_interest += ls.lane_interest;
 			st.useful_tests += ls.useful_tests;
 			st.leaf_groups += ls.leaf_groups;
+			st.pops += ls.pops;
+			st.stale_pops += ls.stale_pops;
 		}
 	}
 	if (stats)
@@ -355,6 +389,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		stats[6] = st.lane_interest;
 		stats[7] = st.useful_tests;
 		stats[8] = st.leaf_groups;
+		stats[9] = st.pops;
+		stats[10] = st.stale_pops;
 	}
 	return err;
 }
