@@ -11,6 +11,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_extension():
+    """The HIP extension (cross-compiled by hipcc, no GPU needed) must exist before any test that
+    loads it -- built artefacts are git-ignored, so a fresh checkout has none."""
+    from discregrid_amd.build import build
+    build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
