@@ -92,7 +92,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("DG_LIB") or LIB_PATH  # DG_LIB: experiment builds (tools/)
     # PyTorch wheels bundle their own libamdhip64.so.7; a process must use ONE HIP runtime.  When
     # torch is installed (tests, bench.py use it for device memory / streams / torch.distributed)
     # let it load its runtime first so that this library binds to the same one.

@@ -609,6 +609,20 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		sdf->wtab_h = support_radius;
 	}
 	P.wtab = static_cast<const double*>(sdf->d_wtab);
+	if (std::getenv("DG_K3_COMPACT") == nullptr)
+	{
+		// brick-ordered launch (default): K1's lattice decomposition, one wave per 4x4x4 brick
+		dg::SampleParams L;
+		dg::MeshDev none;
+		std::memset(&none, 0, sizeof(none));
+		dg::init_params(L, none, sdf->grid.domain_min, sdf->grid.cell_size, 0);
+		dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
+		L.mask = d_pred_mask;
+		L.out = d_out;
+		P.wtab = static_cast<const double*>(sdf->d_wtab);
+		DG_HIP(dg::launch_density_bricks(L, sdf->dev, P, st));
+		return DG_OK;
+	}
 	if (sdf->ws_nodes < n)
 	{
 		if (sdf->d_ws)

@@ -38,6 +38,9 @@ namespace
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 #define DG_CONST_AS __attribute__((address_space(4)))
+#ifndef DG_K3_WAVES
+#define DG_K3_WAVES 1 // min waves per SIMD requested for K3 (register budget)
+#endif
 
 // Wave-uniform loads through the scalar data cache.  The address must be uniform across the
 // wave (callers pass indices that went through readfirstlane); the data is immutable for the
@@ -390,7 +393,48 @@ __global__ __launch_bounds__(256) void k_density_integrate(const FieldDev F, con
 	}
 }
 
+// K3, brick-ordered variant (the one the C ABI uses): one wave = one 4x4x4 brick of lattice nodes
+// (K1's decomposition), so the 64 lanes evaluate the SDF in a 3x3x3-cell neighbourhood at every
+// quadrature step and the 256-byte coefficient rows they read stay in L1.  Lanes whose node is
+// rejected or beyond 2h idle; waves without an active lane exit at once.
+template <bool STAGED>
+__global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const SampleParams L, const FieldDev F, const DensityParams P)
+{
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t within = blockIdx.x >> 3;
+	const uint32_t blk = xcd * L.blocks_per_xcd + within;
+	if (within >= L.blocks_per_xcd || blk >= L.n_blocks)
+		return;
+	const uint64_t brick = (uint64_t)blk; // one wave per block
+	if (brick >= L.total_bricks)
+		return;
+	const LaneNode ln = map_lane(L, brick, (int)(threadIdx.x & 63u));
+	if (!ln.valid)
+		return;
+	double v = 1.7976931348623157e308;
+	if (L.mask == nullptr || L.mask[ln.out_idx] != 0)
+	{
+		double x[3];
+		node_position(ln.cls, ln.a, ln.b, ln.s, L.dmin, L.cell, x);
+		if (density_prefilter(F, P, x, &v))
+			v = density_integral_t<STAGED>(F, P, x);
+	}
+	L.out[ln.out_idx] = v;
+}
+
 } // namespace
+
+hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream)
+{
+	if (layout.total_bricks == 0)
+		return hipSuccess;
+	static_assert(kWavesPerBlock == 1, "k_density_bricks assumes one brick per block");
+	if (f.cells == nullptr && f.cell_map == nullptr) // unreduced field: staged evaluator
+		hipLaunchKernelGGL(k_density_bricks<true>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
+	else
+		hipLaunchKernelGGL(k_density_bricks<false>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
+	return hipGetLastError();
+}
 
 hipError_t launch_density_map(const FieldDev& f, const DensityParams& p, uint64_t begin, uint64_t end,
 							  const uint8_t* d_mask, double* d_out, uint32_t* d_list, uint32_t* d_counter,

@@ -1,0 +1,96 @@
+"""Edge cases of the hot path, on the CPU through the kernel emulator (the same cases run on the
+GPU in test_gpu_edge_cases.py): degenerate / tiny / open meshes, extreme grid shapes, empty inputs."""
+import numpy as np
+import pytest
+
+import dgtest as T
+import emu
+
+DBL_MAX = np.finfo(np.float64).max
+
+
+def meshes():
+    V, F = T.icosphere(4)
+    out = {}
+    out["single_triangle"] = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.2]], dtype=np.float64), np.array([[0, 1, 2]], dtype=np.uint32))
+    out["two_triangles_open"] = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.3]], dtype=np.float64),
+                                 np.array([[0, 1, 2], [1, 3, 2]], dtype=np.uint32))
+    # a zero-area triangle and a duplicated triangle mixed into a closed mesh
+    F2 = np.concatenate([F, [[F[0, 0], F[0, 0], F[0, 1]]], F[5:6]]).astype(np.uint32)
+    out["degenerate_and_duplicate"] = (V, F2)
+    out["open_sphere"] = (V, F[:-7])
+    # needle triangles (aspect ratio 1e6) around a thin box
+    Vn = np.array([[0, 0, 0], [1, 0, 0], [1, 1e-6, 0], [0, 1e-6, 0], [0, 0, 1], [1, 0, 1], [1, 1e-6, 1], [0, 1e-6, 1]], dtype=np.float64)
+    Fn = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6],
+                   [3, 0, 4], [3, 4, 7]], dtype=np.uint32)
+    out["needle_box"] = (Vn, Fn)
+    return out
+
+
+@pytest.mark.parametrize("name", list(meshes()))
+def test_unusual_meshes(name):
+    V, F = meshes()[name]
+    om, em = T.OracleMesh(V, F), emu.EmuMesh(V, F)
+    assert em.check() == 0
+    lo, hi = V.min(axis=0), V.max(axis=0)
+    ext = max((hi - lo).max(), 1e-3)
+    rng = np.random.default_rng(17)
+    P = rng.uniform(lo - ext, hi + ext, size=(3000, 3))
+    a, b = em.signed_distance(P), om.signed_distance(P)
+    # unsigned distances agree bit for bit even on open / degenerate meshes; the sign is only
+    # defined for closed meshes (the reference warns, TriangleMeshDistance.h:422-438) -- but it
+    # is still the same wherever the winning triangle is the same
+    np.testing.assert_array_equal(np.abs(a), np.abs(b))
+    if name in ("degenerate_and_duplicate", "needle_box"):
+        off = np.abs(b) > 1e-7 * ext
+        np.testing.assert_array_equal(a[off], b[off])
+    dom = np.concatenate([lo - 0.1 * ext, hi + 0.1 * ext])
+    got = em.sample_range(dom, [5, 4, 3])
+    want = om.sample_nodes(dom, [5, 4, 3])
+    np.testing.assert_array_equal(np.abs(got), np.abs(want))
+
+
+@pytest.mark.parametrize("res", [[1, 1, 1], [1, 7, 2], [33, 1, 1], [2, 2, 64], [3, 5, 4]])
+def test_extreme_grid_shapes(res):
+    V, F = T.torus()
+    dom = T.oracle_default_domain(V)
+    em = emu.EmuMesh(V, F)
+    got = em.sample_range(dom, res)
+    assert (em.written == 1).all()
+    want = T.OracleMesh(V, F).sample_nodes(dom, res)
+    np.testing.assert_array_equal(got, want)
+    for nr in (2, 5):
+        parts = [em.sample_shard(dom, res, r, nr) for r in range(nr)]
+        stride = (max(len(p) for p in parts) + 63) // 64 * 64
+        G = np.full(stride * nr, np.nan)
+        for r, p in enumerate(parts):
+            G[r * stride:r * stride + len(p)] = p
+        np.testing.assert_array_equal(emu.unpack(res, nr, G, stride), want)
+    P = np.random.default_rng(1).uniform(dom[:3], dom[3:], size=(500, 3))
+    np.testing.assert_array_equal(emu.interpolate(dom, res, want, P), T.oracle_interpolate(dom, res, want, P))
+
+
+def test_anisotropic_domain_and_negative_coordinates():
+    V, F = T.icosphere(5)
+    V = V * np.array([30.0, 0.02, 4.0]) + np.array([-500.0, 7.0, -0.001])
+    dom = T.oracle_default_domain(V)
+    res = [6, 9, 4]
+    got = emu.EmuMesh(V, F).sample_range(dom, res)
+    np.testing.assert_array_equal(got, T.OracleMesh(V, F).sample_nodes(dom, res))
+
+
+def test_domain_not_containing_the_mesh():
+    """The grid may lie anywhere relative to the mesh (far away, or strictly inside it)."""
+    V, F = T.icosphere(6)
+    om, em = T.OracleMesh(V, F), emu.EmuMesh(V, F)
+    for dom in ([5, 5, 5, 6, 6.5, 7], [-0.2, -0.1, -0.3, 0.1, 0.2, 0.0], [-1e3, -1e3, -1e3, 1e3, 1e3, 1e3]):
+        dom = np.array(dom, dtype=np.float64)
+        np.testing.assert_array_equal(em.sample_range(dom, [4, 5, 3]), om.sample_nodes(dom, [4, 5, 3]))
+
+
+def test_empty_batches():
+    V, F = T.box_mesh()
+    em = emu.EmuMesh(V, F)
+    assert len(em.signed_distance(np.empty((0, 3)))) == 0
+    dom = T.oracle_default_domain(V)
+    assert len(emu.interpolate(dom, [2, 2, 2], np.zeros(T.n_nodes([2, 2, 2])), np.empty((0, 3)))) == 0
