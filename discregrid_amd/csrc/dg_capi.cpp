@@ -40,8 +40,6 @@ struct dg_field
 	void* d_cell_major = nullptr;
 	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
 	double wtab_h = -1.0;
-	void* d_ws = nullptr;      // K3 workspace: compaction list + counter
-	uint64_t ws_nodes = 0;
 	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
 	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)
@@ -539,8 +537,6 @@ void dg_field_destroy(dg_field* f)
 		(void)hipFree(f->d_cell_major);
 	if (f->d_wtab)
 		(void)hipFree(f->d_wtab);
-	if (f->d_ws)
-		(void)hipFree(f->d_ws);
 	delete f;
 }
 
@@ -596,7 +592,6 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		return fail(DG_ERR_INVALID, "node range outside the lattice");
 	if (node_begin == node_end)
 		return DG_OK;
-	const uint64_t n = node_end - node_begin;
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	dg::DensityParams P;
 	std::vector<double> w;
@@ -609,35 +604,16 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		sdf->wtab_h = support_radius;
 	}
 	P.wtab = static_cast<const double*>(sdf->d_wtab);
-	if (std::getenv("DG_K3_COMPACT") == nullptr)
-	{
-		// brick-ordered launch (default): K1's lattice decomposition, one wave per 4x4x4 brick
-		dg::SampleParams L;
-		dg::MeshDev none;
-		std::memset(&none, 0, sizeof(none));
-		dg::init_params(L, none, sdf->grid.domain_min, sdf->grid.cell_size, 0);
-		dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
-		L.mask = d_pred_mask;
-		L.out = d_out;
-		P.wtab = static_cast<const double*>(sdf->d_wtab);
-		DG_HIP(dg::launch_density_bricks(L, sdf->dev, P, st));
-		return DG_OK;
-	}
-	if (sdf->ws_nodes < n)
-	{
-		if (sdf->d_ws)
-		{
-			DG_HIP(hipDeviceSynchronize());
-			(void)hipFree(sdf->d_ws);
-			sdf->d_ws = nullptr;
-			sdf->ws_nodes = 0;
-		}
-		DG_HIP(hipMalloc(&sdf->d_ws, (n + 4) * sizeof(uint32_t)));
-		sdf->ws_nodes = n;
-	}
-	uint32_t* counter = static_cast<uint32_t*>(sdf->d_ws);
-	uint32_t* list = counter + 4;
-	DG_HIP(dg::launch_density_map(sdf->dev, P, node_begin, node_end, d_pred_mask, d_out, list, counter, st));
+	// K1's lattice decomposition: one wave per 4x4x4 brick of nodes
+	dg::SampleParams L;
+	dg::MeshDev none;
+	std::memset(&none, 0, sizeof(none));
+	dg::init_params(L, none, sdf->grid.domain_min, sdf->grid.cell_size, 0);
+	dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
+	L.mask = d_pred_mask;
+	L.out = d_out;
+	P.wtab = static_cast<const double*>(sdf->d_wtab);
+	DG_HIP(dg::launch_density_bricks(L, sdf->dev, P, st));
 	return DG_OK;
 }
 

@@ -117,9 +117,6 @@ hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream);
 hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
 								  int32_t* d_entity, double* d_nearest, hipStream_t stream);
 hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream);
-hipError_t launch_density_map(const FieldDev& f, const DensityParams& p, uint64_t begin, uint64_t end,
-							  const uint8_t* d_mask, double* d_out, uint32_t* d_list, uint32_t* d_counter,
-							  hipStream_t stream);
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream);
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,

@@ -351,49 +351,7 @@ __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: SPH boundary density map.  Pass 1 classifies every node (predicate / early-out) and
-// compacts the ones that need the 4096-point quadrature; pass 2 integrates them, one thread
-// per node (the sum must run i, j, k sequentially per node for parity; parallelism = nodes).
-// The loop indices are wave-uniform, so the weights and the W table come through scalar loads;
-// every step is one full interpolate() of the SDF at x + xi.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_density_classify(const FieldDev F, const DensityParams P, uint64_t begin,
-														   uint64_t end, const uint8_t* __restrict__ mask,
-														   double* __restrict__ out, uint32_t* __restrict__ list,
-														   uint32_t* __restrict__ counter)
-{
-	const uint64_t l = begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (l >= end)
-		return;
-	if (mask != nullptr && mask[l - begin] == 0)
-	{
-		out[l - begin] = 1.7976931348623157e308;
-		return;
-	}
-	double x[3];
-	node_position_flat(l, F.res, F.dmin, F.cell, x);
-	double v;
-	if (density_prefilter(F, P, x, &v))
-		list[atomicAdd(counter, 1u)] = (uint32_t)(l - begin);
-	else
-		out[l - begin] = v;
-}
-
-__global__ __launch_bounds__(256) void k_density_integrate(const FieldDev F, const DensityParams P, uint64_t begin,
-															const uint32_t* __restrict__ list,
-															const uint32_t* __restrict__ counter, double* __restrict__ out)
-{
-	const uint32_t n = *counter;
-	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
-	{
-		const uint32_t rel = list[t];
-		double x[3];
-		node_position_flat(begin + rel, F.res, F.dmin, F.cell, x);
-		out[rel] = density_integral(F, P, x);
-	}
-}
-
-// K3, brick-ordered variant (the one the C ABI uses): one wave = one 4x4x4 brick of lattice nodes
+// K3: SPH boundary density map (GenerateDensityMap).  One wave = one 4x4x4 brick of lattice nodes
 // (K1's decomposition), so the 64 lanes evaluate the SDF in a 3x3x3-cell neighbourhood at every
 // quadrature step and the 256-byte coefficient rows they read stay in L1.  Lanes whose node is
 // rejected or beyond 2h idle; waves without an active lane exit at once.
@@ -433,30 +391,6 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 		hipLaunchKernelGGL(k_density_bricks<true>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
 	else
 		hipLaunchKernelGGL(k_density_bricks<false>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
-	return hipGetLastError();
-}
-
-hipError_t launch_density_map(const FieldDev& f, const DensityParams& p, uint64_t begin, uint64_t end,
-							  const uint8_t* d_mask, double* d_out, uint32_t* d_list, uint32_t* d_counter,
-							  hipStream_t stream)
-{
-	if (end <= begin)
-		return hipSuccess;
-	const uint64_t n = end - begin;
-	hipError_t e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), stream);
-	if (e != hipSuccess)
-		return e;
-	hipLaunchKernelGGL(k_density_classify, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, f, p, begin, end,
-					   d_mask, d_out, d_list, d_counter);
-	e = hipGetLastError();
-	if (e != hipSuccess)
-		return e;
-	// grid-stride over the compacted list: enough blocks to fill the chip, the count stays on the device
-	uint64_t blocks = (n + 255) / 256;
-	if (blocks > 256ull * 16ull)
-		blocks = 256ull * 16ull;
-	hipLaunchKernelGGL(k_density_integrate, dim3((uint32_t)blocks), dim3(256), 0, stream, f, p, begin, d_list, d_counter,
-					   d_out);
 	return hipGetLastError();
 }
 
