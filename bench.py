@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pcie", action="store_true", help="also report the PCIe-inclusive rate on stderr")
+    ap.add_argument("--force-shard-path", action="store_true",
+                    help="run the N > 1 protocol (RCCL init, shard, all_gather, unpack) even at N = 1 (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -113,9 +115,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dg.load_library()
     dg.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_shard_path
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     V, F = T.icosphere(71)
     dom = T.oracle_default_domain(V)      # cmd/generate_sdf/main.cpp:83-91
@@ -127,7 +131,7 @@ def main():
     s = stream.cuda_stream
 
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
-    if world > 1:
+    if sharded:
         count, stride = dg.shard_layout(grid, rank, world)
         gathered = torch.empty(world * stride, dtype=torch.float64, device="cuda")
         mine = torch.zeros(stride, dtype=torch.float64, device="cuda")   # this rank's packed shard (+ padding)
@@ -140,31 +144,31 @@ def main():
     def step(i=None):
         if i is not None:
             ev[i][0].record(stream)
-        if world > 1:
+        if sharded:
             mesh.sample_shard_device(grid, rank, world, mine.data_ptr(), stream=s)
         else:
             mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
         if i is not None:
             ev[i][1].record(stream)
-        if world > 1:
+        if sharded:
             dist.all_gather_into_tensor(gathered, mine)          # ONE RCCL collective over xGMI
             dg.unpack_shards_device(grid, world, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -173,6 +177,11 @@ def main():
     # sanity of the result that was just timed (cheap, outside the timed region)
     probe = field[:: max(1, n_nodes // 1000)].cpu().numpy()
     assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0
+    if args.force_shard_path and world == 1:
+        ref = torch.empty_like(field)
+        mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, field), "shard + all_gather + unpack differs from the direct launch"
 
     if rank == 0:
         balg = load_balg()
@@ -215,7 +224,7 @@ def main():
             print("PCIe-inclusive (kernel + D2H into pinned host memory): %.1f Mnodes/s" % (n_nodes / dt / 1e6),
                   file=sys.stderr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

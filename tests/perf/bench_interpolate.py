@@ -5,7 +5,7 @@ uniform in the domain (seed 1234) and an "SPH-like" shell |phi| < 2h, h = 0.1.  
 line per case (Mqueries/s, algorithmic GB/s = 288 or 312 B/query) and, with
 --cpu-seconds > 0, the reference's OpenMP interpolate on a bounded sample of the same queries.
 
-    python bench_interpolate.py [--queries 10000000] [--steps 5] [--cpu-seconds 5]
+    python tests/perf/bench_interpolate.py [--queries 10000000] [--steps 5] [--cpu-seconds 5]
 """
 import argparse
 import json
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

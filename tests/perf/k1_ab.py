@@ -1,12 +1,12 @@
 """K1 A/B harness: times k_sample_nodes on the headline workload for several library variants /
 BVH settings, one child process per variant (run on the GPU box).
-usage: python tools/k1_ab.py variant.so[:ENV=VAL,...] ...   (median of AB_REPS launches)"""
+usage: python tests/perf/k1_ab.py variant.so[:ENV=VAL,...] ...   (median of AB_REPS launches)"""
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
