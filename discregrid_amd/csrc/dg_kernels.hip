@@ -5,23 +5,25 @@
 //                          TriangleMeshDistance.h:269-308, 514-562, 564-820)
 //   K1p k_signed_distance  same traversal for caller-supplied points (TriangleMeshDistance.h:269-314)
 //   K2  k_interpolate      batched CubicLagrangeDiscreteGrid::interpolate (:977-1063)
+//   K3  k_density_bricks   SPH boundary density map (cmd/generate_density_map/main.cpp:86-133)
 //   U   k_unpack_shards    packed all-gather buffer -> reference node order (multi-GPU)
+//       k_expand_cells     cell-major copy of a field (optional K2 layout)
 //
 // Design of K1 (wave64, no MFMA: this is point-vs-BVH, not a contraction):
 //   * ONE WAVEFRONT = ONE 4x4x4 BRICK of lattice nodes.  The 64 query points are spatially
-//     compact, so the wave walks the BVH as a packet: control flow is wave-uniform, every BVH
-//     node (32 B) and triangle packet (128 B) is fetched ONCE per wave through the scalar
-//     unit (s_load_dwordx8 / x16 into SGPRs) and broadcast to all lanes for free; lanes only
-//     differ in their query point and running best.  No per-lane stack, no divergent gathers
-//     in the loop.
+//     compact, so the wave walks the BVH as a packet: control flow is wave-uniform, every bound
+//     record (two siblings, 96 of 128 B) and triangle packet (128 B) is fetched ONCE per wave
+//     through the scalar unit (s_load_dwordx16/x8 into SGPRs) and broadcast to all lanes for
+//     free; lanes only differ in their query point and running best.  No per-lane stack, no
+//     divergent gathers in the loop.
 //   * Near-first traversal with one wave-shared stack (subtree ids in one VGPR, per-lane bounds
 //     parked in LDS); bounds = box AND slab along the (mean) normal, stored as sibling pairs and
-//     evaluated two at a time with packed float math.
-//   * Box tests in conservative float (they only prune); triangle tests in double with the
+//     evaluated two at a time with packed float math (the kernel is VALU-issue bound).
+//   * Bound tests in conservative float (they only prune); triangle tests in double with the
 //     reference's exact operation order (no FMA contraction) so d^2, the winning feature and
 //     the sign reproduce the reference bit for bit.
 //   * Positions are computed from the lattice index (nothing is read from HBM but the mesh);
-//     the only HBM traffic is the 8-byte result per node.
+//     the only compulsory HBM traffic is the 8-byte result per node.
 //   * blockIdx is remapped so that each XCD works on a contiguous chunk of bricks: the BVH
 //     subtrees an XCD touches stay in its private 4 MiB L2.
 //
