@@ -122,7 +122,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     V, F = T.icosphere(71)
-    dom = T.oracle_default_domain(V)      # cmd/generate_sdf/main.cpp:83-91
+    dom = dg.default_domain(V)            # cmd/generate_sdf/main.cpp:83-91
     res = grid_for(world)
     grid = dg.grid_desc(dom[:3], dom[3:], res)
     n_nodes = dg.n_nodes(grid)

@@ -52,6 +52,7 @@ SYMBOLS = {
     "dg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dg_set_device": (C.c_int, [C.c_int]),
     "dg_grid_desc_init": (C.c_int, [_dp, _dp, _u32p, C.POINTER(GridDesc)]),
+    "dg_default_domain": (C.c_int, [_dp, C.c_uint64, _dp]),
     "dg_grid_n_nodes": (C.c_uint64, [C.POINTER(GridDesc)]),
     "dg_grid_n_cells": (C.c_uint64, [C.POINTER(GridDesc)]),
     "dg_mesh_create": (C.c_int, [_dp, C.c_size_t, _u32p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -139,6 +140,14 @@ def grid_desc(domain_min, domain_max, resolution):
     _check(load_library().dg_grid_desc_init(mn.ctypes.data_as(_dp), mx.ctypes.data_as(_dp), res.ctypes.data_as(_u32p),
                                             C.byref(g)))
     return g
+
+
+def default_domain(verts):
+    """dg_default_domain: GenerateSDF's default domain (cmd/generate_sdf/main.cpp:83-91) -> 6 doubles."""
+    v = _f64(verts).reshape(-1, 3)
+    out = np.empty(6)
+    _check(load_library().dg_default_domain(v.ctypes.data_as(_dp), len(v), out.ctypes.data_as(_dp)))
+    return out
 
 
 def n_nodes(grid):

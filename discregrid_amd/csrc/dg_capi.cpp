@@ -148,6 +148,37 @@ dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[
 	return DG_OK;
 }
 
+dg_status dg_default_domain(const double* verts, uint64_t n_vertices, double out_min_max[6])
+{
+	if (!verts || !out_min_max || n_vertices == 0)
+		return fail(DG_ERR_INVALID, "dg_default_domain: no vertices");
+	double* lo = out_min_max;
+	double* hi = out_min_max + 3;
+	for (int d = 0; d < 3; ++d)
+		lo[d] = hi[d] = verts[d];
+	for (uint64_t v = 1; v < n_vertices; ++v)
+		for (int d = 0; d < 3; ++d)
+		{
+			const double x = verts[3 * v + d];
+			lo[d] = x < lo[d] ? x : lo[d];
+			hi[d] = x > hi[d] ? x : hi[d];
+		}
+	// |diagonal| with Eigen's association for fixed 3-vectors: x^2 + (y^2 + z^2)
+	for (int pass = 0; pass < 2; ++pass)
+	{
+		const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+		const double grow = 1.0e-3 * std::sqrt(ex * ex + (ey * ey + ez * ez));
+		for (int d = 0; d < 3; ++d)
+		{
+			if (pass == 0)
+				hi[d] += grow;
+			else
+				lo[d] -= grow;
+		}
+	}
+	return DG_OK;
+}
+
 uint64_t dg_grid_n_nodes(const dg_grid_desc* grid)
 {
 	if (!grid)

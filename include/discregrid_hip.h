@@ -96,6 +96,10 @@ dg_status dg_set_device(int device);
 /* ---- grid helpers (host arithmetic of discrete_grid.hpp:22-29, no device work) ---------- */
 dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
 							dg_grid_desc* out);
+/* Default sampling domain of the reference's GenerateSDF tool (cmd/generate_sdf/main.cpp:83-91): the
+ * bounding box of the vertices, max grown by 1e-3*|diagonal| first, then min by 1e-3*|diagonal of
+ * the already grown box| (the asymmetry is the reference's).  out = {min xyz, max xyz}. */
+dg_status dg_default_domain(const double* verts, uint64_t n_vertices, double out_min_max[6]);
 uint64_t dg_grid_n_nodes(const dg_grid_desc* grid); /* (N+1)^3 + 6N(N+1)^2 generalised, :790-796 */
 uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
 

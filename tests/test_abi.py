@@ -59,6 +59,19 @@ def test_grid_desc_matches_reference_ctor(dg, golden):
     assert dg.n_nodes(dg.grid_desc([0] * 3, [1] * 3, [512] * 3)) == 943460865
 
 
+def test_default_domain_matches_reference_rule(dg, golden):
+    """dg_default_domain == cmd/generate_sdf/main.cpp:83-91 (the oracle's restatement and the domains
+    the unmodified reference computed for the golden vectors), bit for bit."""
+    for name, (V, _) in (("box", T.box_mesh()), ("torus", T.torus()), ("bunny", T.bunny_mesh()),
+                         ("ico", T.icosphere(7))):
+        got = dg.default_domain(V)
+        np.testing.assert_array_equal(got, T.oracle_default_domain(V))
+        if name + "_domain" in golden:
+            np.testing.assert_array_equal(got, golden[name + "_domain"])
+    with pytest.raises(dg.DiscregridError):
+        dg.default_domain(np.zeros((0, 3)))
+
+
 def test_invalid_arguments_are_reported(dg):
     with pytest.raises(dg.DiscregridError) as e:
         dg.grid_desc([0] * 3, [1] * 3, [4, 0, 4])

@@ -80,3 +80,40 @@ def test_host_api_gpu_driver(tmp_path):
     np.testing.assert_array_equal(f1, np.where(pos[:, 2] > 0.0, -1.0 * want, DBL_MAX))
     np.testing.assert_array_equal(d, om.signed_distance(P))
     np.testing.assert_array_equal(phi, T.oracle_interpolate(dom, res, want, P))
+
+
+def _bitmap_cases():
+    import sys
+    sys.path.insert(0, T.GOLDEN)
+    from make_golden_bitmaps import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("name", sorted(_bitmap_cases()))
+def test_discrete_field_to_bitmap_cli_reproduces_reference_bitmaps(tmp_path, name):
+    """DiscreteFieldToBitmap (slice sampled by ONE batched GPU interpolate) == the bitmap the
+    unmodified reference tool wrote for the same options (cmd/discrete_field_to_bitmap), byte
+    for byte; offsets 34..37 (uninitialised biSizeImage in the reference) are 0 on both sides."""
+    exe = _need(os.path.join(BUILD, "DiscreteFieldToBitmap"))
+    src, opts = _bitmap_cases()[name]
+    out = str(tmp_path / "out.bmp")
+    log = subprocess.check_output([exe] + opts + ["-o", out, os.path.join(T.GOLDEN, src)]).decode()
+    assert "bmp resolution" in log
+    got = np.frombuffer(open(out, "rb").read(), np.uint8)
+    want = np.frombuffer(open(os.path.join(T.GOLDEN, "bitmap_%s.bmp" % name), "rb").read(), np.uint8)
+    assert got.shape == want.shape
+    diff = np.flatnonzero(got != want)
+    assert diff.size == 0, "first differing byte at offset %d" % diff[0]
+
+
+def test_discrete_field_to_bitmap_cli_default_output_and_errors(tmp_path):
+    import shutil
+    exe = _need(os.path.join(BUILD, "DiscreteFieldToBitmap"))
+    src = str(tmp_path / "field.cdf")
+    shutil.copyfile(os.path.join(T.GOLDEN, "box.cdf"), src)
+    subprocess.check_call([exe, "--samples=16", "--plane", "yz", src], stdout=subprocess.DEVNULL)
+    b = open(str(tmp_path / "field.bmp"), "rb").read()
+    assert b[:2] == b"BM" and len(b) == 54 + 16 * 16 * 3
+    assert subprocess.call([exe], stdout=subprocess.DEVNULL) == 1
+    assert subprocess.call([exe, "-p", "xyz", src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
+    assert subprocess.call([exe, "-f", "3", src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
