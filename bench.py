@@ -12,8 +12,11 @@ metric is quoted on): synthetic class-I geodesic icosphere, nu = 71 -> 100 820 t
 unit radius; grid 256^3 over the reference's default domain -> 118 425 857 nodes per GPU.
 For N > 1 (weak scaling, BASELINE configs[3]) the grid grows with N -- (256a, 256b, 256c),
 abc = N, i.e. 512^3 at N = 8 -- the lattice is dealt to the ranks in 4-plane slabs, every
-rank samples its shard, ONE RCCL all-gather assembles the packed shards on every GPU and an
-unpack kernel restores reference node order.  value = total nodes / time, max over ranks.
+rank samples its shard, an RCCL all-gather assembles the packed shards on every GPU and an
+unpack kernel restores reference node order.  The gather is issued in --pieces C pieces
+(default 4): piece p of rank r is the shard of "virtual rank" p*N + r of a C*N-way deal, so
+the all-gather of piece p runs on RCCL's stream over xGMI while the kernel samples piece p+1
+(C = 1 is the plain single all-gather).  value = total nodes / time, max over ranks.
 
 Also on the JSON line:
   roofline      achieved = ALGORITHMIC bytes of the reference traversal per launch
@@ -98,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--pcie", action="store_true", help="also report the PCIe-inclusive rate on stderr")
+    ap.add_argument("--pieces", type=int, default=4,
+                    help="N > 1: issue the all-gather in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
                     help="run the N > 1 protocol (RCCL init, shard, all_gather, unpack) even at N = 1 (self-test)")
     args = ap.parse_args()
@@ -132,10 +137,19 @@ def main():
 
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
     if sharded:
-        count, stride = dg.shard_layout(grid, rank, world)
-        gathered = torch.empty(world * stride, dtype=torch.float64, device="cuda")
-        mine = torch.zeros(stride, dtype=torch.float64, device="cuda")   # this rank's packed shard (+ padding)
-        launch_nodes = count
+        # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
+        # 4-plane slabs; all virtual ranks share one slot size, so `gathered` is exactly the buffer a
+        # single all-gather among pieces*world ranks would produce and the unpack kernel is unchanged
+        pieces = max(1, args.pieces)
+        vworld = pieces * world
+        counts = []
+        stride = 0
+        for p in range(pieces):
+            c, stride = dg.shard_layout(grid, p * world + rank, vworld)
+            counts.append(c)
+        gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
+        mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
+        launch_nodes = sum(counts)
     else:
         launch_nodes = n_nodes
 
@@ -145,14 +159,22 @@ def main():
         if i is not None:
             ev[i][0].record(stream)
         if sharded:
-            mesh.sample_shard_device(grid, rank, world, mine.data_ptr(), stream=s)
+            works = []
+            for p in range(pieces):
+                mp = mine[p * stride:(p + 1) * stride]
+                mesh.sample_shard_device(grid, p * world + rank, vworld, mp.data_ptr(), stream=s)
+                # RCCL's stream waits for the kernel just enqueued; this stream goes on with piece p+1
+                works.append(dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp,
+                                                         async_op=True))
+            if i is not None:
+                ev[i][1].record(stream)
+            for w in works:
+                w.wait()
+            dg.unpack_shards_device(grid, vworld, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
         else:
             mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
-        if i is not None:
-            ev[i][1].record(stream)
-        if sharded:
-            dist.all_gather_into_tensor(gathered, mine)          # ONE RCCL collective over xGMI
-            dg.unpack_shards_device(grid, world, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
+            if i is not None:
+                ev[i][1].record(stream)
 
     for _ in range(args.warmup):
         step()
@@ -198,7 +220,8 @@ def main():
                 "workload": "icosphere nu=71 (100820 tris) SDF node sampling, grid %s = %d nodes"
                             % ("x".join(map(str, res)), n_nodes),
                 "nodes_per_gpu_launch": launch_nodes,
-                "sharding": "none" if world == 1 else "4-plane slabs round-robin + 1 all_gather + unpack",
+                "sharding": "none" if not sharded else
+                            "4-plane slabs round-robin, all_gather in %d piece(s) overlapped with sampling, unpack" % pieces,
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {

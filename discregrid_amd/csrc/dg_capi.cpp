@@ -128,6 +128,21 @@ dg_status dg_set_device(int device)
 	return DG_OK;
 }
 
+// XCD chunk size of the K1 launches (dg_kernels.h: logical_block()); tuning knob, default kXcdChunk.
+// DG_XCD_CHUNK=-1 gives every XCD one contiguous eighth of the launch.
+static uint32_t env_xcd_chunk()
+{
+	if (const char* e = std::getenv("DG_XCD_CHUNK"))
+	{
+		const long v = std::atol(e);
+		if (v < 0)
+			return 0xffffffffu;
+		if (v > 0)
+			return (uint32_t)std::min(v, 1L << 24);
+	}
+	return 0;
+}
+
 dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
 							dg_grid_desc* out)
 {
@@ -296,6 +311,7 @@ dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* gr
 
 	dg::SampleParams P;
 	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
+	P.xcd_chunk = env_xcd_chunk();
 	dg::layout_range(P, grid->resolution, node_begin, node_end);
 	P.mask = d_pred_mask;
 	P.out = d_out;
@@ -438,6 +454,7 @@ dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* gr
 		return fail(DG_ERR_INVALID, "rank %d / nranks %d out of range", rank, nranks);
 	dg::SampleParams P;
 	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
+	P.xcd_chunk = env_xcd_chunk();
 	dg::layout_shard(P, grid->resolution, rank, nranks);
 	P.mask = nullptr;
 	P.out = d_packed;

@@ -8,8 +8,9 @@
 namespace dg
 {
 
-static const int kMaxRanks = 16;   // shard table size
+static const int kMaxRanks = 64;   // shard table size
 static const int kSlabPlanes = 4;  // planes per slab == brick depth
+static const uint32_t kXcdChunk = 1024; // logical blocks per XCD chunk (see logical_block())
 #ifndef DG_WAVES_PER_BLOCK
 #define DG_WAVES_PER_BLOCK 1
 #endif
@@ -53,7 +54,8 @@ struct SampleParams
 	ClassDesc cls[4];
 	uint64_t total_bricks;
 	uint32_t n_blocks;       // ceil(total_bricks / kWavesPerBlock)
-	uint32_t blocks_per_xcd; // ceil(n_blocks / 8)
+	uint32_t blocks_per_xcd; // blocks launched per XCD (multiple of xcd_chunk); grid = 8 * blocks_per_xcd
+	uint32_t xcd_chunk;      // consecutive logical blocks that stay on one XCD
 	int32_t shard_rank, shard_n; // shard_n == 1: identity plane map
 	int32_t invert;
 	const uint8_t* mask;     // indexed like out; nullable
@@ -99,6 +101,23 @@ DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
 	n.valid = valid;
 	n.out_idx = C.out_base + (int64_t)(((uint64_t)qp * C.D1 + b) * C.D0 + a);
 	return n;
+}
+
+// XCD-aware remap: hardware deals blockIdx round-robin over the 8 XCDs (each with its own L2).
+// Logical blocks are cut into chunks of xcd_chunk consecutive blocks and the chunks are dealt
+// round-robin to the XCDs: neighbouring bricks -- which walk the same BVH subtrees -- share an
+// L2, while every XCD still sees every region of the lattice (expensive regions, e.g. the
+// inside of the mesh, do not pile up on one XCD).  Returns false for padding blocks.
+DG_HD bool logical_block(const SampleParams& P, uint32_t block_idx, uint32_t* blk)
+{
+	const uint32_t xcd = block_idx & 7u;
+	const uint32_t within = block_idx >> 3;
+	const uint32_t group = within / P.xcd_chunk;
+	// the chunk an XCD takes rotates from group to group, so that a group period close to a
+	// row/plane period of the lattice cannot pin one XCD to one region
+	const uint32_t b = (group * 8u + ((xcd + group) & 7u)) * P.xcd_chunk + within % P.xcd_chunk;
+	*blk = b;
+	return within < P.blocks_per_xcd && b < P.n_blocks;
 }
 
 struct UnpackParams

@@ -203,12 +203,8 @@ __device__ __forceinline__ LaneResult finish(const MeshDev& M, const LaneQuery& 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sample_nodes(const SampleParams P)
 {
-	// XCD-aware remap: hardware deals blockIdx round-robin over the 8 XCDs; give XCD x the
-	// contiguous chunk [x*blocks_per_xcd, (x+1)*blocks_per_xcd) of logical blocks.
-	const uint32_t xcd = blockIdx.x & 7u;
-	const uint32_t within = blockIdx.x >> 3;
-	const uint32_t blk = xcd * P.blocks_per_xcd + within;
-	if (within >= P.blocks_per_xcd || blk >= P.n_blocks)
+	uint32_t blk;
+	if (!logical_block(P, blockIdx.x, &blk)) // XCD-aware remap, dg_kernels.h
 		return;
 	const int wave = uniform((int)(threadIdx.x >> 6));
 	const int lane = (int)(threadIdx.x & 63u);
@@ -360,10 +356,8 @@ __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t
 template <bool STAGED>
 __global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const SampleParams L, const FieldDev F, const DensityParams P)
 {
-	const uint32_t xcd = blockIdx.x & 7u;
-	const uint32_t within = blockIdx.x >> 3;
-	const uint32_t blk = xcd * L.blocks_per_xcd + within;
-	if (within >= L.blocks_per_xcd || blk >= L.n_blocks)
+	uint32_t blk;
+	if (!logical_block(L, blockIdx.x, &blk))
 		return;
 	const uint64_t brick = (uint64_t)blk; // one wave per block
 	if (brick >= L.total_bricks)

@@ -71,7 +71,12 @@ inline void finish_bricks(SampleParams& P)
 	}
 	P.total_bricks = prefix;
 	P.n_blocks = (uint32_t)((prefix + kWavesPerBlock - 1) / kWavesPerBlock);
-	P.blocks_per_xcd = (P.n_blocks + 7) / 8;
+	if (P.xcd_chunk == 0)
+		P.xcd_chunk = kXcdChunk;
+	if (P.xcd_chunk == 0xffffffffu) // one chunk per XCD
+		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
+	const uint32_t per_group = 8u * P.xcd_chunk;
+	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
 }
 
 inline void init_params(SampleParams& P, const MeshDev& mesh, const double dmin[3], const double cell[3], int invert)

@@ -133,7 +133,11 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
  * along its slowest-varying index (k, k, i, j -- i.e. Z-slabs for V and X) and the slabs are
  * dealt round-robin to the ranks.  A rank writes its nodes into a packed buffer of
  * `count` doubles; after ONE all-gather of `stride` doubles per rank,
- * dg_unpack_shards_device() scatters the gathered buffer into reference node order. */
+ * dg_unpack_shards_device() scatters the gathered buffer into reference node order.
+ * `nranks` may exceed the number of GPUs (up to 64): a process that takes the "virtual ranks"
+ * p*G + g, p = 0..C-1, of a C*G-way deal can all-gather piece p among the G GPUs while it samples
+ * piece p+1; the C gathered pieces laid end to end are the buffer a single C*G-rank all-gather
+ * would produce, so the same unpack call (nranks = C*G) applies (bench.py --pieces). */
 dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_shard_info* out);
 dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
 									 double* d_packed, void* stream);

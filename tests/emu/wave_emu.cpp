@@ -319,9 +319,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 #pragma omp parallel for schedule(dynamic, 16)
 	for (long long bid = 0; bid < (long long)grid; ++bid)
 	{
-		const uint32_t xcd = (uint32_t)bid & 7u, within = (uint32_t)bid >> 3;
-		const uint32_t blk = xcd * P.blocks_per_xcd + within;
-		if (within >= P.blocks_per_xcd || blk >= P.n_blocks)
+		uint32_t blk;
+		if (!logical_block(P, (uint32_t)bid, &blk))
 			continue;
 		Stats ls;
 		for (int wave = 0; wave < kWavesPerBlock; ++wave)

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, res, ret):
+def _worker(rank, world, port, res, ret, pieces=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,14 +32,27 @@ def _worker(rank, world, port, res, ret):
         V, F = T.torus()
         dom = T.oracle_default_domain(V)
         grid = dg.grid_desc(dom[:3], dom[3:], res)
-        count, stride = dg.shard_layout(grid, rank, world)          # product bookkeeping (host only)
-        assert count == emu.shard_count(res, rank, world)
-        gathered = torch.full((world * stride,), float("nan"), dtype=torch.float64)
-        mine = gathered[rank * stride:(rank + 1) * stride]
-        shard = emu.EmuMesh(V, F).sample_shard(dom, res, rank, world)
-        mine[:count] = torch.from_numpy(shard)
-        dist.all_gather_into_tensor(gathered, mine.clone())
-        field = emu.unpack(res, world, gathered.numpy(), stride)
+        # bench.py's protocol: piece p of this rank is the shard of virtual rank p*world + rank of a
+        # (pieces*world)-way deal; piece p is all-gathered (async) while piece p+1 is sampled
+        vworld = pieces * world
+        mesh = emu.EmuMesh(V, F)
+        count = 0
+        stride = dg.shard_layout(grid, rank, vworld)[1]              # product bookkeeping (host only)
+        gathered = torch.full((vworld * stride,), float("nan"), dtype=torch.float64)
+        works, keep = [], []
+        for p in range(pieces):
+            v = p * world + rank
+            c, st = dg.shard_layout(grid, v, vworld)
+            assert st == stride and c == emu.shard_count(res, v, vworld)
+            mine = torch.zeros(stride, dtype=torch.float64)
+            mine[:c] = torch.from_numpy(mesh.sample_shard(dom, res, v, vworld))
+            keep.append(mine)
+            works.append(dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mine,
+                                                     async_op=True))
+            count += c
+        for w in works:
+            w.wait()
+        field = emu.unpack(res, vworld, gathered.numpy(), stride)
         want = T.OracleMesh(V, F).sample_nodes(dom, res)
         ok = bool(np.array_equal(field, want))
         # max-over-ranks reduction as bench.py does for the timing
@@ -50,11 +63,12 @@ def _worker(rank, world, port, res, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,res", [(2, [10, 7, 13]), (3, [6, 9, 5])])
-def test_shard_allgather_unpack_gloo(world, res):
+@pytest.mark.parametrize("world,res,pieces", [(2, [10, 7, 13], 1), (3, [6, 9, 5], 1), (2, [9, 17, 21], 4),
+                                              (2, [5, 4, 6], 3)])
+def test_shard_allgather_unpack_gloo(world, res, pieces):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), res, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), res, ret, pieces), nprocs=world, join=True)
     assert len(ret) == world
     assert all(v[0] for v in ret.values())
     assert all(v[1] == float(world) for v in ret.values())
@@ -85,3 +99,8 @@ def test_shard_balance_at_scale():
         counts = [dg.shard_layout(g, r, world)[0] for r in range(world)]
         assert sum(counts) == dg.n_nodes(g)
         assert max(counts) / min(counts) < 1.03, (world, counts)
+        # dealing to 4*world virtual ranks (bench.py --pieces 4) leaves every GPU the same nodes
+        pieces = 4
+        vcounts = [sum(dg.shard_layout(g, p * world + r, pieces * world)[0] for p in range(pieces))
+                   for r in range(world)]
+        assert vcounts == counts
