@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <numeric>
 #include <unordered_map>
@@ -319,6 +320,25 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 
 	out.pairs.swap(B.pairs);
 	out.depth = B.depth;
+	// level-order cut of the tree into <= 64 disjoint subtrees that cover it (heavy bricks are split
+	// over them): split the oldest inner node of the queue until 64 pieces exist or only leaves remain
+	{
+		std::deque<int32_t> open(1, out.root_info);
+		out.sub_roots.clear();
+		while (!open.empty() && out.sub_roots.size() + open.size() < 64)
+		{
+			const int32_t info = open.front();
+			open.pop_front();
+			if (info < 0)
+			{
+				out.sub_roots.push_back(info);
+				continue;
+			}
+			open.push_back(out.pairs[(size_t)info].info[0]);
+			open.push_back(out.pairs[(size_t)info].info[1]);
+		}
+		out.sub_roots.insert(out.sub_roots.end(), open.begin(), open.end());
+	}
 	out.n_vertices = n_vertices;
 	out.n_triangles = n_triangles;
 	const size_t npos = B.order.size(); // even

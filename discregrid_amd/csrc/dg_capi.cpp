@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,6 +23,18 @@
 #include "dg_kernels.h"
 #include "dg_layout.h"
 
+// Scratch of one K1 launch for its heavy bricks (dg_kernels.h: OverflowBuf).  Buffers are kept with
+// the mesh and handed out again once the launch that used them has finished (or to the same stream,
+// where launches are ordered anyway), so steady-state launches allocate nothing.
+struct HeavyScratch
+{
+	void* mem = nullptr;
+	hipEvent_t done = nullptr;
+	hipStream_t stream = nullptr;
+	uint32_t slots = 0;
+	bool busy = false; // between acquire and the event record
+};
+
 struct dg_mesh
 {
 	dg::MeshDev dev;
@@ -31,6 +44,8 @@ struct dg_mesh
 	void* d_pn = nullptr;
 	int device = -1;
 	dg_mesh_info info;
+	mutable std::mutex scratch_mutex;
+	mutable std::vector<HeavyScratch> scratch;
 };
 
 struct dg_field
@@ -259,7 +274,9 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->dev.root_info = B.root_info;
 	m->dev.n_positions = (int32_t)B.tris.size();
 	m->dev.stack_levels = (int32_t)std::min<uint32_t>(B.depth + 1, dg::kStackDepth);
-	m->dev.pad0_ = 0;
+	m->dev.n_sub = (int32_t)B.sub_roots.size();
+	for (size_t i = 0; i < (size_t)dg::kSubtrees; ++i)
+		m->dev.sub_roots[i] = i < B.sub_roots.size() ? B.sub_roots[i] : B.root_info;
 	for (int d = 0; d < 3; ++d)
 		m->dev.origin[d] = B.origin[d];
 	m->dev.mesh_l1 = B.mesh_l1;
@@ -291,10 +308,94 @@ void dg_mesh_destroy(dg_mesh* m)
 	if (m->d_tri_pairs) (void)hipFree(m->d_tri_pairs);
 	if (m->d_tris) (void)hipFree(m->d_tris);
 	if (m->d_pn) (void)hipFree(m->d_pn);
+	for (HeavyScratch& h : m->scratch)
+	{
+		if (h.done) (void)hipEventDestroy(h.done);
+		if (h.mem) (void)hipFree(h.mem);
+	}
 	delete m;
 }
 
 // ---- K1 ----------------------------------------------------------------------------------------------
+static int env_int(const char* name, int fallback, int lo, int hi)
+{
+	if (const char* e = std::getenv(name))
+		return std::max(lo, std::min(hi, std::atoi(e)));
+	return fallback;
+}
+
+// Attaches heavy-brick scratch to a K1 launch (tuning knobs DG_HEAVY_SLOTS, 0 = no splitting, and
+// DG_HEAVY_WORK).  Returns the index of the scratch buffer in use, or -1 when the launch runs
+// without splitting (tiny tree, knob, or no memory -- splitting only shortens the launch).
+static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
+{
+	std::memset(&P.ovf, 0, sizeof(P.ovf));
+	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", dg::kOverflowSlots, 0, dg::kOverflowSlots);
+	if (slots == 0 || mesh->dev.n_sub < 2)
+		return -1;
+	size_t off[6];
+	const size_t bytes = dg::overflow_bytes(slots, off);
+	int idx = -1;
+	{
+		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+		for (size_t i = 0; i < mesh->scratch.size() && idx < 0; ++i)
+		{
+			HeavyScratch& h = mesh->scratch[i];
+			if (!h.busy && h.slots == slots && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
+				idx = (int)i;
+		}
+		if (idx < 0)
+		{
+			HeavyScratch h;
+			h.slots = slots;
+			if (hipMalloc(&h.mem, bytes) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				if (h.mem) (void)hipFree(h.mem);
+				return -1;
+			}
+			mesh->scratch.push_back(h);
+			idx = (int)mesh->scratch.size() - 1;
+		}
+		mesh->scratch[(size_t)idx].busy = true;
+		mesh->scratch[(size_t)idx].stream = stream;
+	}
+	char* base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
+	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
+	P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
+	P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
+	P.ovf.saved_tri = reinterpret_cast<int32_t*>(base + off[3]);
+	P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
+	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
+	P.ovf.slots = slots;
+	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::kHeavyWork, 1, 1 << 30);
+	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+		mesh->scratch[(size_t)idx].busy = false;
+		std::memset(&P.ovf, 0, sizeof(P.ovf));
+		return -1;
+	}
+	return idx;
+}
+static void release_heavy_scratch(const dg_mesh* mesh, int idx, hipStream_t stream)
+{
+	if (idx < 0)
+		return;
+	std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+	HeavyScratch& h = mesh->scratch[(size_t)idx];
+	(void)hipEventRecord(h.done, stream);
+	h.busy = false;
+}
+static hipError_t launch_k1(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
+{
+	const int scratch = acquire_heavy_scratch(mesh, P, stream);
+	const hipError_t e = dg::launch_sample_nodes(P, stream);
+	release_heavy_scratch(mesh, scratch, stream);
+	return e;
+}
+
 dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream)
 {
@@ -315,7 +416,7 @@ dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* gr
 	dg::layout_range(P, grid->resolution, node_begin, node_end);
 	P.mask = d_pred_mask;
 	P.out = d_out;
-	DG_HIP(dg::launch_sample_nodes(P, static_cast<hipStream_t>(stream)));
+	DG_HIP(launch_k1(mesh, P, static_cast<hipStream_t>(stream)));
 	return DG_OK;
 }
 
@@ -458,7 +559,7 @@ dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* gr
 	dg::layout_shard(P, grid->resolution, rank, nranks);
 	P.mask = nullptr;
 	P.out = d_packed;
-	DG_HIP(dg::launch_sample_nodes(P, static_cast<hipStream_t>(stream)));
+	DG_HIP(launch_k1(mesh, P, static_cast<hipStream_t>(stream)));
 	return DG_OK;
 }
 

@@ -16,6 +16,42 @@ static const uint32_t kXcdChunk = 1024; // logical blocks per XCD chunk (see log
 #endif
 static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 
+// Heavy bricks.  A brick whose 64 nodes are (nearly) equidistant from large parts of the surface --
+// the centre of a sphere-like mesh is the extreme -- needs the exact test for thousands of
+// triangles, serially in ONE wave, while the rest of the chip idles at the end of the launch.
+// K1 therefore gives a brick a work budget; a wave that exhausts it parks its running bests in an
+// overflow slot and exits, a second kernel walks each of the kSubtrees top-level subtrees of the
+// BVH for every parked brick in its own wave (starting from the parked bests), and a third kernel
+// takes the per-lane minimum over the subtrees and writes the node values.  min is exact, so the
+// result is the one the single wave would have produced.
+static const int kSubtrees = 64;        // subtree roots the tree is cut into (fewer for tiny trees)
+static const int kOverflowSlots = 256;  // parked bricks per launch; further heavy bricks simply run on
+static const int kHeavyWork = 3000;     // traversal steps + exact triangle tests before a brick counts as heavy
+
+struct OverflowBuf // device scratch of one K1 launch (null count: splitting disabled)
+{
+	uint32_t* count;     // slots claimed so far (may run past `slots`)
+	uint32_t* brick;     // [slots] brick id parked in the slot
+	double* saved_d2;    // [slots][64] running best of every lane when the wave parked
+	int32_t* saved_tri;  // [slots][64]
+	double* cand_d2;     // [slots][kSubtrees][64] best of every lane within one subtree
+	int32_t* cand_tri;   // [slots][kSubtrees][64]
+	uint32_t slots;      // <= kOverflowSlots
+	int32_t heavy_work;  // work budget of a brick
+};
+inline size_t overflow_bytes(uint32_t slots, size_t off[6])
+{
+	size_t o = 0;
+	auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+	off[0] = take(sizeof(uint32_t));
+	off[1] = take(sizeof(uint32_t) * slots);
+	off[2] = take(sizeof(double) * 64 * slots);
+	off[3] = take(sizeof(int32_t) * 64 * slots);
+	off[4] = take(sizeof(double) * 64 * kSubtrees * slots);
+	off[5] = take(sizeof(int32_t) * 64 * kSubtrees * slots);
+	return o;
+}
+
 struct MeshDev
 {
 	const PairRec* pairs;     // node pairs (dg_geom.h)
@@ -25,10 +61,11 @@ struct MeshDev
 	int32_t root_info;
 	int32_t n_positions;
 	int32_t stack_levels; // tree depth + 1 (<= kStackDepth): LDS bound-stack levels a traversal can need
-	int32_t pad0_;
+	int32_t n_sub;        // entries of sub_roots (1..kSubtrees)
 	double origin[3];
 	float mesh_l1;
 	float pad_;
+	int32_t sub_roots[kSubtrees]; // info words of the subtrees the tree is cut into (see "Heavy bricks")
 };
 static const int kStackDepth = 32; // >= tree depth; 2^32 leaves of >= 1 triangle is beyond the 2^27 triangle limit
 
@@ -60,6 +97,7 @@ struct SampleParams
 	int32_t invert;
 	const uint8_t* mask;     // indexed like out; nullable
 	double* out;
+	OverflowBuf ovf;
 };
 
 // Which lattice node does `lane` of brick `brick` own?  Shared by the kernel and by the host-side
@@ -132,6 +170,7 @@ struct UnpackParams
 };
 
 
+// K1 (+ the two heavy-brick kernels when p.ovf.count is set; the caller zeroes *p.ovf.count first)
 hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream);
 hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
 								  int32_t* d_entity, double* d_nearest, hipStream_t stream);

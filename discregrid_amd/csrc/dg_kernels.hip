@@ -40,6 +40,9 @@ namespace
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 #define DG_CONST_AS __attribute__((address_space(4)))
+#ifndef DG_K1_MIN_WAVES
+#define DG_K1_MIN_WAVES 8 // K1 is issue bound and hides its scalar-load latency with waves: cap it at 64 VGPRs
+#endif
 #ifndef DG_K3_WAVES
 #define DG_K3_WAVES 1 // min waves per SIMD requested for K3 (register budget)
 #endif
@@ -88,8 +91,9 @@ __device__ __forceinline__ SPair load_pair(const PairRec* base, int idx)
 // (wave-uniform arguments), handled pair by pair.  A triangle gets the full double-precision
 // test only if some lane's float lower bound -- the larger of the leaf's bound and the
 // triangle's own box+slab bound -- is below that lane's running best.
-__device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
+__device__ __forceinline__ int test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
 {
+	int tests = 0; // wave-uniform
 	for (int g = 0; g < cnt; g += 2)
 	{
 		const SPair pr = load_pair(M.tri_pairs, (first + g) >> 1);
@@ -101,6 +105,7 @@ __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, 
 		{
 			if (!(side == 0 ? w0 : w1))
 				continue;
+			++tests;
 			const int t = first + g + side;
 			const char* base = (const char*)(M.tris + t);
 			const v16i a = sload16(base);
@@ -117,6 +122,7 @@ __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, 
 			offer(q, h.d2, t);
 		}
 	}
+	return tests;
 }
 
 // Packet traversal, near-first.  On return every active lane holds the minimum squared distance
@@ -130,19 +136,39 @@ __device__ __forceinline__ void test_leaf(const MeshDev& M, int first, int cnt, 
 // load fetches the bounds of both children, which are evaluated with packed two-wide float
 // math; a child is entered if ANY lane may still improve there, the child most lanes are
 // closer to first, the other one is pushed.
-__device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q, float* lds_lb /* [M.stack_levels][64] of this wave */)
+//
+// `start` is the info word of the subtree to search.  With `ovf_count` set the wave counts its work
+// (node steps + exact triangle tests); when the count passes heavy_work it claims an
+// overflow slot and returns the slot number at once -- the caller parks the lanes' running
+// bests there (dg_kernels.h, "Heavy bricks").  If all slots are taken the wave simply carries on.
+// Returns -1 when the subtree was searched to the end.
+__device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, float* lds_lb /* [M.stack_levels][64] of this wave */,
+										int start, uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
 {
 	const int lane_id = (int)__lane_id();
 	int stackv = 0; // info words: lane i holds entry i
 	int sp = 0;     // wave-uniform
-	int cur = M.root_info;
+	int cur = start;
 	float lbcur = 0.0f; // this lane's lower bound for `cur`
+	int work = 0;       // wave-uniform
+	int budget = ovf_count ? heavy_work : 0x7fffffff;
 	while (true)
 	{
+		if (work > budget)
+		{
+			int slot = 0;
+			if (lane_id == 0)
+				slot = (int)atomicAdd(ovf_count, 1u);
+			slot = uniform(slot);
+			if ((unsigned)slot < ovf_slots)
+				return slot;
+			budget = 0x7fffffff;
+		}
+		++work;
 		if (cur < 0)
 		{
 			const unsigned code = ~(unsigned)cur;
-			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
+			work += test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
 		}
 		else
 		{
@@ -187,6 +213,7 @@ __device__ __forceinline__ void traverse(const MeshDev& M, LaneQuery& q, float* 
 		if (!found)
 			break;
 	}
+	return -1;
 }
 
 struct DeviceSqrt
@@ -198,10 +225,24 @@ __device__ __forceinline__ LaneResult finish(const MeshDev& M, const LaneQuery& 
 	return finish_query(M.tris, M.pn, q, DeviceSqrt());
 }
 
+// K1 epilogue: the node value of one lane
+__device__ __forceinline__ void write_node(const SampleParams& P, bool valid, bool sample, int64_t out_idx, const LaneQuery& q)
+{
+	if (!valid)
+		return;
+	double v = 1.7976931348623157e308; // predicate-rejected node (:817)
+	if (sample && q.best_tri >= 0)
+	{
+		const LaneResult r = finish(P.mesh, q);
+		v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+	}
+	P.out[out_idx] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: one wave per 4x4x4 brick of one node class.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_sample_nodes(const SampleParams P)
+__global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample_nodes(const SampleParams P)
 {
 	uint32_t blk;
 	if (!logical_block(P, blockIdx.x, &blk)) // XCD-aware remap, dg_kernels.h
@@ -226,18 +267,75 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_sample_nodes(const Samp
 	LaneQuery q;
 	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
 	if (__ballot(sample) != 0ull)
-		traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64));
-
-	if (valid)
 	{
-		double v = 1.7976931348623157e308; // predicate-rejected node (:817)
-		if (sample && q.best_tri >= 0)
+		const int slot = traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64), P.mesh.root_info,
+								  P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		if (slot >= 0) // heavy brick: park the running bests, k_heavy_subtrees / k_heavy_finish take over
 		{
-			const LaneResult r = finish(P.mesh, q);
-			v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+			if (lane == 0)
+				P.ovf.brick[slot] = (uint32_t)brick;
+			P.ovf.saved_d2[slot * 64 + lane] = q.best_d2;
+			P.ovf.saved_tri[slot * 64 + lane] = q.best_tri;
+			return;
 		}
-		P.out[out_idx] = v;
 	}
+	write_node(P, valid, sample, out_idx, q);
+}
+
+// Heavy bricks, step 2: wave (slot, s) searches subtree s of the BVH for the brick parked in `slot`,
+// starting from the parked bests.  blockIdx = slot * n_sub + s.
+__global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
+{
+	const uint32_t n_sub = (uint32_t)P.mesh.n_sub;
+	const uint32_t slot = blockIdx.x / n_sub;
+	const uint32_t s = blockIdx.x - slot * n_sub;
+	const uint32_t parked = min(*P.ovf.count, P.ovf.slots);
+	if (slot >= parked)
+		return;
+	const int lane = (int)threadIdx.x;
+	const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
+	bool sample = ln.valid;
+	if (ln.valid && P.mask != nullptr)
+		sample = P.mask[ln.out_idx] != 0;
+	double x[3];
+	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[];
+	LaneQuery q;
+	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
+	const int tri = P.ovf.saved_tri[slot * 64 + lane];
+	if (sample && tri >= 0)
+		offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
+	traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
+	const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
+	P.ovf.cand_d2[at] = q.best_d2;
+	P.ovf.cand_tri[at] = q.best_tri;
+}
+
+// Heavy bricks, step 3: per lane the minimum over the subtrees (the parked best is part of every
+// candidate; of exactly tied candidates the lowest subtree wins), then K1's epilogue.
+__global__ __launch_bounds__(64) void k_heavy_finish(const SampleParams P)
+{
+	const uint32_t slot = blockIdx.x;
+	if (slot >= min(*P.ovf.count, P.ovf.slots))
+		return;
+	const int lane = (int)threadIdx.x;
+	const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
+	bool sample = ln.valid;
+	if (ln.valid && P.mask != nullptr)
+		sample = P.mask[ln.out_idx] != 0;
+	double x[3];
+	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+	LaneQuery q;
+	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
+	if (sample)
+		for (int s = 0; s < P.mesh.n_sub; ++s)
+		{
+			const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)lane;
+			const int tri = P.ovf.cand_tri[at];
+			if (tri >= 0)
+				offer(q, P.ovf.cand_d2[at], tri);
+		}
+	write_node(P, ln.valid, sample, ln.out_idx, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,7 +351,7 @@ __global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const 
 	LaneQuery q;
 	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [4 waves][stack_levels][64]
 	init_query(M.origin, M.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
-	traverse(M, q, lds_lb + (threadIdx.x >> 6) * (M.stack_levels * 64));
+	traverse(M, q, lds_lb + (threadIdx.x >> 6) * (M.stack_levels * 64), M.root_info, nullptr, 0u, 0);
 	if (!valid)
 		return;
 	if (q.best_tri < 0)
@@ -405,6 +503,12 @@ hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
 	const uint32_t grid = p.blocks_per_xcd * 8u;
 	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
 	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
+	if (p.ovf.count != nullptr)
+	{
+		const size_t lds1 = (size_t)p.mesh.stack_levels * 64 * sizeof(float);
+		hipLaunchKernelGGL(k_heavy_subtrees, dim3(p.ovf.slots * (uint32_t)p.mesh.n_sub), dim3(64), lds1, stream, p);
+		hipLaunchKernelGGL(k_heavy_finish, dim3(p.ovf.slots), dim3(64), 0, stream, p);
+	}
 	return hipGetLastError();
 }
 

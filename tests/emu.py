@@ -31,6 +31,10 @@ def lib():
         L.emu_mesh_check.argtypes = [C.c_void_p, T.c_dp, T.c_up]
         L.emu_sample_nodes.argtypes = [C.c_void_p, T.c_dp, T.c_dp, T.c_up, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                        C.c_void_p, T.c_dp, C.c_void_p, T.c_u64p]
+        L.emu_set_heavy.argtypes = [C.c_uint32, C.c_int]
+        L.emu_n_subtrees.argtypes = [C.c_void_p]
+        L.emu_subtree_triangles.argtypes = [C.c_void_p]
+        L.emu_subtree_triangles.restype = C.c_longlong
         L.emu_signed_distance.argtypes = [C.c_void_p, T.c_dp, C.c_uint64, T.c_dp, T.c_ip, T.c_ip, T.c_dp]
         L.emu_shard_count.restype = C.c_uint64
         L.emu_shard_count.argtypes = [T.c_up, C.c_int, C.c_int]
@@ -55,6 +59,12 @@ class EmuMesh:
         if getattr(self, "h", None):
             self.L.emu_mesh_free(self.h)
             self.h = None
+
+    def n_subtrees(self):
+        return self.L.emu_n_subtrees(self.h)
+
+    def subtree_triangles(self):
+        return self.L.emu_subtree_triangles(self.h)
 
     def check(self):
         return self.L.emu_mesh_check(self.h, T.dp(self.V), T.up(self.F))
@@ -85,14 +95,14 @@ class EmuMesh:
             end = T.n_nodes(res)
         out = np.full(end - begin, np.nan)
         written = np.zeros(end - begin, dtype=np.uint8)
-        st = np.zeros(11, dtype=np.uint64)
+        st = np.zeros(12, dtype=np.uint64)
         dmin = np.ascontiguousarray(domain[:3])
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self.L.emu_sample_nodes(self.h, T.dp(dmin), T.dp(cell), T.up(res), int(invert), 0, begin, end,
                                 None if m is None else m.ctypes.data_as(C.c_void_p), T.dp(out),
                                 written.ctypes.data_as(C.c_void_p), st.ctypes.data_as(T.c_u64p))
         self.written = written
-        self.stats = dict(zip(("bricks", "node_visits", "leaf_visits", "tri_tests", "descent_nodes", "slab_tests", "lane_interest", "useful_tests", "leaf_groups", "pops", "stale_pops"), st.tolist()))
+        self.stats = dict(zip(("bricks", "node_visits", "leaf_visits", "tri_tests", "descent_nodes", "slab_tests", "lane_interest", "useful_tests", "leaf_groups", "pops", "stale_pops", "heavy_bricks"), st.tolist()))
         return out
 
     def sample_shard(self, domain, res, rank, nranks, invert=False):
@@ -164,3 +174,9 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     lib().emu_interpolate(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), T.up(cells), T.up(cell_map),
                           T.dp(P), len(P), T.dp(phi), T.dp(g))
     return (phi, g) if grad else phi
+
+
+def set_heavy(slots=256, work=3000):
+    """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: kOverflowSlots, kHeavyWork);
+    slots = 0 disables the split."""
+    lib().emu_set_heavy(slots, work)

@@ -27,7 +27,7 @@ namespace
 
 struct Stats
 {
-	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0, useful_tests = 0, leaf_groups = 0, pops = 0, stale_pops = 0;
+	uint64_t bricks = 0, node_visits = 0, leaf_visits = 0, tri_tests = 0, descent_nodes = 0, slab_tests = 0, lane_interest = 0, useful_tests = 0, leaf_groups = 0, pops = 0, stale_pops = 0, heavy_bricks = 0;
 };
 
 struct HostSqrt
@@ -40,8 +40,9 @@ struct Wave
 	LaneQuery q[64];
 };
 
-void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane*/, Wave& w, Stats& st)
+int test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane*/, Wave& w, Stats& st)
 {
+	int tests = 0;
 	for (int g = 0; g < cnt; g += 2)
 	{
 		const PairRec& pr = M.tri_pairs[(first + g) >> 1];
@@ -64,6 +65,7 @@ void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per
 			if (!want[side])
 				continue;
 			st.tri_tests++;
+			++tests;
 			st.lane_interest += n_int[side];
 			const int t = first + g + side;
 			const TriPacket& T = M.tris[t];
@@ -77,27 +79,39 @@ void test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per
 			st.useful_tests += useful;
 		}
 	}
+	return tests;
 }
 
 // mirrors traverse() of dg_kernels.hip: near-first packet traversal, wave-shared stack of info
 // words, per-lane bounds of postponed subtrees parked per level
-void traverse(const MeshDev& M, Wave& w, Stats& st)
+// (including the work budget / overflow-slot claim of the heavy-brick path)
+int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf)
 {
 	int stack_info[kStackDepth];
 	static thread_local float stack_lb[kStackDepth][64];
 	int sp = 0;
-	int cur = M.root_info;
+	int cur = start;
 	float lbcur[64];
 	for (int k = 0; k < 64; ++k)
 		lbcur[k] = 0.0f;
+	int work = 0;
+	int budget = ovf ? ovf->heavy_work : 0x7fffffff;
 	while (true)
 	{
+		if (work > budget)
+		{
+			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
+			if (slot < ovf->slots)
+				return (int)slot;
+			budget = 0x7fffffff;
+		}
+		++work;
 		bool descended = false;
 		if (cur < 0)
 		{
 			st.leaf_visits++;
 			const unsigned code = ~(unsigned)cur;
-			test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
+			work += test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
 		}
 		else
 		{
@@ -164,7 +178,12 @@ void traverse(const MeshDev& M, Wave& w, Stats& st)
 		if (!found)
 			break;
 	}
+	return -1;
 }
+
+// heavy-brick settings of the emulated launches (defaults = the product's)
+uint32_t g_heavy_slots = kOverflowSlots;
+int g_heavy_work = kHeavyWork;
 
 struct HostMesh
 {
@@ -195,9 +214,48 @@ void* emu_mesh_create(const double* verts, size_t nv, const uint32_t* tris, size
 	m->dev.stack_levels = (int32_t)std::min<uint32_t>(m->B.depth + 1, kStackDepth);
 	for (int d = 0; d < 3; ++d)
 		m->dev.origin[d] = m->B.origin[d];
+	m->dev.n_sub = (int32_t)m->B.sub_roots.size();
+	for (size_t i = 0; i < (size_t)kSubtrees; ++i)
+		m->dev.sub_roots[i] = i < m->B.sub_roots.size() ? m->B.sub_roots[i] : m->B.root_info;
 	return m;
 }
 void emu_mesh_free(void* h) { delete static_cast<HostMesh*>(h); }
+// slots = 0: no splitting; work: budget of a brick (node steps + exact tests)
+void emu_set_heavy(uint32_t slots, int work)
+{
+	g_heavy_slots = slots < (uint32_t)kOverflowSlots ? slots : (uint32_t)kOverflowSlots;
+	g_heavy_work = work;
+}
+int emu_n_subtrees(void* h) { return static_cast<HostMesh*>(h)->dev.n_sub; }
+// number of triangles reachable from the subtree roots; -1 if a triangle is reachable twice
+long long emu_subtree_triangles(void* h)
+{
+	auto m = static_cast<HostMesh*>(h);
+	std::vector<uint8_t> seen(m->B.tris.size(), 0);
+	long long n = 0;
+	std::vector<int32_t> todo(m->B.sub_roots.begin(), m->B.sub_roots.end());
+	while (!todo.empty())
+	{
+		const int32_t info = todo.back();
+		todo.pop_back();
+		if (info >= 0)
+		{
+			todo.push_back(m->B.pairs[(size_t)info].info[0]);
+			todo.push_back(m->B.pairs[(size_t)info].info[1]);
+			continue;
+		}
+		const unsigned code = ~(unsigned)info;
+		const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
+		for (int t = first; t < first + cnt; ++t)
+		{
+			if (seen[(size_t)t])
+				return -1;
+			seen[(size_t)t] = 1;
+			n += m->B.tris[(size_t)t].tri_id >= 0;
+		}
+	}
+	return n;
+}
 void emu_mesh_info(void* h, uint64_t* n_nodes, uint32_t* depth, uint32_t* flags)
 {
 	auto m = static_cast<HostMesh*>(h);
@@ -301,7 +359,7 @@ int emu_mesh_check(void* h, const double* verts, const uint32_t* tris)
 // mode 0: flat range [a0, a1) -> out[l - a0];  mode 1: shard (rank = a0, nranks = a1) -> packed
 int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const uint32_t res[3], int invert, int mode,
 					 uint64_t a0, uint64_t a1, const uint8_t* mask, double* out, uint8_t* written /*nullable*/,
-					 uint64_t* stats /*11, nullable*/)
+					 uint64_t* stats /*12, nullable*/)
 {
 	auto m = static_cast<HostMesh*>(h);
 	SampleParams P;
@@ -314,6 +372,60 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 	P.out = out;
 	Stats st;
 	int err = 0;
+	// heavy-brick scratch exactly as dg_capi.cpp attaches it
+	uint32_t ovf_count = 0;
+	std::vector<uint32_t> ovf_brick;
+	std::vector<double> saved_d2, cand_d2;
+	std::vector<int32_t> saved_tri, cand_tri;
+	std::memset(&P.ovf, 0, sizeof(P.ovf));
+	if (g_heavy_slots > 0 && P.mesh.n_sub >= 2)
+	{
+		ovf_brick.resize(g_heavy_slots);
+		saved_d2.resize((size_t)g_heavy_slots * 64);
+		saved_tri.resize((size_t)g_heavy_slots * 64);
+		cand_d2.resize((size_t)g_heavy_slots * kSubtrees * 64);
+		cand_tri.resize((size_t)g_heavy_slots * kSubtrees * 64);
+		P.ovf.count = &ovf_count;
+		P.ovf.brick = ovf_brick.data();
+		P.ovf.saved_d2 = saved_d2.data();
+		P.ovf.saved_tri = saved_tri.data();
+		P.ovf.cand_d2 = cand_d2.data();
+		P.ovf.cand_tri = cand_tri.data();
+		P.ovf.slots = g_heavy_slots;
+		P.ovf.heavy_work = g_heavy_work;
+	}
+	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
+		for (int l = 0; l < 64; ++l)
+		{
+			if (!ln[l].valid)
+				continue;
+			double v = 1.7976931348623157e308;
+			if (sample[l] && w.q[l].best_tri >= 0)
+			{
+				const LaneResult r = finish_query(P.mesh.tris, P.mesh.pn, w.q[l], HostSqrt());
+				v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+			}
+			out[ln[l].out_idx] = v;
+			if (written)
+			{
+#pragma omp atomic
+				written[ln[l].out_idx]++;
+			}
+		}
+	};
+	auto init_wave = [&](uint64_t brick, LaneNode* ln, bool* sample, Wave& w) {
+		bool any = false;
+		for (int l = 0; l < 64; ++l)
+		{
+			ln[l] = map_lane(P, brick, l);
+			sample[l] = ln[l].valid && (!mask || mask[ln[l].out_idx] != 0);
+			double x[3];
+			node_position(ln[l].cls, ln[l].a, ln[l].b, ln[l].s, P.dmin, P.cell, x);
+			init_query(P.mesh.origin, P.mesh.mesh_l1, sample[l], x[0], x[1], x[2], w.q[l]);
+			any = any || sample[l];
+		}
+		return any;
+	};
 	// same block/XCD enumeration as the kernel (coverage of the remap is part of the test)
 	const uint32_t grid = P.blocks_per_xcd * 8u;
 #pragma omp parallel for schedule(dynamic, 16)
@@ -331,36 +443,22 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			Wave w;
 			LaneNode ln[64];
 			bool sample[64];
-			bool any = false;
-			for (int l = 0; l < 64; ++l)
-			{
-				ln[l] = map_lane(P, brick, l);
-				sample[l] = ln[l].valid && (!mask || mask[ln[l].out_idx] != 0);
-				double x[3];
-				node_position(ln[l].cls, ln[l].a, ln[l].b, ln[l].s, P.dmin, P.cell, x);
-				init_query(P.mesh.origin, P.mesh.mesh_l1, sample[l], x[0], x[1], x[2], w.q[l]);
-				any = any || sample[l];
-			}
+			const bool any = init_wave(brick, ln, sample, w);
 			ls.bricks++;
+			int slot = -1;
 			if (any)
-				traverse(P.mesh, w, ls);
-			for (int l = 0; l < 64; ++l)
+				slot = traverse(P.mesh, w, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
+			if (slot >= 0) // k_sample_nodes parks the wave
 			{
-				if (!ln[l].valid)
-					continue;
-				double v = 1.7976931348623157e308;
-				if (sample[l] && w.q[l].best_tri >= 0)
+				P.ovf.brick[slot] = (uint32_t)brick;
+				for (int l = 0; l < 64; ++l)
 				{
-					const LaneResult r = finish_query(P.mesh.tris, P.mesh.pn, w.q[l], HostSqrt());
-					v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+					P.ovf.saved_d2[slot * 64 + l] = w.q[l].best_d2;
+					P.ovf.saved_tri[slot * 64 + l] = w.q[l].best_tri;
 				}
-				out[ln[l].out_idx] = v;
-				if (written)
-				{
-#pragma omp atomic
-					written[ln[l].out_idx]++;
-				}
+				continue;
 			}
+			write_nodes(ln, sample, w);
 		}
 #pragma omp critical
 		{
@@ -377,6 +475,40 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.stale_pops += ls.stale_pops;
 		}
 	}
+	// k_heavy_subtrees, k_heavy_finish
+	const uint32_t parked = P.ovf.count ? std::min(ovf_count, P.ovf.slots) : 0u;
+	st.heavy_bricks = parked;
+	for (uint32_t slot = 0; slot < parked; ++slot)
+	{
+		LaneNode ln[64];
+		bool sample[64];
+		for (int s = 0; s < P.mesh.n_sub; ++s)
+		{
+			Wave w;
+			init_wave(P.ovf.brick[slot], ln, sample, w);
+			for (int l = 0; l < 64; ++l)
+				if (sample[l] && P.ovf.saved_tri[slot * 64 + l] >= 0)
+					offer(w.q[l], P.ovf.saved_d2[slot * 64 + l], P.ovf.saved_tri[slot * 64 + l]);
+			traverse(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
+			for (int l = 0; l < 64; ++l)
+			{
+				const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)l;
+				P.ovf.cand_d2[at] = w.q[l].best_d2;
+				P.ovf.cand_tri[at] = w.q[l].best_tri;
+			}
+		}
+		Wave w;
+		init_wave(P.ovf.brick[slot], ln, sample, w);
+		for (int l = 0; l < 64; ++l)
+			if (sample[l])
+				for (int s = 0; s < P.mesh.n_sub; ++s)
+				{
+					const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)l;
+					if (P.ovf.cand_tri[at] >= 0)
+						offer(w.q[l], P.ovf.cand_d2[at], P.ovf.cand_tri[at]);
+				}
+		write_nodes(ln, sample, w);
+	}
 	if (stats)
 	{
 		stats[0] = st.bricks;
@@ -390,6 +522,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		stats[8] = st.leaf_groups;
 		stats[9] = st.pops;
 		stats[10] = st.stale_pops;
+		stats[11] = st.heavy_bricks;
 	}
 	return err;
 }
@@ -411,7 +544,7 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 			const uint64_t g = valid ? gid : n - 1;
 			init_query(m->dev.origin, m->dev.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
 		}
-		traverse(m->dev, w, st);
+		traverse(m->dev, w, st, m->dev.root_info, nullptr);
 		for (int l = 0; l < 64; ++l)
 		{
 			const uint64_t gid = (uint64_t)wv * 64 + l;

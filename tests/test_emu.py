@@ -30,6 +30,57 @@ def test_bvh_structure_and_pseudonormals(name):
     assert em.info()["flags"] == 0
 
 
+@pytest.mark.parametrize("name", list(MESHES))
+def test_subtree_cut_covers_the_tree_once(name):
+    """The <= 64 subtree roots heavy bricks are split over reach every triangle exactly once."""
+    V, F = MESHES[name]()
+    for leaf in (1, 8, 16):
+        em = emu.EmuMesh(V, F, max_leaf=leaf)
+        assert 1 <= em.n_subtrees() <= 64
+        assert em.subtree_triangles() == len(F)
+    if len(F) >= 64 * 16:
+        assert emu.EmuMesh(V, F).n_subtrees() == 64
+
+
+@pytest.fixture
+def heavy_settings():
+    yield emu.set_heavy
+    emu.set_heavy()  # back to the product's defaults
+
+
+@pytest.mark.parametrize("name", ["box", "ico8", "torus", "bunny"])
+def test_heavy_brick_split_is_bit_exact(golden, heavy_settings, name):
+    """Bricks that exhaust their work budget are parked, searched subtree by subtree and merged
+    (k_heavy_subtrees / k_heavy_finish): same bits as the single-wave traversal, with the budget
+    forced so low that (almost) every brick takes the split path, with too few slots (the rest
+    carries on unsplit) and with the split disabled."""
+    V, F = MESHES[name]()
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    want = golden[name + "_coeffs"]
+    em = emu.EmuMesh(V, F)
+    for slots, work, expect_heavy in ((256, 4, True), (3, 1, True), (256, 60, None), (0, 4, False)):
+        heavy_settings(slots, work)
+        got = em.sample_range(dom, res, stats=True)
+        assert (em.written == 1).all()
+        np.testing.assert_array_equal(got, want)
+        if em.n_subtrees() < 2:
+            assert em.stats["heavy_bricks"] == 0
+        elif expect_heavy is True:
+            assert em.stats["heavy_bricks"] == min(slots, em.stats["heavy_bricks"]) > 0
+        elif expect_heavy is False:
+            assert em.stats["heavy_bricks"] == 0
+    # masks, inversion and shards go through the same path
+    heavy_settings(256, 4)
+    rng = np.random.default_rng(5)
+    mask = rng.integers(0, 2, size=len(want)).astype(np.uint8)
+    got = em.sample_range(dom, res, mask=mask, invert=True)
+    np.testing.assert_array_equal(got[mask == 1], -1.0 * want[mask == 1])
+    assert (got[mask == 0] == DBL_MAX).all()
+    for r in range(3):
+        emu_field = em.sample_shard(dom, res, r, 3)
+        assert (em.written == 1).all() and np.isfinite(emu_field).all()
+
+
 def test_open_mesh_is_flagged():
     V, F = T.box_mesh()
     assert emu.EmuMesh(V, F[:-1]).info()["flags"] & 1

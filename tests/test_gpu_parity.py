@@ -88,6 +88,33 @@ def test_ranges_masks_invert(dg, name):
         m.sample_nodes(g, 0, n + 1)
 
 
+@pytest.mark.parametrize("name", list(MESHES))
+def test_heavy_brick_split_is_bit_exact(dg, golden, monkeypatch, name):
+    """Bricks that exhaust their work budget are parked and finished by k_heavy_subtrees /
+    k_heavy_finish.  Forced here with a tiny budget (DG_HEAVY_WORK) so that (almost) every brick
+    takes that path, with only 3 slots (all other heavy bricks carry on unsplit), and switched
+    off: always the bits of the golden vectors; masks, inversion and shards included."""
+    V, F = MESHES[name]()
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    want = golden[name + "_coeffs"]
+    g = grid_of(dg, dom, res)
+    m = dg.Mesh(V, F)
+    for slots, work in (("256", "4"), ("3", "1"), ("256", "60"), ("0", "4")):
+        monkeypatch.setenv("DG_HEAVY_SLOTS", slots)
+        monkeypatch.setenv("DG_HEAVY_WORK", work)
+        for _ in range(2):   # the second launch reuses the scratch of the first
+            assert assert_parity(m.sample_nodes(g), want, name) == 0
+    monkeypatch.setenv("DG_HEAVY_SLOTS", "256")
+    monkeypatch.setenv("DG_HEAVY_WORK", "4")
+    rng = np.random.default_rng(5)
+    mask = rng.integers(0, 2, size=len(want)).astype(np.uint8)
+    got = m.sample_nodes(g, mask=mask, invert=True)
+    np.testing.assert_array_equal(got[mask == 1], -1.0 * want[mask == 1])
+    assert (got[mask == 0] == DBL_MAX).all()
+    b, e = len(want) // 3, 2 * len(want) // 3 + 5
+    np.testing.assert_array_equal(m.sample_nodes(g, b, e), want[b:e])
+
+
 def test_signed_distance_points(dg, golden):
     for name in MESHES:
         V, F = MESHES[name]()
@@ -157,8 +184,8 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(ga2, ga)
 
 
-@pytest.mark.parametrize("nranks", [2, 3, 8])
-def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks):
+@pytest.mark.parametrize("nranks", [2, 3, 8, 32])
+def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks, monkeypatch):
     """Multi-GPU path exercised on one device: every rank's shard is computed in turn, the
     all-gather is a concatenation, the unpack kernel restores reference order -- bit for bit
     the unsharded result."""
@@ -169,6 +196,8 @@ def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks):
     m = dg.Mesh(V, F)
     n = dg.n_nodes(g)
     ref = m.sample_nodes(g)
+    if nranks == 3:
+        monkeypatch.setenv("DG_HEAVY_WORK", "8")   # shards through the heavy-brick path as well
     stride = dg.shard_layout(g, 0, nranks)[1]
     gathered = torch.full((nranks * stride,), float("nan"), dtype=torch.float64, device="cuda")
     total = 0
