@@ -83,6 +83,7 @@ SYMBOLS = {
     "dg_density_map_nodes_device": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_last_kernel_ms": (C.c_double, []),
+    "dg_mesh_last_heavy_bricks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 _lib = None
@@ -182,6 +183,12 @@ class Mesh:
         i = MeshInfo()
         _check(self._lib.dg_mesh_get_info(self.handle, C.byref(i)))
         return {k: getattr(i, k) for k, _ in MeshInfo._fields_}
+
+    def last_heavy_bricks(self):
+        """dg_mesh_last_heavy_bricks: (bricks over budget, bricks actually split) of the last launch."""
+        heavy, split = C.c_uint32(0), C.c_uint32(0)
+        _check(self._lib.dg_mesh_last_heavy_bricks(self.handle, C.byref(heavy), C.byref(split)))
+        return int(heavy.value), int(split.value)
 
     # ---- host-pointer entry points -----------------------------------------------------------
     def sample_nodes(self, grid, begin=0, end=None, invert=False, mask=None):

@@ -14,6 +14,13 @@ namespace dg
 namespace
 {
 
+#ifndef DG_FLAT_PATCH
+#define DG_FLAT_PATCH 0.8
+#endif
+#if DG_OBB
+const double kFlatPatch = DG_FLAT_PATCH; // |mean normal| / area above which a patch gets an oriented box
+#endif
+
 struct D3
 {
 	double x, y, z;
@@ -110,14 +117,123 @@ struct Prim
 	uint32_t tri;
 };
 
+inline float down(double v) { return std::nextafterf(round_down(v), -std::numeric_limits<float>::infinity()); }
+inline float up(double v) { return std::nextafterf(round_up(v), std::numeric_limits<float>::infinity()); }
+
+#if DG_OBB
+// oriented box of a set of primitives (dg_geom.h: PairRec), float, relative to origin, rounded outward
+struct Bounds
+{
+	float u[3][3], lo[3], hi[3];
+};
+
+Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
+{
+	// mean normal and how flat the patch is: |sum of area normals| / sum of areas
+	double m[3] = {0, 0, 0}, area = 0;
+	for (size_t i = 0; i < n; ++i)
+	{
+		for (int d = 0; d < 3; ++d)
+			m[d] += p[i].an[d];
+		area += std::sqrt(p[i].an[0] * p[i].an[0] + p[i].an[1] * p[i].an[1] + p[i].an[2] * p[i].an[2]);
+	}
+	const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+	double ax[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}; // curved or degenerate patch: an ordinary box
+	if (std::isfinite(len) && std::isfinite(area) && area > 0 && len > kFlatPatch * area)
+	{
+		const D3 nrm = {m[0] / len, m[1] / len, m[2] / len};
+		// any tangent frame (t1, t2), then rotate it to the principal directions of the vertices
+		const double an[3] = {std::fabs(nrm.x), std::fabs(nrm.y), std::fabs(nrm.z)};
+		D3 e = {1, 0, 0};
+		if (an[1] <= an[0] && an[1] <= an[2]) e = {0, 1, 0};
+		else if (an[2] <= an[0] && an[2] <= an[1]) e = {0, 0, 1};
+		const D3 t1 = unit3(cross3(nrm, e));
+		const D3 t2 = cross3(nrm, t1);
+		double c1 = 0, c2 = 0;
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+			{
+				c1 += dot3(t1, D3{p[i].v[k][0], p[i].v[k][1], p[i].v[k][2]});
+				c2 += dot3(t2, D3{p[i].v[k][0], p[i].v[k][1], p[i].v[k][2]});
+			}
+		c1 /= (double)(3 * n);
+		c2 /= (double)(3 * n);
+		double s11 = 0, s12 = 0, s22 = 0;
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+			{
+				const D3 v = {p[i].v[k][0], p[i].v[k][1], p[i].v[k][2]};
+				const double a = dot3(t1, v) - c1, b = dot3(t2, v) - c2;
+				s11 += a * a;
+				s12 += a * b;
+				s22 += b * b;
+			}
+		const double phi = 0.5 * std::atan2(2.0 * s12, s11 - s22);
+		const double cs = std::cos(phi), sn = std::sin(phi);
+		const D3 u1 = add(times(cs, t1), times(sn, t2));
+		const D3 u2 = cross3(nrm, u1);
+		const D3 fr[3] = {nrm, u1, u2};
+		bool ok = true;
+		for (int a = 0; a < 3; ++a)
+			ok = ok && std::isfinite(fr[a].x) && std::isfinite(fr[a].y) && std::isfinite(fr[a].z);
+		if (ok)
+			for (int a = 0; a < 3; ++a)
+			{
+				ax[a][0] = fr[a].x;
+				ax[a][1] = fr[a].y;
+				ax[a][2] = fr[a].z;
+			}
+	}
+	Bounds B;
+	for (int a = 0; a < 3; ++a)
+	{
+		// shrunk by 1e-6: after rounding to float the Gram matrix of the three directions still has
+		// no eigenvalue above 1 (the sum of squared projections never exceeds the squared length)
+		for (int d = 0; d < 3; ++d)
+			B.u[a][d] = (float)(ax[a][d] * (1.0 - 1.0e-6));
+		double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+			{
+				const double pr = (double)B.u[a][0] * (p[i].v[k][0] - origin[0]) + (double)B.u[a][1] * (p[i].v[k][1] - origin[1]) +
+								  (double)B.u[a][2] * (p[i].v[k][2] - origin[2]);
+				plo = std::min(plo, pr);
+				phi = std::max(phi, pr);
+			}
+		B.lo[a] = down(plo);
+		B.hi[a] = up(phi);
+	}
+	return B;
+}
+
+void put_side(PairRec& r, int side, const Bounds& B)
+{
+	for (int a = 0; a < 3; ++a)
+	{
+		for (int d = 0; d < 3; ++d)
+			r.f[5 * a + d][side] = B.u[a][d];
+		r.f[5 * a + 3][side] = B.lo[a];
+		r.f[5 * a + 4][side] = B.hi[a];
+	}
+}
+// a side that can never be hit: empty slabs (distance = inf)
+void put_empty(PairRec& r, int side)
+{
+	for (int a = 0; a < 3; ++a)
+	{
+		for (int d = 0; d < 3; ++d)
+			r.f[5 * a + d][side] = 0.0f;
+		r.f[5 * a + 3][side] = std::numeric_limits<float>::max();
+		r.f[5 * a + 4][side] = -std::numeric_limits<float>::max();
+	}
+}
+#else
 // box + slab of a set of primitives, float, relative to origin, rounded outward
 struct Bounds
 {
 	float lo[3], hi[3], u[3], slo, shi;
 };
 
-inline float down(double v) { return std::nextafterf(round_down(v), -std::numeric_limits<float>::infinity()); }
-inline float up(double v) { return std::nextafterf(round_up(v), std::numeric_limits<float>::infinity()); }
 
 Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
 {
@@ -187,6 +303,7 @@ void put_empty(PairRec& r, int side)
 	}
 	r.f[9][side] = r.f[10][side] = 0.0f;
 }
+#endif
 void clear_rec(PairRec& r)
 {
 	std::memset(&r, 0, sizeof(r));

@@ -33,6 +33,7 @@ struct HeavyScratch
 	hipStream_t stream = nullptr;
 	uint32_t slots = 0;
 	bool busy = false; // between acquire and the event record
+	uint64_t serial = 0; // order of use
 };
 
 struct dg_mesh
@@ -46,6 +47,8 @@ struct dg_mesh
 	dg_mesh_info info;
 	mutable std::mutex scratch_mutex;
 	mutable std::vector<HeavyScratch> scratch;
+	mutable uint64_t scratch_serial = 0;
+	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
 };
 
 struct dg_field
@@ -332,7 +335,11 @@ static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipSt
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
 	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", dg::kOverflowSlots, 0, dg::kOverflowSlots);
 	if (slots == 0 || mesh->dev.n_sub < 2)
+	{
+		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+		mesh->unsplit_serial = ++mesh->scratch_serial;
 		return -1;
+	}
 	size_t off[6];
 	const size_t bytes = dg::overflow_bytes(slots, off);
 	int idx = -1;
@@ -359,6 +366,7 @@ static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipSt
 		}
 		mesh->scratch[(size_t)idx].busy = true;
 		mesh->scratch[(size_t)idx].stream = stream;
+		mesh->scratch[(size_t)idx].serial = ++mesh->scratch_serial;
 	}
 	char* base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
 	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
@@ -388,6 +396,36 @@ static void release_heavy_scratch(const dg_mesh* mesh, int idx, hipStream_t stre
 	(void)hipEventRecord(h.done, stream);
 	h.busy = false;
 }
+dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32_t* split)
+{
+	if (!mesh || !heavy || !split)
+		return fail(DG_ERR_INVALID, "null argument");
+	*heavy = *split = 0;
+	void* mem = nullptr;
+	hipEvent_t done = nullptr;
+	uint32_t slots = 0;
+	{
+		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+		uint64_t newest = mesh->unsplit_serial;
+		for (const HeavyScratch& h : mesh->scratch)
+			if (!h.busy && h.serial > newest)
+			{
+				newest = h.serial;
+				mem = h.mem;
+				done = h.done;
+				slots = h.slots;
+			}
+	}
+	if (!mem)
+		return DG_OK;
+	DG_HIP(hipEventSynchronize(done));
+	uint32_t count = 0;
+	DG_HIP(hipMemcpy(&count, mem, sizeof(count), hipMemcpyDeviceToHost)); // the counter is the first word
+	*heavy = count;
+	*split = std::min(count, slots);
+	return DG_OK;
+}
+
 static hipError_t launch_k1(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	const int scratch = acquire_heavy_scratch(mesh, P, stream);

@@ -37,12 +37,31 @@ namespace dg
 // -- a one-direction k-DOP that is tight exactly where boxes are loose: a smooth surface patch is
 // thin along its normal however it is oriented, and a query on the concave side of a curved
 // surface sees dozens of nearly equidistant facets whose boxes all overlap the search sphere.
+#ifndef DG_OBB
+#define DG_OBB 1
+#endif
+#if DG_OBB
+// Bounds of an item (subtree or triangle) = an oriented box given as three slabs
+//     lo_a <= u_a . y <= hi_a   for every point y of the item,  a = 0, 1, 2,
+// with (nearly) orthonormal directions u_a whose Gram matrix has no eigenvalue above 1, so that
+//     dist(p, item)^2 >= sum_a max(u_a.p - hi_a, lo_a - u_a.p, 0)^2.
+// For a flat patch u_0 is its mean normal and u_1, u_2 the principal tangent directions; for a
+// curved one the three directions are the coordinate axes (an ordinary box).
+struct alignas(128) PairRec
+{
+	float f[15][2];  // [5*a + j][side], j: 0..2 direction u_a, 3 lo_a, 4 hi_a
+	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
+};
+static const int kPairFloats = 30;
+#else
 struct alignas(128) PairRec
 {
 	float f[11][2];  // [k][side], k: 0..2 box lo xyz, 3..5 box hi xyz, 6..8 slab direction, 9 slab lo, 10 slab hi
 	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
 	float pad_[8];
 };
+static const int kPairFloats = 22;
+#endif
 static_assert(sizeof(PairRec) == 128, "PairRec must be 128 bytes");
 // info word of a subtree:  >= 0: index of the PairRec holding its two children;
 //                          <  0: leaf, ~info = (first_position << kLeafBits) | (positions - 1),
@@ -348,6 +367,27 @@ DG_HD f2 f2_splat(float a) { return f2_make(a, a); }
 DG_HD float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+#if DG_OBB
+// Squared lower bounds of BOTH items of a pair record for one query: distance to the oriented box,
+// r = the record's 30 interleaved floats (PairRec::f).
+DG_HD f2 pair_lb2(const float* r, const FPoint& p)
+{
+	f2 acc = f2_splat(0.0f);
+	const f2 es = f2_splat(p.es);
+	for (int a = 0; a < 3; ++a)
+	{
+		const float* q = r + 10 * a;
+		f2 t = f2_make(q[4], q[5]) * f2_splat(p.x[2]);
+		t = f2_fma(f2_make(q[2], q[3]), f2_splat(p.x[1]), t);
+		t = f2_fma(f2_make(q[0], q[1]), f2_splat(p.x[0]), t);
+		const f2 q1 = t - es - f2_make(q[8], q[9]);
+		const f2 q2 = f2_make(q[6], q[7]) - t - es;
+		const f2 d = f2_make(fmax3(q1.x, q2.x, 0.0f), fmax3(q1.y, q2.y, 0.0f));
+		acc = f2_fma(d, d, acc);
+	}
+	return acc;
+}
+#else
 // Squared lower bounds (box and slab combined) of BOTH items of a pair record for one query.
 // r = the record's 22 interleaved floats (PairRec::f).
 DG_HD f2 pair_lb2(const float* r, const FPoint& p)
@@ -372,6 +412,7 @@ DG_HD f2 pair_lb2(const float* r, const FPoint& p)
 	const f2 s2 = ds * ds;
 	return f2_make(fmax2(acc.x, s2.x), fmax2(acc.y, s2.y));
 }
+#endif
 // float upper bound of the running best d^2 (strictly above it unless it is 0 or inf)
 DG_HD float best_as_float(double d2)
 {

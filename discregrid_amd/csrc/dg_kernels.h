@@ -25,7 +25,7 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 // takes the per-lane minimum over the subtrees and writes the node values.  min is exact, so the
 // result is the one the single wave would have produced.
 static const int kSubtrees = 64;        // subtree roots the tree is cut into (fewer for tiny trees)
-static const int kOverflowSlots = 256;  // parked bricks per launch; further heavy bricks simply run on
+static const int kOverflowSlots = 1024; // parked bricks per launch (48 KiB of scratch each); further heavy bricks simply run on
 static const int kHeavyWork = 3000;     // traversal steps + exact triangle tests before a brick counts as heavy
 
 struct OverflowBuf // device scratch of one K1 launch (null count: splitting disabled)

@@ -64,18 +64,30 @@ __device__ __forceinline__ double pack_double(int lo, int hi)
 	return __hiloint2double(hi, lo);
 }
 
-// first 24 dwords of a pair record: 22 interleaved bound floats + the two info words
+// a pair record in SGPRs: the interleaved bound floats + the two info words
 struct SPair
 {
-	float r[22];
+	float r[kPairFloats];
 	int info0, info1;
 };
 __device__ __forceinline__ SPair load_pair(const PairRec* base, int idx)
 {
 	const char* p = (const char*)(base + idx);
+	SPair s;
+#if DG_OBB
+	const v16i a = sload16(p);
+	const v16i b = sload16(p + 64);
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		s.r[i] = __int_as_float(a[i]);
+#pragma unroll
+	for (int i = 0; i < 14; ++i)
+		s.r[16 + i] = __int_as_float(b[i]);
+	s.info0 = b[14];
+	s.info1 = b[15];
+#else
 	const v16i a = sload16(p);
 	const v8i b = sload8(p + 64);
-	SPair s;
 #pragma unroll
 	for (int i = 0; i < 16; ++i)
 		s.r[i] = __int_as_float(a[i]);
@@ -84,6 +96,7 @@ __device__ __forceinline__ SPair load_pair(const PairRec* base, int idx)
 		s.r[16 + i] = __int_as_float(b[i]);
 	s.info0 = b[6];
 	s.info1 = b[7];
+#endif
 	return s;
 }
 

@@ -189,6 +189,11 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 /* Device time (HIP events on the launch stream) of the most recent K1 / K2 kernel launch issued
  * by this thread through the HOST entry points, in milliseconds; <0 if none. */
 double dg_last_kernel_ms(void);
+/* Number of 4x4x4-node bricks of the most recent node-sampling launch on `mesh` that exhausted
+ * their work budget and asked for the split path ("heavy bricks"); at most
+ * `*split` of them (the slot count) were actually split, the others ran on in their own wave.
+ * Waits for that launch to finish.  Both zero if that launch ran without the split path. */
+dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32_t* split);
 
 #ifdef __cplusplus
 }

@@ -176,7 +176,7 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     return (phi, g) if grad else phi
 
 
-def set_heavy(slots=256, work=3000):
+def set_heavy(slots=1024, work=3000):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: kOverflowSlots, kHeavyWork);
     slots = 0 disables the split."""
     lib().emu_set_heavy(slots, work)

@@ -292,8 +292,13 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 			const PairRec& tp = m->B.tri_pairs[t >> 1];
 			if (id < 0)
 			{
+#if DG_OBB
+				if (!(tp.f[3][t & 1] > tp.f[4][t & 1])) // padding must have empty slabs
+					return 10;
+#else
 				if (!(tp.f[0][t & 1] > tp.f[3][t & 1])) // padding must have an empty box
 					return 10;
+#endif
 				continue;
 			}
 			seen[id]++;
@@ -305,6 +310,30 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 			{
 				const float* r = all[a];
 				const int sd = sides[a];
+#if DG_OBB
+				// every vertex inside the three slabs; Gram matrix of the directions: no eigenvalue above 1
+				double U[3][3];
+				for (int x = 0; x < 3; ++x)
+					for (int d = 0; d < 3; ++d)
+						U[x][d] = (double)r[2 * (5 * x + d) + sd];
+				for (int x = 0; x < 3; ++x)
+				{
+					double row = 0;
+					for (int y = 0; y < 3; ++y)
+						row += std::fabs(U[x][0] * U[y][0] + U[x][1] * U[y][1] + U[x][2] * U[y][2]);
+					if (row > 1.0)
+						return 11;
+				}
+				for (int k = 0; k < 3; ++k)
+					for (int x = 0; x < 3; ++x)
+					{
+						double pr = 0;
+						for (int d = 0; d < 3; ++d)
+							pr += U[x][d] * (verts[3 * tris[3 * id + k] + d] - m->B.origin[d]);
+						if (!((double)r[2 * (5 * x + 3) + sd] <= pr && pr <= (double)r[2 * (5 * x + 4) + sd]))
+							return 12;
+					}
+#else
 				for (int k = 0; k < 3; ++k)
 				{
 					double pr = 0;
@@ -322,6 +351,7 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 					if (ulen > 0 && !((double)r[18 + sd] <= pr + 1e-12 && pr - 1e-12 <= (double)r[20 + sd]))
 						return 12;
 				}
+#endif
 			}
 		}
 		return 0;
@@ -566,6 +596,35 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 					nearest[3 * gid + d] = r.nearest[d];
 		}
 	}
+}
+
+// work counters of the packet traversal for caller-supplied points, 64 consecutive points per wave
+// (design studies: how does the grouping of lattice nodes into waves change the work?)
+void emu_points_work(void* h, const double* xyz, uint64_t n, uint64_t* stats /*4: waves, node_visits, tri_tests, leaf_groups*/)
+{
+	auto m = static_cast<HostMesh*>(h);
+	const long long n_waves = (long long)((n + 63) / 64);
+	uint64_t nv = 0, tt = 0, lg = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : nv, tt, lg)
+	for (long long wv = 0; wv < n_waves; ++wv)
+	{
+		Wave w;
+		Stats st;
+		for (int l = 0; l < 64; ++l)
+		{
+			const uint64_t gid = (uint64_t)wv * 64 + l;
+			const uint64_t g = gid < n ? gid : n - 1;
+			init_query(m->dev.origin, m->dev.mesh_l1, gid < n, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
+		}
+		traverse(m->dev, w, st, m->dev.root_info, nullptr);
+		nv += st.node_visits;
+		tt += st.tri_tests;
+		lg += st.leaf_groups;
+	}
+	stats[0] = (uint64_t)n_waves;
+	stats[1] = nv;
+	stats[2] = tt;
+	stats[3] = lg;
 }
 
 uint64_t emu_shard_count(const uint32_t res[3], int rank, int nranks) { return shard_count(res, rank, nranks); }

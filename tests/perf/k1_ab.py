@@ -27,7 +27,7 @@ for _ in range(int(os.environ.get("AB_REPS", "4"))):
     e0.record(); m.sample_nodes_device(g, 0, n, out.data_ptr(), stream=s); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 chk = float(out[::9973].sum().item())
-print(json.dumps({"ms": sorted(ts)[len(ts)//2], "min": min(ts), "checksum": chk, "bvh_nodes": m.info()["n_bvh_nodes"]}))
+print(json.dumps({"ms": sorted(ts)[len(ts)//2], "min": min(ts), "checksum": chk, "heavy": m.last_heavy_bricks()}))
 '''
 
 

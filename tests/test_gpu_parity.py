@@ -104,6 +104,11 @@ def test_heavy_brick_split_is_bit_exact(dg, golden, monkeypatch, name):
         monkeypatch.setenv("DG_HEAVY_WORK", work)
         for _ in range(2):   # the second launch reuses the scratch of the first
             assert assert_parity(m.sample_nodes(g), want, name) == 0
+        heavy, split = m.last_heavy_bricks()
+        if slots == "0":
+            assert (heavy, split) == (0, 0)
+        elif work != "60":
+            assert heavy >= split == min(int(slots), heavy) > 0, (heavy, split)   # the path really ran
     monkeypatch.setenv("DG_HEAVY_SLOTS", "256")
     monkeypatch.setenv("DG_HEAVY_WORK", "4")
     rng = np.random.default_rng(5)
