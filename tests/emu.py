@@ -48,7 +48,7 @@ def lib():
 
 
 class EmuMesh:
-    def __init__(self, V, F, max_leaf=8):
+    def __init__(self, V, F, max_leaf=6):
         self.L = lib()
         self.V = np.ascontiguousarray(V, dtype=np.float64)
         self.F = np.ascontiguousarray(F, dtype=np.uint32)
