@@ -22,7 +22,8 @@ Also on the JSON line:
   roofline      achieved = ALGORITHMIC bytes of the reference traversal per launch
                 (B_alg = Vbar*72 + Lbar*84 + 8 bytes/node, SURVEY.md 8(d), frozen in
                 profiles/balg_icosphere71_256.json) / mean K1 kernel duration measured with
-                HIP events on the launch stream; peak = 8 TB/s HBM3E.
+                HIP events on the launch stream; peak = 8 TB/s HBM3E.  (The kernel is VALU-issue
+                bound, not HBM bound: `valu_busy` is the measured fraction of VALU issue slots in use.)
   cpu_baseline  the unmodified reference (oracle/_ref, kind "reference") or this repo's CPU
                 restatement (kind "port") timed on this box's host cores on a bounded,
                 evenly spread sample of the same lattice (rank 0, N = 1 only).
@@ -228,7 +229,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": balg.get("measured_hbm_bytes_per_launch") if world == 1 else None,
-                "kernel": "k_sample_nodes", "kernel_ms": kernel_ms,
+                # one dg_sdf_sample_*_device call = k_sample_nodes + the two heavy-brick kernels (4 % of it)
+                "kernel": "k_sample_nodes (+ k_heavy_subtrees, k_heavy_finish)", "kernel_ms": kernel_ms,
+                # the resource that actually binds K1 (PMC, profiles/r01_pmc_summary.txt): VALU issue
+                "valu_busy": balg.get("measured_valu_busy") if world == 1 else None,
                 "algorithmic_bytes_per_node": balg["bytes_per_node"],
             },
         }
