@@ -16,7 +16,8 @@ rank samples its shard, an RCCL all-gather assembles the packed shards on every 
 unpack kernel restores reference node order.  The gather is issued in --pieces C pieces
 (default 4): piece p of rank r is the shard of "virtual rank" p*N + r of a C*N-way deal, so
 the all-gather of piece p runs on RCCL's stream over xGMI while the kernel samples piece p+1
-(C = 1 is the plain single all-gather).  value = total nodes / time, max over ranks.
+and a third stream unpacks piece p-1 (C = 1 is the plain sample / gather / unpack sequence).
+value = total nodes / time, max over ranks.
 
 Also on the JSON line:
   roofline      achieved = ALGORITHMIC bytes of the reference traversal per launch
@@ -154,24 +155,26 @@ def main():
     else:
         launch_nodes = n_nodes
 
+    unpack_stream = torch.cuda.Stream() if sharded else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record(stream)
         if sharded:
-            works = []
             for p in range(pieces):
                 mp = mine[p * stride:(p + 1) * stride]
                 mesh.sample_shard_device(grid, p * world + rank, vworld, mp.data_ptr(), stream=s)
                 # RCCL's stream waits for the kernel just enqueued; this stream goes on with piece p+1
-                works.append(dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp,
-                                                         async_op=True))
+                work = dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp,
+                                                   async_op=True)
+                with torch.cuda.stream(unpack_stream):
+                    work.wait()          # unpack_stream waits for gather p, not the host
+                    dg.unpack_shard_range_device(grid, vworld, gathered.data_ptr(), stride, p * world, (p + 1) * world,
+                                                 field.data_ptr(), stream=unpack_stream.cuda_stream)
             if i is not None:
                 ev[i][1].record(stream)
-            for w in works:
-                w.wait()
-            dg.unpack_shards_device(grid, vworld, gathered.data_ptr(), stride, field.data_ptr(), stream=s)
+            stream.wait_stream(unpack_stream)
         else:
             mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
             if i is not None:
@@ -222,7 +225,7 @@ def main():
                             % ("x".join(map(str, res)), n_nodes),
                 "nodes_per_gpu_launch": launch_nodes,
                 "sharding": "none" if not sharded else
-                            "4-plane slabs round-robin, all_gather in %d piece(s) overlapped with sampling, unpack" % pieces,
+                            "4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s)" % pieces,
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {

@@ -69,6 +69,8 @@ SYMBOLS = {
                                              C.c_void_p]),
     "dg_unpack_shards_device": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
                                           C.c_void_p]),
+    "dg_unpack_shard_range_device": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]),
     "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
                                   C.POINTER(C.c_void_p)]),
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -234,6 +236,11 @@ class Mesh:
 def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):
     _check(load_library().dg_unpack_shards_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
                                                   C.c_void_p(d_field), C.c_void_p(stream)))
+
+
+def unpack_shard_range_device(grid, nranks, d_gathered, stride, rank_begin, rank_end, d_field, stream=0):
+    _check(load_library().dg_unpack_shard_range_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
+                                                       rank_begin, rank_end, C.c_void_p(d_field), C.c_void_p(stream)))
 
 
 class Field:

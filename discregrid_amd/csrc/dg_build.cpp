@@ -437,12 +437,12 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 
 	out.pairs.swap(B.pairs);
 	out.depth = B.depth;
-	// level-order cut of the tree into <= 64 disjoint subtrees that cover it (heavy bricks are split
-	// over them): split the oldest inner node of the queue until 64 pieces exist or only leaves remain
+	// level-order cut of the tree into <= kSubtrees disjoint subtrees that cover it (heavy bricks are split
+	// over them): split the oldest inner node of the queue until kSubtrees pieces exist or only leaves remain
 	{
 		std::deque<int32_t> open(1, out.root_info);
 		out.sub_roots.clear();
-		while (!open.empty() && out.sub_roots.size() + open.size() < 64)
+		while (!open.empty() && out.sub_roots.size() + open.size() < (size_t)kSubtrees)
 		{
 			const int32_t info = open.front();
 			open.pop_front();

@@ -21,7 +21,7 @@ struct MeshBuild
 	std::vector<TriPacket> tris;    // one per position (leaf order; padding slots have tri_id = -1)
 	std::vector<double> pn;         // kPnSlots * 3 doubles per position
 	int32_t root_info = 0;          // info word of the root (dg_geom.h)
-	std::vector<int32_t> sub_roots; // info words of <= 64 disjoint subtrees covering the tree (breadth-first cut)
+	std::vector<int32_t> sub_roots; // info words of <= kSubtrees disjoint subtrees covering the tree (level-order cut)
 	double origin[3];               // bounds are relative to this point
 	float mesh_l1 = 0;              // max over vertices of |v - origin|_1, rounded up
 	uint32_t depth = 0;

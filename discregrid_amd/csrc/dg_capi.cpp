@@ -623,6 +623,29 @@ dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const do
 	return DG_OK;
 }
 
+dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+									   int rank_begin, int rank_end, double* d_field, void* stream)
+{
+	if (!grid || !d_gathered || !d_field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (nranks < 1 || nranks > dg::kMaxRanks || rank_begin < 0 || rank_begin > rank_end || rank_end > nranks)
+		return fail(DG_ERR_INVALID, "ranks [%d, %d) of %d out of range", rank_begin, rank_end, nranks);
+	dg::UnpackParams U;
+	dg::layout_unpack(U, grid->resolution, nranks);
+	for (int r = rank_begin; r < rank_end; ++r)
+		if (U.count[r] > stride)
+			return fail(DG_ERR_INVALID, "stride %llu smaller than rank %d's shard", (unsigned long long)stride, r);
+	U.stride = stride;
+	U.gathered = d_gathered;
+	U.field = d_field;
+	U.rank_begin = rank_begin;
+	U.rank_end = rank_end;
+	DG_HIP(dg::launch_unpack_ranks(U, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
 // ---- field + K2 ---------------------------------------------------------------------------------------------
 static void fill_field(dg::FieldDev& F, const dg_grid_desc* g)
 {

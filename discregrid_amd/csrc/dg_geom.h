@@ -69,6 +69,10 @@ static_assert(sizeof(PairRec) == 128, "PairRec must be 128 bytes");
 // for leaves with an odd triangle count (padding slots have empty bounds and are never tested).
 static const int kLeafBits = 4;
 static const int kMaxLeaf = 16;
+#ifndef DG_SUBTREES
+#define DG_SUBTREES 256
+#endif
+static const int kSubtrees = DG_SUBTREES; // disjoint subtrees the builder cuts the tree into (dg_kernels.h, "Heavy bricks")
 
 // One triangle packet = 128 bytes, in BVH leaf order.  The point-independent terms of the
 // Eberly test are precomputed on the host WITH THE REFERENCE'S OWN OPERATIONS (same inputs,

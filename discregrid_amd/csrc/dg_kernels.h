@@ -24,8 +24,10 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 // BVH for every parked brick in its own wave (starting from the parked bests), and a third kernel
 // takes the per-lane minimum over the subtrees and writes the node values.  min is exact, so the
 // result is the one the single wave would have produced.
-static const int kSubtrees = 64;        // subtree roots the tree is cut into (fewer for tiny trees)
-static const int kOverflowSlots = 1024; // parked bricks per launch (48 KiB of scratch each); further heavy bricks simply run on
+#ifndef DG_HEAVY_SLOTS
+#define DG_HEAVY_SLOTS 512
+#endif
+static const int kOverflowSlots = DG_HEAVY_SLOTS; // parked bricks per launch (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
 static const int kHeavyWork = 3000;     // traversal steps + exact triangle tests before a brick counts as heavy
 
 struct OverflowBuf // device scratch of one K1 launch (null count: splitting disabled)
@@ -163,18 +165,37 @@ struct UnpackParams
 	uint32_t D0[4], D1[4], D2[4];
 	uint64_t class_off[5];            // global node offset of each class (+ total)
 	uint64_t pack_off[4][kMaxRanks];  // offset of class c inside rank r's packed buffer
+	uint64_t count[kMaxRanks];        // nodes of rank r (its packed buffer holds count[r] <= stride values)
 	int32_t nranks;
+	int32_t rank_begin, rank_end;     // k_unpack_ranks: the slots [rank_begin, rank_end) of `gathered`
 	uint64_t stride;
 	const double* gathered;
 	double* field;
 };
 
 
+// the inverse map k_unpack_ranks uses: global node index of element `off` of rank r's packed buffer
+// (off < U.count[r])
+DG_HD uint64_t unpack_dest(const UnpackParams& U, uint32_t r, uint64_t off)
+{
+	int c = 0;
+	if (off >= U.pack_off[1][r]) c = 1;
+	if (off >= U.pack_off[2][r]) c = 2;
+	if (off >= U.pack_off[3][r]) c = 3;
+	const uint64_t local = off - U.pack_off[c][r];
+	const uint64_t plane = (uint64_t)U.D0[c] * U.D1[c];
+	const uint32_t q = (uint32_t)(local / plane);
+	const uint64_t inplane = local - (uint64_t)q * plane;
+	const uint32_t s = ((q / kSlabPlanes) * (uint32_t)U.nranks + r) * kSlabPlanes + (q % kSlabPlanes);
+	return U.class_off[c] + (uint64_t)s * plane + inplane;
+}
+
 // K1 (+ the two heavy-brick kernels when p.ovf.count is set; the caller zeroes *p.ovf.count first)
 hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream);
 hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
 								  int32_t* d_entity, double* d_nearest, hipStream_t stream);
 hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream);
+hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream);
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream);
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,

@@ -487,6 +487,21 @@ __global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const Sample
 	L.out[ln.out_idx] = v;
 }
 
+// U, one piece: the slots [rank_begin, rank_end) of the gathered buffer -> reference node order.
+// One thread per gathered value: contiguous reads, writes in contiguous runs of one plane.
+__global__ __launch_bounds__(256) void k_unpack_ranks(const UnpackParams P)
+{
+	const uint64_t total = (uint64_t)(P.rank_end - P.rank_begin) * P.stride;
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const uint32_t r = (uint32_t)P.rank_begin + (uint32_t)(e / P.stride);
+		const uint64_t off = e % P.stride;
+		if (off >= P.count[r])
+			continue; // padding of the slot
+		P.field[unpack_dest(P, r, off)] = P.gathered[(uint64_t)r * P.stride + off];
+	}
+}
+
 } // namespace
 
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream)
@@ -545,6 +560,18 @@ hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream)
 	if (blocks > 256ull * 32ull)
 		blocks = 256ull * 32ull;
 	hipLaunchKernelGGL(k_unpack_shards, dim3((uint32_t)blocks), dim3(256), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream)
+{
+	const uint64_t total = (uint64_t)(p.rank_end - p.rank_begin) * p.stride;
+	if (total == 0)
+		return hipSuccess;
+	uint64_t blocks = (total + 255) / 256;
+	if (blocks > 256ull * 32ull)
+		blocks = 256ull * 32ull;
+	hipLaunchKernelGGL(k_unpack_ranks, dim3((uint32_t)blocks), dim3(256), 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -170,8 +170,11 @@ inline void layout_unpack(UnpackParams& U, const uint32_t res[3], int nranks)
 			U.pack_off[c][r] = pack;
 			pack += (uint64_t)owned_planes(cg[c].D[2], r, nranks) * cg[c].D[0] * cg[c].D[1];
 		}
+		U.count[r] = pack;
 	}
 	U.nranks = nranks;
+	U.rank_begin = 0;
+	U.rank_end = nranks;
 }
 
 // K3 launch constants: quadrature offsets/weights and the table of kernel values W(xi) for

@@ -143,6 +143,10 @@ dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* gr
 									 double* d_packed, void* stream);
 dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 								  double* d_field, void* stream);
+/* Same for the slots [rank_begin, rank_end) of the gathered buffer only (d_gathered is still the
+ * base of the whole buffer): lets a pieced gather unpack piece p while piece p+1 is in flight. */
+dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+									   int rank_begin, int rank_end, double* d_field, void* stream);
 
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both

@@ -153,6 +153,12 @@ def unpack(res, nranks, gathered, stride):
     return field
 
 
+def unpack_ranks(res, nranks, gathered, stride, r0, r1, field):
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    lib().emu_unpack_ranks.argtypes = [T.c_up, C.c_int, T.c_dp, C.c_uint64, C.c_int, C.c_int, T.c_dp]
+    lib().emu_unpack_ranks(T.up(res), nranks, T.dp(gathered), stride, r0, r1, T.dp(field))
+
+
 def shard_count(res, rank, nranks):
     res = np.ascontiguousarray(res, dtype=np.uint32)
     return lib().emu_shard_count(T.up(res), rank, nranks)
@@ -176,7 +182,7 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     return (phi, g) if grad else phi
 
 
-def set_heavy(slots=1024, work=3000):
+def set_heavy(slots=512, work=3000):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: kOverflowSlots, kHeavyWork);
     slots = 0 disables the split."""
     lib().emu_set_heavy(slots, work)

@@ -639,6 +639,18 @@ void emu_unpack(const uint32_t res[3], int nranks, const double* gathered, uint6
 		field[l] = gathered[unpack_source(U, l)];
 }
 
+// mirrors k_unpack_ranks: scatter of the slots [r0, r1) (field entries of other ranks untouched)
+void emu_unpack_ranks(const uint32_t res[3], int nranks, const double* gathered, uint64_t stride, int r0, int r1,
+					  double* field)
+{
+	UnpackParams U;
+	layout_unpack(U, res, nranks);
+	U.stride = stride;
+	for (int r = r0; r < r1; ++r)
+		for (uint64_t off = 0; off < U.count[r]; ++off)
+			field[unpack_dest(U, (uint32_t)r, off)] = gathered[(uint64_t)r * stride + off];
+}
+
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)

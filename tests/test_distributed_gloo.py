@@ -50,9 +50,12 @@ def _worker(rank, world, port, res, ret, pieces=1):
             works.append(dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mine,
                                                      async_op=True))
             count += c
-        for w in works:
+        # ... and piece p is unpacked as soon as its gather is done (dg_unpack_shard_range_device's map)
+        field = np.full(T.n_nodes(res), np.nan)
+        for p, w in enumerate(works):
             w.wait()
-        field = emu.unpack(res, vworld, gathered.numpy(), stride)
+            emu.unpack_ranks(res, vworld, gathered.numpy(), stride, p * world, (p + 1) * world, field)
+        assert np.array_equal(field, emu.unpack(res, vworld, gathered.numpy(), stride))
         want = T.OracleMesh(V, F).sample_nodes(dom, res)
         ok = bool(np.array_equal(field, want))
         # max-over-ranks reduction as bench.py does for the timing

@@ -32,14 +32,14 @@ def test_bvh_structure_and_pseudonormals(name):
 
 @pytest.mark.parametrize("name", list(MESHES))
 def test_subtree_cut_covers_the_tree_once(name):
-    """The <= 64 subtree roots heavy bricks are split over reach every triangle exactly once."""
+    """The <= 256 subtree roots heavy bricks are split over reach every triangle exactly once."""
     V, F = MESHES[name]()
     for leaf in (1, 8, 16):
         em = emu.EmuMesh(V, F, max_leaf=leaf)
-        assert 1 <= em.n_subtrees() <= 64
+        assert 1 <= em.n_subtrees() <= 256
         assert em.subtree_triangles() == len(F)
-    if len(F) >= 64 * 16:
-        assert emu.EmuMesh(V, F).n_subtrees() == 64
+    if len(F) >= 256 * 16:
+        assert emu.EmuMesh(V, F).n_subtrees() == 256
 
 
 @pytest.fixture
@@ -118,7 +118,7 @@ def test_ranges_masks_invert(name):
     np.testing.assert_array_equal(em.sample_range(dom, res, invert=True), -1.0 * ref)
 
 
-@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8, 24])
 def test_shard_pack_unpack(nranks):
     V, F = T.torus()
     dom = T.oracle_default_domain(V)
@@ -136,6 +136,14 @@ def test_shard_pack_unpack(nranks):
     for r, p in enumerate(parts):
         G[r * stride:r * stride + len(p)] = p
     np.testing.assert_array_equal(emu.unpack(res, nranks, G, stride), ref)
+    # slot ranges unpacked one after the other (pieced gather) fill the field exactly once
+    field = np.full(len(ref), np.nan)
+    cuts = sorted({0, nranks // 3, nranks // 2, nranks})
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        before = np.isnan(field).sum()
+        emu.unpack_ranks(res, nranks, G, stride, r0, r1, field)
+        assert before - np.isnan(field).sum() == sum(len(p) for p in parts[r0:r1])
+    np.testing.assert_array_equal(field, ref)
 
 
 def test_signed_distance_points(golden):

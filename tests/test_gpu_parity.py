@@ -219,6 +219,16 @@ def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks, monkeypatch):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(field.cpu().numpy(), ref)
     np.testing.assert_array_equal(ref, T.OracleMesh(V, F).sample_nodes(dom, res))
+    # the same buffer unpacked slot range by slot range (pieced gather)
+    field.fill_(float("nan"))
+    cuts = sorted({0, nranks // 3, nranks // 2, nranks})
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        dg.unpack_shard_range_device(g, nranks, gathered.data_ptr(), stride, r0, r1, field.data_ptr(),
+                                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(field.cpu().numpy(), ref)
+    with pytest.raises(dg.DiscregridError):
+        dg.unpack_shard_range_device(g, nranks, gathered.data_ptr(), stride, 1, nranks + 1, field.data_ptr())
 
 
 def test_config2_bunny_128(dg, torch, golden):
