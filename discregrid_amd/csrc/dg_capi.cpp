@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <cmath>
@@ -31,7 +32,8 @@ struct HeavyScratch
 	void* mem = nullptr;
 	hipEvent_t done = nullptr;
 	hipStream_t stream = nullptr;
-	uint32_t slots = 0;
+	uint32_t slots = 0;      // capacity the buffer was laid out for
+	uint32_t used_slots = 0; // slots the most recent launch was given
 	bool busy = false; // between acquire and the event record
 	uint64_t serial = 0; // order of use
 };
@@ -333,29 +335,28 @@ static int env_int(const char* name, int fallback, int lo, int hi)
 static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
-	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", dg::kOverflowSlots, 0, dg::kOverflowSlots);
+	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
 	if (slots == 0 || mesh->dev.n_sub < 2)
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		mesh->unsplit_serial = ++mesh->scratch_serial;
 		return -1;
 	}
-	size_t off[6];
-	const size_t bytes = dg::overflow_bytes(slots, off);
 	int idx = -1;
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		for (size_t i = 0; i < mesh->scratch.size() && idx < 0; ++i)
 		{
 			HeavyScratch& h = mesh->scratch[i];
-			if (!h.busy && h.slots == slots && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
+			if (!h.busy && h.slots >= slots && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
 				idx = (int)i;
 		}
 		if (idx < 0)
 		{
 			HeavyScratch h;
 			h.slots = slots;
-			if (hipMalloc(&h.mem, bytes) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
+			size_t unused[6];
+			if (hipMalloc(&h.mem, dg::overflow_bytes(slots, unused)) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
 			{
 				(void)hipGetLastError();
 				if (h.mem) (void)hipFree(h.mem);
@@ -367,8 +368,11 @@ static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipSt
 		mesh->scratch[(size_t)idx].busy = true;
 		mesh->scratch[(size_t)idx].stream = stream;
 		mesh->scratch[(size_t)idx].serial = ++mesh->scratch_serial;
+		mesh->scratch[(size_t)idx].used_slots = slots;
 	}
 	char* base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
+	size_t off[6];
+	dg::overflow_bytes(mesh->scratch[(size_t)idx].slots, off); // the layout the buffer was allocated with
 	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
 	P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
 	P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
@@ -413,7 +417,7 @@ dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32
 				newest = h.serial;
 				mem = h.mem;
 				done = h.done;
-				slots = h.slots;
+				slots = h.used_slots;
 			}
 	}
 	if (!mem)
@@ -458,6 +462,113 @@ dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* gr
 	return DG_OK;
 }
 
+// ---- host-pointer K1: device buffers, kernel and the copy back to pageable memory, pipelined --------------
+// The caller's array is ordinary pageable memory (a std::vector in the C++ API), which the runtime
+// can only fill at ~13 GB/s in one blocking hipMemcpy -- three times the kernel time at 256^3.  The
+// range is therefore cut into chunks of whole 4-plane slabs of one node class (= whole bricks, so no
+// brick is traversed twice): while K1 samples chunk k into one of two device buffers, the copy
+// stream moves chunk k-1 into pinned staging memory and host threads move chunk k-2 from there into
+// the caller's array.  Staging memory is kept for the lifetime of the process.
+namespace
+{
+struct HostPipe
+{
+	std::mutex mutex; // one host-pointer launch at a time uses the staging buffers
+	int device = -1;
+	size_t chunk_bytes = 0;
+	void* d_buf[2] = {nullptr, nullptr};
+	void* h_buf[2] = {nullptr, nullptr};
+	hipStream_t compute = nullptr, copy = nullptr;
+	hipEvent_t k_begin[2] = {nullptr, nullptr}, k_end[2] = {nullptr, nullptr}, c_end[2] = {nullptr, nullptr};
+
+	void release()
+	{
+		for (int i = 0; i < 2; ++i)
+		{
+			if (d_buf[i]) (void)hipFree(d_buf[i]);
+			if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+			if (k_begin[i]) (void)hipEventDestroy(k_begin[i]);
+			if (k_end[i]) (void)hipEventDestroy(k_end[i]);
+			if (c_end[i]) (void)hipEventDestroy(c_end[i]);
+			d_buf[i] = h_buf[i] = nullptr;
+			k_begin[i] = k_end[i] = c_end[i] = nullptr;
+		}
+		if (compute) (void)hipStreamDestroy(compute);
+		if (copy) (void)hipStreamDestroy(copy);
+		compute = copy = nullptr;
+		chunk_bytes = 0;
+		device = -1;
+	}
+	hipError_t prepare(size_t bytes)
+	{
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
+		if (e != hipSuccess)
+			return e;
+		if (dev == device && bytes <= chunk_bytes)
+			return hipSuccess;
+		release();
+		device = dev;
+		e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+		for (int i = 0; i < 2 && e == hipSuccess; ++i)
+		{
+			e = hipMalloc(&d_buf[i], bytes);
+			if (e == hipSuccess) e = hipHostMalloc(&h_buf[i], bytes, hipHostMallocDefault);
+			if (e == hipSuccess) e = hipEventCreate(&k_begin[i]);
+			if (e == hipSuccess) e = hipEventCreate(&k_end[i]);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&c_end[i], hipEventDisableTiming);
+		}
+		if (e == hipSuccess)
+			chunk_bytes = bytes;
+		else
+			release();
+		return e;
+	}
+};
+HostPipe g_pipe;
+
+// dst <- src with a few threads (one thread tops out near 10 GB/s, the PCIe link delivers 50+)
+void parallel_copy(void* dst, const void* src, size_t bytes)
+{
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, hw), std::max<size_t>(1, bytes >> 22));
+	if (nt <= 1)
+	{
+		std::memcpy(dst, src, bytes);
+		return;
+	}
+	std::vector<std::thread> th;
+	const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+	for (unsigned t = 0; t < nt; ++t)
+	{
+		const size_t b = std::min(bytes, per * t), e = std::min(bytes, per * (t + 1));
+		if (e > b)
+			th.emplace_back([=]() { std::memcpy((char*)dst + b, (const char*)src + b, e - b); });
+	}
+	for (auto& t : th)
+		t.join();
+}
+
+// [node_begin, node_end) cut at multiples of `slabs` 4-plane slabs of each node class
+void chunk_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end, uint64_t target_nodes,
+				std::vector<uint64_t>& cuts)
+{
+	dg::ClassGeom cg[4];
+	dg::class_geometry(res, cg);
+	cuts.assign(1, node_begin);
+	for (int c = 0; c < 4; ++c)
+	{
+		const uint64_t slab = (uint64_t)dg::kSlabPlanes * cg[c].D[0] * cg[c].D[1];
+		const uint64_t step = std::max<uint64_t>(1, target_nodes / slab) * slab;
+		for (uint64_t at = cg[c].off; at < cg[c].off + cg[c].size; at += step)
+			if (at > cuts.back() && at < node_end)
+				cuts.push_back(at);
+	}
+	cuts.push_back(node_end);
+}
+} // namespace
+
 dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 							  uint64_t node_end, const uint8_t* pred_mask, double* out)
 {
@@ -465,46 +576,92 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		return fail(DG_ERR_INVALID, "null argument");
 	if (node_begin > node_end)
 		return fail(DG_ERR_INVALID, "node_begin > node_end");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
 	const uint64_t n = node_end - node_begin;
 	if (n == 0)
 		return DG_OK;
+	if (node_end > dg_grid_n_nodes(grid))
+		return fail(DG_ERR_INVALID, "node range [%llu, %llu) outside [0, %llu)", (unsigned long long)node_begin,
+					(unsigned long long)node_end, (unsigned long long)dg_grid_n_nodes(grid));
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	double* d_out = nullptr;
+
+	// ~10 chunks per call (every chunk costs a kernel tail, ~0.4 ms), 32..256 MiB of results each
+	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
+	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
+	std::vector<uint64_t> cuts;
+	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
+	uint64_t longest = 0;
+	for (size_t k = 0; k + 1 < cuts.size(); ++k)
+		longest = std::max(longest, cuts[k + 1] - cuts[k]);
+
+	std::lock_guard<std::mutex> lock(g_pipe.mutex);
+	hipError_t e = g_pipe.prepare(longest * sizeof(double));
 	uint8_t* d_mask = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	dg_status st = DG_OK;
-	hipError_t e = hipMalloc((void**)&d_out, n * sizeof(double));
 	if (e == hipSuccess && pred_mask)
 	{
 		e = hipMalloc((void**)&d_mask, n);
 		if (e == hipSuccess) e = hipMemcpy(d_mask, pred_mask, n, hipMemcpyHostToDevice);
 	}
-	if (e == hipSuccess) e = hipEventCreate(&e0);
-	if (e == hipSuccess) e = hipEventCreate(&e1);
-	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-	if (e == hipSuccess)
+	dg_status st = DG_OK;
+	double kernel_ms = 0.0;
+	const size_t n_chunks = cuts.size() - 1;
+	double t_wait = 0, t_copy = 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	auto drain = [&](size_t k) -> hipError_t { // chunk k: wait for its copy, move it into the caller's array
+		const int b = (int)(k & 1);
+		const double t0 = now();
+		hipError_t err = hipEventSynchronize(g_pipe.c_end[b]);
+		if (err != hipSuccess)
+			return err;
+		const double t1 = now();
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, g_pipe.k_begin[b], g_pipe.k_end[b]) == hipSuccess)
+			kernel_ms += ms;
+		parallel_copy(out + (cuts[k] - node_begin), g_pipe.h_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double));
+		t_wait += t1 - t0;
+		t_copy += now() - t1;
+		return hipSuccess;
+	};
+	for (size_t k = 0; k < n_chunks && e == hipSuccess && st == DG_OK; ++k)
 	{
-		st = dg_sdf_sample_nodes_device(mesh, grid, invert, node_begin, node_end, d_mask, d_out, nullptr);
-		if (st == DG_OK)
-		{
-			e = hipEventRecord(e1, nullptr);
-			if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost);
-			float ms = -1.f;
-			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
-				g_last_ms = ms;
-		}
+		const int b = (int)(k & 1);
+		// device buffer b was last read by the copy of chunk k-2, which drain(k-2) has waited for
+		e = hipEventRecord(g_pipe.k_begin[b], g_pipe.compute);
+		if (e != hipSuccess)
+			break;
+		st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask ? d_mask + (cuts[k] - node_begin) : nullptr,
+										static_cast<double*>(g_pipe.d_buf[b]), g_pipe.compute);
+		if (st != DG_OK)
+			break;
+		e = hipEventRecord(g_pipe.k_end[b], g_pipe.compute);
+		if (e == hipSuccess) e = hipStreamWaitEvent(g_pipe.copy, g_pipe.k_end[b], 0);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(g_pipe.h_buf[b], g_pipe.d_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double), hipMemcpyDeviceToHost,
+							   g_pipe.copy);
+		if (e == hipSuccess) e = hipEventRecord(g_pipe.c_end[b], g_pipe.copy);
+		if (e == hipSuccess && k >= 1)
+			e = drain(k - 1);
 	}
-	if (e0) (void)hipEventDestroy(e0);
-	if (e1) (void)hipEventDestroy(e1);
-	if (d_out) (void)hipFree(d_out);
+	if (e == hipSuccess && st == DG_OK)
+		e = drain(n_chunks - 1);
+	else
+	{
+		(void)hipStreamSynchronize(g_pipe.compute);
+		(void)hipStreamSynchronize(g_pipe.copy);
+	}
 	if (d_mask) (void)hipFree(d_mask);
 	if (st != DG_OK)
 		return st;
 	if (e != hipSuccess)
 		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes: %s",
 					hipGetErrorString(e));
+	g_last_ms = kernel_ms;
+	if (std::getenv("DG_HOST_DEBUG"))
+		std::fprintf(stderr, "dg_sdf_sample_nodes: %zu chunks, kernels %.1f ms, host waited %.1f ms, host copies %.1f ms\n", n_chunks,
+					 kernel_ms, t_wait * 1e3, t_copy * 1e3);
 	return DG_OK;
 }
 

@@ -25,10 +25,16 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 // takes the per-lane minimum over the subtrees and writes the node values.  min is exact, so the
 // result is the one the single wave would have produced.
 #ifndef DG_HEAVY_SLOTS
-#define DG_HEAVY_SLOTS 512
+#define DG_HEAVY_SLOTS 2048
 #endif
-static const int kOverflowSlots = DG_HEAVY_SLOTS; // parked bricks per launch (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
-static const int kHeavyWork = 3000;     // traversal steps + exact triangle tests before a brick counts as heavy
+static const int kOverflowSlots = DG_HEAVY_SLOTS; // most bricks one launch can park (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
+static const int kHeavyWork = 1600;     // traversal steps + exact triangle tests before a brick counts as heavy (~0.7 ms of one wave)
+// slots a launch of `bricks` bricks gets: heavy bricks are a small, slowly growing fraction of a launch
+inline uint32_t overflow_slots_for(uint64_t bricks)
+{
+	const uint64_t want = bricks / 2048;
+	return (uint32_t)(want < 256 ? 256 : (want > (uint64_t)kOverflowSlots ? (uint64_t)kOverflowSlots : want));
+}
 
 struct OverflowBuf // device scratch of one K1 launch (null count: splitting disabled)
 {

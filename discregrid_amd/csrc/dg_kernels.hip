@@ -295,33 +295,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 	write_node(P, valid, sample, out_idx, q);
 }
 
-// Heavy bricks, step 2: wave (slot, s) searches subtree s of the BVH for the brick parked in `slot`,
-// starting from the parked bests.  blockIdx = slot * n_sub + s.
+// Heavy bricks, step 2: job (slot, s) searches subtree s of the BVH for the brick parked in `slot`,
+// starting from the parked bests.  One wave per block, jobs dealt grid-stride (the number of parked
+// bricks is only known on the device).
 __global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
 {
 	const uint32_t n_sub = (uint32_t)P.mesh.n_sub;
-	const uint32_t slot = blockIdx.x / n_sub;
-	const uint32_t s = blockIdx.x - slot * n_sub;
 	const uint32_t parked = min(*P.ovf.count, P.ovf.slots);
-	if (slot >= parked)
-		return;
 	const int lane = (int)threadIdx.x;
-	const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
-	bool sample = ln.valid;
-	if (ln.valid && P.mask != nullptr)
-		sample = P.mask[ln.out_idx] != 0;
-	double x[3];
-	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
 	extern __shared__ __attribute__((aligned(16))) float lds_lb[];
-	LaneQuery q;
-	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
-	const int tri = P.ovf.saved_tri[slot * 64 + lane];
-	if (sample && tri >= 0)
-		offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
-	traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
-	const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
-	P.ovf.cand_d2[at] = q.best_d2;
-	P.ovf.cand_tri[at] = q.best_tri;
+	for (uint32_t job = blockIdx.x; job < parked * n_sub; job += gridDim.x)
+	{
+		const uint32_t slot = job / n_sub;
+		const uint32_t s = job - slot * n_sub;
+		const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
+		bool sample = ln.valid;
+		if (ln.valid && P.mask != nullptr)
+			sample = P.mask[ln.out_idx] != 0;
+		double x[3];
+		node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+		LaneQuery q;
+		init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
+		const int tri = P.ovf.saved_tri[slot * 64 + lane];
+		if (sample && tri >= 0)
+			offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
+		traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
+		const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
+		P.ovf.cand_d2[at] = q.best_d2;
+		P.ovf.cand_tri[at] = q.best_tri;
+	}
 }
 
 // Heavy bricks, step 3: per lane the minimum over the subtrees (the parked best is part of every
@@ -534,7 +536,8 @@ hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
 	if (p.ovf.count != nullptr)
 	{
 		const size_t lds1 = (size_t)p.mesh.stack_levels * 64 * sizeof(float);
-		hipLaunchKernelGGL(k_heavy_subtrees, dim3(p.ovf.slots * (uint32_t)p.mesh.n_sub), dim3(64), lds1, stream, p);
+		const uint32_t jobs = p.ovf.slots * (uint32_t)p.mesh.n_sub;
+		hipLaunchKernelGGL(k_heavy_subtrees, dim3(jobs < 32768u ? jobs : 32768u), dim3(64), lds1, stream, p);
 		hipLaunchKernelGGL(k_heavy_finish, dim3(p.ovf.slots), dim3(64), 0, stream, p);
 	}
 	return hipGetLastError();

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../discregrid_amd/csrc/dg_build.h"
@@ -182,7 +183,8 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 }
 
 // heavy-brick settings of the emulated launches (defaults = the product's)
-uint32_t g_heavy_slots = kOverflowSlots;
+const uint32_t kAutoSlots = 0xffffffffu; // slots chosen per launch as dg_capi.cpp does
+uint32_t g_heavy_slots = kAutoSlots;
 int g_heavy_work = kHeavyWork;
 
 struct HostMesh
@@ -223,7 +225,7 @@ void emu_mesh_free(void* h) { delete static_cast<HostMesh*>(h); }
 // slots = 0: no splitting; work: budget of a brick (node steps + exact tests)
 void emu_set_heavy(uint32_t slots, int work)
 {
-	g_heavy_slots = slots < (uint32_t)kOverflowSlots ? slots : (uint32_t)kOverflowSlots;
+	g_heavy_slots = slots == kAutoSlots ? kAutoSlots : (slots < (uint32_t)kOverflowSlots ? slots : (uint32_t)kOverflowSlots);
 	g_heavy_work = work;
 }
 int emu_n_subtrees(void* h) { return static_cast<HostMesh*>(h)->dev.n_sub; }
@@ -404,24 +406,25 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 	int err = 0;
 	// heavy-brick scratch exactly as dg_capi.cpp attaches it
 	uint32_t ovf_count = 0;
-	std::vector<uint32_t> ovf_brick;
-	std::vector<double> saved_d2, cand_d2;
-	std::vector<int32_t> saved_tri, cand_tri;
+	std::unique_ptr<uint32_t[]> ovf_brick;
+	std::unique_ptr<double[]> saved_d2, cand_d2; // uninitialised on purpose: only parked slots are ever touched
+	std::unique_ptr<int32_t[]> saved_tri, cand_tri;
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
-	if (g_heavy_slots > 0 && P.mesh.n_sub >= 2)
+	const uint32_t slots = g_heavy_slots == kAutoSlots ? overflow_slots_for(P.total_bricks) : g_heavy_slots;
+	if (slots > 0 && P.mesh.n_sub >= 2)
 	{
-		ovf_brick.resize(g_heavy_slots);
-		saved_d2.resize((size_t)g_heavy_slots * 64);
-		saved_tri.resize((size_t)g_heavy_slots * 64);
-		cand_d2.resize((size_t)g_heavy_slots * kSubtrees * 64);
-		cand_tri.resize((size_t)g_heavy_slots * kSubtrees * 64);
+		ovf_brick.reset(new uint32_t[slots]);
+		saved_d2.reset(new double[(size_t)slots * 64]);
+		saved_tri.reset(new int32_t[(size_t)slots * 64]);
+		cand_d2.reset(new double[(size_t)slots * kSubtrees * 64]);
+		cand_tri.reset(new int32_t[(size_t)slots * kSubtrees * 64]);
 		P.ovf.count = &ovf_count;
-		P.ovf.brick = ovf_brick.data();
-		P.ovf.saved_d2 = saved_d2.data();
-		P.ovf.saved_tri = saved_tri.data();
-		P.ovf.cand_d2 = cand_d2.data();
-		P.ovf.cand_tri = cand_tri.data();
-		P.ovf.slots = g_heavy_slots;
+		P.ovf.brick = ovf_brick.get();
+		P.ovf.saved_d2 = saved_d2.get();
+		P.ovf.saved_tri = saved_tri.get();
+		P.ovf.cand_d2 = cand_d2.get();
+		P.ovf.cand_tri = cand_tri.get();
+		P.ovf.slots = slots;
 		P.ovf.heavy_work = g_heavy_work;
 	}
 	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
