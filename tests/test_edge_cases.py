@@ -24,6 +24,16 @@ def meshes():
     Fn = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6],
                    [3, 0, 4], [3, 4, 7]], dtype=np.uint32)
     out["needle_box"] = (Vn, Fn)
+    # a closed mesh far from the coordinate origin (absolute coordinates ~3e5, features ~1e-1)
+    out["far_from_origin"] = (V + np.array([1.0e5, -2.0e5, 3.0e5]), F)
+    # a tiny and a huge copy (bounds are relative floats: the scale must not matter)
+    out["tiny"] = (V * 1.0e-6, F)
+    out["huge"] = (V * 1.0e6 + 12345.0, F)
+    # triangle soup: 400 random, mutually intersecting triangles (no manifold structure at all)
+    rng = np.random.default_rng(99)
+    Vs = rng.uniform(-1, 1, size=(1200, 3))
+    Vs[600:] = Vs[:600] + rng.normal(scale=0.05, size=(600, 3))   # big and small ones
+    out["soup"] = (Vs, np.arange(1200, dtype=np.uint32).reshape(400, 3))
     return out
 
 
@@ -41,6 +51,8 @@ def test_unusual_meshes(name):
     # defined for closed meshes (the reference warns, TriangleMeshDistance.h:422-438) -- but it
     # is still the same wherever the winning triangle is the same
     np.testing.assert_array_equal(np.abs(a), np.abs(b))
+    if name in ("far_from_origin", "tiny", "huge"):
+        np.testing.assert_array_equal(a, b)        # closed, well-conditioned: signs as well
     if name in ("degenerate_and_duplicate", "needle_box"):
         off = np.abs(b) > 1e-7 * ext
         np.testing.assert_array_equal(a[off], b[off])
