@@ -124,7 +124,7 @@ inline float up(double v) { return std::nextafterf(round_up(v), std::numeric_lim
 // oriented box of a set of primitives (dg_geom.h: PairRec), float, relative to origin, rounded outward
 struct Bounds
 {
-	float u[3][3], lo[3], hi[3];
+	float c[3], u[3][3], half[3];
 };
 
 Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
@@ -185,47 +185,60 @@ Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
 			}
 	}
 	Bounds B;
+	// directions shrunk by 1e-6: after rounding to float the Gram matrix of the three still has no
+	// eigenvalue above 1 (the sum of squared projections never exceeds the squared length)
 	for (int a = 0; a < 3; ++a)
-	{
-		// shrunk by 1e-6: after rounding to float the Gram matrix of the three directions still has
-		// no eigenvalue above 1 (the sum of squared projections never exceeds the squared length)
 		for (int d = 0; d < 3; ++d)
 			B.u[a][d] = (float)(ax[a][d] * (1.0 - 1.0e-6));
+	// centre = midpoint of the projection ranges, mapped back (any point would do: the half widths
+	// below are measured from the float centre actually stored)
+	double mid[3];
+	for (int a = 0; a < 3; ++a)
+	{
 		double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
 		for (size_t i = 0; i < n; ++i)
 			for (int k = 0; k < 3; ++k)
 			{
-				const double pr = (double)B.u[a][0] * (p[i].v[k][0] - origin[0]) + (double)B.u[a][1] * (p[i].v[k][1] - origin[1]) +
-								  (double)B.u[a][2] * (p[i].v[k][2] - origin[2]);
+				const double pr = ax[a][0] * (p[i].v[k][0] - origin[0]) + ax[a][1] * (p[i].v[k][1] - origin[1]) +
+								  ax[a][2] * (p[i].v[k][2] - origin[2]);
 				plo = std::min(plo, pr);
 				phi = std::max(phi, pr);
 			}
-		B.lo[a] = down(plo);
-		B.hi[a] = up(phi);
+		mid[a] = 0.5 * (plo + phi);
+	}
+	for (int d = 0; d < 3; ++d)
+		B.c[d] = (float)(mid[0] * ax[0][d] + mid[1] * ax[1][d] + mid[2] * ax[2][d]);
+	for (int a = 0; a < 3; ++a)
+	{
+		double h = 0.0;
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+				h = std::max(h, std::fabs((double)B.u[a][0] * (p[i].v[k][0] - origin[0] - (double)B.c[0]) +
+										  (double)B.u[a][1] * (p[i].v[k][1] - origin[1] - (double)B.c[1]) +
+										  (double)B.u[a][2] * (p[i].v[k][2] - origin[2] - (double)B.c[2])));
+		B.half[a] = up(h);
 	}
 	return B;
 }
 
 void put_side(PairRec& r, int side, const Bounds& B)
 {
+	for (int d = 0; d < 3; ++d)
+		r.f[d][side] = B.c[d];
 	for (int a = 0; a < 3; ++a)
 	{
 		for (int d = 0; d < 3; ++d)
-			r.f[5 * a + d][side] = B.u[a][d];
-		r.f[5 * a + 3][side] = B.lo[a];
-		r.f[5 * a + 4][side] = B.hi[a];
+			r.f[3 + 3 * a + d][side] = B.u[a][d];
+		r.f[12 + a][side] = B.half[a];
 	}
 }
-// a side that can never be hit: empty slabs (distance = inf)
+// a side that can never be hit: slabs of half width -FLT_MAX (distance^2 = inf)
 void put_empty(PairRec& r, int side)
 {
+	for (int k = 0; k < 12; ++k)
+		r.f[k][side] = 0.0f;
 	for (int a = 0; a < 3; ++a)
-	{
-		for (int d = 0; d < 3; ++d)
-			r.f[5 * a + d][side] = 0.0f;
-		r.f[5 * a + 3][side] = std::numeric_limits<float>::max();
-		r.f[5 * a + 4][side] = -std::numeric_limits<float>::max();
-	}
+		r.f[12 + a][side] = -std::numeric_limits<float>::max();
 }
 #else
 // box + slab of a set of primitives, float, relative to origin, rounded outward

@@ -41,15 +41,15 @@ namespace dg
 #define DG_OBB 1
 #endif
 #if DG_OBB
-// Bounds of an item (subtree or triangle) = an oriented box given as three slabs
-//     lo_a <= u_a . y <= hi_a   for every point y of the item,  a = 0, 1, 2,
+// Bounds of an item (subtree or triangle) = an oriented box: centre c, directions u_a, half widths
+//     |u_a . (y - c)| <= half_a   for every point y of the item,  a = 0, 1, 2,
 // with (nearly) orthonormal directions u_a whose Gram matrix has no eigenvalue above 1, so that
-//     dist(p, item)^2 >= sum_a max(u_a.p - hi_a, lo_a - u_a.p, 0)^2.
+//     dist(p, item)^2 >= sum_a max(|u_a.(p - c)| - half_a, 0)^2.
 // For a flat patch u_0 is its mean normal and u_1, u_2 the principal tangent directions; for a
 // curved one the three directions are the coordinate axes (an ordinary box).
 struct alignas(128) PairRec
 {
-	float f[15][2];  // [5*a + j][side], j: 0..2 direction u_a, 3 lo_a, 4 hi_a
+	float f[15][2];  // [k][side], k: 0..2 centre, 3 + 3*a + d component d of u_a, 12 + a half_a (an empty item has half_a = -FLT_MAX)
 	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
 };
 static const int kPairFloats = 30;
@@ -364,6 +364,7 @@ struct f2
 };
 DG_HD f2 f2_make(float a, float b) { return f2{a, b}; }
 DG_HD f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+DG_HD f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
 DG_HD f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
 DG_HD f2 f2_fma(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 #endif
@@ -373,20 +374,24 @@ DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_
 
 #if DG_OBB
 // Squared lower bounds of BOTH items of a pair record for one query: distance to the oriented box,
-// r = the record's 30 interleaved floats (PairRec::f).
+// r = the record's 30 interleaved floats (PairRec::f).  d = p - centre, then per axis
+// excess = |u.d| - (half + es), clamped at 0 and squared: 30 VALU instructions for the two items
+// (everything but the abs/clamp is packed two-wide; every instruction reads one SGPR pair).
 DG_HD f2 pair_lb2(const float* r, const FPoint& p)
 {
-	f2 acc = f2_splat(0.0f);
+	const f2 dx = f2_splat(p.x[0]) - f2_make(r[0], r[1]);
+	const f2 dy = f2_splat(p.x[1]) - f2_make(r[2], r[3]);
+	const f2 dz = f2_splat(p.x[2]) - f2_make(r[4], r[5]);
 	const f2 es = f2_splat(p.es);
+	f2 acc = f2_splat(0.0f);
 	for (int a = 0; a < 3; ++a)
 	{
-		const float* q = r + 10 * a;
-		f2 t = f2_make(q[4], q[5]) * f2_splat(p.x[2]);
-		t = f2_fma(f2_make(q[2], q[3]), f2_splat(p.x[1]), t);
-		t = f2_fma(f2_make(q[0], q[1]), f2_splat(p.x[0]), t);
-		const f2 q1 = t - es - f2_make(q[8], q[9]);
-		const f2 q2 = f2_make(q[6], q[7]) - t - es;
-		const f2 d = f2_make(fmax3(q1.x, q2.x, 0.0f), fmax3(q1.y, q2.y, 0.0f));
+		const float* q = r + 6 + 6 * a;
+		f2 t = f2_make(q[4], q[5]) * dz;
+		t = f2_fma(f2_make(q[2], q[3]), dy, t);
+		t = f2_fma(f2_make(q[0], q[1]), dx, t);
+		const f2 hes = f2_make(r[24 + 2 * a], r[25 + 2 * a]) + es;
+		const f2 d = f2_make(fmax2(__builtin_fabsf(t.x) - hes.x, 0.0f), fmax2(__builtin_fabsf(t.y) - hes.y, 0.0f));
 		acc = f2_fma(d, d, acc);
 	}
 	return acc;

@@ -295,7 +295,7 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 			if (id < 0)
 			{
 #if DG_OBB
-				if (!(tp.f[3][t & 1] > tp.f[4][t & 1])) // padding must have empty slabs
+				if (!(tp.f[12][t & 1] < 0.0f)) // padding must have empty slabs
 					return 10;
 #else
 				if (!(tp.f[0][t & 1] > tp.f[3][t & 1])) // padding must have an empty box
@@ -317,7 +317,7 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 				double U[3][3];
 				for (int x = 0; x < 3; ++x)
 					for (int d = 0; d < 3; ++d)
-						U[x][d] = (double)r[2 * (5 * x + d) + sd];
+						U[x][d] = (double)r[2 * (3 + 3 * x + d) + sd];
 				for (int x = 0; x < 3; ++x)
 				{
 					double row = 0;
@@ -331,8 +331,8 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 					{
 						double pr = 0;
 						for (int d = 0; d < 3; ++d)
-							pr += U[x][d] * (verts[3 * tris[3 * id + k] + d] - m->B.origin[d]);
-						if (!((double)r[2 * (5 * x + 3) + sd] <= pr && pr <= (double)r[2 * (5 * x + 4) + sd]))
+							pr += U[x][d] * (verts[3 * tris[3 * id + k] + d] - m->B.origin[d] - (double)r[2 * d + sd]);
+						if (!(std::fabs(pr) <= (double)r[2 * (12 + x) + sd]))
 							return 12;
 					}
 #else
