@@ -53,9 +53,69 @@ struct dg_mesh
 	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
 };
 
+// Stream-ordered scratch buffers kept with a handle: a buffer is handed out again once the work that
+// used it has finished (or to the same stream, where work is ordered anyway).
+struct ScratchPool
+{
+	struct Buf
+	{
+		void* mem = nullptr;
+		size_t bytes = 0;
+		hipEvent_t done = nullptr;
+		hipStream_t stream = nullptr;
+		bool busy = false;
+	};
+	std::mutex mutex;
+	std::vector<Buf> bufs;
+
+	int acquire(size_t bytes, hipStream_t stream, void** mem)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		int idx = -1;
+		for (size_t i = 0; i < bufs.size() && idx < 0; ++i)
+			if (!bufs[i].busy && bufs[i].bytes >= bytes && (bufs[i].stream == stream || hipEventQuery(bufs[i].done) == hipSuccess))
+				idx = (int)i;
+		if (idx < 0)
+		{
+			Buf b;
+			b.bytes = bytes;
+			if (hipMalloc(&b.mem, bytes) != hipSuccess || hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				if (b.mem) (void)hipFree(b.mem);
+				return -1;
+			}
+			bufs.push_back(b);
+			idx = (int)bufs.size() - 1;
+		}
+		bufs[(size_t)idx].busy = true;
+		bufs[(size_t)idx].stream = stream;
+		*mem = bufs[(size_t)idx].mem;
+		return idx;
+	}
+	void release(int idx, hipStream_t stream)
+	{
+		if (idx < 0)
+			return;
+		std::lock_guard<std::mutex> lock(mutex);
+		(void)hipEventRecord(bufs[(size_t)idx].done, stream);
+		bufs[(size_t)idx].busy = false;
+	}
+	void destroy()
+	{
+		for (Buf& b : bufs)
+		{
+			if (b.done) (void)hipEventDestroy(b.done);
+			if (b.mem) (void)hipFree(b.mem);
+		}
+		bufs.clear();
+	}
+};
+
 struct dg_field
 {
 	dg::FieldDev dev;
+	mutable ScratchPool scratch; // K2 query binning
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
 	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
@@ -904,6 +964,7 @@ void dg_field_destroy(dg_field* f)
 		(void)hipFree(f->d_cell_major);
 	if (f->d_wtab)
 		(void)hipFree(f->d_wtab);
+	f->scratch.destroy();
 	delete f;
 }
 
@@ -1040,7 +1101,33 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 {
 	if (!field || (n && (!d_xyz || !d_phi)))
 		return fail(DG_ERR_INVALID, "null argument");
-	DG_HIP(dg::launch_interpolate(field->dev, d_xyz, n, d_phi, d_grad, static_cast<hipStream_t>(stream)));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// Large batches against a field that does not fit the L2s go through the binned path (queries in
+	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and
+	// run as they are).  DG_K2_BINNING=0 switches it off, =2 forces it for any size.
+	const int binning = env_int("DG_K2_BINNING", 1, 0, 2);
+	const bool big = n >= (1u << 18) && field->n_coeffs * sizeof(double) >= (32u << 20);
+	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
+	{
+		size_t off[4];
+		const size_t bytes = dg::bin_scratch_bytes(dg::bin_tiles(field->dev.res), n, off);
+		void* mem = nullptr;
+		const int idx = field->scratch.acquire(bytes, st, &mem);
+		if (idx >= 0)
+		{
+			char* base = static_cast<char*>(mem);
+			dg::BinScratch S;
+			S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
+			S.start = reinterpret_cast<uint32_t*>(base + off[1]);
+			S.cursor = reinterpret_cast<uint32_t*>(base + off[2]);
+			S.perm = reinterpret_cast<uint32_t*>(base + off[3]);
+			const hipError_t e = dg::launch_interpolate_binned(field->dev, d_xyz, n, d_phi, d_grad, S, st);
+			field->scratch.release(idx, st);
+			DG_HIP(e);
+			return DG_OK;
+		}
+	}
+	DG_HIP(dg::launch_interpolate(field->dev, d_xyz, n, d_phi, d_grad, st));
 	return DG_OK;
 }
 

@@ -207,4 +207,38 @@ hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 							  hipStream_t stream);
 
+// K2 with query binning.  Queries in arbitrary order touch 16 scattered cache lines of a GB-sized
+// array each; processing them tile by tile (8x8x8 cells, 28 KB of coefficients) lets a wave's
+// gathers hit lines its neighbours just fetched.  The decision is taken on the device (a probe of
+// the first queries counts how often consecutive queries change tile), so the call stays
+// asynchronous: for inputs that are already spatially ordered the binning kernels return at once
+// and K2 runs in input order.
+struct BinScratch
+{
+	uint32_t* flag;   // [1] 1 = use the permutation
+	uint32_t* start;  // [n_tiles] histogram, then start offset of every tile
+	uint32_t* cursor; // [n_tiles]
+	uint32_t* perm;   // [n]
+};
+#ifndef DG_TILE_CELLS
+#define DG_TILE_CELLS 8
+#endif
+static const uint32_t kTileCells = DG_TILE_CELLS;
+inline uint32_t bin_tiles(const uint32_t res[3])
+{
+	return ((res[0] + kTileCells - 1) / kTileCells) * ((res[1] + kTileCells - 1) / kTileCells) * ((res[2] + kTileCells - 1) / kTileCells);
+}
+inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[4])
+{
+	size_t o = 0;
+	auto take = [&](size_t b) { const size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+	off[0] = take(4);
+	off[1] = take((size_t)n_tiles * 4);
+	off[2] = take((size_t)n_tiles * 4);
+	off[3] = take((size_t)n * 4);
+	return o;
+}
+hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+									 const BinScratch& scratch, hipStream_t stream);
+
 } // namespace dg

@@ -30,6 +30,7 @@
 // Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "dg_kernels.h"
 
 namespace dg
@@ -436,6 +437,109 @@ __global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const dou
 	}
 }
 
+// ---- K2 query binning (dg_kernels.h: BinScratch) ---------------------------------------------------------
+__device__ __forceinline__ uint32_t query_tile(const FieldDev& F, const double* __restrict__ xyz, uint64_t i)
+{
+	uint32_t t[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d)
+	{
+		const double x = xyz[3 * i + d];
+		uint32_t mi = 0;
+		if (F.dmin[d] <= x && x <= F.dmax[d])
+		{
+			mi = (uint32_t)((x - F.dmin[d]) * F.inv_cell[d]);
+			if (mi >= F.res[d])
+				mi = F.res[d] - 1;
+		}
+		t[d] = mi / kTileCells;
+	}
+	const uint32_t tx = (F.res[0] + kTileCells - 1) / kTileCells, ty = (F.res[1] + kTileCells - 1) / kTileCells;
+	return (t[2] * ty + t[1]) * tx + t[0];
+}
+// one block: how often do consecutive queries (among the first 4096) change tile?
+__global__ __launch_bounds__(256) void k_bin_probe(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+{
+	__shared__ uint32_t changes;
+	if (threadIdx.x == 0)
+		changes = 0;
+	__syncthreads();
+	const uint64_t m = n < 4096 ? n : 4096;
+	uint32_t mine = 0;
+	for (uint64_t i = threadIdx.x; i + 1 < m; i += blockDim.x)
+		mine += query_tile(F, xyz, i) != query_tile(F, xyz, i + 1);
+	atomicAdd(&changes, mine);
+	__syncthreads();
+	if (threadIdx.x == 0)
+		S.flag[0] = (4ull * changes > m) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_bin_hist(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+{
+	if (S.flag[0] == 0)
+		return;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		atomicAdd(&S.start[query_tile(F, xyz, i)], 1u);
+}
+// one block of 1024 threads: exclusive prefix sum of the histogram (start, and a copy in cursor)
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t n_tiles, BinScratch S)
+{
+	if (S.flag[0] == 0)
+		return;
+	__shared__ uint32_t part[1024];
+	const uint32_t per = (n_tiles + 1023u) / 1024u;
+	const uint32_t b = threadIdx.x * per, e = min(n_tiles, b + per);
+	uint32_t sum = 0;
+	for (uint32_t i = b; i < e; ++i)
+		sum += S.start[i];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t run = 0;
+		for (int i = 0; i < 1024; ++i)
+		{
+			const uint32_t v = part[i];
+			part[i] = run;
+			run += v;
+		}
+	}
+	__syncthreads();
+	uint32_t run = part[threadIdx.x];
+	for (uint32_t i = b; i < e; ++i)
+	{
+		const uint32_t v = S.start[i];
+		S.start[i] = run;
+		S.cursor[i] = run;
+		run += v;
+	}
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+{
+	if (S.flag[0] == 0)
+		return;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		S.perm[atomicAdd(&S.cursor[query_tile(F, xyz, i)], 1u)] = (uint32_t)i;
+}
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+															 double* __restrict__ phi_out, double* __restrict__ grad_out, BinScratch S)
+{
+	uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= n)
+		return;
+	if (S.flag[0] != 0)
+		gid = S.perm[gid];
+	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
+	double g[3];
+	phi_out[gid] = interpolate_point<GRAD>(F, x, g);
+	if (GRAD)
+	{
+		grad_out[3 * gid] = g[0];
+		grad_out[3 * gid + 1] = g[1];
+		grad_out[3 * gid + 2] = g[2];
+	}
+}
+
 // Builds the cell-major copy of a field (FieldDev::cell_major): one thread per cell row.
 __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t n_rows, double* __restrict__ out)
 {
@@ -588,6 +692,28 @@ hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n
 		hipLaunchKernelGGL(k_interpolate<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
 	else
 		hipLaunchKernelGGL(k_interpolate<false>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+									 const BinScratch& S, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t n_tiles = bin_tiles(f.res);
+	hipError_t e = hipMemsetAsync(S.start, 0, (size_t)n_tiles * sizeof(uint32_t), stream);
+	if (e != hipSuccess)
+		return e;
+	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, f, d_xyz, n, S);
+	hipLaunchKernelGGL(k_bin_hist, dim3(wide), dim3(256), 0, stream, f, d_xyz, n, S);
+	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, n_tiles, S);
+	hipLaunchKernelGGL(k_bin_scatter, dim3(wide), dim3(256), 0, stream, f, d_xyz, n, S);
+	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	if (d_grad)
+		hipLaunchKernelGGL(k_interpolate_binned<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
+	else
+		hipLaunchKernelGGL(k_interpolate_binned<false>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
 	return hipGetLastError();
 }
 

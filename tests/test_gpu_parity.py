@@ -189,6 +189,32 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(ga2, ga)
 
 
+@pytest.mark.parametrize("name", ["torus", "bunny"])
+def test_interpolate_binned_path(dg, golden, monkeypatch, name):
+    """K2 with query binning (tile-by-tile processing of unordered queries; the ordered/unordered
+    decision is taken on the device): forced on for a small batch, results and gradients must be
+    the bits of the direct path for random, cell-sorted, out-of-domain and duplicated queries."""
+    dom, res = golden[name + "_domain"], golden[name + "_res"]
+    coeffs = golden[name + "_coeffs"]
+    f = dg.Field(grid_of(dg, dom, res), coeffs)
+    rng = np.random.default_rng(3)
+    lo, hi = dom[:3], dom[3:]
+    P = rng.uniform(lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo), size=(70001, 3))   # some outside
+    P[1000:2000] = P[1000]                                                            # duplicates
+    cell = np.floor((np.clip(P, lo, hi) - lo) / (hi - lo) * res).astype(np.int64)
+    order = np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))
+    monkeypatch.setenv("DG_K2_BINNING", "0")
+    want = {k: f.interpolate(Q, grad=True) for k, Q in (("random", P), ("sorted", P[order]))}
+    np.testing.assert_array_equal(want["random"][0], T.oracle_interpolate(dom, res, coeffs, P))
+    monkeypatch.setenv("DG_K2_BINNING", "2")
+    for k, Q in (("random", P), ("sorted", P[order]), ("random", P)):
+        phi, grad = f.interpolate(Q, grad=True)
+        np.testing.assert_array_equal(phi, want[k][0])
+        np.testing.assert_array_equal(grad, want[k][1])
+        np.testing.assert_array_equal(f.interpolate(Q), want[k][0])
+    np.testing.assert_array_equal(f.interpolate(P[:5]), want["random"][0][:5])            # tiny batch
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8, 32])
 def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks, monkeypatch):
     """Multi-GPU path exercised on one device: every rank's shard is computed in turn, the
