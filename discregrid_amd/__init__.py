@@ -51,8 +51,11 @@ SYMBOLS = {
     "dg_last_error": (C.c_char_p, []),
     "dg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dg_set_device": (C.c_int, [C.c_int]),
+    "dg_current_device": (C.c_int, [C.POINTER(C.c_int)]),
     "dg_grid_desc_init": (C.c_int, [_dp, _dp, _u32p, C.POINTER(GridDesc)]),
     "dg_default_domain": (C.c_int, [_dp, C.c_uint64, _dp]),
+    "dg_sdf_sample_nodes_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(GridDesc), C.c_int, C.c_uint64,
+                                            C.c_uint64, C.c_void_p, _dp]),
     "dg_grid_n_nodes": (C.c_uint64, [C.POINTER(GridDesc)]),
     "dg_grid_n_cells": (C.c_uint64, [C.POINTER(GridDesc)]),
     "dg_mesh_create": (C.c_int, [_dp, C.c_size_t, _u32p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -231,6 +234,19 @@ class Mesh:
         _check(self._lib.dg_signed_distance_device(self.handle, C.c_void_p(d_xyz), n, C.c_void_p(d_dist),
                                                    C.c_void_p(d_tri), C.c_void_p(d_entity), C.c_void_p(d_nearest),
                                                    C.c_void_p(stream)))
+
+
+def sample_nodes_multi(meshes, grid, begin=0, end=None, invert=False, mask=None):
+    """dg_sdf_sample_nodes_multi: one Mesh per device (or several on one), results in host memory."""
+    if end is None:
+        end = n_nodes(grid)
+    out = np.empty(end - begin, dtype=np.float64)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    handles = (C.c_void_p * len(meshes))(*[x.handle for x in meshes])
+    _check(load_library().dg_sdf_sample_nodes_multi(handles, len(meshes), C.byref(grid), int(invert), begin, end,
+                                                    None if m is None else m.ctypes.data_as(C.c_void_p),
+                                                    out.ctypes.data_as(_dp)))
+    return out
 
 
 def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):

@@ -127,6 +127,8 @@ public:
 	std::size_t nTriangles() const;
 	// opaque dg_mesh* of include/discregrid_hip.h (used by CubicLagrangeDiscreteGrid)
 	const void* deviceMesh() const;
+	// the primary mesh followed by its replicas on the other devices of DG_DEVICES (if any)
+	const std::vector<const void*>& deviceMeshes() const;
 
 private:
 	void constructFlat(const std::vector<double>& v, const std::vector<unsigned int>& t);

@@ -220,8 +220,16 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 			std::cout << "DistanceTriangleMesh error: not constructed." << std::endl;
 			throw std::runtime_error("DistanceTriangleMesh error: not constructed.");
 		}
-		if (dg_sdf_sample_nodes(mesh, &g, sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr,
-								coeffs.data()) != DG_OK)
+		// one GPU, or -- when the mesh has replicas on further devices (DG_DEVICES) -- all of them,
+		// each with its own copy pipeline writing into `coeffs`
+		auto const& all = sdf->distance->deviceMeshes();
+		dg_status st;
+		if (all.size() > 1)
+			st = dg_sdf_sample_nodes_multi(reinterpret_cast<const dg_mesh* const*>(all.data()), (int)all.size(), &g,
+										   sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr, coeffs.data());
+		else
+			st = dg_sdf_sample_nodes(mesh, &g, sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr, coeffs.data());
+		if (st != DG_OK)
 			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addFunction (GPU): ") + dg_last_error());
 		m_last_used_gpu = true;
 		if (verbose)

@@ -2,6 +2,7 @@
 // distance queries run on the GPU; there is no host implementation of the query here.
 #include <Discregrid/geometry/TriangleMeshDistance.h>
 
+#include <cstdlib>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -13,9 +14,16 @@ namespace Discregrid
 
 struct TriangleMeshDistance::Impl
 {
-	dg_mesh* mesh = nullptr;
+	dg_mesh* mesh = nullptr;          // on the device that was current at construction: all point queries
+	std::vector<dg_mesh*> replicas;   // further copies, one per extra device of DG_DEVICES (addFunction only)
+	std::vector<const void*> all;     // mesh + replicas
 	dg_mesh_info info;
-	~Impl() { dg_mesh_destroy(mesh); }
+	~Impl()
+	{
+		dg_mesh_destroy(mesh);
+		for (dg_mesh* m : replicas)
+			dg_mesh_destroy(m);
+	}
 };
 
 namespace
@@ -39,6 +47,58 @@ void TriangleMeshDistance::constructFlat(const std::vector<double>& v, const std
 					   &impl->mesh) != DG_OK)
 		fail("TriangleMeshDistance::construct");
 	dg_mesh_get_info(impl->mesh, &impl->info);
+	impl->all.push_back(impl->mesh);
+	// DG_DEVICES = "all" or a comma-separated list of device ordinals: replicate the mesh there so that
+	// CubicLagrangeDiscreteGrid::addFunction can spread the node lattice over those GPUs
+	if (const char* env = std::getenv("DG_DEVICES"))
+	{
+		int count = 0, current = 0;
+		dg_device_count(&count);
+		std::vector<int> devices;
+		const std::string spec = env;
+		std::size_t at = 0;
+		while (at <= spec.size())
+		{
+			const std::size_t comma = spec.find(',', at);
+			const std::string tok = spec.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+			if (tok == "all")
+				for (int d = 0; d < count; ++d)
+					devices.push_back(d);
+			else if (!tok.empty())
+			{
+				char* end = nullptr;
+				const long d = std::strtol(tok.c_str(), &end, 10);
+				if (end == tok.c_str() || *end != '\0')
+					throw std::runtime_error("DG_DEVICES: cannot parse '" + tok + "'");
+				devices.push_back((int)d);
+			}
+			if (comma == std::string::npos)
+				break;
+			at = comma + 1;
+		}
+		if (dg_current_device(&current) != DG_OK)
+			fail("TriangleMeshDistance::construct");
+		bool first = true; // the first mention of the current device is the primary mesh itself
+		for (int d : devices)
+		{
+			if (d < 0 || d >= count)
+				throw std::runtime_error("DG_DEVICES names device " + std::to_string(d) + ", but only " +
+										 std::to_string(count) + " device(s) are visible");
+			if (d == current && first)
+			{
+				first = false;
+				continue;
+			}
+			dg_mesh* m = nullptr;
+			const bool ok = dg_set_device(d) == DG_OK &&
+							dg_mesh_create(v.data(), v.size() / 3, reinterpret_cast<const uint32_t*>(t.data()), t.size() / 3, &m) == DG_OK;
+			dg_set_device(current);
+			if (!ok)
+				fail("TriangleMeshDistance::construct (replica)");
+			impl->replicas.push_back(m);
+			impl->all.push_back(m);
+		}
+	}
 	if (impl->info.not_watertight & 1u)
 		std::cout << "DistanceTriangleMesh warning: mesh is not watertight. At least one edge found belonging to "
 					 "just one triangle."
@@ -103,5 +163,10 @@ std::vector<Result> TriangleMeshDistance::signed_distance(const std::vector<std:
 bool TriangleMeshDistance::isWatertight() const { return m_impl && m_impl->info.not_watertight == 0; }
 std::size_t TriangleMeshDistance::nTriangles() const { return m_impl ? (std::size_t)m_impl->info.n_triangles : 0; }
 const void* TriangleMeshDistance::deviceMesh() const { return m_impl ? m_impl->mesh : nullptr; }
+const std::vector<const void*>& TriangleMeshDistance::deviceMeshes() const
+{
+	static const std::vector<const void*> none;
+	return m_impl ? m_impl->all : none;
+}
 
 } // namespace Discregrid

@@ -208,6 +208,17 @@ dg_status dg_set_device(int device)
 	return DG_OK;
 }
 
+dg_status dg_current_device(int* device)
+{
+	if (!device)
+		return fail(DG_ERR_INVALID, "null argument");
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	DG_HIP(hipGetDevice(device));
+	return DG_OK;
+}
+
 // XCD chunk size of the K1 launches (dg_kernels.h: logical_block()); tuning knob, default kXcdChunk.
 // DG_XCD_CHUNK=-1 gives every XCD one contiguous eighth of the launch.
 static uint32_t env_xcd_chunk()
@@ -536,8 +547,10 @@ struct HostPipe
 	std::mutex mutex; // one host-pointer launch at a time uses the staging buffers
 	int device = -1;
 	size_t chunk_bytes = 0;
+	size_t mask_bytes = 0;
 	void* d_buf[2] = {nullptr, nullptr};
 	void* h_buf[2] = {nullptr, nullptr};
+	void* d_mask[2] = {nullptr, nullptr};
 	hipStream_t compute = nullptr, copy = nullptr;
 	hipEvent_t k_begin[2] = {nullptr, nullptr}, k_end[2] = {nullptr, nullptr}, c_end[2] = {nullptr, nullptr};
 
@@ -546,27 +559,30 @@ struct HostPipe
 		for (int i = 0; i < 2; ++i)
 		{
 			if (d_buf[i]) (void)hipFree(d_buf[i]);
+			if (d_mask[i]) (void)hipFree(d_mask[i]);
 			if (h_buf[i]) (void)hipHostFree(h_buf[i]);
 			if (k_begin[i]) (void)hipEventDestroy(k_begin[i]);
 			if (k_end[i]) (void)hipEventDestroy(k_end[i]);
 			if (c_end[i]) (void)hipEventDestroy(c_end[i]);
-			d_buf[i] = h_buf[i] = nullptr;
+			d_buf[i] = h_buf[i] = d_mask[i] = nullptr;
 			k_begin[i] = k_end[i] = c_end[i] = nullptr;
 		}
 		if (compute) (void)hipStreamDestroy(compute);
 		if (copy) (void)hipStreamDestroy(copy);
 		compute = copy = nullptr;
-		chunk_bytes = 0;
+		chunk_bytes = mask_bytes = 0;
 		device = -1;
 	}
-	hipError_t prepare(size_t bytes)
+	hipError_t prepare(size_t bytes, size_t mask)
 	{
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess)
 			return e;
-		if (dev == device && bytes <= chunk_bytes)
+		if (dev == device && bytes <= chunk_bytes && mask <= mask_bytes)
 			return hipSuccess;
+		bytes = std::max(bytes, dev == device ? chunk_bytes : 0);
+		mask = std::max(mask, dev == device ? mask_bytes : 0);
 		release();
 		device = dev;
 		e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
@@ -574,19 +590,24 @@ struct HostPipe
 		for (int i = 0; i < 2 && e == hipSuccess; ++i)
 		{
 			e = hipMalloc(&d_buf[i], bytes);
+			if (e == hipSuccess && mask) e = hipMalloc(&d_mask[i], mask);
 			if (e == hipSuccess) e = hipHostMalloc(&h_buf[i], bytes, hipHostMallocDefault);
 			if (e == hipSuccess) e = hipEventCreate(&k_begin[i]);
 			if (e == hipSuccess) e = hipEventCreate(&k_end[i]);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&c_end[i], hipEventDisableTiming);
 		}
 		if (e == hipSuccess)
+		{
 			chunk_bytes = bytes;
+			mask_bytes = mask;
+		}
 		else
 			release();
 		return e;
 	}
 };
-HostPipe g_pipe;
+const int kMaxPipes = 16;
+HostPipe g_pipes[kMaxPipes]; // [0]: single-mesh calls; [i]: worker i of dg_sdf_sample_nodes_multi
 
 // dst <- src with a few threads (one thread tops out near 10 GB/s, the PCIe link delivers 50+)
 void parallel_copy(void* dst, const void* src, size_t bytes)
@@ -629,99 +650,173 @@ void chunk_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end, u
 }
 } // namespace
 
+// Chunks first, first + stride, ... of `cuts` through one pipeline (the caller holds pipe.mutex and
+// has made the mesh's device current).  kernel_ms accumulates the K1 time of the chunks.
+static dg_status run_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+							const std::vector<uint64_t>& cuts, size_t first, size_t stride, const uint8_t* pred_mask,
+							double* out, double* kernel_ms, double* t_wait, double* t_copy)
+{
+	const size_t n_chunks = cuts.size() - 1;
+	uint64_t longest = 0;
+	for (size_t k = first; k < n_chunks; k += stride)
+		longest = std::max(longest, cuts[k + 1] - cuts[k]);
+	if (longest == 0)
+		return DG_OK;
+	hipError_t e = pipe.prepare(longest * sizeof(double), pred_mask ? longest : 0);
+	dg_status st = DG_OK;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	auto drain = [&](size_t k, int b) -> hipError_t { // chunk k: wait for its copy, move it into the caller's array
+		const double t0 = now();
+		hipError_t err = hipEventSynchronize(pipe.c_end[b]);
+		if (err != hipSuccess)
+			return err;
+		const double t1 = now();
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pipe.k_begin[b], pipe.k_end[b]) == hipSuccess)
+			*kernel_ms += ms;
+		parallel_copy(out + (cuts[k] - node_begin), pipe.h_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double));
+		*t_wait += t1 - t0;
+		*t_copy += now() - t1;
+		return hipSuccess;
+	};
+	size_t prev = n_chunks; // chunk whose results still sit in the staging buffers
+	int turn = 0;
+	for (size_t k = first; k < n_chunks && e == hipSuccess && st == DG_OK; k += stride, turn ^= 1)
+	{
+		const int b = turn;
+		const uint64_t cn = cuts[k + 1] - cuts[k];
+		// buffers b were last used by the chunk before `prev`, which has been drained
+		uint8_t* d_mask = nullptr;
+		if (pred_mask)
+		{
+			d_mask = static_cast<uint8_t*>(pipe.d_mask[b]);
+			e = hipMemcpyAsync(d_mask, pred_mask + (cuts[k] - node_begin), cn, hipMemcpyHostToDevice, pipe.compute);
+			if (e != hipSuccess)
+				break;
+		}
+		e = hipEventRecord(pipe.k_begin[b], pipe.compute);
+		if (e != hipSuccess)
+			break;
+		st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask, static_cast<double*>(pipe.d_buf[b]),
+										pipe.compute);
+		if (st != DG_OK)
+			break;
+		e = hipEventRecord(pipe.k_end[b], pipe.compute);
+		if (e == hipSuccess) e = hipStreamWaitEvent(pipe.copy, pipe.k_end[b], 0);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(pipe.h_buf[b], pipe.d_buf[b], cn * sizeof(double), hipMemcpyDeviceToHost, pipe.copy);
+		if (e == hipSuccess) e = hipEventRecord(pipe.c_end[b], pipe.copy);
+		if (e == hipSuccess && prev < n_chunks)
+			e = drain(prev, b ^ 1);
+		prev = k;
+	}
+	if (e == hipSuccess && st == DG_OK && prev < n_chunks)
+		e = drain(prev, turn ^ 1);
+	else
+	{
+		(void)hipStreamSynchronize(pipe.compute);
+		(void)hipStreamSynchronize(pipe.copy);
+	}
+	if (st != DG_OK)
+		return st;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes: %s", hipGetErrorString(e));
+	return DG_OK;
+}
+
+static dg_status check_host_range(const dg_grid_desc* grid, uint64_t node_begin, uint64_t node_end)
+{
+	if (node_begin > node_end)
+		return fail(DG_ERR_INVALID, "node_begin > node_end");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (node_end > dg_grid_n_nodes(grid))
+		return fail(DG_ERR_INVALID, "node range [%llu, %llu) outside [0, %llu)", (unsigned long long)node_begin,
+					(unsigned long long)node_end, (unsigned long long)dg_grid_n_nodes(grid));
+	return DG_OK;
+}
+
 dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 							  uint64_t node_end, const uint8_t* pred_mask, double* out)
 {
 	if (!mesh || !grid || !out)
 		return fail(DG_ERR_INVALID, "null argument");
-	if (node_begin > node_end)
-		return fail(DG_ERR_INVALID, "node_begin > node_end");
-	if (!valid_grid(grid))
-		return fail(DG_ERR_INVALID, "invalid grid");
+	dg_status s = check_host_range(grid, node_begin, node_end);
+	if (s != DG_OK)
+		return s;
 	const uint64_t n = node_end - node_begin;
 	if (n == 0)
 		return DG_OK;
-	if (node_end > dg_grid_n_nodes(grid))
-		return fail(DG_ERR_INVALID, "node range [%llu, %llu) outside [0, %llu)", (unsigned long long)node_begin,
-					(unsigned long long)node_end, (unsigned long long)dg_grid_n_nodes(grid));
-	dg_status s = require_device();
+	s = require_device();
 	if (s != DG_OK)
 		return s;
-
 	// ~10 chunks per call (every chunk costs a kernel tail, ~0.4 ms), 32..256 MiB of results each
 	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
 	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
 	std::vector<uint64_t> cuts;
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
-	uint64_t longest = 0;
-	for (size_t k = 0; k + 1 < cuts.size(); ++k)
-		longest = std::max(longest, cuts[k + 1] - cuts[k]);
-
-	std::lock_guard<std::mutex> lock(g_pipe.mutex);
-	hipError_t e = g_pipe.prepare(longest * sizeof(double));
-	uint8_t* d_mask = nullptr;
-	if (e == hipSuccess && pred_mask)
-	{
-		e = hipMalloc((void**)&d_mask, n);
-		if (e == hipSuccess) e = hipMemcpy(d_mask, pred_mask, n, hipMemcpyHostToDevice);
-	}
-	dg_status st = DG_OK;
-	double kernel_ms = 0.0;
-	const size_t n_chunks = cuts.size() - 1;
-	double t_wait = 0, t_copy = 0;
-	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	auto drain = [&](size_t k) -> hipError_t { // chunk k: wait for its copy, move it into the caller's array
-		const int b = (int)(k & 1);
-		const double t0 = now();
-		hipError_t err = hipEventSynchronize(g_pipe.c_end[b]);
-		if (err != hipSuccess)
-			return err;
-		const double t1 = now();
-		float ms = 0.f;
-		if (hipEventElapsedTime(&ms, g_pipe.k_begin[b], g_pipe.k_end[b]) == hipSuccess)
-			kernel_ms += ms;
-		parallel_copy(out + (cuts[k] - node_begin), g_pipe.h_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double));
-		t_wait += t1 - t0;
-		t_copy += now() - t1;
-		return hipSuccess;
-	};
-	for (size_t k = 0; k < n_chunks && e == hipSuccess && st == DG_OK; ++k)
-	{
-		const int b = (int)(k & 1);
-		// device buffer b was last read by the copy of chunk k-2, which drain(k-2) has waited for
-		e = hipEventRecord(g_pipe.k_begin[b], g_pipe.compute);
-		if (e != hipSuccess)
-			break;
-		st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask ? d_mask + (cuts[k] - node_begin) : nullptr,
-										static_cast<double*>(g_pipe.d_buf[b]), g_pipe.compute);
-		if (st != DG_OK)
-			break;
-		e = hipEventRecord(g_pipe.k_end[b], g_pipe.compute);
-		if (e == hipSuccess) e = hipStreamWaitEvent(g_pipe.copy, g_pipe.k_end[b], 0);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(g_pipe.h_buf[b], g_pipe.d_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double), hipMemcpyDeviceToHost,
-							   g_pipe.copy);
-		if (e == hipSuccess) e = hipEventRecord(g_pipe.c_end[b], g_pipe.copy);
-		if (e == hipSuccess && k >= 1)
-			e = drain(k - 1);
-	}
-	if (e == hipSuccess && st == DG_OK)
-		e = drain(n_chunks - 1);
-	else
-	{
-		(void)hipStreamSynchronize(g_pipe.compute);
-		(void)hipStreamSynchronize(g_pipe.copy);
-	}
-	if (d_mask) (void)hipFree(d_mask);
-	if (st != DG_OK)
-		return st;
-	if (e != hipSuccess)
-		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes: %s",
-					hipGetErrorString(e));
+	double kernel_ms = 0, t_wait = 0, t_copy = 0;
+	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
+	s = run_chunks(g_pipes[0], mesh, grid, invert, node_begin, cuts, 0, 1, pred_mask, out, &kernel_ms, &t_wait, &t_copy);
+	if (s != DG_OK)
+		return s;
 	g_last_ms = kernel_ms;
 	if (std::getenv("DG_HOST_DEBUG"))
-		std::fprintf(stderr, "dg_sdf_sample_nodes: %zu chunks, kernels %.1f ms, host waited %.1f ms, host copies %.1f ms\n", n_chunks,
-					 kernel_ms, t_wait * 1e3, t_copy * 1e3);
+		std::fprintf(stderr, "dg_sdf_sample_nodes: %zu chunks, kernels %.1f ms, host waited %.1f ms, host copies %.1f ms\n",
+					 cuts.size() - 1, kernel_ms, t_wait * 1e3, t_copy * 1e3);
+	return DG_OK;
+}
+
+dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, const dg_grid_desc* grid, int invert,
+									uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out)
+{
+	if (!meshes || !grid || !out || n_meshes < 1 || n_meshes > kMaxPipes)
+		return fail(DG_ERR_INVALID, "null argument or mesh count outside 1..%d", kMaxPipes);
+	for (int i = 0; i < n_meshes; ++i)
+		if (!meshes[i])
+			return fail(DG_ERR_INVALID, "meshes[%d] is null", i);
+	dg_status s = check_host_range(grid, node_begin, node_end);
+	if (s != DG_OK)
+		return s;
+	const uint64_t n = node_end - node_begin;
+	if (n == 0)
+		return DG_OK;
+	s = require_device();
+	if (s != DG_OK)
+		return s;
+	// chunks are dealt round-robin: thin interleaved pieces equalise the very uneven cost per node
+	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / (10ull * (uint64_t)n_meshes), 1u << 21), 1u << 25);
+	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
+	std::vector<uint64_t> cuts;
+	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
+	std::vector<dg_status> status((size_t)n_meshes, DG_OK);
+	std::vector<std::string> message((size_t)n_meshes);
+	std::vector<double> kernel_ms((size_t)n_meshes, 0.0);
+	std::vector<std::thread> workers;
+	int caller_device = 0;
+	(void)hipGetDevice(&caller_device);
+	for (int i = 0; i < n_meshes; ++i)
+		workers.emplace_back([&, i]() {
+			if (hipSetDevice(meshes[i]->device) != hipSuccess)
+			{
+				status[(size_t)i] = DG_ERR_HIP;
+				message[(size_t)i] = "hipSetDevice failed";
+				return;
+			}
+			double t_wait = 0, t_copy = 0;
+			std::lock_guard<std::mutex> lock(g_pipes[i].mutex);
+			status[(size_t)i] = run_chunks(g_pipes[i], meshes[i], grid, invert, node_begin, cuts, (size_t)i, (size_t)n_meshes,
+										   pred_mask, out, &kernel_ms[(size_t)i], &t_wait, &t_copy);
+			if (status[(size_t)i] != DG_OK)
+				message[(size_t)i] = dg_last_error(); // thread-local: carry it to the caller
+		});
+	for (auto& w : workers)
+		w.join();
+	(void)hipSetDevice(caller_device);
+	for (int i = 0; i < n_meshes; ++i)
+		if (status[(size_t)i] != DG_OK)
+			return fail(status[(size_t)i], "mesh %d (device %d): %s", i, meshes[i]->device, message[(size_t)i].c_str());
+	g_last_ms = *std::max_element(kernel_ms.begin(), kernel_ms.end());
 	return DG_OK;
 }
 

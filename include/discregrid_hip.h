@@ -92,6 +92,7 @@ const char* dg_version(void);
 const char* dg_last_error(void);
 dg_status dg_device_count(int* count);
 dg_status dg_set_device(int device);
+dg_status dg_current_device(int* device); /* the calling thread's current device (hipGetDevice) */
 
 /* ---- grid helpers (host arithmetic of discrete_grid.hpp:22-29, no device work) ---------- */
 dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
@@ -120,6 +121,13 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 							  uint64_t node_end, const uint8_t* pred_mask, double* out);
 dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream);
+/* Several devices, one process (host results): meshes[i] is the same mesh created once per device
+ * (dg_set_device + dg_mesh_create; the same device may appear more than once).  The node range is cut
+ * into chunks of whole 4-plane slabs that are dealt round-robin to the meshes; every mesh runs its
+ * own kernel / copy pipeline from its own host thread straight into `out`, so no collective is
+ * needed (the all-gather of the sharded device path exists to leave the field on every GPU). */
+dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, const dg_grid_desc* grid, int invert,
+									uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out);
 
 /* Signed distance at arbitrary points (3*n doubles) -> dist[n]; optional nearest triangle id
  * (original index), nearest entity (0..6 = V0,V1,V2,E01,E12,E02,F) and nearest point. */

@@ -40,6 +40,30 @@ def test_generate_sdf_cli_reproduces_box_cdf(tmp_path):
     np.testing.assert_array_equal(g["res"], [4, 5, 6])
 
 
+def test_generate_sdf_cli_on_several_devices(tmp_path):
+    """DG_DEVICES replicates the mesh on the listed devices and addFunction spreads the lattice over
+    them (dg_sdf_sample_nodes_multi).  One GPU here, so the list names it twice -- same code path:
+    two handles, two host threads, two copy pipelines; the file must not change by a byte."""
+    exe = _need(os.path.join(BUILD, "GenerateSDF"))
+    obj = str(tmp_path / "box.obj")
+    V, F = T.box_mesh()
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "box.cdf")
+    env = dict(os.environ, DG_DEVICES="0,0,0", DG_HOST_CHUNK_NODES="1024")
+    subprocess.check_call([exe, "-r", "5 5 5", "-o", out, obj], stdout=subprocess.DEVNULL, env=env)
+    assert open(out, "rb").read() == open(os.path.join(T.GOLDEN, "box.cdf"), "rb").read()
+    tor = str(tmp_path / "torus.obj")
+    Vt, Ft = T.torus()
+    T.write_obj(tor, Vt, Ft)
+    subprocess.check_call([exe, "-r", "21 18 26", "-o", out, tor], stdout=subprocess.DEVNULL, env=dict(os.environ, DG_DEVICES="all,0"))
+    a = open(out, "rb").read()
+    subprocess.check_call([exe, "-r", "21 18 26", "-o", out, tor], stdout=subprocess.DEVNULL)
+    assert a == open(out, "rb").read()
+    bad = subprocess.run([exe, "-r", "5 5 5", "-o", out, obj], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                         env=dict(os.environ, DG_DEVICES="0,63"))
+    assert bad.returncode != 0
+
+
 def test_generate_sdf_cli_explicit_domain(tmp_path):
     exe = _need(os.path.join(BUILD, "GenerateSDF"))
     obj = str(tmp_path / "torus.obj")

@@ -189,6 +189,34 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(ga2, ga)
 
 
+@pytest.mark.parametrize("n_meshes", [1, 2, 3])
+def test_multi_device_host_path(dg, golden, monkeypatch, n_meshes):
+    """dg_sdf_sample_nodes_multi: chunks of the lattice dealt round-robin to several mesh handles, each
+    with its own host thread and copy pipeline writing straight into the caller's array.  (One GPU
+    here: the handles share the device, which exercises the same code.)  Small chunks force many
+    pipeline turns; masks, inversion and sub-ranges included."""
+    V, F = T.torus()
+    dom, res = golden["torus_domain"], golden["torus_res"]
+    want = golden["torus_coeffs"]
+    g = grid_of(dg, dom, res)
+    meshes = [dg.Mesh(V, F) for _ in range(n_meshes)]
+    for chunk in ("2000", "100000000"):
+        monkeypatch.setenv("DG_HOST_CHUNK_NODES", chunk)
+        np.testing.assert_array_equal(dg.sample_nodes_multi(meshes, g), want)
+        rng = np.random.default_rng(8)
+        mask = rng.integers(0, 2, size=len(want)).astype(np.uint8)
+        got = dg.sample_nodes_multi(meshes, g, mask=mask, invert=True)
+        np.testing.assert_array_equal(got[mask == 1], -1.0 * want[mask == 1])
+        assert (got[mask == 0] == DBL_MAX).all()
+        b, e = 1234, len(want) - 777
+        np.testing.assert_array_equal(dg.sample_nodes_multi(meshes, g, b, e, mask=mask[b:e])[mask[b:e] == 1],
+                                      want[b:e][mask[b:e] == 1])
+        # the single-mesh host path shares the pipeline code
+        np.testing.assert_array_equal(meshes[0].sample_nodes(g, mask=mask)[mask == 1], want[mask == 1])
+    with pytest.raises(dg.DiscregridError):
+        dg.sample_nodes_multi(meshes, g, 0, len(want) + 1)
+
+
 @pytest.mark.parametrize("name", ["torus", "bunny"])
 def test_interpolate_binned_path(dg, golden, monkeypatch, name):
     """K2 with query binning (tile-by-tile processing of unordered queries; the ordered/unordered
