@@ -4,28 +4,33 @@
 //                          discregrid/src/cubic_lagrange_discrete_grid.cpp:806-831 +
 //                          TriangleMeshDistance.h:269-308, 514-562, 564-820)
 //   K1p k_signed_distance  same traversal for caller-supplied points (TriangleMeshDistance.h:269-314)
-//   K2  k_interpolate      batched CubicLagrangeDiscreteGrid::interpolate (:977-1063)
+//   K2  k_interpolate      batched CubicLagrangeDiscreteGrid::interpolate (:977-1063), with
+//       k_bin_*            device-side binning of unordered query batches into 8^3-cell tiles
 //   K3  k_density_bricks   SPH boundary density map (cmd/generate_density_map/main.cpp:86-133)
-//   U   k_unpack_shards    packed all-gather buffer -> reference node order (multi-GPU)
+//   U   k_unpack_shards    packed all-gather buffer -> reference node order (multi-GPU),
+//       k_unpack_ranks     the same for a range of rank slots (pieced gather)
 //       k_expand_cells     cell-major copy of a field (optional K2 layout)
 //
 // Design of K1 (wave64, no MFMA: this is point-vs-BVH, not a contraction):
 //   * ONE WAVEFRONT = ONE 4x4x4 BRICK of lattice nodes.  The 64 query points are spatially
 //     compact, so the wave walks the BVH as a packet: control flow is wave-uniform, every bound
-//     record (two siblings, 96 of 128 B) and triangle packet (128 B) is fetched ONCE per wave
-//     through the scalar unit (s_load_dwordx16/x8 into SGPRs) and broadcast to all lanes for
-//     free; lanes only differ in their query point and running best.  No per-lane stack, no
-//     divergent gathers in the loop.
+//     record (two siblings, 128 B) and triangle packet (128 B) is fetched ONCE per wave through
+//     the scalar unit (s_load_dwordx16 into SGPRs) and broadcast to all lanes for free; lanes only
+//     differ in their query point and running best.  No per-lane stack, no divergent gathers in
+//     the loop.
 //   * Near-first traversal with one wave-shared stack (subtree ids in one VGPR, per-lane bounds
-//     parked in LDS); bounds = box AND slab along the (mean) normal, stored as sibling pairs and
-//     evaluated two at a time with packed float math (the kernel is VALU-issue bound).
+//     parked in LDS); bounds = oriented boxes (normal + principal tangents for flat patches),
+//     stored as sibling pairs and evaluated two at a time with packed float math (the kernel is
+//     VALU-issue bound: 96 % of the issue slots are busy).
+//   * Heavy bricks (work budget exhausted) are parked and finished by k_heavy_subtrees /
+//     k_heavy_finish, one wave per top-level subtree (dg_kernels.h).
 //   * Bound tests in conservative float (they only prune); triangle tests in double with the
 //     reference's exact operation order (no FMA contraction) so d^2, the winning feature and
 //     the sign reproduce the reference bit for bit.
 //   * Positions are computed from the lattice index (nothing is read from HBM but the mesh);
 //     the only compulsory HBM traffic is the 8-byte result per node.
-//   * blockIdx is remapped so that each XCD works on a contiguous chunk of bricks: the BVH
-//     subtrees an XCD touches stay in its private 4 MiB L2.
+//   * blockIdx is remapped so that chunks of 1024 consecutive bricks stay on one XCD (the BVH
+//     subtrees they touch share its private 4 MiB L2) while the chunks rotate over the XCDs.
 //
 // Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
 #include <hip/hip_runtime.h>
