@@ -54,6 +54,20 @@ def test_oracle_and_product_code_vs_reference(golden, name, res, h, key):
     assert (want == DBL_MAX).any() or name.startswith("torus_9")
 
 
+@pytest.mark.parametrize("tag,h", [("h012", 0.12), ("h045", 0.45)])
+def test_box_sized_grid_vs_reference(tag, h):
+    """tests/golden/density_box.npz (torus 12 x 11 x 9, made by the unmodified reference): the grid
+    that is wide enough for the LDS-staged GPU kernel; the oracle is pinned on it here."""
+    d = np.load(os.path.join(T.GOLDEN, "density_box.npz"))
+    want = d["density_" + tag]
+    integrated = (want != DBL_MAX) & (want != 0.0)
+    assert integrated.sum() > 500
+    n = len(want)
+    for b in (0, n // 3, n - 400):
+        got = T.oracle_density_map(d["domain"], d["res"], d["sdf"], h, 1000.0, True, b, b + 400)
+        np.testing.assert_array_equal(got, want[b:b + 400])
+
+
 def test_no_predicate_and_table_mode(golden):
     g = T.read_cdf(os.path.join(T.GOLDEN, "torus_9_14_6.cdf"))
     want = golden["torus_density_h015_nopred"]
