@@ -119,7 +119,6 @@ struct dg_field
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
 	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
-	void* d_box_delta = nullptr; // K3: field indices of the staged box's nodes (depends on the grid only)
 	double wtab_h = -1.0;
 	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
@@ -1060,8 +1059,6 @@ void dg_field_destroy(dg_field* f)
 		(void)hipFree(f->d_cell_major);
 	if (f->d_wtab)
 		(void)hipFree(f->d_wtab);
-	if (f->d_box_delta)
-		(void)hipFree(f->d_box_delta);
 	f->scratch.destroy();
 	delete f;
 }
@@ -1130,20 +1127,6 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		sdf->wtab_h = support_radius;
 	}
 	P.wtab = static_cast<const double*>(sdf->d_wtab);
-	// unreduced fields at least one box wide: the LDS-staged kernel (DG_K3_LDS=0: direct gathers)
-	const uint32_t* res = sdf->grid.resolution;
-	if (sdf->dev.cells == nullptr && sdf->dev.cell_map == nullptr && sdf->dev.cell_major == nullptr && res[0] >= dg::kBox[0] &&
-		res[1] >= dg::kBox[1] && res[2] >= dg::kBox[2] && env_int("DG_K3_LDS", 1, 0, 1) != 0)
-	{
-		std::vector<uint32_t> delta;
-		dg::init_density_box(P, res, sdf->grid.inv_cell_size, delta);
-		if (!sdf->d_box_delta)
-		{
-			DG_HIP(hipMalloc(&sdf->d_box_delta, delta.size() * sizeof(uint32_t)));
-			DG_HIP(hipMemcpy(sdf->d_box_delta, delta.data(), delta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-		}
-		P.box_delta = static_cast<const uint32_t*>(sdf->d_box_delta);
-	}
 	// K1's lattice decomposition: one wave per 4x4x4 brick of nodes
 	dg::SampleParams L;
 	dg::MeshDev none;

@@ -805,23 +805,7 @@ struct DensityParams
 	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
 	double w[16];       // weights
 	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
-	// LDS-staged kernel (dg_kernels.hip: k_density_bricks_lds): k-steps [k, kwin_end[k]) of a
-	// z-sweep share one staged box of cells; box_delta[e] = index of box node e in the field,
-	// relative to the box origin of its node class.  Null box_delta: direct gathers.
-	const uint32_t* box_delta;
-	uint8_t kwin_end[16];
 };
-// The box of cells whose coefficients one wave stages in LDS: kBox cells per axis, laid out like a
-// small grid of its own ([V | X | Y | Z] node order), so cell_node_indices(r, kBox) addresses it.
-#ifndef DG_BOX_Z
-#define DG_BOX_Z 8
-#endif
-constexpr uint32_t kBox[3] = {5, 5, DG_BOX_Z};
-constexpr uint32_t kBoxV = (kBox[0] + 1) * (kBox[1] + 1) * (kBox[2] + 1);
-constexpr uint32_t kBoxX = 2 * kBox[0] * (kBox[1] + 1) * (kBox[2] + 1);
-constexpr uint32_t kBoxY = 2 * (kBox[0] + 1) * kBox[1] * (kBox[2] + 1);
-constexpr uint32_t kBoxZ = 2 * (kBox[0] + 1) * (kBox[1] + 1) * kBox[2];
-constexpr uint32_t kBoxNodes = kBoxV + kBoxX + kBoxY + kBoxZ;
 
 // CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector
 DG_HD double cubic_kernel_k(double radius)
@@ -921,64 +905,6 @@ DG_HD Axis1D axis_eval(const FieldDev& F, int d, double y)
 	return a;
 }
 
-// phi = sum_q cf[q] * N_q at the point described by the three per-axis evaluations (unreduced
-// fields; cf in the cell's node order).  NOVAL if a coefficient is NOVAL.  The products that depend
-// on x and y only are passed in (the density map forms them once per (i, j)).
-DG_HD double staged_phi(const Axis1D& ax, const Axis1D& ay, const Axis1D& az, double mxmy, double mxpy, double pxmy,
-						double pxpy, double x2y2, const double cf[32])
-{
-	const double NOVAL = 1.7976931348623157e308;
-	const double mz = az.m, pz = az.p;
-	const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
-	// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
-	// consumed (same products as shape_functions(), no 32-entry array kept live)
-	bool ok = true;
-	double phi = 0.0;
-#define DG_ACC(q, n)                  \
-	ok = ok && (cf[q] != NOVAL); \
-	phi += cf[q] * (n);
-	DG_ACC(0, fac * mxmy * mz)
-	DG_ACC(1, fac * pxmy * mz)
-	DG_ACC(2, fac * mxpy * mz)
-	DG_ACC(3, fac * pxpy * mz)
-	DG_ACC(4, fac * mxmy * pz)
-	DG_ACC(5, fac * pxmy * pz)
-	DG_ACC(6, fac * mxpy * pz)
-	DG_ACC(7, fac * pxpy * pz)
-	{
-		const double mymz = ay.m * mz, mypz = ay.m * pz, pymz = ay.p * mz, pypz = ay.p * pz;
-		DG_ACC(8, ax.fm3 * mymz)
-		DG_ACC(9, ax.fp3 * mymz)
-		DG_ACC(10, ax.fm3 * mypz)
-		DG_ACC(11, ax.fp3 * mypz)
-		DG_ACC(12, ax.fm3 * pymz)
-		DG_ACC(13, ax.fp3 * pymz)
-		DG_ACC(14, ax.fm3 * pypz)
-		DG_ACC(15, ax.fp3 * pypz)
-	}
-	{
-		const double mxmz = ax.m * mz, mxpz = ax.m * pz, pxmz = ax.p * mz, pxpz = ax.p * pz;
-		DG_ACC(16, ay.fm3 * mxmz)
-		DG_ACC(17, ay.fp3 * mxmz)
-		DG_ACC(18, ay.fm3 * pxmz)
-		DG_ACC(19, ay.fp3 * pxmz)
-		DG_ACC(20, ay.fm3 * mxpz)
-		DG_ACC(21, ay.fp3 * mxpz)
-		DG_ACC(22, ay.fm3 * pxpz)
-		DG_ACC(23, ay.fp3 * pxpz)
-	}
-	DG_ACC(24, az.fm3 * mxmy)
-	DG_ACC(25, az.fp3 * mxmy)
-	DG_ACC(26, az.fm3 * mxpy)
-	DG_ACC(27, az.fp3 * mxpy)
-	DG_ACC(28, az.fm3 * pxmy)
-	DG_ACC(29, az.fp3 * pxmy)
-	DG_ACC(30, az.fm3 * pxpy)
-	DG_ACC(31, az.fp3 * pxpy)
-#undef DG_ACC
-	return ok ? phi : NOVAL;
-}
-
 // Stage 2: rho0 * integral over [-h,h]^3 of gamma(x + xi) W(xi), 16^3 Gauss points, summed in
 // the reference's i, j, k order (gauss_quadrature.cpp:5941-5958).  Unreduced fields take the
 // staged path (per-axis work hoisted out of the inner loops); reduced fields go through
@@ -1040,7 +966,55 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 								cf[q + 1] = pr[1];
 							}
 						}
-						d = staged_phi(ax, ay, az, mxmy, mxpy, pxmy, pxpy, x2y2, cf);
+						const double mz = az.m, pz = az.p;
+						const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
+						// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
+						// consumed (same products as shape_functions(), no 32-entry array kept live)
+						bool ok = true;
+						double phi = 0.0;
+#define DG_ACC(q, n)                  \
+	ok = ok && (cf[q] != NOVAL); \
+	phi += cf[q] * (n);
+						DG_ACC(0, fac * mxmy * mz)
+						DG_ACC(1, fac * pxmy * mz)
+						DG_ACC(2, fac * mxpy * mz)
+						DG_ACC(3, fac * pxpy * mz)
+						DG_ACC(4, fac * mxmy * pz)
+						DG_ACC(5, fac * pxmy * pz)
+						DG_ACC(6, fac * mxpy * pz)
+						DG_ACC(7, fac * pxpy * pz)
+						{
+							const double mymz = ay.m * mz, mypz = ay.m * pz, pymz = ay.p * mz, pypz = ay.p * pz;
+							DG_ACC(8, ax.fm3 * mymz)
+							DG_ACC(9, ax.fp3 * mymz)
+							DG_ACC(10, ax.fm3 * mypz)
+							DG_ACC(11, ax.fp3 * mypz)
+							DG_ACC(12, ax.fm3 * pymz)
+							DG_ACC(13, ax.fp3 * pymz)
+							DG_ACC(14, ax.fm3 * pypz)
+							DG_ACC(15, ax.fp3 * pypz)
+						}
+						{
+							const double mxmz = ax.m * mz, mxpz = ax.m * pz, pxmz = ax.p * mz, pxpz = ax.p * pz;
+							DG_ACC(16, ay.fm3 * mxmz)
+							DG_ACC(17, ay.fp3 * mxmz)
+							DG_ACC(18, ay.fm3 * pxmz)
+							DG_ACC(19, ay.fp3 * pxmz)
+							DG_ACC(20, ay.fm3 * mxpz)
+							DG_ACC(21, ay.fp3 * mxpz)
+							DG_ACC(22, ay.fm3 * pxpz)
+							DG_ACC(23, ay.fp3 * pxpz)
+						}
+						DG_ACC(24, az.fm3 * mxmy)
+						DG_ACC(25, az.fp3 * mxmy)
+						DG_ACC(26, az.fm3 * mxpy)
+						DG_ACC(27, az.fp3 * mxpy)
+						DG_ACC(28, az.fm3 * pxmy)
+						DG_ACC(29, az.fp3 * pxmy)
+						DG_ACC(30, az.fm3 * pxpy)
+						DG_ACC(31, az.fp3 * pxpy)
+#undef DG_ACC
+						d = ok ? phi : NOVAL;
 					}
 					else
 						d = NOVAL;

@@ -613,148 +613,6 @@ __global__ __launch_bounds__(256) void k_unpack_ranks(const UnpackParams P)
 	}
 }
 
-// wave-wide minimum (all 64 lanes participate; inactive callers pass 0xffffffff)
-__device__ __forceinline__ uint32_t wave_min(uint32_t v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-	{
-		const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-		v = o < v ? o : v;
-	}
-	return (uint32_t)uniform((int)v);
-}
-// cell index a lane needs along one axis, for the box origin: its own cell if the point is inside,
-// 0 if it lies below the domain (it may enter later in the sweep), "none" if above
-__device__ __forceinline__ uint32_t box_candidate(const FieldDev& F, int d, const Axis1D& a, double y, bool active)
-{
-	if (!active)
-		return 0xffffffffu;
-	if (a.inside)
-		return a.mi;
-	return (y < F.dmin[d]) ? 0u : 0xffffffffu;
-}
-
-// K3 with the coefficients staged through LDS.  Same decomposition and arithmetic as
-// k_density_bricks<true>; what changes is the data path: for every (i, j) the z-sweep is cut into
-// windows of k-steps (DensityParams::kwin_end), the wave copies the box of kBox cells that holds
-// every lane's cell for the whole window into LDS with coalesced row loads (31 eight-byte loads per
-// lane and window) and the 32 coefficients of every evaluation come from there -- instead of 16
-// scattered 16-byte gathers per lane and step, which is what bounds the direct kernel (L1/TA).
-// The box is laid out like a small grid of its own, so cell_node_indices(local cell, kBox) is its
-// address map; DensityParams::box_delta maps its nodes to field indices.
-__global__ __launch_bounds__(64) void k_density_bricks_lds(const SampleParams L, const FieldDev F, const DensityParams P)
-{
-	__shared__ double box[kBoxNodes];
-	uint32_t blk;
-	if (!logical_block(L, blockIdx.x, &blk))
-		return;
-	const uint64_t brick = (uint64_t)blk;
-	if (brick >= L.total_bricks)
-		return;
-	const int lane = (int)(threadIdx.x & 63u);
-	const LaneNode ln = map_lane(L, brick, lane);
-	double v = 1.7976931348623157e308;
-	double x[3] = {0.0, 0.0, 0.0};
-	bool active = false;
-	if (ln.valid && (L.mask == nullptr || L.mask[ln.out_idx] != 0))
-	{
-		node_position(ln.cls, ln.a, ln.b, ln.s, L.dmin, L.cell, x);
-		active = density_prefilter(F, P, x, &v);
-	}
-	if (__ballot(active) == 0ull) // nothing to integrate in this brick
-	{
-		if (ln.valid)
-			L.out[ln.out_idx] = v;
-		return;
-	}
-	const double NOVAL = 1.7976931348623157e308;
-	const uint32_t nx = F.res[0], ny = F.res[1], nz = F.res[2];
-	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1), nex2 = 2 * nx * (ny + 1) * (nz + 1), ney2 = 2 * (nx + 1) * ny * (nz + 1);
-	double res = 0.0;
-	DG_NOUNROLL
-	for (int i = 0; i < 16; ++i)
-	{
-		const double wi = P.w[i];
-		const double yx = x[0] + P.xi[i];
-		const Axis1D ax = axis_eval(F, 0, yx);
-		uint32_t X0 = wave_min(box_candidate(F, 0, ax, yx, active));
-		X0 = X0 == 0xffffffffu ? 0u : min(X0, nx - kBox[0]);
-		DG_NOUNROLL
-		for (int j = 0; j < 16; ++j)
-		{
-			const double wij = wi * P.w[j];
-			const double yy = x[1] + P.xi[j];
-			const Axis1D ay = axis_eval(F, 1, yy);
-			uint32_t Y0 = wave_min(box_candidate(F, 1, ay, yy, active));
-			Y0 = Y0 == 0xffffffffu ? 0u : min(Y0, ny - kBox[1]);
-			const double mxmy = ax.m * ay.m, mxpy = ax.m * ay.p, pxmy = ax.p * ay.m, pxpy = ax.p * ay.p;
-			const double x2y2 = ax.t2 + ay.t2;
-			const bool in_xy = active && ax.inside && ay.inside;
-			int k = 0;
-			while (k < 16)
-			{
-				const int k_end = (int)P.kwin_end[k];
-				// ---- stage the window's box ---------------------------------------------------
-				const double z_first = x[2] + P.xi[k];
-				const Axis1D az0 = axis_eval(F, 2, z_first);
-				uint32_t Z0 = wave_min(box_candidate(F, 2, az0, z_first, active));
-				Z0 = Z0 == 0xffffffffu ? 0u : min(Z0, nz - kBox[2]);
-				__syncthreads(); // the previous window's reads are done
-				{
-					const uint32_t base_v = (Z0 * (ny + 1) + Y0) * (nx + 1) + X0;
-					const uint32_t base_x = nv + (Z0 * (ny + 1) + Y0) * (2 * nx) + 2 * X0;
-					const uint32_t base_y = nv + nex2 + (X0 * (nz + 1) + Z0) * (2 * ny) + 2 * Y0;
-					const uint32_t base_z = nv + nex2 + ney2 + (Y0 * (nx + 1) + X0) * (2 * nz) + 2 * Z0;
-					for (uint32_t e = (uint32_t)lane; e < kBoxV; e += 64u)
-						box[e] = F.coeffs[base_v + P.box_delta[e]];
-					for (uint32_t e = kBoxV + (uint32_t)lane; e < kBoxV + kBoxX; e += 64u)
-						box[e] = F.coeffs[base_x + P.box_delta[e]];
-					for (uint32_t e = kBoxV + kBoxX + (uint32_t)lane; e < kBoxV + kBoxX + kBoxY; e += 64u)
-						box[e] = F.coeffs[base_y + P.box_delta[e]];
-					for (uint32_t e = kBoxV + kBoxX + kBoxY + (uint32_t)lane; e < kBoxNodes; e += 64u)
-						box[e] = F.coeffs[base_z + P.box_delta[e]];
-				}
-				__syncthreads();
-				// ---- the window's k-steps ------------------------------------------------------
-				for (; k < k_end; ++k)
-				{
-					const double wijk = wij * P.w[k];
-					const double yz = x[2] + P.xi[k];
-					const Axis1D az = axis_eval(F, 2, yz);
-					double d = NOVAL;
-					if (in_xy && az.inside)
-					{
-						const uint32_t rx = ax.mi - X0, ry = ay.mi - Y0, rz = az.mi - Z0;
-						if (rx >= kBox[0] || ry >= kBox[1] || rz >= kBox[2])
-							__builtin_trap(); // cannot happen (window rule, dg_layout.h): fail loudly, never silently
-						uint32_t idx[32];
-						const uint32_t box_res[3] = {kBox[0], kBox[1], kBox[2]};
-						cell_node_indices(rx, ry, rz, box_res, idx);
-						double cf[32];
-#pragma unroll
-						for (int q = 0; q < 32; ++q)
-							cf[q] = box[idx[q]];
-						d = staged_phi(ax, ay, az, mxmy, mxpy, pxmy, pxpy, x2y2, cf);
-					}
-					if (active)
-					{
-						const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
-						res += wijk * (gamma * P.wtab[(i * 16 + j) * 16 + k]);
-					}
-				}
-			}
-		}
-	}
-	if (active)
-	{
-		res *= P.c0prod;
-		v = P.rho0 * res;
-	}
-	if (ln.valid)
-		L.out[ln.out_idx] = v;
-}
-
 } // namespace
 
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream)
@@ -762,9 +620,7 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 	if (layout.total_bricks == 0)
 		return hipSuccess;
 	static_assert(kWavesPerBlock == 1, "k_density_bricks assumes one brick per block");
-	if (p.box_delta != nullptr) // unreduced field at least one box wide: coefficients staged through LDS
-		hipLaunchKernelGGL(k_density_bricks_lds, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
-	else if (f.cells == nullptr && f.cell_map == nullptr) // unreduced field: staged evaluator
+	if (f.cells == nullptr && f.cell_map == nullptr) // unreduced field: staged evaluator
 		hipLaunchKernelGGL(k_density_bricks<true>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
 	else
 		hipLaunchKernelGGL(k_density_bricks<false>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);

@@ -203,46 +203,6 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 			for (int kk = 0; kk < 16; ++kk)
 				wtab_host[(i * 16 + j) * 16 + kk] = cubic_kernel_W(P.xi[i], P.xi[j], P.xi[kk], h, k, HostSqrt());
 	P.wtab = nullptr;
-	P.box_delta = nullptr;
-	for (int k = 0; k < 16; ++k)
-		P.kwin_end[k] = (uint8_t)(k + 1);
-}
-
-// Tables of the LDS-staged K3 kernel.  delta[e]: field index of node e of the staged box (box-local
-// [V | X | Y | Z] order) minus the field index of the box origin in e's node class.  Windows: the
-// k-steps [k, kwin_end[k]) of a z-sweep advance the evaluation points by at most kBox[2] - 5 cells,
-// so that with the <= 3 cells the nodes of a brick span and the two cells lost to rounding every
-// lane's cell stays inside a box of kBox[2] cells.
-inline void init_density_box(DensityParams& P, const uint32_t res[3], const double inv_cell[3], std::vector<uint32_t>& delta)
-{
-	delta.assign(kBoxNodes, 0u);
-	const uint32_t nx = res[0], ny = res[1], nz = res[2];
-	const uint32_t bx = kBox[0], by = kBox[1], bz = kBox[2];
-	size_t e = 0;
-	for (uint32_t s = 0; s <= bz; ++s) // V: (i, j, k)
-		for (uint32_t b = 0; b <= by; ++b)
-			for (uint32_t a = 0; a <= bx; ++a)
-				delta[e++] = (s * (ny + 1) + b) * (nx + 1) + a;
-	for (uint32_t s = 0; s <= bz; ++s) // X: (2i+h, j, k)
-		for (uint32_t b = 0; b <= by; ++b)
-			for (uint32_t a = 0; a < 2 * bx; ++a)
-				delta[e++] = (s * (ny + 1) + b) * (2 * nx) + a;
-	for (uint32_t s = 0; s <= bx; ++s) // Y: (2j+h, k, i)
-		for (uint32_t b = 0; b <= bz; ++b)
-			for (uint32_t a = 0; a < 2 * by; ++a)
-				delta[e++] = (s * (nz + 1) + b) * (2 * ny) + a;
-	for (uint32_t s = 0; s <= by; ++s) // Z: (2k+h, i, j)
-		for (uint32_t b = 0; b <= bx; ++b)
-			for (uint32_t a = 0; a < 2 * bz; ++a)
-				delta[e++] = (s * (nx + 1) + b) * (2 * nz) + a;
-	const double room = (double)kBox[2] - 5.0;
-	for (int k = 0; k < 16; ++k)
-	{
-		int end = k + 1;
-		while (end < 16 && (P.xi[end] - P.xi[k]) * inv_cell[2] <= room)
-			++end;
-		P.kwin_end[k] = (uint8_t)end;
-	}
 }
 
 // the source index k_unpack_shards reads for global node l (host mirror, used by tests)

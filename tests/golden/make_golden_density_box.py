@@ -1,7 +1,7 @@
-"""Golden density maps on a grid wide enough for the LDS-staged K3 kernel (>= 5 x 5 x 8 cells; the
-other density fixtures are 6 cells deep and take the direct kernel): torus SDF 12 x 11 x 9 from the
-UNMODIFIED reference (oracle/_ref), density map for a small and a large support radius (the large
-one needs several staging windows per z-sweep).  Writes tests/golden/density_box.npz.
+"""Golden density maps on a deeper grid than the other density fixtures (which are 6 cells deep):
+torus SDF 12 x 11 x 9 from the UNMODIFIED reference (oracle/_ref), density map for a small and a
+large support radius (h = 0.45 is two cells: the quadrature box spans four cells per axis).
+Writes tests/golden/density_box.npz.
 
 Run:  python tests/golden/make_golden_density_box.py
 """

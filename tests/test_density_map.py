@@ -56,8 +56,8 @@ def test_oracle_and_product_code_vs_reference(golden, name, res, h, key):
 
 @pytest.mark.parametrize("tag,h", [("h012", 0.12), ("h045", 0.45)])
 def test_box_sized_grid_vs_reference(tag, h):
-    """tests/golden/density_box.npz (torus 12 x 11 x 9, made by the unmodified reference): the grid
-    that is wide enough for the LDS-staged GPU kernel; the oracle is pinned on it here."""
+    """tests/golden/density_box.npz (torus 12 x 11 x 9, small and large support radius, made by the
+    unmodified reference): the oracle is pinned on it here, the GPU kernel in test_gpu_density_map.py."""
     d = np.load(os.path.join(T.GOLDEN, "density_box.npz"))
     want = d["density_" + tag]
     integrated = (want != DBL_MAX) & (want != 0.0)

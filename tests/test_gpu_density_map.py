@@ -49,31 +49,28 @@ def test_density_map_vs_reference_golden(dg, golden, name, res, h, key):
 
 
 @pytest.mark.parametrize("tag,h", [("h012", 0.12), ("h045", 0.45)])
-def test_lds_staged_kernel_vs_reference_golden(dg, monkeypatch, tag, h):
-    """k_density_bricks_lds (coefficients staged through LDS, several staging windows per z-sweep for
-    the large radius) and the direct-gather kernel both reproduce the reference's density map of
-    tests/golden/density_box.npz bit for bit; ranges and masks included."""
+def test_density_map_on_a_deeper_grid_vs_reference_golden(dg, tag, h):
+    """tests/golden/density_box.npz: torus 12 x 11 x 9, a small and a large support radius (up to
+    four cells per h), made by the unmodified reference; ranges and masks included."""
     d = np.load(os.path.join(T.GOLDEN, "density_box.npz"))
     want = d["density_" + tag]
     grid = dg.grid_desc(d["domain"][:3], d["domain"][3:], d["res"])
     f = dg.Field(grid, d["sdf"])
     n = dg.n_nodes(grid)
-    for lds in ("1", "0"):
-        monkeypatch.setenv("DG_K3_LDS", lds)
-        got = f.density_map_nodes(n, h, 1000.0, True)
-        assert T.rel_err(got, want) <= 1e-10
-        np.testing.assert_array_equal(got, want)
-        np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 1234, 4321), want[1234:4321])
-        mask = (np.arange(n) % 5 != 0).astype(np.uint8)
-        m = f.density_map_nodes(n, h, 1000.0, True, mask=mask)
-        np.testing.assert_array_equal(m[mask == 1], want[mask == 1])
-        assert (m[mask == 0] == DBL_MAX).all()
+    got = f.density_map_nodes(n, h, 1000.0, True)
+    assert T.rel_err(got, want) <= 1e-10
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 1234, 4321), want[1234:4321])
+    mask = (np.arange(n) % 5 != 0).astype(np.uint8)
+    m = f.density_map_nodes(n, h, 1000.0, True, mask=mask)
+    np.testing.assert_array_equal(m[mask == 1], want[mask == 1])
+    assert (m[mask == 0] == DBL_MAX).all()
 
 
-def test_lds_staged_kernel_equals_direct_kernel_on_a_bigger_grid(dg, monkeypatch):
+def test_density_map_without_predicate_on_a_bigger_grid(dg):
     """Icosphere SDF 40 x 36 x 33 (made by K1), h = 0.2 and no band predicate (every node near the
-    surface integrates, domain boundaries included): LDS-staged == direct, and == the oracle on
-    a few hundred nodes."""
+    surface integrates, domain boundaries included): == the oracle on a few hundred nodes, and the
+    cell-major layout gives the same bits."""
     V, F = T.icosphere(8)
     dom = T.oracle_default_domain(V)
     res = [40, 36, 33]
@@ -81,14 +78,12 @@ def test_lds_staged_kernel_equals_direct_kernel_on_a_bigger_grid(dg, monkeypatch
     sdf = dg.Mesh(V, F).sample_nodes(grid)
     f = dg.Field(grid, sdf)
     n = dg.n_nodes(grid)
-    out = {}
-    for lds in ("1", "0"):
-        monkeypatch.setenv("DG_K3_LDS", lds)
-        out[lds] = f.density_map_nodes(n, 0.2, 1000.0, False)
-    np.testing.assert_array_equal(out["1"], out["0"])
-    assert ((out["1"] != 0.0) & (out["1"] != DBL_MAX)).sum() > 50000
+    got = f.density_map_nodes(n, 0.2, 1000.0, False)
+    assert ((got != 0.0) & (got != DBL_MAX)).sum() > 50000
     for b in (0, n // 2, n - 150):
-        np.testing.assert_array_equal(out["1"][b:b + 150], T.oracle_density_map(dom, res, sdf, 0.2, 1000.0, False, b, b + 150))
+        np.testing.assert_array_equal(got[b:b + 150], T.oracle_density_map(dom, res, sdf, 0.2, 1000.0, False, b, b + 150))
+    f.build_cell_major()
+    np.testing.assert_array_equal(f.density_map_nodes(n, 0.2, 1000.0, False), got)
 
 
 def test_generate_density_map_cli(tmp_path):
