@@ -24,35 +24,6 @@
 #include "dg_kernels.h"
 #include "dg_layout.h"
 
-// Scratch of one K1 launch for its heavy bricks (dg_kernels.h: OverflowBuf).  Buffers are kept with
-// the mesh and handed out again once the launch that used them has finished (or to the same stream,
-// where launches are ordered anyway), so steady-state launches allocate nothing.
-struct HeavyScratch
-{
-	void* mem = nullptr;
-	hipEvent_t done = nullptr;
-	hipStream_t stream = nullptr;
-	uint32_t slots = 0;      // capacity the buffer was laid out for
-	uint32_t used_slots = 0; // slots the most recent launch was given
-	bool busy = false; // between acquire and the event record
-	uint64_t serial = 0; // order of use
-};
-
-struct dg_mesh
-{
-	dg::MeshDev dev;
-	void* d_pairs = nullptr;
-	void* d_tri_pairs = nullptr;
-	void* d_tris = nullptr;
-	void* d_pn = nullptr;
-	int device = -1;
-	dg_mesh_info info;
-	mutable std::mutex scratch_mutex;
-	mutable std::vector<HeavyScratch> scratch;
-	mutable uint64_t scratch_serial = 0;
-	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
-};
-
 // Stream-ordered scratch buffers kept with a handle: a buffer is handed out again once the work that
 // used it has finished (or to the same stream, where work is ordered anyway).
 struct ScratchPool
@@ -110,6 +81,37 @@ struct ScratchPool
 		}
 		bufs.clear();
 	}
+};
+
+// Scratch of one K1 launch for its heavy bricks (dg_kernels.h: OverflowBuf).  Buffers are kept with
+// the mesh and handed out again once the launch that used them has finished (or to the same stream,
+// where launches are ordered anyway), so steady-state launches allocate nothing.
+struct HeavyScratch
+{
+	void* mem = nullptr;
+	hipEvent_t done = nullptr;
+	hipStream_t stream = nullptr;
+	uint32_t slots = 0;      // capacity the buffer was laid out for
+	uint32_t used_slots = 0; // slots the most recent launch was given
+	bool busy = false; // between acquire and the event record
+	uint64_t serial = 0; // order of use
+};
+
+struct dg_mesh
+{
+	dg::MeshDev dev;
+	void* d_pairs = nullptr;
+	void* d_tri_pairs = nullptr;
+	void* d_tris = nullptr;
+	void* d_pn = nullptr;
+	int device = -1;
+	dg_mesh_info info;
+	mutable std::mutex scratch_mutex;
+	mutable std::vector<HeavyScratch> scratch;
+	mutable uint64_t scratch_serial = 0;
+	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
+	mutable ScratchPool bin_scratch;     // K1p point binning
+	double bbox_lo[3], bbox_hi[3];       // of the vertices
 };
 
 struct dg_field
@@ -357,6 +359,15 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 		m->dev.origin[d] = B.origin[d];
 	m->dev.mesh_l1 = B.mesh_l1;
 	m->dev.pad_ = 0.0f;
+	for (int d = 0; d < 3; ++d)
+	{
+		m->bbox_lo[d] = m->bbox_hi[d] = verts[d];
+		for (uint64_t v = 1; v < n_vertices; ++v)
+		{
+			m->bbox_lo[d] = std::min(m->bbox_lo[d], verts[3 * v + d]);
+			m->bbox_hi[d] = std::max(m->bbox_hi[d], verts[3 * v + d]);
+		}
+	}
 	m->info.n_vertices = n_vertices;
 	m->info.n_triangles = n_triangles;
 	m->info.n_bvh_nodes = 2 * B.pairs.size() + 1;
@@ -389,6 +400,7 @@ void dg_mesh_destroy(dg_mesh* m)
 		if (h.done) (void)hipEventDestroy(h.done);
 		if (h.mem) (void)hipFree(h.mem);
 	}
+	m->bin_scratch.destroy();
 	delete m;
 }
 
@@ -825,8 +837,40 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 {
 	if (!mesh || (n && (!d_xyz || !d_dist)))
 		return fail(DG_ERR_INVALID, "null argument");
-	DG_HIP(dg::launch_signed_distance(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest,
-									  static_cast<hipStream_t>(stream)));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// Batches go through the binned launch: a wave's traversal costs the union of what its 64 points
+	// need, so points that arrive in arbitrary order are grouped into compact tiles first (decided on
+	// the device; ordered inputs run as they are).  The tile grid covers the mesh's bounding box grown
+	// by its own size; points farther out are clamped into the border tiles.  DG_K1P_BINNING=0: off.
+	if (n >= 4096 && n < 0xffffffffull && env_int("DG_K1P_BINNING", 1, 0, 1) != 0)
+	{
+		double lo[3], hi[3];
+		for (int d = 0; d < 3; ++d)
+		{
+			const double ext = mesh->bbox_hi[d] - mesh->bbox_lo[d];
+			lo[d] = mesh->bbox_lo[d] - 0.5 * ext;
+			hi[d] = mesh->bbox_hi[d] + 0.5 * ext;
+		}
+		const dg::TileGrid tiles = dg::point_tiles(lo, hi, n);
+		size_t off[4];
+		const size_t bytes = dg::bin_scratch_bytes(dg::tile_count(tiles), n, off);
+		void* mem = nullptr;
+		const int idx = mesh->bin_scratch.acquire(bytes, st, &mem);
+		if (idx >= 0)
+		{
+			char* base = static_cast<char*>(mem);
+			dg::BinScratch S;
+			S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
+			S.start = reinterpret_cast<uint32_t*>(base + off[1]);
+			S.cursor = reinterpret_cast<uint32_t*>(base + off[2]);
+			S.perm = reinterpret_cast<uint32_t*>(base + off[3]);
+			const hipError_t e = dg::launch_signed_distance_binned(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest, tiles, S, st);
+			mesh->bin_scratch.release(idx, st);
+			DG_HIP(e);
+			return DG_OK;
+		}
+	}
+	DG_HIP(dg::launch_signed_distance(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest, st));
 	return DG_OK;
 }
 
@@ -1205,7 +1249,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
 		size_t off[4];
-		const size_t bytes = dg::bin_scratch_bytes(dg::bin_tiles(field->dev.res), n, off);
+		const size_t bytes = dg::bin_scratch_bytes(dg::tile_count(dg::field_tiles(field->dev)), n, off);
 		void* mem = nullptr;
 		const int idx = field->scratch.acquire(bytes, st, &mem);
 		if (idx >= 0)

@@ -213,6 +213,13 @@ hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n
 // the first queries counts how often consecutive queries change tile), so the call stays
 // asynchronous: for inputs that are already spatially ordered the binning kernels return at once
 // and K2 runs in input order.
+struct TileGrid // uniform grid of tiles the points are binned into (points outside are clamped to it)
+{
+	double origin[3];
+	double inv_size[3]; // 1 / tile edge
+	uint32_t dims[3];
+};
+inline uint32_t tile_count(const TileGrid& g) { return g.dims[0] * g.dims[1] * g.dims[2]; }
 struct BinScratch
 {
 	uint32_t* flag;   // [1] 1 = use the permutation
@@ -224,9 +231,33 @@ struct BinScratch
 #define DG_TILE_CELLS 8
 #endif
 static const uint32_t kTileCells = DG_TILE_CELLS;
-inline uint32_t bin_tiles(const uint32_t res[3])
+// K2: tiles of kTileCells^3 grid cells
+inline TileGrid field_tiles(const FieldDev& f)
 {
-	return ((res[0] + kTileCells - 1) / kTileCells) * ((res[1] + kTileCells - 1) / kTileCells) * ((res[2] + kTileCells - 1) / kTileCells);
+	TileGrid g;
+	for (int d = 0; d < 3; ++d)
+	{
+		g.origin[d] = f.dmin[d];
+		g.inv_size[d] = f.inv_cell[d] / (double)kTileCells;
+		g.dims[d] = (f.res[d] + kTileCells - 1) / kTileCells;
+	}
+	return g;
+}
+// K1p: about 64 points per tile if the n points fill the box [lo, hi] evenly
+inline TileGrid point_tiles(const double lo[3], const double hi[3], uint64_t n)
+{
+	TileGrid g;
+	double per_axis = 1.0;
+	while (per_axis * per_axis * per_axis * 64.0 < (double)n && per_axis < 64.0)
+		per_axis += 1.0;
+	for (int d = 0; d < 3; ++d)
+	{
+		const double ext = hi[d] > lo[d] ? hi[d] - lo[d] : 1.0;
+		g.origin[d] = lo[d];
+		g.inv_size[d] = per_axis / ext;
+		g.dims[d] = (uint32_t)per_axis;
+	}
+	return g;
 }
 inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[4])
 {
@@ -240,5 +271,10 @@ inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[4])
 }
 hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 									 const BinScratch& scratch, hipStream_t stream);
+// K1p with the same binning: the packet traversal of a wave costs the UNION of what its 64 points
+// need, so points in arbitrary order (7 x slower than lattice order) are grouped into compact tiles
+hipError_t launch_signed_distance_binned(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
+										 int32_t* d_entity, double* d_nearest, const TileGrid& tiles, const BinScratch& scratch,
+										 hipStream_t stream);
 
 } // namespace dg

@@ -364,10 +364,14 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const SampleParams P)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const double* __restrict__ xyz, uint64_t n,
 														  double* __restrict__ dist, int32_t* __restrict__ tri,
-														  int32_t* __restrict__ entity, double* __restrict__ nearest)
+														  int32_t* __restrict__ entity, double* __restrict__ nearest,
+														  const uint32_t* __restrict__ bin_flag, const uint32_t* __restrict__ perm)
 {
-	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const bool valid = gid < n;
+	// binned launch: thread t handles point perm[t], i.e. the points tile by tile (dg_kernels.h)
+	if (bin_flag != nullptr && bin_flag[0] != 0)
+		gid = perm[valid ? gid : (n - 1)];
 	const uint64_t g = valid ? gid : (n - 1);
 	LaneQuery q;
 	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [4 waves][stack_levels][64]
@@ -443,27 +447,20 @@ __global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const dou
 }
 
 // ---- K2 query binning (dg_kernels.h: BinScratch) ---------------------------------------------------------
-__device__ __forceinline__ uint32_t query_tile(const FieldDev& F, const double* __restrict__ xyz, uint64_t i)
+__device__ __forceinline__ uint32_t tile_of(const TileGrid& G, const double* __restrict__ xyz, uint64_t i)
 {
 	uint32_t t[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d)
 	{
-		const double x = xyz[3 * i + d];
-		uint32_t mi = 0;
-		if (F.dmin[d] <= x && x <= F.dmax[d])
-		{
-			mi = (uint32_t)((x - F.dmin[d]) * F.inv_cell[d]);
-			if (mi >= F.res[d])
-				mi = F.res[d] - 1;
-		}
-		t[d] = mi / kTileCells;
+		const double u = (xyz[3 * i + d] - G.origin[d]) * G.inv_size[d];
+		uint32_t c = u > 0.0 ? (uint32_t)(u < 4.0e9 ? u : 4.0e9) : 0u; // NaN -> 0
+		t[d] = c < G.dims[d] ? c : G.dims[d] - 1;
 	}
-	const uint32_t tx = (F.res[0] + kTileCells - 1) / kTileCells, ty = (F.res[1] + kTileCells - 1) / kTileCells;
-	return (t[2] * ty + t[1]) * tx + t[0];
+	return (t[2] * G.dims[1] + t[1]) * G.dims[0] + t[0];
 }
 // one block: how often do consecutive queries (among the first 4096) change tile?
-__global__ __launch_bounds__(256) void k_bin_probe(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+__global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
 {
 	__shared__ uint32_t changes;
 	if (threadIdx.x == 0)
@@ -472,18 +469,18 @@ __global__ __launch_bounds__(256) void k_bin_probe(const FieldDev F, const doubl
 	const uint64_t m = n < 4096 ? n : 4096;
 	uint32_t mine = 0;
 	for (uint64_t i = threadIdx.x; i + 1 < m; i += blockDim.x)
-		mine += query_tile(F, xyz, i) != query_tile(F, xyz, i + 1);
+		mine += tile_of(F, xyz, i) != tile_of(F, xyz, i + 1);
 	atomicAdd(&changes, mine);
 	__syncthreads();
 	if (threadIdx.x == 0)
 		S.flag[0] = (4ull * changes > m) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void k_bin_hist(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+__global__ __launch_bounds__(256) void k_bin_hist(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
 {
 	if (S.flag[0] == 0)
 		return;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		atomicAdd(&S.start[query_tile(F, xyz, i)], 1u);
+		atomicAdd(&S.start[tile_of(F, xyz, i)], 1u);
 }
 // one block of 1024 threads: exclusive prefix sum of the histogram (start, and a copy in cursor)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t n_tiles, BinScratch S)
@@ -518,12 +515,12 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t n_tiles, BinScratch 
 		run += v;
 	}
 }
-__global__ __launch_bounds__(256) void k_bin_scatter(const FieldDev F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+__global__ __launch_bounds__(256) void k_bin_scatter(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
 {
 	if (S.flag[0] == 0)
 		return;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		S.perm[atomicAdd(&S.cursor[query_tile(F, xyz, i)], 1u)] = (uint32_t)i;
+		S.perm[atomicAdd(&S.cursor[tile_of(F, xyz, i)], 1u)] = (uint32_t)i;
 }
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
@@ -659,7 +656,37 @@ hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_
 		return hipSuccess;
 	const uint32_t grid = (uint32_t)((n + 255) / 256);
 	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), (size_t)4 * m.stack_levels * 64 * sizeof(float), stream, m, d_xyz, n, d_dist, d_tri, d_entity,
-					   d_nearest);
+					   d_nearest, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+	return hipGetLastError();
+}
+
+// the binning passes shared by K2 and K1p: S.flag / S.perm describe the order to process the points in
+static hipError_t launch_binning(const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, hipStream_t stream)
+{
+	const uint32_t n_tiles = tile_count(tiles);
+	hipError_t e = hipMemsetAsync(S.start, 0, (size_t)n_tiles * sizeof(uint32_t), stream);
+	if (e != hipSuccess)
+		return e;
+	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	hipLaunchKernelGGL(k_bin_hist, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, n_tiles, S);
+	hipLaunchKernelGGL(k_bin_scatter, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	return hipGetLastError();
+}
+
+hipError_t launch_signed_distance_binned(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
+										 int32_t* d_entity, double* d_nearest, const TileGrid& tiles, const BinScratch& S,
+										 hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const hipError_t e = launch_binning(tiles, d_xyz, n, S, stream);
+	if (e != hipSuccess)
+		return e;
+	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), (size_t)4 * m.stack_levels * 64 * sizeof(float), stream, m, d_xyz, n, d_dist, d_tri, d_entity,
+					   d_nearest, (const uint32_t*)S.flag, (const uint32_t*)S.perm);
 	return hipGetLastError();
 }
 
@@ -705,15 +732,9 @@ hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uin
 {
 	if (n == 0)
 		return hipSuccess;
-	const uint32_t n_tiles = bin_tiles(f.res);
-	hipError_t e = hipMemsetAsync(S.start, 0, (size_t)n_tiles * sizeof(uint32_t), stream);
+	const hipError_t e = launch_binning(field_tiles(f), d_xyz, n, S, stream);
 	if (e != hipSuccess)
 		return e;
-	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
-	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, f, d_xyz, n, S);
-	hipLaunchKernelGGL(k_bin_hist, dim3(wide), dim3(256), 0, stream, f, d_xyz, n, S);
-	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, n_tiles, S);
-	hipLaunchKernelGGL(k_bin_scatter, dim3(wide), dim3(256), 0, stream, f, d_xyz, n, S);
 	const uint32_t grid = (uint32_t)((n + 255) / 256);
 	if (d_grad)
 		hipLaunchKernelGGL(k_interpolate_binned<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);

@@ -133,6 +133,36 @@ def test_signed_distance_points(dg, golden):
         np.testing.assert_array_equal(near[same], golden[name + "_near"][same])
 
 
+def test_signed_distance_binned_launch(dg, monkeypatch):
+    """K1p groups unordered points into compact tiles before the packet traversal (device-side
+    decision).  Distances are order-independent, so the binned launch must return the bits of the
+    plain launch for random, line-ordered, far-away and duplicated inputs; the winning triangle
+    may differ only where several triangles tie exactly."""
+    V, F = T.bunny_mesh()
+    m = dg.Mesh(V, F)
+    lo, hi = V.min(axis=0), V.max(axis=0)
+    rng = np.random.default_rng(21)
+    P = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(50021, 3))
+    P[:3000] = rng.uniform(lo - 40 * (hi - lo), hi + 40 * (hi - lo), size=(3000, 3))     # far outside the tile grid
+    P[3000:4000] = P[3000]                                                              # duplicates
+    line = np.linspace(lo - 0.1, hi + 0.1, 20000)                                       # one long line
+    for Q in (P, line, P[np.argsort(P[:, 0])]):
+        monkeypatch.setenv("DG_K1P_BINNING", "0")
+        d0, t0, e0, n0 = m.signed_distance(Q, full=True)
+        monkeypatch.setenv("DG_K1P_BINNING", "1")
+        d1, t1, e1, n1 = m.signed_distance(Q, full=True)
+        np.testing.assert_array_equal(d1, d0)
+        # exact ties (nearest point on a shared edge or vertex: identical d^2 from several triangles)
+        # are broken by visiting order, which depends on which points share a wave: the triangle may
+        # differ, the nearest point is the same point
+        same = t1 == t0
+        assert same.mean() > 0.5
+        np.testing.assert_array_equal(e1[same], e0[same])
+        np.testing.assert_array_equal(n1[same], n0[same])
+        assert np.abs(n1 - n0).max() <= 1e-12 * np.abs(hi - lo).max()
+    np.testing.assert_array_equal(d1[:2000], T.OracleMesh(V, F).signed_distance(P[np.argsort(P[:, 0])][:2000]))
+
+
 def test_far_and_on_surface_queries(dg):
     V, F = T.icosphere(6)
     for shift, scale in ((0.0, 1.0), (1000.0, 1.0), (-3.0e4, 250.0), (0.5, 1e-3)):
