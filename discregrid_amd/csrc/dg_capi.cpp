@@ -180,6 +180,68 @@ bool valid_grid(const dg_grid_desc* g)
 
 } // namespace
 
+// ---- helpers of the host-pointer entry points --------------------------------------------------------------
+// Device allocations and the timing events of ONE call: released when the call returns, whichever
+// way it returns.  The first failing HIP call is remembered in `err`; later steps become no-ops.
+struct HostCall
+{
+	std::vector<void*> allocations;
+	hipEvent_t begin = nullptr, end = nullptr;
+	hipError_t err = hipSuccess;
+
+	~HostCall()
+	{
+		for (void* p : allocations)
+			(void)hipFree(p);
+		if (begin) (void)hipEventDestroy(begin);
+		if (end) (void)hipEventDestroy(end);
+	}
+	template <class T>
+	T* device(uint64_t count, bool wanted = true)
+	{
+		if (!wanted || err != hipSuccess)
+			return nullptr;
+		void* p = nullptr;
+		err = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 1));
+		if (err != hipSuccess)
+			return nullptr;
+		allocations.push_back(p);
+		return static_cast<T*>(p);
+	}
+	void upload(void* dst, const void* src, size_t bytes)
+	{
+		if (err == hipSuccess && dst)
+			err = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+	}
+	void download(void* dst, const void* src, size_t bytes)
+	{
+		if (err == hipSuccess && dst)
+			err = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+	}
+	void start_timer()
+	{
+		if (err == hipSuccess) err = hipEventCreate(&begin);
+		if (err == hipSuccess) err = hipEventCreate(&end);
+		if (err == hipSuccess) err = hipEventRecord(begin, nullptr);
+	}
+	void stop_timer()
+	{
+		if (err == hipSuccess) err = hipEventRecord(end, nullptr);
+	}
+	void publish_time() // after the downloads (they synchronise with the null stream)
+	{
+		float ms = -1.f;
+		if (err == hipSuccess && begin && end && hipEventElapsedTime(&ms, begin, end) == hipSuccess)
+			g_last_ms = ms;
+	}
+	dg_status status(const char* what) const
+	{
+		if (err == hipSuccess)
+			return DG_OK;
+		return fail(err == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+	}
+};
+
 extern "C"
 {
 
@@ -884,37 +946,24 @@ dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n,
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	double *d_xyz = nullptr, *d_dist = nullptr, *d_near = nullptr;
-	int32_t *d_tri = nullptr, *d_ent = nullptr;
-	hipError_t e = hipMalloc((void**)&d_xyz, 3 * n * sizeof(double));
-	if (e == hipSuccess) e = hipMalloc((void**)&d_dist, n * sizeof(double));
-	if (e == hipSuccess && tri) e = hipMalloc((void**)&d_tri, n * sizeof(int32_t));
-	if (e == hipSuccess && entity) e = hipMalloc((void**)&d_ent, n * sizeof(int32_t));
-	if (e == hipSuccess && nearest) e = hipMalloc((void**)&d_near, 3 * n * sizeof(double));
-	if (e == hipSuccess) e = hipMemcpy(d_xyz, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice);
-	dg_status st = DG_OK;
-	if (e == hipSuccess)
+	HostCall call;
+	double* d_xyz = call.device<double>(3 * n);
+	double* d_dist = call.device<double>(n);
+	int32_t* d_tri = call.device<int32_t>(n, tri != nullptr);
+	int32_t* d_ent = call.device<int32_t>(n, entity != nullptr);
+	double* d_near = call.device<double>(3 * n, nearest != nullptr);
+	call.upload(d_xyz, xyz, 3 * n * sizeof(double));
+	if (call.err == hipSuccess)
 	{
-		st = dg_signed_distance_device(mesh, d_xyz, n, d_dist, d_tri, d_ent, d_near, nullptr);
-		if (st == DG_OK)
-		{
-			e = hipMemcpy(dist, d_dist, n * sizeof(double), hipMemcpyDeviceToHost);
-			if (e == hipSuccess && tri) e = hipMemcpy(tri, d_tri, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-			if (e == hipSuccess && entity) e = hipMemcpy(entity, d_ent, n * sizeof(int32_t), hipMemcpyDeviceToHost);
-			if (e == hipSuccess && nearest) e = hipMemcpy(nearest, d_near, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
-		}
+		s = dg_signed_distance_device(mesh, d_xyz, n, d_dist, d_tri, d_ent, d_near, nullptr);
+		if (s != DG_OK)
+			return s;
 	}
-	if (d_xyz) (void)hipFree(d_xyz);
-	if (d_dist) (void)hipFree(d_dist);
-	if (d_tri) (void)hipFree(d_tri);
-	if (d_ent) (void)hipFree(d_ent);
-	if (d_near) (void)hipFree(d_near);
-	if (st != DG_OK)
-		return st;
-	if (e != hipSuccess)
-		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_signed_distance: %s",
-					hipGetErrorString(e));
-	return DG_OK;
+	call.download(dist, d_dist, n * sizeof(double));
+	call.download(tri, d_tri, n * sizeof(int32_t));
+	call.download(entity, d_ent, n * sizeof(int32_t));
+	call.download(nearest, d_near, 3 * n * sizeof(double));
+	return call.status("dg_signed_distance");
 }
 
 // ---- sharding -------------------------------------------------------------------------------------------
@@ -1197,42 +1246,21 @@ dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	double* d_out = nullptr;
-	uint8_t* d_mask = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	dg_status st = DG_OK;
-	hipError_t e = hipMalloc((void**)&d_out, n * sizeof(double));
-	if (e == hipSuccess && pred_mask)
+	HostCall call;
+	double* d_out = call.device<double>(n);
+	uint8_t* d_mask = call.device<uint8_t>(n, pred_mask != nullptr);
+	call.upload(d_mask, pred_mask, n);
+	call.start_timer();
+	if (call.err == hipSuccess)
 	{
-		e = hipMalloc((void**)&d_mask, n);
-		if (e == hipSuccess) e = hipMemcpy(d_mask, pred_mask, n, hipMemcpyHostToDevice);
+		s = dg_density_map_nodes_device(sdf, support_radius, rho0, band_predicate, node_begin, node_end, d_mask, d_out, nullptr);
+		if (s != DG_OK)
+			return s;
 	}
-	if (e == hipSuccess) e = hipEventCreate(&e0);
-	if (e == hipSuccess) e = hipEventCreate(&e1);
-	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-	if (e == hipSuccess)
-	{
-		st = dg_density_map_nodes_device(sdf, support_radius, rho0, band_predicate, node_begin, node_end, d_mask, d_out,
-										 nullptr);
-		if (st == DG_OK)
-		{
-			e = hipEventRecord(e1, nullptr);
-			if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost);
-			float ms = -1.f;
-			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
-				g_last_ms = ms;
-		}
-	}
-	if (e0) (void)hipEventDestroy(e0);
-	if (e1) (void)hipEventDestroy(e1);
-	if (d_out) (void)hipFree(d_out);
-	if (d_mask) (void)hipFree(d_mask);
-	if (st != DG_OK)
-		return st;
-	if (e != hipSuccess)
-		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_density_map_nodes: %s",
-					hipGetErrorString(e));
-	return DG_OK;
+	call.stop_timer();
+	call.download(out, d_out, n * sizeof(double));
+	call.publish_time();
+	return call.status("dg_density_map_nodes");
 }
 
 dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
@@ -1279,40 +1307,23 @@ dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	double *d_xyz = nullptr, *d_phi = nullptr, *d_grad = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	hipError_t e = hipMalloc((void**)&d_xyz, 3 * n * sizeof(double));
-	if (e == hipSuccess) e = hipMalloc((void**)&d_phi, n * sizeof(double));
-	if (e == hipSuccess && grad) e = hipMalloc((void**)&d_grad, 3 * n * sizeof(double));
-	if (e == hipSuccess) e = hipMemcpy(d_xyz, xyz, 3 * n * sizeof(double), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipEventCreate(&e0);
-	if (e == hipSuccess) e = hipEventCreate(&e1);
-	if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-	dg_status st = DG_OK;
-	if (e == hipSuccess)
+	HostCall call;
+	double* d_xyz = call.device<double>(3 * n);
+	double* d_phi = call.device<double>(n);
+	double* d_grad = call.device<double>(3 * n, grad != nullptr);
+	call.upload(d_xyz, xyz, 3 * n * sizeof(double));
+	call.start_timer();
+	if (call.err == hipSuccess)
 	{
-		st = dg_interpolate_batch_device(field, d_xyz, n, d_phi, d_grad, nullptr);
-		if (st == DG_OK)
-		{
-			e = hipEventRecord(e1, nullptr);
-			if (e == hipSuccess) e = hipMemcpy(phi, d_phi, n * sizeof(double), hipMemcpyDeviceToHost);
-			if (e == hipSuccess && grad) e = hipMemcpy(grad, d_grad, 3 * n * sizeof(double), hipMemcpyDeviceToHost);
-			float ms = -1.f;
-			if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
-				g_last_ms = ms;
-		}
+		s = dg_interpolate_batch_device(field, d_xyz, n, d_phi, d_grad, nullptr);
+		if (s != DG_OK)
+			return s;
 	}
-	if (e0) (void)hipEventDestroy(e0);
-	if (e1) (void)hipEventDestroy(e1);
-	if (d_xyz) (void)hipFree(d_xyz);
-	if (d_phi) (void)hipFree(d_phi);
-	if (d_grad) (void)hipFree(d_grad);
-	if (st != DG_OK)
-		return st;
-	if (e != hipSuccess)
-		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_interpolate_batch: %s",
-					hipGetErrorString(e));
-	return DG_OK;
+	call.stop_timer();
+	call.download(phi, d_phi, n * sizeof(double));
+	call.download(grad, d_grad, 3 * n * sizeof(double));
+	call.publish_time();
+	return call.status("dg_interpolate_batch");
 }
 
 } // extern "C"
