@@ -142,7 +142,7 @@ def main():
         # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
         # 4-plane slabs; all virtual ranks share one slot size, so `gathered` is exactly the buffer a
         # single all-gather among pieces*world ranks would produce and the unpack kernel is unchanged
-        pieces = max(1, args.pieces)
+        pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
         vworld = pieces * world
         counts = []
         stride = 0
