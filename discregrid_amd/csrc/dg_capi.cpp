@@ -525,7 +525,7 @@ static int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipSt
 	P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
 	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
 	P.ovf.slots = slots;
-	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::kHeavyWork, 1, 1 << 30);
+	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
 	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
 	{
 		(void)hipGetLastError();

@@ -29,6 +29,14 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 #endif
 static const int kOverflowSlots = DG_HEAVY_SLOTS; // most bricks one launch can park (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
 static const int kHeavyWork = 1600;     // traversal steps + exact triangle tests before a brick counts as heavy (~0.7 ms of one wave)
+// Budget of a brick for a mesh of n_positions triangle slots.  Cutting a brick's search over the
+// top-level subtrees pays only when it needs a sizeable part of the WHOLE tree; a brick whose 64
+// nodes merely face a few thousand triangles of a finely tessellated mesh is local work.
+inline int heavy_work_for(int32_t n_positions)
+{
+	const int scaled = n_positions / 64;
+	return scaled > kHeavyWork ? scaled : kHeavyWork;
+}
 // slots a launch of `bricks` bricks gets: heavy bricks are a small, slowly growing fraction of a launch
 inline uint32_t overflow_slots_for(uint64_t bricks)
 {

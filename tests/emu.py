@@ -182,7 +182,7 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     return (phi, g) if grad else phi
 
 
-def set_heavy(slots=0xffffffff, work=1600):
+def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
-    slots = 0 disables the split, the default sizes the slots per launch as the product does."""
+    slots = 0 disables the split; the defaults size slots and budget as the product does."""
     lib().emu_set_heavy(slots, work)

@@ -185,7 +185,7 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 // heavy-brick settings of the emulated launches (defaults = the product's)
 const uint32_t kAutoSlots = 0xffffffffu; // slots chosen per launch as dg_capi.cpp does
 uint32_t g_heavy_slots = kAutoSlots;
-int g_heavy_work = kHeavyWork;
+int g_heavy_work = 0; // 0: the product's rule (heavy_work_for)
 
 struct HostMesh
 {
@@ -425,7 +425,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		P.ovf.cand_d2 = cand_d2.get();
 		P.ovf.cand_tri = cand_tri.get();
 		P.ovf.slots = slots;
-		P.ovf.heavy_work = g_heavy_work;
+		P.ovf.heavy_work = g_heavy_work > 0 ? g_heavy_work : heavy_work_for(P.mesh.n_positions);
 	}
 	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
 		for (int l = 0; l < 64; ++l)
