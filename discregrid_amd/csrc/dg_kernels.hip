@@ -202,7 +202,7 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, float* l
 				{
 					// both children are needed: the one most lanes are closer to first, the other is
 					// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
-					const unsigned long long pref = __ballot((hl || hr) && (lb.x <= lb.y));
+					const unsigned long long pref = __ballot(lb.x <= lb.y) & (bl | br);
 					left = 2 * __popcll(pref) >= __popcll(bl | br);
 					if (sp < M.stack_levels) // always true: one push per tree level at most
 					{
