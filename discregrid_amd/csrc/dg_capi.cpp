@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -621,10 +622,8 @@ struct HostPipe
 	std::mutex mutex; // one host-pointer launch at a time uses the staging buffers
 	int device = -1;
 	size_t chunk_bytes = 0;
-	size_t mask_bytes = 0;
 	void* d_buf[2] = {nullptr, nullptr};
 	void* h_buf[2] = {nullptr, nullptr};
-	void* d_mask[2] = {nullptr, nullptr};
 	hipStream_t compute = nullptr, copy = nullptr;
 	hipEvent_t k_begin[2] = {nullptr, nullptr}, k_end[2] = {nullptr, nullptr}, c_end[2] = {nullptr, nullptr};
 
@@ -633,30 +632,27 @@ struct HostPipe
 		for (int i = 0; i < 2; ++i)
 		{
 			if (d_buf[i]) (void)hipFree(d_buf[i]);
-			if (d_mask[i]) (void)hipFree(d_mask[i]);
 			if (h_buf[i]) (void)hipHostFree(h_buf[i]);
 			if (k_begin[i]) (void)hipEventDestroy(k_begin[i]);
 			if (k_end[i]) (void)hipEventDestroy(k_end[i]);
 			if (c_end[i]) (void)hipEventDestroy(c_end[i]);
-			d_buf[i] = h_buf[i] = d_mask[i] = nullptr;
+			d_buf[i] = h_buf[i] = nullptr;
 			k_begin[i] = k_end[i] = c_end[i] = nullptr;
 		}
 		if (compute) (void)hipStreamDestroy(compute);
 		if (copy) (void)hipStreamDestroy(copy);
 		compute = copy = nullptr;
-		chunk_bytes = mask_bytes = 0;
+		chunk_bytes = 0;
 		device = -1;
 	}
-	hipError_t prepare(size_t bytes, size_t mask)
+	hipError_t prepare(size_t bytes)
 	{
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess)
 			return e;
-		if (dev == device && bytes <= chunk_bytes && mask <= mask_bytes)
+		if (dev == device && bytes <= chunk_bytes)
 			return hipSuccess;
-		bytes = std::max(bytes, dev == device ? chunk_bytes : 0);
-		mask = std::max(mask, dev == device ? mask_bytes : 0);
 		release();
 		device = dev;
 		e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
@@ -664,17 +660,13 @@ struct HostPipe
 		for (int i = 0; i < 2 && e == hipSuccess; ++i)
 		{
 			e = hipMalloc(&d_buf[i], bytes);
-			if (e == hipSuccess && mask) e = hipMalloc(&d_mask[i], mask);
 			if (e == hipSuccess) e = hipHostMalloc(&h_buf[i], bytes, hipHostMallocDefault);
 			if (e == hipSuccess) e = hipEventCreate(&k_begin[i]);
 			if (e == hipSuccess) e = hipEventCreate(&k_end[i]);
 			if (e == hipSuccess) e = hipEventCreateWithFlags(&c_end[i], hipEventDisableTiming);
 		}
 		if (e == hipSuccess)
-		{
 			chunk_bytes = bytes;
-			mask_bytes = mask;
-		}
 		else
 			release();
 		return e;
@@ -724,11 +716,26 @@ void chunk_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end, u
 }
 } // namespace
 
-// Chunks first, first + stride, ... of `cuts` through one pipeline (the caller holds pipe.mutex and
-// has made the mesh's device current).  kernel_ms accumulates the K1 time of the chunks.
-static dg_status run_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
-							const std::vector<uint64_t>& cuts, size_t first, size_t stride, const uint8_t* pred_mask,
-							double* out, double* kernel_ms, double* t_wait, double* t_copy)
+// One array of a pipelined host-pointer call: read from the host (`in`) or written back to it (`out`),
+// item_bytes per item; null in and out = absent (optional outputs).  Host pointers address item cuts[0].
+struct PipeArray
+{
+	const void* in;
+	void* out;
+	size_t item_bytes;
+};
+// launch(begin, count, d_arrays, stream): enqueue the device work for items [begin, begin + count);
+// d_arrays[i] is the device copy of array i for exactly those items (null if the array is absent)
+typedef std::function<dg_status(uint64_t, uint64_t, void* const*, hipStream_t)> PipeLaunch;
+
+// Chunks first, first + stride, ... of `cuts` through one pipeline (the caller holds pipe.mutex and has
+// made the right device current).  Per chunk: host threads copy the inputs into pinned staging
+// memory, the compute stream uploads them and runs `launch`, the copy stream brings the outputs back
+// into pinned memory, host threads move them into the caller's arrays -- while the GPU is already
+// busy with the next chunk.  kernel_ms accumulates upload + kernel time of the chunks.
+static dg_status run_pipeline(HostPipe& pipe, const std::vector<uint64_t>& cuts, size_t first, size_t stride,
+							  const std::vector<PipeArray>& arrays, const PipeLaunch& launch, const char* what, double* kernel_ms,
+							  double* t_wait, double* t_copy)
 {
 	const size_t n_chunks = cuts.size() - 1;
 	uint64_t longest = 0;
@@ -736,10 +743,16 @@ static dg_status run_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_d
 		longest = std::max(longest, cuts[k + 1] - cuts[k]);
 	if (longest == 0)
 		return DG_OK;
-	hipError_t e = pipe.prepare(longest * sizeof(double), pred_mask ? longest : 0);
+	std::vector<size_t> off(arrays.size() + 1, 0);
+	for (size_t i = 0; i < arrays.size(); ++i)
+	{
+		const bool present = arrays[i].in != nullptr || arrays[i].out != nullptr;
+		off[i + 1] = off[i] + (present ? ((longest * arrays[i].item_bytes + 255) & ~(size_t)255) : 0);
+	}
+	hipError_t e = pipe.prepare(off.back());
 	dg_status st = DG_OK;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-	auto drain = [&](size_t k, int b) -> hipError_t { // chunk k: wait for its copy, move it into the caller's array
+	auto drain = [&](size_t k, int b) -> hipError_t { // chunk k: wait for its copies, move the outputs into the caller's arrays
 		const double t0 = now();
 		hipError_t err = hipEventSynchronize(pipe.c_end[b]);
 		if (err != hipSuccess)
@@ -748,37 +761,47 @@ static dg_status run_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_d
 		float ms = 0.f;
 		if (hipEventElapsedTime(&ms, pipe.k_begin[b], pipe.k_end[b]) == hipSuccess)
 			*kernel_ms += ms;
-		parallel_copy(out + (cuts[k] - node_begin), pipe.h_buf[b], (cuts[k + 1] - cuts[k]) * sizeof(double));
+		for (size_t i = 0; i < arrays.size(); ++i)
+			if (arrays[i].out)
+				parallel_copy(static_cast<char*>(arrays[i].out) + (cuts[k] - cuts[0]) * arrays[i].item_bytes,
+							  static_cast<char*>(pipe.h_buf[b]) + off[i], (cuts[k + 1] - cuts[k]) * arrays[i].item_bytes);
 		*t_wait += t1 - t0;
 		*t_copy += now() - t1;
 		return hipSuccess;
 	};
-	size_t prev = n_chunks; // chunk whose results still sit in the staging buffers
+	std::vector<void*> d_arrays(arrays.size(), nullptr);
+	size_t prev = n_chunks; // chunk whose results still sit in the other pair of buffers
 	int turn = 0;
 	for (size_t k = first; k < n_chunks && e == hipSuccess && st == DG_OK; k += stride, turn ^= 1)
 	{
-		const int b = turn;
+		const int b = turn; // buffers b were last used by the chunk before `prev`, which has been drained
 		const uint64_t cn = cuts[k + 1] - cuts[k];
-		// buffers b were last used by the chunk before `prev`, which has been drained
-		uint8_t* d_mask = nullptr;
-		if (pred_mask)
+		const double t0 = now();
+		for (size_t i = 0; i < arrays.size(); ++i)
 		{
-			d_mask = static_cast<uint8_t*>(pipe.d_mask[b]);
-			e = hipMemcpyAsync(d_mask, pred_mask + (cuts[k] - node_begin), cn, hipMemcpyHostToDevice, pipe.compute);
-			if (e != hipSuccess)
-				break;
+			const bool present = arrays[i].in != nullptr || arrays[i].out != nullptr;
+			d_arrays[i] = present ? static_cast<char*>(pipe.d_buf[b]) + off[i] : nullptr;
+			if (arrays[i].in)
+				parallel_copy(static_cast<char*>(pipe.h_buf[b]) + off[i],
+							  static_cast<const char*>(arrays[i].in) + (cuts[k] - cuts[0]) * arrays[i].item_bytes, cn * arrays[i].item_bytes);
 		}
+		*t_copy += now() - t0;
 		e = hipEventRecord(pipe.k_begin[b], pipe.compute);
+		for (size_t i = 0; i < arrays.size() && e == hipSuccess; ++i)
+			if (arrays[i].in)
+				e = hipMemcpyAsync(d_arrays[i], static_cast<char*>(pipe.h_buf[b]) + off[i], cn * arrays[i].item_bytes,
+								   hipMemcpyHostToDevice, pipe.compute);
 		if (e != hipSuccess)
 			break;
-		st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask, static_cast<double*>(pipe.d_buf[b]),
-										pipe.compute);
+		st = launch(cuts[k], cn, d_arrays.data(), pipe.compute);
 		if (st != DG_OK)
 			break;
 		e = hipEventRecord(pipe.k_end[b], pipe.compute);
 		if (e == hipSuccess) e = hipStreamWaitEvent(pipe.copy, pipe.k_end[b], 0);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(pipe.h_buf[b], pipe.d_buf[b], cn * sizeof(double), hipMemcpyDeviceToHost, pipe.copy);
+		for (size_t i = 0; i < arrays.size() && e == hipSuccess; ++i)
+			if (arrays[i].out)
+				e = hipMemcpyAsync(static_cast<char*>(pipe.h_buf[b]) + off[i], d_arrays[i], cn * arrays[i].item_bytes,
+								   hipMemcpyDeviceToHost, pipe.copy);
 		if (e == hipSuccess) e = hipEventRecord(pipe.c_end[b], pipe.copy);
 		if (e == hipSuccess && prev < n_chunks)
 			e = drain(prev, b ^ 1);
@@ -794,8 +817,31 @@ static dg_status run_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_d
 	if (st != DG_OK)
 		return st;
 	if (e != hipSuccess)
-		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes: %s", hipGetErrorString(e));
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 	return DG_OK;
+}
+
+// K1 through the pipeline: node range cuts, optional predicate mask in, coefficients out
+static dg_status run_k1_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_desc* grid, int invert,
+							   const std::vector<uint64_t>& cuts, size_t first, size_t stride, const uint8_t* pred_mask, double* out,
+							   double* kernel_ms, double* t_wait, double* t_copy)
+{
+	const std::vector<PipeArray> arrays = {{pred_mask, nullptr, 1}, {nullptr, out, sizeof(double)}};
+	const PipeLaunch launch = [&](uint64_t begin, uint64_t count, void* const* d, hipStream_t stream) {
+		return dg_sdf_sample_nodes_device(mesh, grid, invert, begin, begin + count, static_cast<const uint8_t*>(d[0]),
+										  static_cast<double*>(d[1]), stream);
+	};
+	return run_pipeline(pipe, cuts, first, stride, arrays, launch, "dg_sdf_sample_nodes", kernel_ms, t_wait, t_copy);
+}
+
+// items [0, n) in uniform chunks (K1p, K2): big enough to amortise the launches, small enough to overlap
+static void uniform_cuts(uint64_t n, int default_chunk, std::vector<uint64_t>& cuts)
+{
+	const uint64_t chunk = (uint64_t)env_int("DG_HOST_CHUNK_ITEMS", default_chunk, 1 << 8, 1 << 28);
+	cuts.clear();
+	for (uint64_t at = 0; at < n; at += chunk)
+		cuts.push_back(at);
+	cuts.push_back(n);
 }
 
 static dg_status check_host_range(const dg_grid_desc* grid, uint64_t node_begin, uint64_t node_end)
@@ -831,7 +877,7 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
 	double kernel_ms = 0, t_wait = 0, t_copy = 0;
 	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
-	s = run_chunks(g_pipes[0], mesh, grid, invert, node_begin, cuts, 0, 1, pred_mask, out, &kernel_ms, &t_wait, &t_copy);
+	s = run_k1_chunks(g_pipes[0], mesh, grid, invert, cuts, 0, 1, pred_mask, out, &kernel_ms, &t_wait, &t_copy);
 	if (s != DG_OK)
 		return s;
 	g_last_ms = kernel_ms;
@@ -879,8 +925,8 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 			}
 			double t_wait = 0, t_copy = 0;
 			std::lock_guard<std::mutex> lock(g_pipes[i].mutex);
-			status[(size_t)i] = run_chunks(g_pipes[i], meshes[i], grid, invert, node_begin, cuts, (size_t)i, (size_t)n_meshes,
-										   pred_mask, out, &kernel_ms[(size_t)i], &t_wait, &t_copy);
+			status[(size_t)i] = run_k1_chunks(g_pipes[i], meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
+											  &kernel_ms[(size_t)i], &t_wait, &t_copy);
 			if (status[(size_t)i] != DG_OK)
 				message[(size_t)i] = dg_last_error(); // thread-local: carry it to the caller
 		});
@@ -946,24 +992,23 @@ dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n,
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	HostCall call;
-	double* d_xyz = call.device<double>(3 * n);
-	double* d_dist = call.device<double>(n);
-	int32_t* d_tri = call.device<int32_t>(n, tri != nullptr);
-	int32_t* d_ent = call.device<int32_t>(n, entity != nullptr);
-	double* d_near = call.device<double>(3 * n, nearest != nullptr);
-	call.upload(d_xyz, xyz, 3 * n * sizeof(double));
-	if (call.err == hipSuccess)
-	{
-		s = dg_signed_distance_device(mesh, d_xyz, n, d_dist, d_tri, d_ent, d_near, nullptr);
-		if (s != DG_OK)
-			return s;
-	}
-	call.download(dist, d_dist, n * sizeof(double));
-	call.download(tri, d_tri, n * sizeof(int32_t));
-	call.download(entity, d_ent, n * sizeof(int32_t));
-	call.download(nearest, d_near, 3 * n * sizeof(double));
-	return call.status("dg_signed_distance");
+	std::vector<uint64_t> cuts;
+	uniform_cuts(n, 1 << 23, cuts); // K1p launches end with a long tail (a few waves with costly points): few, big chunks
+	const std::vector<PipeArray> arrays = {{xyz, nullptr, 3 * sizeof(double)},
+										   {nullptr, dist, sizeof(double)},
+										   {nullptr, tri, sizeof(int32_t)},
+										   {nullptr, entity, sizeof(int32_t)},
+										   {nullptr, nearest, 3 * sizeof(double)}};
+	const PipeLaunch launch = [&](uint64_t, uint64_t count, void* const* d, hipStream_t stream) {
+		return dg_signed_distance_device(mesh, static_cast<const double*>(d[0]), count, static_cast<double*>(d[1]),
+										 static_cast<int32_t*>(d[2]), static_cast<int32_t*>(d[3]), static_cast<double*>(d[4]), stream);
+	};
+	double kernel_ms = 0, t_wait = 0, t_copy = 0;
+	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
+	s = run_pipeline(g_pipes[0], cuts, 0, 1, arrays, launch, "dg_signed_distance", &kernel_ms, &t_wait, &t_copy);
+	if (s == DG_OK)
+		g_last_ms = kernel_ms;
+	return s;
 }
 
 // ---- sharding -------------------------------------------------------------------------------------------
@@ -1307,23 +1352,19 @@ dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
-	HostCall call;
-	double* d_xyz = call.device<double>(3 * n);
-	double* d_phi = call.device<double>(n);
-	double* d_grad = call.device<double>(3 * n, grad != nullptr);
-	call.upload(d_xyz, xyz, 3 * n * sizeof(double));
-	call.start_timer();
-	if (call.err == hipSuccess)
-	{
-		s = dg_interpolate_batch_device(field, d_xyz, n, d_phi, d_grad, nullptr);
-		if (s != DG_OK)
-			return s;
-	}
-	call.stop_timer();
-	call.download(phi, d_phi, n * sizeof(double));
-	call.download(grad, d_grad, 3 * n * sizeof(double));
-	call.publish_time();
-	return call.status("dg_interpolate_batch");
+	std::vector<uint64_t> cuts;
+	uniform_cuts(n, 1 << 20, cuts);
+	const std::vector<PipeArray> arrays = {{xyz, nullptr, 3 * sizeof(double)}, {nullptr, phi, sizeof(double)}, {nullptr, grad, 3 * sizeof(double)}};
+	const PipeLaunch launch = [&](uint64_t, uint64_t count, void* const* d, hipStream_t stream) {
+		return dg_interpolate_batch_device(field, static_cast<const double*>(d[0]), count, static_cast<double*>(d[1]),
+										   static_cast<double*>(d[2]), stream);
+	};
+	double kernel_ms = 0, t_wait = 0, t_copy = 0;
+	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
+	s = run_pipeline(g_pipes[0], cuts, 0, 1, arrays, launch, "dg_interpolate_batch", &kernel_ms, &t_wait, &t_copy);
+	if (s == DG_OK)
+		g_last_ms = kernel_ms;
+	return s;
 }
 
 } // extern "C"

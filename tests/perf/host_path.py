@@ -32,5 +32,35 @@ def main():
                 "x".join(map(str, res)), rep, dt * 1e3, dg.last_kernel_ms(), n / dt / 1e6, float(out[::9973].sum())), flush=True)
 
 
+def others():
+    """Host-pointer K2 (10 M queries, value + gradient) and K1p (2 M points) end to end."""
+    import dgtest as T
+    import discregrid_amd as dg
+    V, F = T.icosphere(71)
+    dom = dg.default_domain(V)
+    grid = dg.grid_desc(dom[:3], dom[3:], [128] * 3)
+    mesh = dg.Mesh(V, F)
+    coeffs = mesh.sample_nodes(grid)
+    field = dg.Field(grid, coeffs)
+    rng = np.random.default_rng(2)
+    Q = rng.uniform(dom[:3], dom[3:], size=(10_000_000, 3))
+    for grad in (False, True):
+        for rep in range(3):
+            t0 = time.perf_counter()
+            out = field.interpolate(Q, grad=grad)
+            dt = time.perf_counter() - t0
+        print("interpolate host, 10 M queries, grad=%s: %.1f ms (device part %.1f ms) = %.0f Mq/s" % (
+            grad, dt * 1e3, dg.last_kernel_ms(), len(Q) / dt / 1e6), flush=True)
+        del out
+    P = Q[:2_000_000]
+    for rep in range(3):
+        t0 = time.perf_counter()
+        d = mesh.signed_distance(P)
+        dt = time.perf_counter() - t0
+    print("signed_distance host, 2 M points: %.1f ms (device part %.1f ms) = %.0f Mpoints/s" % (
+        dt * 1e3, dg.last_kernel_ms(), len(P) / dt / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    others()
