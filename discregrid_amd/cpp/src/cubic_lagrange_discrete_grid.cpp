@@ -479,25 +479,29 @@ double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vect
 // ---------------------------------------------------------------------------------------------
 void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pred)
 {
+	using clock = std::chrono::steady_clock;
+	const bool timing = std::getenv("DG_REDUCE_TIMING") != nullptr;
+	auto tick = [&](const char* what) {
+		static thread_local clock::time_point last = clock::now();
+		const auto now = clock::now();
+		if (timing)
+			std::cerr << "reduceField: " << what << " " << std::chrono::duration<double>(now - last).count() << " s" << std::endl;
+		last = now;
+	};
+	tick("start");
 	materializeCells(field_id);
 	invalidateDevice(field_id);
+	tick("materialize cells");
 	auto& coeffs = m_nodes[field_id];
 	auto& cells = m_cells[field_id];
 	auto& cell_map = m_cell_map[field_id];
 	const std::size_t n = coeffs.size();
 
-	// nodes that satisfy the predicate, and the Morton key of every node position
+	// nodes that satisfy the predicate (user code: called serially, as the reference does)
 	std::vector<char> keep(n);
-	std::vector<uint64_t> z(n);
-	const double zscale = 4.0 * std::min(std::min(m_inv_cell_size[0], m_inv_cell_size[1]), m_inv_cell_size[2]);
 	for (std::size_t l = 0; l < n; ++l)
-	{
-		const Eigen::Vector3d x = indexToNodePosition((unsigned int)l);
-		keep[l] = pred(x, coeffs[l]) && coeffs[l] != kNoValue;
-		const double p[3] = {x[0], x[1], x[2]};
-		z[l] = z_value(p, zscale);
-	}
-
+		keep[l] = pred(indexToNodePosition((unsigned int)l), coeffs[l]) && coeffs[l] != kNoValue;
+	tick("predicate + keys");
 	// keep a cell if any of its 32 nodes is kept
 	const std::vector<std::array<unsigned int, 32>> old_cells = cells;
 	cells.clear();
@@ -517,6 +521,7 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 			cell_map[i] = kNoCell;
 	}
 
+	tick("cells");
 	// nodes referenced by a surviving cell stay; the others are removed by moving the current
 	// last node into the hole, scanning from the back (:1131-1150) -- simulated on a permutation
 	std::vector<char> used(n, 0);
@@ -534,12 +539,24 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 		}
 	const std::size_t m = (std::size_t)(last + 1);
 
-	// Morton sort of the survivors (std::sort as in the reference; keys are distinct for any
-	// lattice this class can represent, so the order is unique)
+	tick("compaction");
+	// Morton sort of the survivors: the reference's std::sort on the reference's keys, over the same
+	// sequence (so that even tied keys -- possible only on strongly anisotropic lattices -- end up
+	// in the order libstdc++ gives them there).  Keys are computed for the survivors only.
+	const double zscale = 4.0 * std::min(std::min(m_inv_cell_size[0], m_inv_cell_size[1]), m_inv_cell_size[2]);
+	std::vector<uint64_t> z(m);
+#pragma omp parallel for schedule(static)
+	for (long long a = 0; a < (long long)m; ++a)
+	{
+		const Eigen::Vector3d x = indexToNodePosition(at[(std::size_t)a]);
+		const double p[3] = {x[0], x[1], x[2]};
+		z[(std::size_t)a] = z_value(p, zscale);
+	}
 	std::vector<unsigned int> order(m);
 	std::iota(order.begin(), order.end(), 0u);
-	std::sort(order.begin(), order.end(), [&](unsigned int a, unsigned int b) { return z[at[a]] < z[at[b]]; });
+	std::sort(order.begin(), order.end(), [&](unsigned int a, unsigned int b) { return z[a] < z[b]; });
 
+	tick("sort");
 	std::vector<unsigned int> new_id(n, kNoCell);
 	std::vector<double> out(m);
 	for (std::size_t i = 0; i < m; ++i)
@@ -551,6 +568,7 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 		for (auto& v : cell)
 			v = new_id[v];
 	coeffs.swap(out);
+	tick("renumber");
 }
 
 void CubicLagrangeDiscreteGrid::forEachCell(
