@@ -109,6 +109,7 @@ def main():
                     help="run the N > 1 protocol (RCCL init, shard, all_gather, unpack) even at N = 1 (self-test)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
     import torch
     import torch.distributed as dist
     import dgtest as T
