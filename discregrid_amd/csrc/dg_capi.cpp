@@ -122,6 +122,7 @@ struct dg_field
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
 	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
+	void* d_unsafe = nullptr;  // K3: flag written by k_field_check
 	double wtab_h = -1.0;
 	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
@@ -1197,6 +1198,8 @@ void dg_field_destroy(dg_field* f)
 		(void)hipFree(f->d_cell_major);
 	if (f->d_wtab)
 		(void)hipFree(f->d_wtab);
+	if (f->d_unsafe)
+		(void)hipFree(f->d_unsafe);
 	f->scratch.destroy();
 	delete f;
 }
@@ -1274,7 +1277,16 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	L.mask = d_pred_mask;
 	L.out = d_out;
 	P.wtab = static_cast<const double*>(sdf->d_wtab);
-	DG_HIP(dg::launch_density_bricks(L, sdf->dev, P, st));
+	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
+	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
+	if (env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12)
+	{
+		if (!sdf->d_unsafe)
+			DG_HIP(hipMalloc(&sdf->d_unsafe, sizeof(uint32_t)));
+		P.skip_mode = 2;
+		P.unsafe = static_cast<const uint32_t*>(sdf->d_unsafe);
+	}
+	DG_HIP(dg::launch_density_bricks(L, sdf->dev, sdf->n_coeffs, P, st));
 	return DG_OK;
 }
 

@@ -805,6 +805,15 @@ struct DensityParams
 	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
 	double w[16];       // weights
 	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
+	// Quadrature points outside the kernel's support (|xi| > h: 48 % of the cube) contribute
+	// w * (gamma * 0.0) = +0.0 to a sum of non-negative terms, i.e. nothing -- provided gamma is
+	// finite, which holds whenever every coefficient other than DBL_MAX is finite and below 1e290.
+	// kmask[i*16 + j] has bit k set where W(xi_i, xi_j, xi_k) != 0.
+	// skip_mode 0: evaluate every point; 1: skip the zero-weight points; 2 (device): skip them unless
+	// *unsafe != 0 (set by k_field_check when the field holds NaN / Inf / huge values).
+	uint16_t kmask[256];
+	int32_t skip_mode;
+	const uint32_t* unsafe;
 };
 
 // CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector
@@ -916,6 +925,7 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 	double g[3];
 	double res = 0.0;
 	const bool staged = STAGED;
+	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && P.unsafe[0] == 0u);
 	DG_NOUNROLL
 	for (int i = 0; i < 16; ++i)
 	{
@@ -925,6 +935,9 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 		DG_NOUNROLL
 		for (int j = 0; j < 16; ++j)
 		{
+			const uint32_t kmask = skip ? (uint32_t)P.kmask[i * 16 + j] : 0xffffu;
+			if (kmask == 0u)
+				continue; // the whole column lies outside the kernel's support
 			const double wij = wi * P.w[j];
 			const double yy = x[1] + P.xi[j];
 			const Axis1D ay = axis_eval(F, 1, yy);
@@ -933,6 +946,8 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 			DG_NOUNROLL
 			for (int k = 0; k < 16; ++k)
 			{
+				if (((kmask >> k) & 1u) == 0u)
+					continue;
 				const double wijk = wij * P.w[k];
 				const double yz = x[2] + P.xi[k];
 				double d;

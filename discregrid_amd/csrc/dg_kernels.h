@@ -210,7 +210,9 @@ hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_
 								  int32_t* d_entity, double* d_nearest, hipStream_t stream);
 hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream);
 hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream);
-hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream);
+// K3; with p.skip_mode == 2 a check of the n_coeffs coefficients (NaN / Inf / huge values -> *p.unsafe) runs first
+hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, uint64_t n_coeffs, const DensityParams& p,
+								 hipStream_t stream);
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 							  hipStream_t stream);

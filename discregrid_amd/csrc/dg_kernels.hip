@@ -610,12 +610,35 @@ __global__ __launch_bounds__(256) void k_unpack_ranks(const UnpackParams P)
 	}
 }
 
+// K3 pre-pass: does the field hold values for which skipping the zero-weight quadrature points would
+// change the result (NaN, Inf, |c| >= 1e290)?  DBL_MAX is the regular "no value" marker.
+__global__ __launch_bounds__(256) void k_field_check(const double* __restrict__ coeffs, uint64_t n, uint32_t* __restrict__ unsafe)
+{
+	bool bad = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const double c = coeffs[i];
+		bad = bad || (c != 1.7976931348623157e308 && !(fabs(c) < 1.0e290));
+	}
+	if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u)
+		atomicOr(unsafe, 1u);
+}
+
 } // namespace
 
-hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, const DensityParams& p, hipStream_t stream)
+hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, uint64_t n_coeffs, const DensityParams& p,
+								 hipStream_t stream)
 {
 	if (layout.total_bricks == 0)
 		return hipSuccess;
+	if (p.skip_mode == 2)
+	{
+		const hipError_t e = hipMemsetAsync(const_cast<uint32_t*>(p.unsafe), 0, sizeof(uint32_t), stream);
+		if (e != hipSuccess)
+			return e;
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_coeffs + 255) / 256, 256ull * 16ull);
+		hipLaunchKernelGGL(k_field_check, dim3(blocks), dim3(256), 0, stream, f.coeffs, n_coeffs, const_cast<uint32_t*>(p.unsafe));
+	}
 	static_assert(kWavesPerBlock == 1, "k_density_bricks assumes one brick per block");
 	if (f.cells == nullptr && f.cell_map == nullptr) // unreduced field: staged evaluator
 		hipLaunchKernelGGL(k_density_bricks<true>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);

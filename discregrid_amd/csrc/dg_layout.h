@@ -203,7 +203,20 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 			for (int kk = 0; kk < 16; ++kk)
 				wtab_host[(i * 16 + j) * 16 + kk] = cubic_kernel_W(P.xi[i], P.xi[j], P.xi[kk], h, k, HostSqrt());
 	P.wtab = nullptr;
+	for (int i = 0; i < 16; ++i)
+		for (int j = 0; j < 16; ++j)
+		{
+			uint32_t m = 0;
+			for (int kk = 0; kk < 16; ++kk)
+				if (wtab_host[(i * 16 + j) * 16 + kk] != 0.0)
+					m |= 1u << kk;
+			P.kmask[i * 16 + j] = (uint16_t)m;
+		}
+	P.skip_mode = 0;
+	P.unsafe = nullptr;
 }
+// may the zero-weight points be skipped for this coefficient? (host mirror of k_field_check)
+inline bool density_value_unsafe(double c) { return c != 1.7976931348623157e308 && !(std::fabs(c) < 1.0e290); }
 
 // the source index k_unpack_shards reads for global node l (host mirror, used by tests)
 inline uint64_t unpack_source(const UnpackParams& U, uint64_t l)

@@ -682,6 +682,8 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	}
 }
 
+int g_density_skip = 1;
+void emu_set_density_skip(int on) { g_density_skip = on; }
 // K3 on the host: the product's density_prefilter / density_integral and launch constants
 void emu_density_map(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, double h, double rho0, int band,
@@ -704,6 +706,18 @@ void emu_density_map(const double domain[6], const double cell[3], const double 
 	std::vector<double> w;
 	init_density_params(P, h, rho0, cell, band, w);
 	P.wtab = w.data();
+	// the product's rule for skipping the zero-weight quadrature points (dg_capi.cpp + k_field_check)
+	{
+		dg::ClassGeom cg[4];
+		const uint64_t n_coeffs = dg::class_geometry(res, cg);
+		bool unsafe = false;
+		if (cells == nullptr && cell_map == nullptr) // (a reduced field has fewer coefficients: leave it at "evaluate all")
+			for (uint64_t i = 0; i < n_coeffs; ++i)
+				unsafe = unsafe || density_value_unsafe(coeffs[i]);
+		else
+			unsafe = true;
+		P.skip_mode = (!unsafe && h >= 1.0e-12 && g_density_skip) ? 1 : 0;
+	}
 #pragma omp parallel for schedule(dynamic, 16)
 	for (long long l = (long long)begin; l < (long long)end; ++l)
 	{
