@@ -805,7 +805,7 @@ struct DensityParams
 	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
 	double w[16];       // weights
 	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
-	// Quadrature points outside the kernel's support (|xi| > h: 48 % of the cube) contribute
+	// Quadrature points outside the kernel's support (|xi| > h: 3088 of the 4096 points) contribute
 	// w * (gamma * 0.0) = +0.0 to a sum of non-negative terms, i.e. nothing -- provided gamma is
 	// finite, which holds whenever every coefficient other than DBL_MAX is finite and below 1e290.
 	// kmask[i*16 + j] has bit k set where W(xi_i, xi_j, xi_k) != 0.
