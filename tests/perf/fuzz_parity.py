@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (run on the GPU box): random meshes x random lattices x random point
-sets, K1 / K1p / K2 through the C ABI against the CPU oracle, bit for bit (unsigned distance for
+sets, K1 / K1p / K2 / K3 through the C ABI against the CPU oracle, bit for bit (unsigned distance for
 meshes that are not closed).  usage: fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
@@ -49,6 +49,7 @@ def main():
     rng = np.random.default_rng(seed)
     t0 = time.time()
     rounds = nodes = points = 0
+    k3_rounds = [0]
     while time.time() - t0 < budget:
         name, V, F, closed = random_mesh(rng)
         om, m = T.OracleMesh(V, F), dg.Mesh(V, F)
@@ -75,13 +76,32 @@ def main():
         same_field = np.array_equal(got, want)
         if same_field:
             ok = ok and np.array_equal(phi, wphi) and np.array_equal(grad[inside], wgrad[inside])
+        # K3 on a slice of the lattice, now and then on a field spoilt with NaN / Inf / huge / DBL_MAX values
+        # (those must take the evaluate-every-point path and still match the oracle, NaNs included)
+        if rounds % 4 == 0 and len(got) > 64:
+            sdf = want.copy()
+            spoil = rng.integers(0, 4)
+            if spoil == 1:
+                sdf[rng.integers(0, len(sdf), size=3)] = [np.nan, np.inf, -1.0e300]
+            elif spoil == 2:
+                sdf[rng.integers(0, len(sdf), size=5)] = np.finfo(np.float64).max
+            h = float(rng.uniform(0.05, 0.6)) * float(ext.max())
+            band = bool(rng.integers(0, 2))
+            b = int(rng.integers(0, len(sdf) - 60))
+            e = b + int(rng.integers(1, 60))
+            fk = dg.Field(grid, sdf)
+            k3 = fk.density_map_nodes(len(sdf), h, 1000.0, band, b, e)
+            w3 = T.oracle_density_map(dom, res, sdf, h, 1000.0, band, b, e)
+            ok = ok and np.array_equal(k3, w3, equal_nan=True)
+            k3_rounds[0] += 1
         rounds += 1
         nodes += len(got)
         points += len(P)
         if not ok:
             print("MISMATCH in round %d (seed %d): %s, %d triangles, res %s" % (rounds, seed, name, len(F), res))
             sys.exit(1)
-    print("fuzz ok: %d rounds, %d lattice nodes, %d points, seed %d, %.0f s" % (rounds, nodes, points, seed, time.time() - t0))
+    print("fuzz ok: %d rounds (%d with a density-map slice), %d lattice nodes, %d points, seed %d, %.0f s" % (
+        rounds, k3_rounds[0], nodes, points, seed, time.time() - t0))
 
 
 if __name__ == "__main__":
