@@ -946,11 +946,27 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 {
 	if (!mesh || (n && (!d_xyz || !d_dist)))
 		return fail(DG_ERR_INVALID, "null argument");
+	if (n == 0)
+		return DG_OK;
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// Batches go through the binned launch: a wave's traversal costs the union of what its 64 points
-	// need, so points that arrive in arbitrary order are grouped into compact tiles first (decided on
-	// the device; ordered inputs run as they are).  The tile grid covers the mesh's bounding box grown
-	// by its own size; points farther out are clamped into the border tiles.  DG_K1P_BINNING=0: off.
+	dg::SampleParams P;
+	const double zero[3] = {0.0, 0.0, 0.0};
+	dg::init_params(P, mesh->dev, zero, zero, 0);
+	P.xcd_chunk = env_xcd_chunk();
+	P.pts.xyz = d_xyz;
+	P.pts.n = n;
+	P.pts.dist = d_dist;
+	P.pts.tri = d_tri;
+	P.pts.entity = d_entity;
+	P.pts.nearest = d_nearest;
+	dg::layout_points(P, n);
+	// Batches are binned first: a wave's traversal costs the union of what its 64 points need, so points
+	// that arrive in arbitrary order are grouped into compact tiles (decided on the device; ordered
+	// inputs run as they are).  The tile grid covers the mesh's bounding box grown by its own size;
+	// points farther out are clamped into the border tiles.  DG_K1P_BINNING=0: off.
+	dg::TileGrid tiles;
+	dg::BinScratch S;
+	int bin_idx = -1;
 	if (n >= 4096 && n < 0xffffffffull && env_int("DG_K1P_BINNING", 1, 0, 1) != 0)
 	{
 		double lo[3], hi[3];
@@ -960,26 +976,27 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 			lo[d] = mesh->bbox_lo[d] - 0.5 * ext;
 			hi[d] = mesh->bbox_hi[d] + 0.5 * ext;
 		}
-		const dg::TileGrid tiles = dg::point_tiles(lo, hi, n);
+		tiles = dg::point_tiles(lo, hi, n);
 		size_t off[4];
 		const size_t bytes = dg::bin_scratch_bytes(dg::tile_count(tiles), n, off);
 		void* mem = nullptr;
-		const int idx = mesh->bin_scratch.acquire(bytes, st, &mem);
-		if (idx >= 0)
+		bin_idx = mesh->bin_scratch.acquire(bytes, st, &mem);
+		if (bin_idx >= 0)
 		{
 			char* base = static_cast<char*>(mem);
-			dg::BinScratch S;
 			S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
 			S.start = reinterpret_cast<uint32_t*>(base + off[1]);
 			S.cursor = reinterpret_cast<uint32_t*>(base + off[2]);
 			S.perm = reinterpret_cast<uint32_t*>(base + off[3]);
-			const hipError_t e = dg::launch_signed_distance_binned(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest, tiles, S, st);
-			mesh->bin_scratch.release(idx, st);
-			DG_HIP(e);
-			return DG_OK;
+			P.pts.bin_flag = S.flag;
+			P.pts.perm = S.perm;
 		}
 	}
-	DG_HIP(dg::launch_signed_distance(mesh->dev, d_xyz, n, d_dist, d_tri, d_entity, d_nearest, st));
+	const int heavy_idx = acquire_heavy_scratch(mesh, P, st);
+	const hipError_t e = dg::launch_signed_distance(P, bin_idx >= 0 ? &tiles : nullptr, bin_idx >= 0 ? &S : nullptr, st);
+	release_heavy_scratch(mesh, heavy_idx, st);
+	mesh->bin_scratch.release(bin_idx, st);
+	DG_HIP(e);
 	return DG_OK;
 }
 

@@ -85,6 +85,19 @@ struct MeshDev
 };
 static const int kStackDepth = 32; // >= tree depth; 2^32 leaves of >= 1 triangle is beyond the 2^27 triangle limit
 
+// K1p: caller-supplied points instead of lattice nodes (xyz == nullptr: lattice mode).
+struct PointsDesc
+{
+	const double* xyz;        // 3 doubles per point
+	uint64_t n;
+	const uint32_t* bin_flag; // nullable; *bin_flag != 0: thread t takes point perm[t] (points binned into tiles)
+	const uint32_t* perm;
+	double* dist;             // outputs, indexed like xyz; tri / entity / nearest nullable
+	int32_t* tri;
+	int32_t* entity;
+	double* nearest;
+};
+
 // One of the four node classes of the lattice as the K1 kernel sees it (see dg_geom.h
 // node_position() for the (a, b, s) coordinates).  The kernel walks "packed planes"
 // q in [q_begin, q_end); plane q is lattice plane s = q (whole-grid / range mode) or the
@@ -114,6 +127,7 @@ struct SampleParams
 	const uint8_t* mask;     // indexed like out; nullable
 	double* out;
 	OverflowBuf ovf;
+	PointsDesc pts;          // K1p: "brick" b = the 64 points (in processing order) b*64 .. b*64+63
 };
 
 // Which lattice node does `lane` of brick `brick` own?  Shared by the kernel and by the host-side
@@ -206,8 +220,6 @@ DG_HD uint64_t unpack_dest(const UnpackParams& U, uint32_t r, uint64_t off)
 
 // K1 (+ the two heavy-brick kernels when p.ovf.count is set; the caller zeroes *p.ovf.count first)
 hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream);
-hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
-								  int32_t* d_entity, double* d_nearest, hipStream_t stream);
 hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream);
 hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream);
 // K3; with p.skip_mode == 2 a check of the n_coeffs coefficients (NaN / Inf / huge values -> *p.unsafe) runs first
@@ -281,10 +293,12 @@ inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[4])
 }
 hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 									 const BinScratch& scratch, hipStream_t stream);
-// K1p with the same binning: the packet traversal of a wave costs the UNION of what its 64 points
-// need, so points in arbitrary order (7 x slower than lattice order) are grouped into compact tiles
-hipError_t launch_signed_distance_binned(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
-										 int32_t* d_entity, double* d_nearest, const TileGrid& tiles, const BinScratch& scratch,
-										 hipStream_t stream);
+// K1p: p.pts describes the points and outputs, p.total_bricks etc. come from layout_points().  The
+// packet traversal of a wave costs the UNION of what its 64 points need, so with tiles != nullptr
+// points that arrive in arbitrary order (7 x slower than lattice order) are first grouped into
+// compact tiles (scratch = the BinScratch behind p.pts.bin_flag / perm).  Heavy "bricks" (64 points
+// around the centre of a sphere-like mesh) are split like K1's when p.ovf is set.
+hipError_t launch_signed_distance(const SampleParams& p, const TileGrid* tiles, const BinScratch* scratch, hipStream_t stream);
+
 
 } // namespace dg

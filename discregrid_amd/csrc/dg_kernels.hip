@@ -3,7 +3,7 @@
 //   K1  k_sample_nodes     lattice node -> signed distance to the mesh   (addFunction node loop,
 //                          discregrid/src/cubic_lagrange_discrete_grid.cpp:806-831 +
 //                          TriangleMeshDistance.h:269-308, 514-562, 564-820)
-//   K1p k_signed_distance  same traversal for caller-supplied points (TriangleMeshDistance.h:269-314)
+//   K1p k_sample_nodes<1>  same kernels for caller-supplied points (TriangleMeshDistance.h:269-314)
 //   K2  k_interpolate      batched CubicLagrangeDiscreteGrid::interpolate (:977-1063), with
 //       k_bin_*            device-side binning of unordered query batches into 8^3-cell tiles
 //   K3  k_density_bricks   SPH boundary density map (cmd/generate_density_map/main.cpp:86-133)
@@ -244,23 +244,94 @@ __device__ __forceinline__ LaneResult finish(const MeshDev& M, const LaneQuery& 
 	return finish_query(M.tris, M.pn, q, DeviceSqrt());
 }
 
-// K1 epilogue: the node value of one lane
-__device__ __forceinline__ void write_node(const SampleParams& P, bool valid, bool sample, int64_t out_idx, const LaneQuery& q)
+// What one lane of a K1 wave works on: a lattice node of the wave's brick (POINTS = false) or one of
+// 64 consecutive caller-supplied points (K1p, POINTS = true; "consecutive" in processing order, i.e.
+// through SampleParams::pts.perm when the points were binned).
+struct LaneTask
 {
-	if (!valid)
-		return;
-	double v = 1.7976931348623157e308; // predicate-rejected node (:817)
-	if (sample && q.best_tri >= 0)
+	bool valid;     // the lane owns a result
+	bool sample;    // ... and has to compute it (not masked off)
+	int64_t out_idx;
+	double x0, x1, x2;
+};
+template <bool POINTS>
+__device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t brick, int lane)
+{
+	LaneTask t;
+	if (POINTS)
 	{
-		const LaneResult r = finish(P.mesh, q);
-		v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+		const uint64_t slot = brick * 64u + (uint64_t)lane;
+		t.valid = slot < P.pts.n;
+		uint64_t i = t.valid ? slot : P.pts.n - 1;
+		if (P.pts.bin_flag != nullptr && P.pts.bin_flag[0] != 0u)
+			i = P.pts.perm[i];
+		t.sample = t.valid;
+		t.out_idx = (int64_t)i;
+		t.x0 = P.pts.xyz[3 * i];
+		t.x1 = P.pts.xyz[3 * i + 1];
+		t.x2 = P.pts.xyz[3 * i + 2];
 	}
-	P.out[out_idx] = v;
+	else
+	{
+		const LaneNode ln = map_lane(P, brick, lane);
+		t.valid = ln.valid;
+		t.out_idx = ln.out_idx;
+		t.sample = ln.valid;
+		if (ln.valid && P.mask != nullptr)
+			t.sample = P.mask[ln.out_idx] != 0;
+		// masked-off lanes still carry a sane (clamped) point; they never hit anything
+		double x[3];
+		node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+		t.x0 = x[0];
+		t.x1 = x[1];
+		t.x2 = x[2];
+	}
+	return t;
+}
+// epilogue: the lane's result(s)
+template <bool POINTS>
+__device__ __forceinline__ void write_result(const SampleParams& P, const LaneTask& t, const LaneQuery& q)
+{
+	if (!t.valid)
+		return;
+	const bool hit = t.sample && q.best_tri >= 0;
+	if (POINTS)
+	{
+		const int64_t i = t.out_idx;
+		if (!hit)
+		{
+			P.pts.dist[i] = 1.7976931348623157e308;
+			if (P.pts.tri) P.pts.tri[i] = -1;
+			if (P.pts.entity) P.pts.entity[i] = -1;
+			return;
+		}
+		const LaneResult r = finish(P.mesh, q);
+		P.pts.dist[i] = r.signed_dist;
+		if (P.pts.tri) P.pts.tri[i] = r.tri_id;
+		if (P.pts.entity) P.pts.entity[i] = r.entity;
+		if (P.pts.nearest)
+		{
+			P.pts.nearest[3 * i] = r.nearest[0];
+			P.pts.nearest[3 * i + 1] = r.nearest[1];
+			P.pts.nearest[3 * i + 2] = r.nearest[2];
+		}
+	}
+	else
+	{
+		double v = 1.7976931348623157e308; // predicate-rejected node (:817)
+		if (hit)
+		{
+			const LaneResult r = finish(P.mesh, q);
+			v = P.invert ? -1.0 * r.signed_dist : r.signed_dist;
+		}
+		P.out[t.out_idx] = v;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one wave per 4x4x4 brick of one node class.
+// K1 / K1p: one wave per 4x4x4 brick of one node class, or per 64 points.
 // ------------------------------------------------------------------------------------------------
+template <bool POINTS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample_nodes(const SampleParams P)
 {
 	uint32_t blk;
@@ -271,21 +342,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 	const uint64_t brick = (uint64_t)blk * (uint64_t)kWavesPerBlock + (uint64_t)wave;
 	if (brick >= P.total_bricks)
 		return;
-
-	const LaneNode ln = map_lane(P, brick, lane);
-	const bool valid = ln.valid;
-	const int64_t out_idx = ln.out_idx;
-	bool sample = valid;
-	if (valid && P.mask != nullptr)
-		sample = P.mask[out_idx] != 0;
-	// masked-off lanes still carry a sane (clamped) point; they never hit anything
-	double x[3];
-	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+	const LaneTask t = lane_task<POINTS>(P, brick, lane);
 
 	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [waves][stack_levels][64]
 	LaneQuery q;
-	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
-	if (__ballot(sample) != 0ull)
+	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	if (__ballot(t.sample) != 0ull)
 	{
 		const int slot = traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64), P.mesh.root_info,
 								  P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
@@ -298,12 +360,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 			return;
 		}
 	}
-	write_node(P, valid, sample, out_idx, q);
+	write_result<POINTS>(P, t, q);
 }
 
 // Heavy bricks, step 2: job (slot, s) searches subtree s of the BVH for the brick parked in `slot`,
 // starting from the parked bests.  One wave per block, jobs dealt grid-stride (the number of parked
 // bricks is only known on the device).
+template <bool POINTS>
 __global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
 {
 	const uint32_t n_sub = (uint32_t)P.mesh.n_sub;
@@ -314,16 +377,11 @@ __global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
 	{
 		const uint32_t slot = job / n_sub;
 		const uint32_t s = job - slot * n_sub;
-		const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
-		bool sample = ln.valid;
-		if (ln.valid && P.mask != nullptr)
-			sample = P.mask[ln.out_idx] != 0;
-		double x[3];
-		node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+		const LaneTask t = lane_task<POINTS>(P, (uint64_t)P.ovf.brick[slot], lane);
 		LaneQuery q;
-		init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
+		init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
 		const int tri = P.ovf.saved_tri[slot * 64 + lane];
-		if (sample && tri >= 0)
+		if (t.sample && tri >= 0)
 			offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
 		traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
 		const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
@@ -334,21 +392,17 @@ __global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
 
 // Heavy bricks, step 3: per lane the minimum over the subtrees (the parked best is part of every
 // candidate; of exactly tied candidates the lowest subtree wins), then K1's epilogue.
+template <bool POINTS>
 __global__ __launch_bounds__(64) void k_heavy_finish(const SampleParams P)
 {
 	const uint32_t slot = blockIdx.x;
 	if (slot >= min(*P.ovf.count, P.ovf.slots))
 		return;
 	const int lane = (int)threadIdx.x;
-	const LaneNode ln = map_lane(P, (uint64_t)P.ovf.brick[slot], lane);
-	bool sample = ln.valid;
-	if (ln.valid && P.mask != nullptr)
-		sample = P.mask[ln.out_idx] != 0;
-	double x[3];
-	node_position(ln.cls, ln.a, ln.b, ln.s, P.dmin, P.cell, x);
+	const LaneTask t = lane_task<POINTS>(P, (uint64_t)P.ovf.brick[slot], lane);
 	LaneQuery q;
-	init_query(P.mesh.origin, P.mesh.mesh_l1, sample, x[0], x[1], x[2], q);
-	if (sample)
+	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	if (t.sample)
 		for (int s = 0; s < P.mesh.n_sub; ++s)
 		{
 			const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)lane;
@@ -356,46 +410,7 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const SampleParams P)
 			if (tri >= 0)
 				offer(q, P.ovf.cand_d2[at], tri);
 		}
-	write_node(P, ln.valid, sample, ln.out_idx, q);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1p: caller-supplied points, 64 consecutive points per wave.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_signed_distance(const MeshDev M, const double* __restrict__ xyz, uint64_t n,
-														  double* __restrict__ dist, int32_t* __restrict__ tri,
-														  int32_t* __restrict__ entity, double* __restrict__ nearest,
-														  const uint32_t* __restrict__ bin_flag, const uint32_t* __restrict__ perm)
-{
-	uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const bool valid = gid < n;
-	// binned launch: thread t handles point perm[t], i.e. the points tile by tile (dg_kernels.h)
-	if (bin_flag != nullptr && bin_flag[0] != 0)
-		gid = perm[valid ? gid : (n - 1)];
-	const uint64_t g = valid ? gid : (n - 1);
-	LaneQuery q;
-	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [4 waves][stack_levels][64]
-	init_query(M.origin, M.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], q);
-	traverse(M, q, lds_lb + (threadIdx.x >> 6) * (M.stack_levels * 64), M.root_info, nullptr, 0u, 0);
-	if (!valid)
-		return;
-	if (q.best_tri < 0)
-	{
-		dist[gid] = 1.7976931348623157e308;
-		if (tri) tri[gid] = -1;
-		if (entity) entity[gid] = -1;
-		return;
-	}
-	const LaneResult r = finish(M, q);
-	dist[gid] = r.signed_dist;
-	if (tri) tri[gid] = r.tri_id;
-	if (entity) entity[gid] = r.entity;
-	if (nearest)
-	{
-		nearest[3 * gid] = r.nearest[0];
-		nearest[3 * gid + 1] = r.nearest[1];
-		nearest[3 * gid + 2] = r.nearest[2];
-	}
+	write_result<POINTS>(P, t, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,7 +475,7 @@ __device__ __forceinline__ uint32_t tile_of(const TileGrid& G, const double* __r
 	return (t[2] * G.dims[1] + t[1]) * G.dims[0] + t[0];
 }
 // one block: how often do consecutive queries (among the first 4096) change tile?
-__global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+__global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S, uint32_t one_in)
 {
 	__shared__ uint32_t changes;
 	if (threadIdx.x == 0)
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const doubl
 	atomicAdd(&changes, mine);
 	__syncthreads();
 	if (threadIdx.x == 0)
-		S.flag[0] = (4ull * changes > m) ? 1u : 0u;
+		S.flag[0] = ((uint64_t)one_in * changes > m) ? 1u : 0u; // more than one change of tile in `one_in` steps
 }
 __global__ __launch_bounds__(256) void k_bin_hist(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
 {
@@ -655,62 +670,53 @@ hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out
 	return hipGetLastError();
 }
 
-hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream)
+template <bool POINTS>
+static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 {
 	if (p.total_bricks == 0)
 		return hipSuccess;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
 	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
-	hipLaunchKernelGGL(k_sample_nodes, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
+	hipLaunchKernelGGL(k_sample_nodes<POINTS>, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
 	if (p.ovf.count != nullptr)
 	{
 		const size_t lds1 = (size_t)p.mesh.stack_levels * 64 * sizeof(float);
 		const uint32_t jobs = p.ovf.slots * (uint32_t)p.mesh.n_sub;
-		hipLaunchKernelGGL(k_heavy_subtrees, dim3(jobs < 32768u ? jobs : 32768u), dim3(64), lds1, stream, p);
-		hipLaunchKernelGGL(k_heavy_finish, dim3(p.ovf.slots), dim3(64), 0, stream, p);
+		hipLaunchKernelGGL(k_heavy_subtrees<POINTS>, dim3(jobs < 32768u ? jobs : 32768u), dim3(64), lds1, stream, p);
+		hipLaunchKernelGGL(k_heavy_finish<POINTS>, dim3(p.ovf.slots), dim3(64), 0, stream, p);
 	}
 	return hipGetLastError();
 }
 
-hipError_t launch_signed_distance(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
-								  int32_t* d_entity, double* d_nearest, hipStream_t stream)
-{
-	if (n == 0)
-		return hipSuccess;
-	const uint32_t grid = (uint32_t)((n + 255) / 256);
-	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), (size_t)4 * m.stack_levels * 64 * sizeof(float), stream, m, d_xyz, n, d_dist, d_tri, d_entity,
-					   d_nearest, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-	return hipGetLastError();
-}
+hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream) { return launch_k1<false>(p, stream); }
 
 // the binning passes shared by K2 and K1p: S.flag / S.perm describe the order to process the points in
-static hipError_t launch_binning(const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, hipStream_t stream)
+static hipError_t launch_binning(const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
 {
 	const uint32_t n_tiles = tile_count(tiles);
 	hipError_t e = hipMemsetAsync(S.start, 0, (size_t)n_tiles * sizeof(uint32_t), stream);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
-	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, tiles, d_xyz, n, S, one_in);
 	hipLaunchKernelGGL(k_bin_hist, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
 	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, n_tiles, S);
 	hipLaunchKernelGGL(k_bin_scatter, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
 	return hipGetLastError();
 }
 
-hipError_t launch_signed_distance_binned(const MeshDev& m, const double* d_xyz, uint64_t n, double* d_dist, int32_t* d_tri,
-										 int32_t* d_entity, double* d_nearest, const TileGrid& tiles, const BinScratch& S,
-										 hipStream_t stream)
+hipError_t launch_signed_distance(const SampleParams& p, const TileGrid* tiles, const BinScratch* scratch, hipStream_t stream)
 {
-	if (n == 0)
+	if (p.pts.n == 0)
 		return hipSuccess;
-	const hipError_t e = launch_binning(tiles, d_xyz, n, S, stream);
-	if (e != hipSuccess)
-		return e;
-	const uint32_t grid = (uint32_t)((n + 255) / 256);
-	hipLaunchKernelGGL(k_signed_distance, dim3(grid), dim3(256), (size_t)4 * m.stack_levels * 64 * sizeof(float), stream, m, d_xyz, n, d_dist, d_tri, d_entity,
-					   d_nearest, (const uint32_t*)S.flag, (const uint32_t*)S.perm);
-	return hipGetLastError();
+	if (tiles != nullptr && scratch != nullptr)
+	{
+		// K1p gains from 3-D compactness even for row-ordered input: bin unless consecutive points share a tile 15 times out of 16
+		const hipError_t e = launch_binning(*tiles, p.pts.xyz, p.pts.n, *scratch, 16u, stream);
+		if (e != hipSuccess)
+			return e;
+	}
+	return launch_k1<true>(p, stream);
 }
 
 hipError_t launch_unpack(const UnpackParams& p, hipStream_t stream)
@@ -755,7 +761,8 @@ hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uin
 {
 	if (n == 0)
 		return hipSuccess;
-	const hipError_t e = launch_binning(field_tiles(f), d_xyz, n, S, stream);
+	// K2: row-ordered queries are coherent enough; bin only if more than a quarter of the steps change tile
+	const hipError_t e = launch_binning(field_tiles(f), d_xyz, n, S, 4u, stream);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = (uint32_t)((n + 255) / 256);

@@ -149,6 +149,23 @@ inline void layout_shard(SampleParams& P, const uint32_t res[3], int rank, int n
 	finish_bricks(P);
 }
 
+// K1p: n points, 64 per wave in processing order (P.pts filled by the caller)
+inline void layout_points(SampleParams& P, uint64_t n)
+{
+	for (int c = 0; c < 4; ++c)
+		std::memset(&P.cls[c], 0, sizeof(ClassDesc));
+	P.shard_rank = 0;
+	P.shard_n = 1;
+	P.total_bricks = (n + 63) / 64;
+	P.n_blocks = (uint32_t)((P.total_bricks + kWavesPerBlock - 1) / kWavesPerBlock);
+	if (P.xcd_chunk == 0)
+		P.xcd_chunk = kXcdChunk;
+	if (P.xcd_chunk == 0xffffffffu)
+		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
+	const uint32_t per_group = 8u * P.xcd_chunk;
+	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
+}
+
 inline void layout_unpack(UnpackParams& U, const uint32_t res[3], int nranks)
 {
 	std::memset(&U, 0, sizeof(U));
