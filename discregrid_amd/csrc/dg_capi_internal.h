@@ -1,0 +1,215 @@
+// dg_capi_internal.h -- shared by the translation units that implement include/discregrid_hip.h:
+//   dg_capi.cpp        runtime, grid helpers, mesh handle, K1 / K1p device entry points, sharding
+//   dg_capi_field.cpp  field handle, K2 and K3 device entry points
+//   dg_capi_host.cpp   the host-pointer entry points (pinned staging pipeline)
+#pragma once
+#include "../../include/discregrid_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dg_build.h"
+#include "dg_kernels.h"
+#include "dg_layout.h"
+
+// Stream-ordered scratch buffers kept with a handle: a buffer is handed out again once the work that
+// used it has finished (or to the same stream, where work is ordered anyway).
+struct ScratchPool
+{
+	struct Buf
+	{
+		void* mem = nullptr;
+		size_t bytes = 0;
+		hipEvent_t done = nullptr;
+		hipStream_t stream = nullptr;
+		bool busy = false;
+	};
+	std::mutex mutex;
+	std::vector<Buf> bufs;
+
+	int acquire(size_t bytes, hipStream_t stream, void** mem)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		int idx = -1;
+		for (size_t i = 0; i < bufs.size() && idx < 0; ++i)
+			if (!bufs[i].busy && bufs[i].bytes >= bytes && (bufs[i].stream == stream || hipEventQuery(bufs[i].done) == hipSuccess))
+				idx = (int)i;
+		if (idx < 0)
+		{
+			Buf b;
+			b.bytes = bytes;
+			if (hipMalloc(&b.mem, bytes) != hipSuccess || hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				if (b.mem) (void)hipFree(b.mem);
+				return -1;
+			}
+			bufs.push_back(b);
+			idx = (int)bufs.size() - 1;
+		}
+		bufs[(size_t)idx].busy = true;
+		bufs[(size_t)idx].stream = stream;
+		*mem = bufs[(size_t)idx].mem;
+		return idx;
+	}
+	void release(int idx, hipStream_t stream)
+	{
+		if (idx < 0)
+			return;
+		std::lock_guard<std::mutex> lock(mutex);
+		(void)hipEventRecord(bufs[(size_t)idx].done, stream);
+		bufs[(size_t)idx].busy = false;
+	}
+	void destroy()
+	{
+		for (Buf& b : bufs)
+		{
+			if (b.done) (void)hipEventDestroy(b.done);
+			if (b.mem) (void)hipFree(b.mem);
+		}
+		bufs.clear();
+	}
+};
+
+// Scratch of one K1 launch for its heavy bricks (dg_kernels.h: OverflowBuf).  Buffers are kept with
+// the mesh and handed out again once the launch that used them has finished (or to the same stream,
+// where launches are ordered anyway), so steady-state launches allocate nothing.
+struct HeavyScratch
+{
+	void* mem = nullptr;
+	hipEvent_t done = nullptr;
+	hipStream_t stream = nullptr;
+	uint32_t slots = 0;      // capacity the buffer was laid out for
+	uint32_t used_slots = 0; // slots the most recent launch was given
+	bool busy = false; // between acquire and the event record
+	uint64_t serial = 0; // order of use
+};
+
+struct dg_mesh
+{
+	dg::MeshDev dev;
+	void* d_pairs = nullptr;
+	void* d_tri_pairs = nullptr;
+	void* d_tris = nullptr;
+	void* d_pn = nullptr;
+	int device = -1;
+	dg_mesh_info info;
+	mutable std::mutex scratch_mutex;
+	mutable std::vector<HeavyScratch> scratch;
+	mutable uint64_t scratch_serial = 0;
+	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
+	mutable ScratchPool bin_scratch;     // K1p point binning
+	double bbox_lo[3], bbox_hi[3];       // of the vertices
+};
+
+struct dg_field
+{
+	dg::FieldDev dev;
+	mutable ScratchPool scratch; // K2 query binning
+	void* owned[3] = {nullptr, nullptr, nullptr};
+	void* d_cell_major = nullptr;
+	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
+	void* d_unsafe = nullptr;  // K3: flag written by k_field_check
+	double wtab_h = -1.0;
+	dg_grid_desc grid;
+	uint64_t n_coeffs = 0;
+	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)
+	int device = -1;
+};
+
+
+// ---- shared internals (defined in dg_capi.cpp) ---------------------------------------------------------------
+extern thread_local std::string g_error;  // dg_last_error()
+extern thread_local double g_last_ms;     // dg_last_kernel_ms()
+dg_status fail(dg_status s, const char* fmt, ...);
+dg_status require_device();
+bool valid_grid(const dg_grid_desc* g);
+int env_int(const char* name, int fallback, int lo, int hi);
+uint32_t env_xcd_chunk();
+// heavy-brick scratch of a K1 / K1p launch (dg_kernels.h: OverflowBuf)
+int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream);
+void release_heavy_scratch(const dg_mesh* mesh, int idx, hipStream_t stream);
+
+#define DG_HIP(call)                                                                                         \
+	do                                                                                                       \
+	{                                                                                                        \
+		hipError_t e_ = (call);                                                                              \
+		if (e_ != hipSuccess)                                                                                \
+			return fail(DG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+// ---- helpers of the host-pointer entry points --------------------------------------------------------------
+// Device allocations and the timing events of ONE call: released when the call returns, whichever
+// way it returns.  The first failing HIP call is remembered in `err`; later steps become no-ops.
+struct HostCall
+{
+	std::vector<void*> allocations;
+	hipEvent_t begin = nullptr, end = nullptr;
+	hipError_t err = hipSuccess;
+
+	~HostCall()
+	{
+		for (void* p : allocations)
+			(void)hipFree(p);
+		if (begin) (void)hipEventDestroy(begin);
+		if (end) (void)hipEventDestroy(end);
+	}
+	template <class T>
+	T* device(uint64_t count, bool wanted = true)
+	{
+		if (!wanted || err != hipSuccess)
+			return nullptr;
+		void* p = nullptr;
+		err = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 1));
+		if (err != hipSuccess)
+			return nullptr;
+		allocations.push_back(p);
+		return static_cast<T*>(p);
+	}
+	void upload(void* dst, const void* src, size_t bytes)
+	{
+		if (err == hipSuccess && dst)
+			err = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+	}
+	void download(void* dst, const void* src, size_t bytes)
+	{
+		if (err == hipSuccess && dst)
+			err = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+	}
+	void start_timer()
+	{
+		if (err == hipSuccess) err = hipEventCreate(&begin);
+		if (err == hipSuccess) err = hipEventCreate(&end);
+		if (err == hipSuccess) err = hipEventRecord(begin, nullptr);
+	}
+	void stop_timer()
+	{
+		if (err == hipSuccess) err = hipEventRecord(end, nullptr);
+	}
+	void publish_time() // after the downloads (they synchronise with the null stream)
+	{
+		float ms = -1.f;
+		if (err == hipSuccess && begin && end && hipEventElapsedTime(&ms, begin, end) == hipSuccess)
+			g_last_ms = ms;
+	}
+	dg_status status(const char* what) const
+	{
+		if (err == hipSuccess)
+			return DG_OK;
+		return fail(err == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+	}
+};
+

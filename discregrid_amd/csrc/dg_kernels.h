@@ -1,4 +1,4 @@
-// dg_kernels.h -- launch interface between the C ABI (dg_capi.cpp) and the gfx950 kernels
+// dg_kernels.h -- launch interface between the C ABI (dg_capi*.cpp) and the gfx950 kernels
 // (dg_kernels.hip).  Plain C++ structs, no HIP types in the signatures except the stream.
 #pragma once
 #include <cstdint>

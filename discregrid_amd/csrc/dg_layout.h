@@ -1,7 +1,7 @@
 // dg_layout.h -- host-side decomposition of the node lattice into the 4x4x4 bricks the K1
 // kernel consumes, for (a) a flat node range [node_begin, node_end) and (b) one rank's shard
 // of a multi-GPU run.  Pure index arithmetic, no device work.  Shared by the C ABI
-// (dg_capi.cpp) and the wave emulator of the CPU tests.
+// (dg_capi*.cpp) and the wave emulator of the CPU tests.
 #pragma once
 #include <algorithm>
 #include <cmath>

@@ -706,7 +706,7 @@ void emu_density_map(const double domain[6], const double cell[3], const double 
 	std::vector<double> w;
 	init_density_params(P, h, rho0, cell, band, w);
 	P.wtab = w.data();
-	// the product's rule for skipping the zero-weight quadrature points (dg_capi.cpp + k_field_check)
+	// the product's rule for skipping the zero-weight quadrature points (dg_capi_field.cpp + k_field_check)
 	{
 		dg::ClassGeom cg[4];
 		const uint64_t n_coeffs = dg::class_geometry(res, cg);
