@@ -19,7 +19,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 SOURCES_HIP = ["dg_kernels.hip"]
 SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_build.cpp"]
-HEADERS = ["dg_geom.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
+HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
 
 
 def _stale():

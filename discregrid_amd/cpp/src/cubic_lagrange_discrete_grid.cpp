@@ -20,7 +20,7 @@
 #include <stdexcept>
 
 #include "discregrid_hip.h"
-#include "dg_geom.h"
+#include "dg_lattice.h"
 
 namespace Discregrid
 {

@@ -5,10 +5,10 @@
 // level set).  No function in this header touches memory other than its
 // arguments.
 //
-// Reference lines restated (paths relative to the Discregrid tree):
-//   point/triangle distance  discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:564-820
-//   node positions           discregrid/src/cubic_lagrange_discrete_grid.cpp:604-665
-//   shape functions          discregrid/src/cubic_lagrange_discrete_grid.cpp:339-580
+// This header: the mesh side -- bound records, triangle packets, the point/triangle test and the
+// per-lane query state (reference: discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:564-820).
+// The grid side is in dg_lattice.h (node positions, shape functions, interpolation) and
+// dg_density.h (the density-map integrand).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -487,593 +487,6 @@ DG_HD LaneResult finish_query(const TriPacket* tris, const double* pn_all, const
 	r.tri_id = T.tri_id;
 	r.entity = h.entity;
 	return r;
-}
-
-// ---- lattice node positions ---------------------------------------------------------------------------
-// Node class c in {0:V, 1:X, 2:Y, 3:Z}; (a, b, s) are the class' own (fastest, middle, slowest)
-// lattice coordinates, i.e. class-local flat index = (s*D1 + b)*D0 + a with
-//   V: (i, j, k)         D = (nx+1, ny+1, nz+1)
-//   X: (2i+h, j, k)      D = (2nx,  ny+1, nz+1)      h = 0: node at 1/3, h = 1: at 2/3 of the edge
-//   Y: (2j+h, k, i)      D = (2ny,  nz+1, nx+1)
-//   Z: (2k+h, i, j)      D = (2nz,  nx+1, ny+1)
-// which is exactly the order indexToNodePosition() enumerates (cubic_lagrange_discrete_grid.cpp:618-662).
-DG_HD void class_dims(int c, const uint32_t res[3], uint32_t D[3])
-{
-	const uint32_t nx = res[0], ny = res[1], nz = res[2];
-	if (c == 0) { D[0] = nx + 1; D[1] = ny + 1; D[2] = nz + 1; }
-	else if (c == 1) { D[0] = 2 * nx; D[1] = ny + 1; D[2] = nz + 1; }
-	else if (c == 2) { D[0] = 2 * ny; D[1] = nz + 1; D[2] = nx + 1; }
-	else { D[0] = 2 * nz; D[1] = nx + 1; D[2] = ny + 1; }
-}
-DG_HD void node_position(int c, uint32_t a, uint32_t b, uint32_t s, const double dmin[3], const double cell[3],
-						 double x[3])
-{
-	uint32_t i, j, k, h = a & 1u;
-	if (c == 0) { i = a; j = b; k = s; }
-	else if (c == 1) { i = a >> 1; j = b; k = s; }
-	else if (c == 2) { j = a >> 1; k = b; i = s; }
-	else { k = a >> 1; i = b; j = s; }
-	x[0] = dmin[0] + cell[0] * (double)i;
-	x[1] = dmin[1] + cell[1] * (double)j;
-	x[2] = dmin[2] + cell[2] * (double)k;
-	if (c > 0)
-		x[c - 1] += (1.0 + (double)h) / 3.0 * cell[c - 1];
-}
-
-// ---- 32 serendipity-cubic shape functions (+ derivatives) -------------------------------------------------
-// N[j], j = 0..31 in the reference's node order; dN (if GRAD) as dNx[32], dNy[32], dNz[32].
-// Same products in the same order as shape_function_() (cubic_lagrange_discrete_grid.cpp:339-580);
-// everything is fully unrolled so the arrays live in registers.
-template <bool GRAD>
-DG_HD void shape_functions(double x, double y, double z, double N[32], double dNx[32], double dNy[32], double dNz[32])
-{
-	const double x2 = x * x, y2 = y * y, z2 = z * z;
-	const double mx = 1.0 - x, my = 1.0 - y, mz = 1.0 - z;
-	const double px = 1.0 + x, py = 1.0 + y, pz = 1.0 + z;
-	const double m3x = 1.0 - 3.0 * x, m3y = 1.0 - 3.0 * y, m3z = 1.0 - 3.0 * z;
-	const double p3x = 1.0 + 3.0 * x, p3y = 1.0 + 3.0 * y, p3z = 1.0 + 3.0 * z;
-	const double mxmy = mx * my, mxpy = mx * py, pxmy = px * my, pxpy = px * py;
-	const double mxmz = mx * mz, mxpz = mx * pz, pxmz = px * mz, pxpz = px * pz;
-	const double mymz = my * mz, mypz = my * pz, pymz = py * mz, pypz = py * pz;
-	const double omx2 = 1.0 - x2, omy2 = 1.0 - y2, omz2 = 1.0 - z2;
-
-	double fac = 1.0 / 64.0 * (9.0 * (x2 + y2 + z2) - 19.0);
-	N[0] = fac * mxmy * mz;
-	N[1] = fac * pxmy * mz;
-	N[2] = fac * mxpy * mz;
-	N[3] = fac * pxpy * mz;
-	N[4] = fac * mxmy * pz;
-	N[5] = fac * pxmy * pz;
-	N[6] = fac * mxpy * pz;
-	N[7] = fac * pxpy * pz;
-
-	fac = 9.0 / 64.0 * omx2;
-	const double fm3x = fac * m3x, fp3x = fac * p3x;
-	N[8] = fm3x * mymz;
-	N[9] = fp3x * mymz;
-	N[10] = fm3x * mypz;
-	N[11] = fp3x * mypz;
-	N[12] = fm3x * pymz;
-	N[13] = fp3x * pymz;
-	N[14] = fm3x * pypz;
-	N[15] = fp3x * pypz;
-
-	fac = 9.0 / 64.0 * omy2;
-	const double fm3y = fac * m3y, fp3y = fac * p3y;
-	N[16] = fm3y * mxmz;
-	N[17] = fp3y * mxmz;
-	N[18] = fm3y * pxmz;
-	N[19] = fp3y * pxmz;
-	N[20] = fm3y * mxpz;
-	N[21] = fp3y * mxpz;
-	N[22] = fm3y * pxpz;
-	N[23] = fp3y * pxpz;
-
-	fac = 9.0 / 64.0 * omz2;
-	const double fm3z = fac * m3z, fp3z = fac * p3z;
-	N[24] = fm3z * mxmy;
-	N[25] = fp3z * mxmy;
-	N[26] = fm3z * mxpy;
-	N[27] = fp3z * mxpy;
-	N[28] = fm3z * pxmy;
-	N[29] = fp3z * pxmy;
-	N[30] = fm3z * pxpy;
-	N[31] = fp3z * pxpy;
-
-	if (!GRAD)
-		return;
-
-	const double gx = 9.0 * (3.0 * x2 + y2 + z2) - 19.0;
-	const double gy = 9.0 * (x2 + 3.0 * y2 + z2) - 19.0;
-	const double gz = 9.0 * (x2 + y2 + 3.0 * z2) - 19.0;
-	const double x18 = 18.0 * x, y18 = 18.0 * y, z18 = 18.0 * z;
-	const double hxm = x18 - gx, hxp = x18 + gx;
-	const double hym = y18 - gy, hyp = y18 + gy;
-	const double hzm = z18 - gz, hzp = z18 + gz;
-	// corners: value / 64 (topRows(8) /= 64)
-	dNx[0] = hxm * mymz / 64.0; dNy[0] = mxmz * hym / 64.0; dNz[0] = mxmy * hzm / 64.0;
-	dNx[1] = hxp * mymz / 64.0; dNy[1] = pxmz * hym / 64.0; dNz[1] = pxmy * hzm / 64.0;
-	dNx[2] = hxm * pymz / 64.0; dNy[2] = mxmz * hyp / 64.0; dNz[2] = mxpy * hzm / 64.0;
-	dNx[3] = hxp * pymz / 64.0; dNy[3] = pxmz * hyp / 64.0; dNz[3] = pxpy * hzm / 64.0;
-	dNx[4] = hxm * mypz / 64.0; dNy[4] = mxpz * hym / 64.0; dNz[4] = mxmy * hzp / 64.0;
-	dNx[5] = hxp * mypz / 64.0; dNy[5] = pxpz * hym / 64.0; dNz[5] = pxmy * hzp / 64.0;
-	dNx[6] = hxm * pypz / 64.0; dNy[6] = mxpz * hyp / 64.0; dNz[6] = mxpy * hzp / 64.0;
-	dNx[7] = hxp * pypz / 64.0; dNy[7] = pxpz * hyp / 64.0; dNz[7] = pxpy * hzp / 64.0;
-
-	const double k = 9.0 / 64.0; // bottomRows(24) *= 9/64
-	const double t3x = 3.0 - 9.0 * x2, t3y = 3.0 - 9.0 * y2, t3z = 3.0 - 9.0 * z2;
-	const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
-	const double qxm = -t3x - tx, qxp = t3x - tx;
-	const double qym = -t3y - ty, qyp = t3y - ty;
-	const double qzm = -t3z - tz, qzp = t3z - tz;
-	const double wxm = omx2 * m3x, wxp = omx2 * p3x;
-	const double wym = omy2 * m3y, wyp = omy2 * p3y;
-	const double wzm = omz2 * m3z, wzp = omz2 * p3z;
-	// x-edges
-	dNx[8] = qxm * mymz * k;  dNy[8] = -wxm * mz * k;  dNz[8] = -wxm * my * k;
-	dNx[9] = qxp * mymz * k;  dNy[9] = -wxp * mz * k;  dNz[9] = -wxp * my * k;
-	dNx[10] = qxm * mypz * k; dNy[10] = -wxm * pz * k; dNz[10] = wxm * my * k;
-	dNx[11] = qxp * mypz * k; dNy[11] = -wxp * pz * k; dNz[11] = wxp * my * k;
-	dNx[12] = qxm * pymz * k; dNy[12] = wxm * mz * k;  dNz[12] = -wxm * py * k;
-	dNx[13] = qxp * pymz * k; dNy[13] = wxp * mz * k;  dNz[13] = -wxp * py * k;
-	dNx[14] = qxm * pypz * k; dNy[14] = wxm * pz * k;  dNz[14] = wxm * py * k;
-	dNx[15] = qxp * pypz * k; dNy[15] = wxp * pz * k;  dNz[15] = wxp * py * k;
-	// y-edges
-	dNx[16] = -wym * mz * k; dNy[16] = qym * mxmz * k; dNz[16] = -wym * mx * k;
-	dNx[17] = -wyp * mz * k; dNy[17] = qyp * mxmz * k; dNz[17] = -wyp * mx * k;
-	dNx[18] = wym * mz * k;  dNy[18] = qym * pxmz * k; dNz[18] = -wym * px * k;
-	dNx[19] = wyp * mz * k;  dNy[19] = qyp * pxmz * k; dNz[19] = -wyp * px * k;
-	dNx[20] = -wym * pz * k; dNy[20] = qym * mxpz * k; dNz[20] = wym * mx * k;
-	dNx[21] = -wyp * pz * k; dNy[21] = qyp * mxpz * k; dNz[21] = wyp * mx * k;
-	dNx[22] = wym * pz * k;  dNy[22] = qym * pxpz * k; dNz[22] = wym * px * k;
-	dNx[23] = wyp * pz * k;  dNy[23] = qyp * pxpz * k; dNz[23] = wyp * px * k;
-	// z-edges
-	dNx[24] = -wzm * my * k; dNy[24] = -wzm * mx * k; dNz[24] = qzm * mxmy * k;
-	dNx[25] = -wzp * my * k; dNy[25] = -wzp * mx * k; dNz[25] = qzp * mxmy * k;
-	dNx[26] = -wzm * py * k; dNy[26] = wzm * mx * k;  dNz[26] = qzm * mxpy * k;
-	dNx[27] = -wzp * py * k; dNy[27] = wzp * mx * k;  dNz[27] = qzp * mxpy * k;
-	dNx[28] = wzm * my * k;  dNy[28] = -wzm * px * k; dNz[28] = qzm * pxmy * k;
-	dNx[29] = wzp * my * k;  dNy[29] = -wzp * px * k; dNz[29] = qzp * pxmy * k;
-	dNx[30] = wzm * py * k;  dNy[30] = wzm * px * k;  dNz[30] = qzm * pxpy * k;
-	dNx[31] = wzp * py * k;  dNy[31] = wzp * px * k;  dNz[31] = qzp * pxpy * k;
-}
-
-// 32 node indices of grid cell (i,j,k) for an unreduced field -- the rows the reference's
-// serial loop materialises (cubic_lagrange_discrete_grid.cpp:836-886).  Entries come in
-// adjacent pairs (2m, 2m+1) for m >= 4, and corner pairs (0,1),(2,3),(4,5),(6,7) are adjacent
-// too: the evaluator fetches 16 x 16-byte segments.
-DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t res[3], uint32_t out[32])
-{
-	const uint32_t nx = res[0], ny = res[1], nz = res[2];
-	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
-	const uint32_t nex = nx * (ny + 1) * (nz + 1);
-	const uint32_t ney = (nx + 1) * ny * (nz + 1);
-	const uint32_t r0 = (nx + 1) * (ny + 1) * k + (nx + 1) * j + i;
-	out[0] = r0;
-	out[1] = r0 + 1;
-	out[2] = r0 + (nx + 1);
-	out[3] = r0 + (nx + 1) + 1;
-	const uint32_t r1 = r0 + (nx + 1) * (ny + 1);
-	out[4] = r1;
-	out[5] = r1 + 1;
-	out[6] = r1 + (nx + 1);
-	out[7] = r1 + (nx + 1) + 1;
-	uint32_t off = nv;
-	out[8] = off + 2 * (nx * (ny + 1) * k + nx * j + i);
-	out[10] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * j + i);
-	out[12] = off + 2 * (nx * (ny + 1) * k + nx * (j + 1) + i);
-	out[14] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * (j + 1) + i);
-	off += 2 * nex;
-	out[16] = off + 2 * (ny * (nz + 1) * i + ny * k + j);
-	out[18] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * k + j);
-	out[20] = off + 2 * (ny * (nz + 1) * i + ny * (k + 1) + j);
-	out[22] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * (k + 1) + j);
-	off += 2 * ney;
-	out[24] = off + 2 * (nz * (nx + 1) * j + nz * i + k);
-	out[26] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * i + k);
-	out[28] = off + 2 * (nz * (nx + 1) * j + nz * (i + 1) + k);
-	out[30] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * (i + 1) + k);
-	for (int m = 8; m < 32; m += 2)
-		out[m + 1] = out[m] + 1;
-}
-
-// ---- K2 per-query body -------------------------------------------------------------------------------
-// Host or device arrays, same code (the C++ host API evaluates single points with it).
-struct FieldDev
-{
-	double dmin[3], dmax[3];
-	double cell[3], inv_cell[3];
-	uint32_t res[3];
-	const double* coeffs;
-	const uint32_t* cells;    // nullable => closed-form rows
-	const uint32_t* cell_map; // nullable => identity
-	// Optional cell-major copy of the field: 32 doubles (256 B, 2 cache lines) per cell row, in
-	// the row's node order.  Trades 4.6x the memory (288 GB of HBM3E is the point of this chip)
-	// for a gather-free evaluator: one query reads 256 contiguous bytes instead of 16 scattered
-	// 16-byte segments in 16 different lines.
-	const double* cell_major;
-};
-
-// Per-query body of K2 = CubicLagrangeDiscreteGrid::interpolate(field, x, gradient*)
-// (discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063).  The 32-term sum runs in j order
-// (parity), the 32 coefficients are fetched as 16 adjacent pairs for unreduced fields.  Returns
-// DBL_MAX ("no value") outside the domain, in removed cells, or if a coefficient is DBL_MAX;
-// the gradient is zero in those cases.
-template <bool GRAD>
-DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
-{
-	const double NOVAL = 1.7976931348623157e308;
-	g[0] = g[1] = g[2] = 0.0;
-	for (int d = 0; d < 3; ++d)
-		if (!((F.dmin[d] <= x[d]) && (x[d] <= F.dmax[d]))) // AlignedBox::contains, inclusive (:981)
-			return NOVAL;
-	uint32_t mi[3];
-	for (int d = 0; d < 3; ++d)
-	{
-		mi[d] = (uint32_t)((x[d] - F.dmin[d]) * F.inv_cell[d]); // :984
-		if (mi[d] >= F.res[d])
-			mi[d] = F.res[d] - 1;
-	}
-	const uint32_t ci = F.res[1] * F.res[0] * mi[2] + F.res[0] * mi[1] + mi[0];
-	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
-	if (cm == 0xffffffffu)
-		return NOVAL;
-	double c0[3], xi[3];
-	for (int d = 0; d < 3; ++d)
-	{
-		const double lo = F.dmin[d] + (double)mi[d] * F.cell[d]; // subdomain(), discrete_grid.cpp:26-32
-		const double hi = lo + F.cell[d];
-		const double den = hi - lo; // :1000
-		c0[d] = 2.0 / den;
-		const double c1 = (hi + lo) / den;
-		xi[d] = c0[d] * x[d] - c1;
-	}
-	double cf[32];
-	if (F.cell_major)
-	{
-		const double* row = F.cell_major + 32 * (size_t)cm;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int j = 0; j < 32; ++j)
-			cf[j] = row[j];
-	}
-	else if (F.cells)
-	{
-		const uint32_t* row = F.cells + 32 * (size_t)cm;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int j = 0; j < 32; ++j)
-			cf[j] = F.coeffs[row[j]];
-	}
-	else
-	{
-		uint32_t idx[32];
-		cell_node_indices(mi[0], mi[1], mi[2], F.res, idx);
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int m = 0; m < 32; m += 2)
-		{
-			const double* pr = F.coeffs + idx[m]; // adjacent pair: one 16-byte load
-			cf[m] = pr[0];
-			cf[m + 1] = pr[1];
-		}
-	}
-	double N[32], dNx[32], dNy[32], dNz[32];
-	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
-	bool ok = true;
-	double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-	for (int j = 0; j < 32; ++j)
-	{
-		ok = ok && (cf[j] != NOVAL);
-		phi += cf[j] * N[j];
-		if (GRAD)
-		{
-			gx += cf[j] * dNx[j];
-			gy += cf[j] * dNy[j];
-			gz += cf[j] * dNz[j];
-		}
-	}
-	if (!ok)
-		return NOVAL;
-	if (GRAD)
-	{
-		g[0] = gx * c0[0];
-		g[1] = gy * c0[1];
-		g[2] = gz * c0[2];
-	}
-	return phi;
-}
-
-// ---- K3: SPH boundary density map (GenerateDensityMap) ------------------------------------------------
-// Restates cmd/generate_density_map/main.cpp:86-112 (gamma, density_func), :119-133 (node
-// predicate), sph_kernel.hpp:11-42 (CubicKernel::W) and gauss_quadrature.cpp:5927-5960 (the
-// 16^3-point tensor Gauss-Legendre rule for p = 30), with the reference's operation order:
-// the 4096-term sum runs i, j, k sequentially per node.
-struct DensityParams
-{
-	double h;           // kernel support radius ("ar")
-	double rho0;
-	double c0prod;      // (0.5*diag).prod() = h*(h*h)
-	double cell_diag;   // cellSize().norm(), Eigen association x^2 + (y^2 + z^2)
-	int band_predicate; // apply the node predicate of main.cpp:119-133
-	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
-	double w[16];       // weights
-	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
-	// Quadrature points outside the kernel's support (|xi| > h: 3088 of the 4096 points) contribute
-	// w * (gamma * 0.0) = +0.0 to a sum of non-negative terms, i.e. nothing -- provided gamma is
-	// finite, which holds whenever every coefficient other than DBL_MAX is finite and below 1e290.
-	// kmask[i*16 + j] has bit k set where W(xi_i, xi_j, xi_k) != 0.
-	// skip_mode 0: evaluate every point; 1: skip the zero-weight points; 2 (device): skip them unless
-	// *unsafe != 0 (set by k_field_check when the field holds NaN / Inf / huge values).
-	uint16_t kmask[256];
-	int32_t skip_mode;
-	const uint32_t* unsafe;
-};
-
-// CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector
-DG_HD double cubic_kernel_k(double radius)
-{
-	const double pi = 3.14159265358979323846; // M_PI
-	const double h3 = radius * radius * radius;
-	return 8.0 / (pi * h3);
-}
-template <class Sqrt>
-DG_HD double cubic_kernel_W(double rx, double ry, double rz, double radius, double k, Sqrt sqrt_fn)
-{
-	double res = 0.0;
-	const double rl = sqrt_fn(rx * rx + (ry * ry + rz * rz));
-	const double q = rl / radius;
-	if (q <= 1.0)
-	{
-		if (q <= 0.5)
-		{
-			const double q2 = q * q;
-			const double q3 = q2 * q;
-			res = k * (6.0 * q3 - 6.0 * q2 + 1.0);
-		}
-		else
-		{
-			const double omq = 1.0 - q;
-			res = k * (2.0 * omq * omq * omq);
-		}
-	}
-	return res;
-}
-
-// Stage 1 (cheap): node predicate (main.cpp:119-133) and the early-out of density_func (:98-102).
-// Returns true if the node needs the quadrature; otherwise *value is the final field value
-// (DBL_MAX for predicate-rejected nodes, 0.0 for nodes farther than 2h from the surface).
-DG_HD bool density_prefilter(const FieldDev& F, const DensityParams& P, const double x[3], double* value)
-{
-	const double NOVAL = 1.7976931348623157e308;
-	double g[3];
-	if (P.band_predicate)
-	{
-		double xc[3];
-		for (int d = 0; d < 3; ++d) // x.cwiseMax(domain.min()).cwiseMin(domain.max())
-		{
-			const double a = x[d] < F.dmin[d] ? F.dmin[d] : x[d];
-			xc[d] = a < F.dmax[d] ? a : F.dmax[d];
-		}
-		const double dist = interpolate_point<false>(F, xc, g);
-		if (dist == NOVAL || !(-6.0 * P.h < dist + P.cell_diag && dist - P.cell_diag < 2.0 * P.h))
-		{
-			*value = NOVAL;
-			return false;
-		}
-	}
-	const double dist = interpolate_point<false>(F, x, g);
-	if (dist > 2.0 * P.h)
-	{
-		*value = 0.0;
-		return false;
-	}
-	return true;
-}
-
-// One coordinate axis of interpolate_point(): everything that depends on a single coordinate of
-// the evaluation point.  Same expressions as in interpolate_point()/shape_functions(), so staging
-// them per axis changes no bits -- it only avoids recomputing the x- and y-dependent parts (cell
-// lookup, affine map with its two divisions, polynomial factors) 16 and 256 times.
-struct Axis1D
-{
-	double t;              // local coordinate in [-1, 1]
-	double t2, m, p;       // t^2, 1 - t, 1 + t
-	double fm3, fp3;       // 9/64 * (1 - t^2) * (1 -+ 3t)
-	uint32_t mi;           // cell index along the axis
-	bool inside;
-};
-DG_HD Axis1D axis_eval(const FieldDev& F, int d, double y)
-{
-	Axis1D a;
-	a.inside = (F.dmin[d] <= y) && (y <= F.dmax[d]);
-	uint32_t mi = (uint32_t)((y - F.dmin[d]) * F.inv_cell[d]);
-	if (mi >= F.res[d])
-		mi = F.res[d] - 1;
-	if (!a.inside)
-		mi = 0;
-	a.mi = mi;
-	const double lo = F.dmin[d] + (double)mi * F.cell[d];
-	const double hi = lo + F.cell[d];
-	const double den = hi - lo;
-	const double c0 = 2.0 / den;
-	const double c1 = (hi + lo) / den;
-	a.t = c0 * y - c1;
-	a.t2 = a.t * a.t;
-	a.m = 1.0 - a.t;
-	a.p = 1.0 + a.t;
-	const double fac = 9.0 / 64.0 * (1.0 - a.t2);
-	a.fm3 = fac * (1.0 - 3.0 * a.t);
-	a.fp3 = fac * (1.0 + 3.0 * a.t);
-	return a;
-}
-
-// Stage 2: rho0 * integral over [-h,h]^3 of gamma(x + xi) W(xi), 16^3 Gauss points, summed in
-// the reference's i, j, k order (gauss_quadrature.cpp:5941-5958).  Unreduced fields take the
-// staged path (per-axis work hoisted out of the inner loops); reduced fields go through
-// interpolate_point().  Both produce the same bits (tests/test_density_map.py).
-template <bool STAGED>
-DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const double x[3])
-{
-	const double NOVAL = 1.7976931348623157e308;
-	double g[3];
-	double res = 0.0;
-	const bool staged = STAGED;
-	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && P.unsafe[0] == 0u);
-	DG_NOUNROLL
-	for (int i = 0; i < 16; ++i)
-	{
-		const double wi = P.w[i];
-		const double yx = x[0] + P.xi[i];
-		const Axis1D ax = axis_eval(F, 0, yx);
-		DG_NOUNROLL
-		for (int j = 0; j < 16; ++j)
-		{
-			const uint32_t kmask = skip ? (uint32_t)P.kmask[i * 16 + j] : 0xffffu;
-			if (kmask == 0u)
-				continue; // the whole column lies outside the kernel's support
-			const double wij = wi * P.w[j];
-			const double yy = x[1] + P.xi[j];
-			const Axis1D ay = axis_eval(F, 1, yy);
-			const double mxmy = ax.m * ay.m, mxpy = ax.m * ay.p, pxmy = ax.p * ay.m, pxpy = ax.p * ay.p;
-			const double x2y2 = ax.t2 + ay.t2;
-			DG_NOUNROLL
-			for (int k = 0; k < 16; ++k)
-			{
-				if (((kmask >> k) & 1u) == 0u)
-					continue;
-				const double wijk = wij * P.w[k];
-				const double yz = x[2] + P.xi[k];
-				double d;
-				if (staged)
-				{
-					const Axis1D az = axis_eval(F, 2, yz);
-					if (ax.inside && ay.inside && az.inside)
-					{
-						const uint32_t ci = F.res[1] * F.res[0] * az.mi + F.res[0] * ay.mi + ax.mi;
-						double cf[32];
-						if (F.cell_major)
-						{
-							const double* row = F.cell_major + 32 * (size_t)ci;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-							for (int q = 0; q < 32; ++q)
-								cf[q] = row[q];
-						}
-						else
-						{
-							uint32_t idx[32];
-							cell_node_indices(ax.mi, ay.mi, az.mi, F.res, idx);
-#if defined(__HIP__)
-#pragma unroll
-#endif
-							for (int q = 0; q < 32; q += 2)
-							{
-								const double* pr = F.coeffs + idx[q]; // adjacent pair: one 16-byte load
-								cf[q] = pr[0];
-								cf[q + 1] = pr[1];
-							}
-						}
-						const double mz = az.m, pz = az.p;
-						const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
-						// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
-						// consumed (same products as shape_functions(), no 32-entry array kept live)
-						bool ok = true;
-						double phi = 0.0;
-#define DG_ACC(q, n)                  \
-	ok = ok && (cf[q] != NOVAL); \
-	phi += cf[q] * (n);
-						DG_ACC(0, fac * mxmy * mz)
-						DG_ACC(1, fac * pxmy * mz)
-						DG_ACC(2, fac * mxpy * mz)
-						DG_ACC(3, fac * pxpy * mz)
-						DG_ACC(4, fac * mxmy * pz)
-						DG_ACC(5, fac * pxmy * pz)
-						DG_ACC(6, fac * mxpy * pz)
-						DG_ACC(7, fac * pxpy * pz)
-						{
-							const double mymz = ay.m * mz, mypz = ay.m * pz, pymz = ay.p * mz, pypz = ay.p * pz;
-							DG_ACC(8, ax.fm3 * mymz)
-							DG_ACC(9, ax.fp3 * mymz)
-							DG_ACC(10, ax.fm3 * mypz)
-							DG_ACC(11, ax.fp3 * mypz)
-							DG_ACC(12, ax.fm3 * pymz)
-							DG_ACC(13, ax.fp3 * pymz)
-							DG_ACC(14, ax.fm3 * pypz)
-							DG_ACC(15, ax.fp3 * pypz)
-						}
-						{
-							const double mxmz = ax.m * mz, mxpz = ax.m * pz, pxmz = ax.p * mz, pxpz = ax.p * pz;
-							DG_ACC(16, ay.fm3 * mxmz)
-							DG_ACC(17, ay.fp3 * mxmz)
-							DG_ACC(18, ay.fm3 * pxmz)
-							DG_ACC(19, ay.fp3 * pxmz)
-							DG_ACC(20, ay.fm3 * mxpz)
-							DG_ACC(21, ay.fp3 * mxpz)
-							DG_ACC(22, ay.fm3 * pxpz)
-							DG_ACC(23, ay.fp3 * pxpz)
-						}
-						DG_ACC(24, az.fm3 * mxmy)
-						DG_ACC(25, az.fp3 * mxmy)
-						DG_ACC(26, az.fm3 * mxpy)
-						DG_ACC(27, az.fp3 * mxpy)
-						DG_ACC(28, az.fm3 * pxmy)
-						DG_ACC(29, az.fp3 * pxmy)
-						DG_ACC(30, az.fm3 * pxpy)
-						DG_ACC(31, az.fp3 * pxpy)
-#undef DG_ACC
-						d = ok ? phi : NOVAL;
-					}
-					else
-						d = NOVAL;
-				}
-				else
-				{
-					const double y[3] = {yx, yy, yz};
-					d = interpolate_point<false>(F, y, g);
-				}
-				const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
-				res += wijk * (gamma * P.wtab[(i * 16 + j) * 16 + k]);
-			}
-		}
-	}
-	res *= P.c0prod;
-	return P.rho0 * res;
-}
-DG_HD double density_integral(const FieldDev& F, const DensityParams& P, const double x[3])
-{
-	if ((F.cells == nullptr) && (F.cell_map == nullptr))
-		return density_integral_t<true>(F, P, x);
-	return density_integral_t<false>(F, P, x);
-}
-
-// flat node index -> position (the inverse of the class decomposition; used where nodes are
-// addressed individually rather than as bricks)
-DG_HD void node_position_flat(uint64_t l, const uint32_t res[3], const double dmin[3], const double cell[3], double x[3])
-{
-	uint32_t D[3];
-	int c = 0;
-	uint64_t off = 0;
-	for (; c < 4; ++c)
-	{
-		class_dims(c, res, D);
-		const uint64_t size = (uint64_t)D[0] * D[1] * D[2];
-		if (l < off + size || c == 3)
-			break;
-		off += size;
-	}
-	const uint64_t lc = l - off;
-	const uint32_t a = (uint32_t)(lc % D[0]);
-	const uint32_t b = (uint32_t)((lc / D[0]) % D[1]);
-	const uint32_t s = (uint32_t)(lc / ((uint64_t)D[0] * D[1]));
-	node_position(c, a, b, s, dmin, cell, x);
 }
 
 } // namespace dg

@@ -3,7 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime_api.h>
-#include "dg_geom.h"
+#include "dg_density.h"
 
 namespace dg
 {

@@ -1,0 +1,339 @@
+// dg_lattice.h -- the grid side of the per-lane arithmetic shared by kernels and host code: node
+// classes and positions, the 32 serendipity-cubic shape functions, the closed-form cell -> node
+// table and the per-query body of K2.  Same rules as dg_geom.h: the reference's association order,
+// -ffp-contract=off, no memory touched other than the arguments.
+//
+// Reference lines restated (paths relative to the Discregrid tree):
+//   node positions           discregrid/src/cubic_lagrange_discrete_grid.cpp:604-665
+//   shape functions          discregrid/src/cubic_lagrange_discrete_grid.cpp:339-580
+//   interpolate              discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063
+#pragma once
+#include "dg_geom.h"
+
+namespace dg
+{
+
+// ---- lattice node positions ---------------------------------------------------------------------------
+// Node class c in {0:V, 1:X, 2:Y, 3:Z}; (a, b, s) are the class' own (fastest, middle, slowest)
+// lattice coordinates, i.e. class-local flat index = (s*D1 + b)*D0 + a with
+//   V: (i, j, k)         D = (nx+1, ny+1, nz+1)
+//   X: (2i+h, j, k)      D = (2nx,  ny+1, nz+1)      h = 0: node at 1/3, h = 1: at 2/3 of the edge
+//   Y: (2j+h, k, i)      D = (2ny,  nz+1, nx+1)
+//   Z: (2k+h, i, j)      D = (2nz,  nx+1, ny+1)
+// which is exactly the order indexToNodePosition() enumerates (cubic_lagrange_discrete_grid.cpp:618-662).
+DG_HD void class_dims(int c, const uint32_t res[3], uint32_t D[3])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	if (c == 0) { D[0] = nx + 1; D[1] = ny + 1; D[2] = nz + 1; }
+	else if (c == 1) { D[0] = 2 * nx; D[1] = ny + 1; D[2] = nz + 1; }
+	else if (c == 2) { D[0] = 2 * ny; D[1] = nz + 1; D[2] = nx + 1; }
+	else { D[0] = 2 * nz; D[1] = nx + 1; D[2] = ny + 1; }
+}
+DG_HD void node_position(int c, uint32_t a, uint32_t b, uint32_t s, const double dmin[3], const double cell[3],
+						 double x[3])
+{
+	uint32_t i, j, k, h = a & 1u;
+	if (c == 0) { i = a; j = b; k = s; }
+	else if (c == 1) { i = a >> 1; j = b; k = s; }
+	else if (c == 2) { j = a >> 1; k = b; i = s; }
+	else { k = a >> 1; i = b; j = s; }
+	x[0] = dmin[0] + cell[0] * (double)i;
+	x[1] = dmin[1] + cell[1] * (double)j;
+	x[2] = dmin[2] + cell[2] * (double)k;
+	if (c > 0)
+		x[c - 1] += (1.0 + (double)h) / 3.0 * cell[c - 1];
+}
+
+// ---- 32 serendipity-cubic shape functions (+ derivatives) -------------------------------------------------
+// N[j], j = 0..31 in the reference's node order; dN (if GRAD) as dNx[32], dNy[32], dNz[32].
+// Same products in the same order as shape_function_() (cubic_lagrange_discrete_grid.cpp:339-580);
+// everything is fully unrolled so the arrays live in registers.
+template <bool GRAD>
+DG_HD void shape_functions(double x, double y, double z, double N[32], double dNx[32], double dNy[32], double dNz[32])
+{
+	const double x2 = x * x, y2 = y * y, z2 = z * z;
+	const double mx = 1.0 - x, my = 1.0 - y, mz = 1.0 - z;
+	const double px = 1.0 + x, py = 1.0 + y, pz = 1.0 + z;
+	const double m3x = 1.0 - 3.0 * x, m3y = 1.0 - 3.0 * y, m3z = 1.0 - 3.0 * z;
+	const double p3x = 1.0 + 3.0 * x, p3y = 1.0 + 3.0 * y, p3z = 1.0 + 3.0 * z;
+	const double mxmy = mx * my, mxpy = mx * py, pxmy = px * my, pxpy = px * py;
+	const double mxmz = mx * mz, mxpz = mx * pz, pxmz = px * mz, pxpz = px * pz;
+	const double mymz = my * mz, mypz = my * pz, pymz = py * mz, pypz = py * pz;
+	const double omx2 = 1.0 - x2, omy2 = 1.0 - y2, omz2 = 1.0 - z2;
+
+	double fac = 1.0 / 64.0 * (9.0 * (x2 + y2 + z2) - 19.0);
+	N[0] = fac * mxmy * mz;
+	N[1] = fac * pxmy * mz;
+	N[2] = fac * mxpy * mz;
+	N[3] = fac * pxpy * mz;
+	N[4] = fac * mxmy * pz;
+	N[5] = fac * pxmy * pz;
+	N[6] = fac * mxpy * pz;
+	N[7] = fac * pxpy * pz;
+
+	fac = 9.0 / 64.0 * omx2;
+	const double fm3x = fac * m3x, fp3x = fac * p3x;
+	N[8] = fm3x * mymz;
+	N[9] = fp3x * mymz;
+	N[10] = fm3x * mypz;
+	N[11] = fp3x * mypz;
+	N[12] = fm3x * pymz;
+	N[13] = fp3x * pymz;
+	N[14] = fm3x * pypz;
+	N[15] = fp3x * pypz;
+
+	fac = 9.0 / 64.0 * omy2;
+	const double fm3y = fac * m3y, fp3y = fac * p3y;
+	N[16] = fm3y * mxmz;
+	N[17] = fp3y * mxmz;
+	N[18] = fm3y * pxmz;
+	N[19] = fp3y * pxmz;
+	N[20] = fm3y * mxpz;
+	N[21] = fp3y * mxpz;
+	N[22] = fm3y * pxpz;
+	N[23] = fp3y * pxpz;
+
+	fac = 9.0 / 64.0 * omz2;
+	const double fm3z = fac * m3z, fp3z = fac * p3z;
+	N[24] = fm3z * mxmy;
+	N[25] = fp3z * mxmy;
+	N[26] = fm3z * mxpy;
+	N[27] = fp3z * mxpy;
+	N[28] = fm3z * pxmy;
+	N[29] = fp3z * pxmy;
+	N[30] = fm3z * pxpy;
+	N[31] = fp3z * pxpy;
+
+	if (!GRAD)
+		return;
+
+	const double gx = 9.0 * (3.0 * x2 + y2 + z2) - 19.0;
+	const double gy = 9.0 * (x2 + 3.0 * y2 + z2) - 19.0;
+	const double gz = 9.0 * (x2 + y2 + 3.0 * z2) - 19.0;
+	const double x18 = 18.0 * x, y18 = 18.0 * y, z18 = 18.0 * z;
+	const double hxm = x18 - gx, hxp = x18 + gx;
+	const double hym = y18 - gy, hyp = y18 + gy;
+	const double hzm = z18 - gz, hzp = z18 + gz;
+	// corners: value / 64 (topRows(8) /= 64)
+	dNx[0] = hxm * mymz / 64.0; dNy[0] = mxmz * hym / 64.0; dNz[0] = mxmy * hzm / 64.0;
+	dNx[1] = hxp * mymz / 64.0; dNy[1] = pxmz * hym / 64.0; dNz[1] = pxmy * hzm / 64.0;
+	dNx[2] = hxm * pymz / 64.0; dNy[2] = mxmz * hyp / 64.0; dNz[2] = mxpy * hzm / 64.0;
+	dNx[3] = hxp * pymz / 64.0; dNy[3] = pxmz * hyp / 64.0; dNz[3] = pxpy * hzm / 64.0;
+	dNx[4] = hxm * mypz / 64.0; dNy[4] = mxpz * hym / 64.0; dNz[4] = mxmy * hzp / 64.0;
+	dNx[5] = hxp * mypz / 64.0; dNy[5] = pxpz * hym / 64.0; dNz[5] = pxmy * hzp / 64.0;
+	dNx[6] = hxm * pypz / 64.0; dNy[6] = mxpz * hyp / 64.0; dNz[6] = mxpy * hzp / 64.0;
+	dNx[7] = hxp * pypz / 64.0; dNy[7] = pxpz * hyp / 64.0; dNz[7] = pxpy * hzp / 64.0;
+
+	const double k = 9.0 / 64.0; // bottomRows(24) *= 9/64
+	const double t3x = 3.0 - 9.0 * x2, t3y = 3.0 - 9.0 * y2, t3z = 3.0 - 9.0 * z2;
+	const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+	const double qxm = -t3x - tx, qxp = t3x - tx;
+	const double qym = -t3y - ty, qyp = t3y - ty;
+	const double qzm = -t3z - tz, qzp = t3z - tz;
+	const double wxm = omx2 * m3x, wxp = omx2 * p3x;
+	const double wym = omy2 * m3y, wyp = omy2 * p3y;
+	const double wzm = omz2 * m3z, wzp = omz2 * p3z;
+	// x-edges
+	dNx[8] = qxm * mymz * k;  dNy[8] = -wxm * mz * k;  dNz[8] = -wxm * my * k;
+	dNx[9] = qxp * mymz * k;  dNy[9] = -wxp * mz * k;  dNz[9] = -wxp * my * k;
+	dNx[10] = qxm * mypz * k; dNy[10] = -wxm * pz * k; dNz[10] = wxm * my * k;
+	dNx[11] = qxp * mypz * k; dNy[11] = -wxp * pz * k; dNz[11] = wxp * my * k;
+	dNx[12] = qxm * pymz * k; dNy[12] = wxm * mz * k;  dNz[12] = -wxm * py * k;
+	dNx[13] = qxp * pymz * k; dNy[13] = wxp * mz * k;  dNz[13] = -wxp * py * k;
+	dNx[14] = qxm * pypz * k; dNy[14] = wxm * pz * k;  dNz[14] = wxm * py * k;
+	dNx[15] = qxp * pypz * k; dNy[15] = wxp * pz * k;  dNz[15] = wxp * py * k;
+	// y-edges
+	dNx[16] = -wym * mz * k; dNy[16] = qym * mxmz * k; dNz[16] = -wym * mx * k;
+	dNx[17] = -wyp * mz * k; dNy[17] = qyp * mxmz * k; dNz[17] = -wyp * mx * k;
+	dNx[18] = wym * mz * k;  dNy[18] = qym * pxmz * k; dNz[18] = -wym * px * k;
+	dNx[19] = wyp * mz * k;  dNy[19] = qyp * pxmz * k; dNz[19] = -wyp * px * k;
+	dNx[20] = -wym * pz * k; dNy[20] = qym * mxpz * k; dNz[20] = wym * mx * k;
+	dNx[21] = -wyp * pz * k; dNy[21] = qyp * mxpz * k; dNz[21] = wyp * mx * k;
+	dNx[22] = wym * pz * k;  dNy[22] = qym * pxpz * k; dNz[22] = wym * px * k;
+	dNx[23] = wyp * pz * k;  dNy[23] = qyp * pxpz * k; dNz[23] = wyp * px * k;
+	// z-edges
+	dNx[24] = -wzm * my * k; dNy[24] = -wzm * mx * k; dNz[24] = qzm * mxmy * k;
+	dNx[25] = -wzp * my * k; dNy[25] = -wzp * mx * k; dNz[25] = qzp * mxmy * k;
+	dNx[26] = -wzm * py * k; dNy[26] = wzm * mx * k;  dNz[26] = qzm * mxpy * k;
+	dNx[27] = -wzp * py * k; dNy[27] = wzp * mx * k;  dNz[27] = qzp * mxpy * k;
+	dNx[28] = wzm * my * k;  dNy[28] = -wzm * px * k; dNz[28] = qzm * pxmy * k;
+	dNx[29] = wzp * my * k;  dNy[29] = -wzp * px * k; dNz[29] = qzp * pxmy * k;
+	dNx[30] = wzm * py * k;  dNy[30] = wzm * px * k;  dNz[30] = qzm * pxpy * k;
+	dNx[31] = wzp * py * k;  dNy[31] = wzp * px * k;  dNz[31] = qzp * pxpy * k;
+}
+
+// 32 node indices of grid cell (i,j,k) for an unreduced field -- the rows the reference's
+// serial loop materialises (cubic_lagrange_discrete_grid.cpp:836-886).  Entries come in
+// adjacent pairs (2m, 2m+1) for m >= 4, and corner pairs (0,1),(2,3),(4,5),(6,7) are adjacent
+// too: the evaluator fetches 16 x 16-byte segments.
+DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t res[3], uint32_t out[32])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
+	const uint32_t nex = nx * (ny + 1) * (nz + 1);
+	const uint32_t ney = (nx + 1) * ny * (nz + 1);
+	const uint32_t r0 = (nx + 1) * (ny + 1) * k + (nx + 1) * j + i;
+	out[0] = r0;
+	out[1] = r0 + 1;
+	out[2] = r0 + (nx + 1);
+	out[3] = r0 + (nx + 1) + 1;
+	const uint32_t r1 = r0 + (nx + 1) * (ny + 1);
+	out[4] = r1;
+	out[5] = r1 + 1;
+	out[6] = r1 + (nx + 1);
+	out[7] = r1 + (nx + 1) + 1;
+	uint32_t off = nv;
+	out[8] = off + 2 * (nx * (ny + 1) * k + nx * j + i);
+	out[10] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * j + i);
+	out[12] = off + 2 * (nx * (ny + 1) * k + nx * (j + 1) + i);
+	out[14] = off + 2 * (nx * (ny + 1) * (k + 1) + nx * (j + 1) + i);
+	off += 2 * nex;
+	out[16] = off + 2 * (ny * (nz + 1) * i + ny * k + j);
+	out[18] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * k + j);
+	out[20] = off + 2 * (ny * (nz + 1) * i + ny * (k + 1) + j);
+	out[22] = off + 2 * (ny * (nz + 1) * (i + 1) + ny * (k + 1) + j);
+	off += 2 * ney;
+	out[24] = off + 2 * (nz * (nx + 1) * j + nz * i + k);
+	out[26] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * i + k);
+	out[28] = off + 2 * (nz * (nx + 1) * j + nz * (i + 1) + k);
+	out[30] = off + 2 * (nz * (nx + 1) * (j + 1) + nz * (i + 1) + k);
+	for (int m = 8; m < 32; m += 2)
+		out[m + 1] = out[m] + 1;
+}
+
+// ---- K2 per-query body -------------------------------------------------------------------------------
+// Host or device arrays, same code (the C++ host API evaluates single points with it).
+struct FieldDev
+{
+	double dmin[3], dmax[3];
+	double cell[3], inv_cell[3];
+	uint32_t res[3];
+	const double* coeffs;
+	const uint32_t* cells;    // nullable => closed-form rows
+	const uint32_t* cell_map; // nullable => identity
+	// Optional cell-major copy of the field: 32 doubles (256 B, 2 cache lines) per cell row, in
+	// the row's node order.  Trades 4.6x the memory (288 GB of HBM3E is the point of this chip)
+	// for a gather-free evaluator: one query reads 256 contiguous bytes instead of 16 scattered
+	// 16-byte segments in 16 different lines.
+	const double* cell_major;
+};
+
+// Per-query body of K2 = CubicLagrangeDiscreteGrid::interpolate(field, x, gradient*)
+// (discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063).  The 32-term sum runs in j order
+// (parity), the 32 coefficients are fetched as 16 adjacent pairs for unreduced fields.  Returns
+// DBL_MAX ("no value") outside the domain, in removed cells, or if a coefficient is DBL_MAX;
+// the gradient is zero in those cases.
+template <bool GRAD>
+DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
+{
+	const double NOVAL = 1.7976931348623157e308;
+	g[0] = g[1] = g[2] = 0.0;
+	for (int d = 0; d < 3; ++d)
+		if (!((F.dmin[d] <= x[d]) && (x[d] <= F.dmax[d]))) // AlignedBox::contains, inclusive (:981)
+			return NOVAL;
+	uint32_t mi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		mi[d] = (uint32_t)((x[d] - F.dmin[d]) * F.inv_cell[d]); // :984
+		if (mi[d] >= F.res[d])
+			mi[d] = F.res[d] - 1;
+	}
+	const uint32_t ci = F.res[1] * F.res[0] * mi[2] + F.res[0] * mi[1] + mi[0];
+	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
+	if (cm == 0xffffffffu)
+		return NOVAL;
+	double c0[3], xi[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		const double lo = F.dmin[d] + (double)mi[d] * F.cell[d]; // subdomain(), discrete_grid.cpp:26-32
+		const double hi = lo + F.cell[d];
+		const double den = hi - lo; // :1000
+		c0[d] = 2.0 / den;
+		const double c1 = (hi + lo) / den;
+		xi[d] = c0[d] * x[d] - c1;
+	}
+	double cf[32];
+	if (F.cell_major)
+	{
+		const double* row = F.cell_major + 32 * (size_t)cm;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int j = 0; j < 32; ++j)
+			cf[j] = row[j];
+	}
+	else if (F.cells)
+	{
+		const uint32_t* row = F.cells + 32 * (size_t)cm;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int j = 0; j < 32; ++j)
+			cf[j] = F.coeffs[row[j]];
+	}
+	else
+	{
+		uint32_t idx[32];
+		cell_node_indices(mi[0], mi[1], mi[2], F.res, idx);
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int m = 0; m < 32; m += 2)
+		{
+			const double* pr = F.coeffs + idx[m]; // adjacent pair: one 16-byte load
+			cf[m] = pr[0];
+			cf[m + 1] = pr[1];
+		}
+	}
+	double N[32], dNx[32], dNy[32], dNz[32];
+	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
+	bool ok = true;
+	double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 32; ++j)
+	{
+		ok = ok && (cf[j] != NOVAL);
+		phi += cf[j] * N[j];
+		if (GRAD)
+		{
+			gx += cf[j] * dNx[j];
+			gy += cf[j] * dNy[j];
+			gz += cf[j] * dNz[j];
+		}
+	}
+	if (!ok)
+		return NOVAL;
+	if (GRAD)
+	{
+		g[0] = gx * c0[0];
+		g[1] = gy * c0[1];
+		g[2] = gz * c0[2];
+	}
+	return phi;
+}
+
+// flat node index -> position (the inverse of the class decomposition; used where nodes are
+// addressed individually rather than as bricks)
+DG_HD void node_position_flat(uint64_t l, const uint32_t res[3], const double dmin[3], const double cell[3], double x[3])
+{
+	uint32_t D[3];
+	int c = 0;
+	uint64_t off = 0;
+	for (; c < 4; ++c)
+	{
+		class_dims(c, res, D);
+		const uint64_t size = (uint64_t)D[0] * D[1] * D[2];
+		if (l < off + size || c == 3)
+			break;
+		off += size;
+	}
+	const uint64_t lc = l - off;
+	const uint32_t a = (uint32_t)(lc % D[0]);
+	const uint32_t b = (uint32_t)((lc / D[0]) % D[1]);
+	const uint32_t s = (uint32_t)(lc / ((uint64_t)D[0] * D[1]));
+	node_position(c, a, b, s, dmin, cell, x);
+}
+
+} // namespace dg
