@@ -106,8 +106,9 @@ uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
 
 /* ---- mesh / BVH handle ----------------------------------------------------------------- */
 /* verts: 3*n_vertices doubles (xyzxyz...), tris: 3*n_triangles vertex indices.  Builds the
- * pseudonormals exactly as the reference does and a flattened AABB BVH of this library's own
- * design on the host, then uploads everything to the current device. */
+ * pseudonormals exactly as the reference does and a flattened BVH of this library's own design
+ * (oriented-box bounds, sibling-pair records) on the host, then uploads everything to the
+ * current device. */
 dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
 						 dg_mesh** out);
 dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info);
@@ -130,7 +131,11 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 									uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out);
 
 /* Signed distance at arbitrary points (3*n doubles) -> dist[n]; optional nearest triangle id
- * (original index), nearest entity (0..6 = V0,V1,V2,E01,E12,E02,F) and nearest point. */
+ * (original index), nearest entity (0..6 = V0,V1,V2,E01,E12,E02,F) and nearest point
+ * (TriangleMeshDistance::signed_distance, TriangleMeshDistance.h:269-314).  Batches of >= 4096
+ * points that arrive in no spatial order are processed tile by tile (decided on the device, the
+ * results land at the caller's positions); where several triangles are exactly equidistant the
+ * id of any of them may be returned, as in the reference the first one met wins. */
 dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n, double* dist, int32_t* tri,
 							 int32_t* entity, double* nearest);
 dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
