@@ -55,6 +55,19 @@ inline uint64_t shard_count(const uint32_t res[3], int rank, int nranks)
 	return cnt;
 }
 
+// blocks -> XCD chunks (dg_kernels.h: logical_block()).  Default chunk: kXcdChunk blocks, but at least
+// 8 chunks per XCD so that small launches are still spread evenly (a 64^3 lattice has 29 k bricks:
+// 29 chunks of 1024 would leave some XCDs with 4 chunks and others with 3).
+inline void finish_blocks(SampleParams& P)
+{
+	if (P.xcd_chunk == 0)
+		P.xcd_chunk = std::max(16u, std::min(kXcdChunk, P.n_blocks / 64u));
+	if (P.xcd_chunk == 0xffffffffu) // one chunk per XCD
+		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
+	const uint32_t per_group = 8u * P.xcd_chunk;
+	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
+}
+
 inline void finish_bricks(SampleParams& P)
 {
 	uint64_t prefix = 0;
@@ -71,12 +84,7 @@ inline void finish_bricks(SampleParams& P)
 	}
 	P.total_bricks = prefix;
 	P.n_blocks = (uint32_t)((prefix + kWavesPerBlock - 1) / kWavesPerBlock);
-	if (P.xcd_chunk == 0)
-		P.xcd_chunk = kXcdChunk;
-	if (P.xcd_chunk == 0xffffffffu) // one chunk per XCD
-		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
-	const uint32_t per_group = 8u * P.xcd_chunk;
-	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
+	finish_blocks(P);
 }
 
 inline void init_params(SampleParams& P, const MeshDev& mesh, const double dmin[3], const double cell[3], int invert)
@@ -158,12 +166,7 @@ inline void layout_points(SampleParams& P, uint64_t n)
 	P.shard_n = 1;
 	P.total_bricks = (n + 63) / 64;
 	P.n_blocks = (uint32_t)((P.total_bricks + kWavesPerBlock - 1) / kWavesPerBlock);
-	if (P.xcd_chunk == 0)
-		P.xcd_chunk = kXcdChunk;
-	if (P.xcd_chunk == 0xffffffffu)
-		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
-	const uint32_t per_group = 8u * P.xcd_chunk;
-	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
+	finish_blocks(P);
 }
 
 inline void layout_unpack(UnpackParams& U, const uint32_t res[3], int nranks)
