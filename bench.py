@@ -118,6 +118,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Self-test of the N > 1 protocol on a box with ONE GPU: all ranks share device 0 and the collective
+    # goes through gloo (RCCL refuses two ranks on one device).  Timings of such a run mean nothing.
+    selftest = os.environ.get("DG_BENCH_SELFTEST_ONE_GPU") == "1"
+    if selftest:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -127,7 +132,10 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     V, F = T.icosphere(71)
     dom = dg.default_domain(V)            # cmd/generate_sdf/main.cpp:83-91
@@ -204,7 +212,7 @@ def main():
     # sanity of the result that was just timed (cheap, outside the timed region)
     probe = field[:: max(1, n_nodes // 1000)].cpu().numpy()
     assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0
-    if args.force_shard_path and world == 1:
+    if (args.force_shard_path and world == 1) or selftest:
         ref = torch.empty_like(field)
         mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
         torch.cuda.synchronize()
