@@ -266,6 +266,7 @@ void dg_mesh_destroy(dg_mesh* m)
 		if (h.mem) (void)hipFree(h.mem);
 	}
 	m->bin_scratch.destroy();
+	if (m->bin_flag_host) (void)hipHostFree(m->bin_flag_host);
 	delete m;
 }
 
@@ -280,6 +281,34 @@ extern "C++" int env_int(const char* name, int fallback, int lo, int hi)
 // Attaches heavy-brick scratch to a K1 launch (tuning knobs DG_HEAVY_SLOTS, 0 = no splitting, and
 // DG_HEAVY_WORK).  Returns the index of the scratch buffer in use, or -1 when the launch runs
 // without splitting (tiny tree, knob, or no memory -- splitting only shortens the launch).
+extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, const dg::TileGrid& tiles, uint64_t n, hipStream_t stream,
+									 dg::BinScratch& S)
+{
+	std::memset(&S, 0, sizeof(S));
+	if (*flag_host == nullptr)
+	{
+		void* p = nullptr;
+		if (hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+		{
+			(void)hipGetLastError();
+			return -1;
+		}
+		*flag_host = static_cast<uint32_t*>(p);
+		**flag_host = 1u; // nothing known yet: assume the first batch is unordered
+	}
+	size_t off[6];
+	const uint32_t n_tiles = dg::tile_count(tiles);
+	const size_t bytes = dg::bin_scratch_bytes(n_tiles, n, off);
+	void* mem = nullptr;
+	const int idx = pool.acquire(bytes, stream, &mem);
+	if (idx < 0)
+		return -1;
+	dg::bin_scratch_assign(S, mem, off, n_tiles, n);
+	S.flag_host = *flag_host;
+	S.sort_launched = *reinterpret_cast<volatile uint32_t*>(*flag_host) != 0u ? 1 : 0;
+	return idx;
+}
+
 extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
@@ -446,19 +475,11 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 			hi[d] = mesh->bbox_hi[d] + 0.5 * ext;
 		}
 		tiles = dg::point_tiles(lo, hi, n);
-		size_t off[4];
-		const size_t bytes = dg::bin_scratch_bytes(dg::tile_count(tiles), n, off);
-		void* mem = nullptr;
-		bin_idx = mesh->bin_scratch.acquire(bytes, st, &mem);
+		bin_idx = acquire_bin_scratch(mesh->bin_scratch, &mesh->bin_flag_host, tiles, n, st, S);
 		if (bin_idx >= 0)
 		{
-			char* base = static_cast<char*>(mem);
-			S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
-			S.start = reinterpret_cast<uint32_t*>(base + off[1]);
-			S.cursor = reinterpret_cast<uint32_t*>(base + off[2]);
-			S.perm = reinterpret_cast<uint32_t*>(base + off[3]);
 			P.pts.bin_flag = S.flag;
-			P.pts.perm = S.perm;
+			P.pts.perm = S.sort_launched ? S.perm : nullptr;
 		}
 	}
 	const int heavy_idx = acquire_heavy_scratch(mesh, P, st);

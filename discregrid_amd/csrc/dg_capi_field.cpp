@@ -110,6 +110,7 @@ void dg_field_destroy(dg_field* f)
 	if (f->d_unsafe)
 		(void)hipFree(f->d_unsafe);
 	f->scratch.destroy();
+	if (f->bin_flag_host) (void)hipHostFree(f->bin_flag_host);
 	delete f;
 }
 
@@ -212,18 +213,10 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	const bool big = n >= (1u << 18) && field->n_coeffs * sizeof(double) >= (32u << 20);
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
-		size_t off[4];
-		const size_t bytes = dg::bin_scratch_bytes(dg::tile_count(dg::field_tiles(field->dev)), n, off);
-		void* mem = nullptr;
-		const int idx = field->scratch.acquire(bytes, st, &mem);
+		dg::BinScratch S;
+		const int idx = acquire_bin_scratch(field->scratch, &field->bin_flag_host, dg::field_tiles(field->dev), n, st, S);
 		if (idx >= 0)
 		{
-			char* base = static_cast<char*>(mem);
-			dg::BinScratch S;
-			S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
-			S.start = reinterpret_cast<uint32_t*>(base + off[1]);
-			S.cursor = reinterpret_cast<uint32_t*>(base + off[2]);
-			S.perm = reinterpret_cast<uint32_t*>(base + off[3]);
 			const hipError_t e = dg::launch_interpolate_binned(field->dev, d_xyz, n, d_phi, d_grad, S, st);
 			field->scratch.release(idx, st);
 			DG_HIP(e);

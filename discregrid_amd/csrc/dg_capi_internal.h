@@ -112,6 +112,7 @@ struct dg_mesh
 	mutable uint64_t scratch_serial = 0;
 	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
 	mutable ScratchPool bin_scratch;     // K1p point binning
+	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	double bbox_lo[3], bbox_hi[3];       // of the vertices
 };
 
@@ -119,6 +120,7 @@ struct dg_field
 {
 	dg::FieldDev dev;
 	mutable ScratchPool scratch; // K2 query binning
+	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
 	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
@@ -139,6 +141,10 @@ dg_status require_device();
 bool valid_grid(const dg_grid_desc* g);
 int env_int(const char* name, int fallback, int lo, int hi);
 uint32_t env_xcd_chunk();
+// binning scratch of a K1p / K2 batch (dg_kernels.h: BinScratch): fills S from `pool`; *flag_host is the
+// handle's pinned prediction word (allocated on first use).  Returns the pool index or -1 (no binning).
+int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, const dg::TileGrid& tiles, uint64_t n, hipStream_t stream,
+						dg::BinScratch& S);
 // heavy-brick scratch of a K1 / K1p launch (dg_kernels.h: OverflowBuf)
 int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream);
 void release_heavy_scratch(const dg_mesh* mesh, int idx, hipStream_t stream);

@@ -242,12 +242,23 @@ struct TileGrid // uniform grid of tiles the points are binned into (points outs
 	uint32_t dims[3];
 };
 inline uint32_t tile_count(const TileGrid& g) { return g.dims[0] * g.dims[1] * g.dims[2]; }
+// The points are ordered by a radix sort of (tile, index) pairs (rocPRIM).  Two decisions are
+// involved: whether the batch is unordered at all -- taken exactly, on the device, by a probe of the
+// first points (flag) -- and whether the sort is launched, which only the host can decide and which it
+// bases on the probe result of the handle's PREVIOUS batch (flag_host, pinned memory the probe also
+// writes; a stale or wrong value costs time, never correctness: the kernels take point perm[t] only if
+// the sort was launched AND this batch's flag says unordered).
 struct BinScratch
 {
-	uint32_t* flag;   // [1] 1 = use the permutation
-	uint32_t* start;  // [n_tiles] histogram, then start offset of every tile
-	uint32_t* cursor; // [n_tiles]
-	uint32_t* perm;   // [n]
+	uint32_t* flag;       // [1] device: 1 = this batch is unordered
+	uint32_t* flag_host;  // pinned host copy of the flag, read by the NEXT call as its prediction
+	uint32_t* keys;       // [n] tile of every point
+	uint32_t* keys_out;   // [n]
+	uint32_t* vals;       // [n] 0..n-1
+	uint32_t* perm;       // [n] point indices in tile order
+	void* sort_tmp;       // rocPRIM's temporary storage
+	size_t sort_tmp_bytes;
+	int sort_launched;    // host decision for this batch
 };
 #ifndef DG_TILE_CELLS
 #define DG_TILE_CELLS 8
@@ -281,15 +292,30 @@ inline TileGrid point_tiles(const double lo[3], const double hi[3], uint64_t n)
 	}
 	return g;
 }
-inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[4])
+size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles); // rocPRIM's requirement for n pairs
+inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[6])
 {
 	size_t o = 0;
 	auto take = [&](size_t b) { const size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
 	off[0] = take(4);
-	off[1] = take((size_t)n_tiles * 4);
-	off[2] = take((size_t)n_tiles * 4);
+	off[1] = take((size_t)n * 4);
+	off[2] = take((size_t)n * 4);
 	off[3] = take((size_t)n * 4);
+	off[4] = take((size_t)n * 4);
+	off[5] = take(bin_sort_tmp_bytes(n, n_tiles));
 	return o;
+}
+// fills the pointers of S from one scratch allocation laid out by bin_scratch_bytes()
+inline void bin_scratch_assign(BinScratch& S, void* mem, const size_t off[6], uint32_t n_tiles, uint64_t n)
+{
+	char* base = static_cast<char*>(mem);
+	S.flag = reinterpret_cast<uint32_t*>(base + off[0]);
+	S.keys = reinterpret_cast<uint32_t*>(base + off[1]);
+	S.keys_out = reinterpret_cast<uint32_t*>(base + off[2]);
+	S.vals = reinterpret_cast<uint32_t*>(base + off[3]);
+	S.perm = reinterpret_cast<uint32_t*>(base + off[4]);
+	S.sort_tmp = base + off[5];
+	S.sort_tmp_bytes = bin_sort_tmp_bytes(n, n_tiles);
 }
 hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 									 const BinScratch& scratch, hipStream_t stream);

@@ -34,6 +34,7 @@
 //
 // Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
 #include <algorithm>
 #include "dg_kernels.h"
@@ -263,7 +264,7 @@ __device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t br
 		const uint64_t slot = brick * 64u + (uint64_t)lane;
 		t.valid = slot < P.pts.n;
 		uint64_t i = t.valid ? slot : P.pts.n - 1;
-		if (P.pts.bin_flag != nullptr && P.pts.bin_flag[0] != 0u)
+		if (P.pts.perm != nullptr && P.pts.bin_flag[0] != 0u) // perm is set only if this batch was sorted
 			i = P.pts.perm[i];
 		t.sample = t.valid;
 		t.out_idx = (int64_t)i;
@@ -488,54 +489,20 @@ __global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const doubl
 	atomicAdd(&changes, mine);
 	__syncthreads();
 	if (threadIdx.x == 0)
-		S.flag[0] = ((uint64_t)one_in * changes > m) ? 1u : 0u; // more than one change of tile in `one_in` steps
-}
-__global__ __launch_bounds__(256) void k_bin_hist(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
-{
-	if (S.flag[0] == 0)
-		return;
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		atomicAdd(&S.start[tile_of(F, xyz, i)], 1u);
-}
-// one block of 1024 threads: exclusive prefix sum of the histogram (start, and a copy in cursor)
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t n_tiles, BinScratch S)
-{
-	if (S.flag[0] == 0)
-		return;
-	__shared__ uint32_t part[1024];
-	const uint32_t per = (n_tiles + 1023u) / 1024u;
-	const uint32_t b = threadIdx.x * per, e = min(n_tiles, b + per);
-	uint32_t sum = 0;
-	for (uint32_t i = b; i < e; ++i)
-		sum += S.start[i];
-	part[threadIdx.x] = sum;
-	__syncthreads();
-	if (threadIdx.x == 0)
 	{
-		uint32_t run = 0;
-		for (int i = 0; i < 1024; ++i)
-		{
-			const uint32_t v = part[i];
-			part[i] = run;
-			run += v;
-		}
-	}
-	__syncthreads();
-	uint32_t run = part[threadIdx.x];
-	for (uint32_t i = b; i < e; ++i)
-	{
-		const uint32_t v = S.start[i];
-		S.start[i] = run;
-		S.cursor[i] = run;
-		run += v;
+		const uint32_t unordered = ((uint64_t)one_in * changes > m) ? 1u : 0u; // more than one change of tile in `one_in` steps
+		S.flag[0] = unordered;
+		*(volatile uint32_t*)S.flag_host = unordered; // prediction for the handle's next batch
 	}
 }
-__global__ __launch_bounds__(256) void k_bin_scatter(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+// sort keys: tile of every point, values: the point indices
+__global__ __launch_bounds__(256) void k_bin_keys(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
 {
-	if (S.flag[0] == 0)
-		return;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		S.perm[atomicAdd(&S.cursor[tile_of(F, xyz, i)], 1u)] = (uint32_t)i;
+	{
+		S.keys[i] = tile_of(F, xyz, i);
+		S.vals[i] = (uint32_t)i;
+	}
 }
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
@@ -544,7 +511,7 @@ __global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, co
 	uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= n)
 		return;
-	if (S.flag[0] != 0)
+	if (S.sort_launched != 0 && S.flag[0] != 0)
 		gid = S.perm[gid];
 	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
 	double g[3];
@@ -691,18 +658,33 @@ static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 hipError_t launch_sample_nodes(const SampleParams& p, hipStream_t stream) { return launch_k1<false>(p, stream); }
 
 // the binning passes shared by K2 and K1p: S.flag / S.perm describe the order to process the points in
+static uint32_t key_bits(uint32_t n_tiles)
+{
+	uint32_t bits = 1;
+	while (bits < 32 && (1u << bits) < n_tiles)
+		++bits;
+	return bits;
+}
+size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles)
+{
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+									(uint32_t*)nullptr, (size_t)n, 0u, key_bits(n_tiles), (hipStream_t) nullptr);
+	return bytes;
+}
+// the binning passes shared by K2 and K1p: probe (always), and -- if the host predicts an unordered batch
+// (S.sort_launched) -- tile keys + radix sort, which leaves the processing order in S.perm
 static hipError_t launch_binning(const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
 {
-	const uint32_t n_tiles = tile_count(tiles);
-	hipError_t e = hipMemsetAsync(S.start, 0, (size_t)n_tiles * sizeof(uint32_t), stream);
-	if (e != hipSuccess)
-		return e;
-	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
 	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, tiles, d_xyz, n, S, one_in);
-	hipLaunchKernelGGL(k_bin_hist, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
-	hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, n_tiles, S);
-	hipLaunchKernelGGL(k_bin_scatter, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
-	return hipGetLastError();
+	if (S.sort_launched == 0)
+		return hipGetLastError();
+	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_bin_keys, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	size_t bytes = S.sort_tmp_bytes;
+	const hipError_t e = rocprim::radix_sort_pairs(S.sort_tmp, bytes, (const uint32_t*)S.keys, S.keys_out, (const uint32_t*)S.vals, S.perm,
+												  (size_t)n, 0u, key_bits(tile_count(tiles)), stream);
+	return e != hipSuccess ? e : hipGetLastError();
 }
 
 hipError_t launch_signed_distance(const SampleParams& p, const TileGrid* tiles, const BinScratch* scratch, hipStream_t stream)
