@@ -214,7 +214,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
 		dg::BinScratch S;
-		const int idx = acquire_bin_scratch(field->scratch, &field->bin_flag_host, dg::field_tiles(field->dev), n, st, S);
+		const int idx = acquire_bin_scratch(field->scratch, &field->bin_flag_host, dg::field_tiles(field->dev, dg::kSortCells), n, st, S);
 		if (idx >= 0)
 		{
 			const hipError_t e = dg::launch_interpolate_binned(field->dev, d_xyz, n, d_phi, d_grad, S, st);

@@ -264,15 +264,19 @@ struct BinScratch
 #define DG_TILE_CELLS 8
 #endif
 static const uint32_t kTileCells = DG_TILE_CELLS;
-// K2: tiles of kTileCells^3 grid cells
-inline TileGrid field_tiles(const FieldDev& f)
+#ifndef DG_SORT_CELLS
+#define DG_SORT_CELLS 4
+#endif
+static const uint32_t kSortCells = DG_SORT_CELLS; // K2 sorts by tiles of kSortCells^3 cells (the probe looks at kTileCells^3)
+// K2: tiles of cells^3 grid cells
+inline TileGrid field_tiles(const FieldDev& f, uint32_t cells = kTileCells)
 {
 	TileGrid g;
 	for (int d = 0; d < 3; ++d)
 	{
 		g.origin[d] = f.dmin[d];
-		g.inv_size[d] = f.inv_cell[d] / (double)kTileCells;
-		g.dims[d] = (f.res[d] + kTileCells - 1) / kTileCells;
+		g.inv_size[d] = f.inv_cell[d] / (double)cells;
+		g.dims[d] = (f.res[d] + cells - 1) / cells;
 	}
 	return g;
 }

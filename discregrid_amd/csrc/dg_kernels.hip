@@ -674,9 +674,9 @@ size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles)
 }
 // the binning passes shared by K2 and K1p: probe (always), and -- if the host predicts an unordered batch
 // (S.sort_launched) -- tile keys + radix sort, which leaves the processing order in S.perm
-static hipError_t launch_binning(const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
+static hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, tiles, d_xyz, n, S, one_in);
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, probe_tiles, d_xyz, n, S, one_in);
 	if (S.sort_launched == 0)
 		return hipGetLastError();
 	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
@@ -694,7 +694,7 @@ hipError_t launch_signed_distance(const SampleParams& p, const TileGrid* tiles, 
 	if (tiles != nullptr && scratch != nullptr)
 	{
 		// K1p gains from 3-D compactness even for row-ordered input: bin unless consecutive points share a tile 15 times out of 16
-		const hipError_t e = launch_binning(*tiles, p.pts.xyz, p.pts.n, *scratch, 16u, stream);
+		const hipError_t e = launch_binning(*tiles, *tiles, p.pts.xyz, p.pts.n, *scratch, 16u, stream);
 		if (e != hipSuccess)
 			return e;
 	}
@@ -744,7 +744,7 @@ hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uin
 	if (n == 0)
 		return hipSuccess;
 	// K2: row-ordered queries are coherent enough; bin only if more than a quarter of the steps change tile
-	const hipError_t e = launch_binning(field_tiles(f), d_xyz, n, S, 4u, stream);
+	const hipError_t e = launch_binning(field_tiles(f), field_tiles(f, kSortCells), d_xyz, n, S, 4u, stream);
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = (uint32_t)((n + 255) / 256);
