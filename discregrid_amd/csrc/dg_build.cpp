@@ -4,7 +4,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
+#include <future>
+#include <thread>
 #include <limits>
 #include <numeric>
 #include <unordered_map>
@@ -324,6 +330,11 @@ void clear_rec(PairRec& r)
 	put_empty(r, 1);
 }
 
+// The tree over n primitives has a SHAPE that depends on n alone (object-median splits with the left
+// half rounded up to whole leaves), so the record index of every node and the position of every leaf
+// are known before the primitives are partitioned: subtrees write into disjoint, precomputed ranges,
+// the top levels of the recursion run on separate threads, and the arrays come out exactly as a
+// sequential depth-first build would number them.
 struct Builder
 {
 	std::vector<Prim> prims;
@@ -331,22 +342,56 @@ struct Builder
 	std::vector<int64_t> order; // position (leaf order, padded to even per leaf) -> prim index or -1
 	const double* origin;
 	int max_leaf;
-	uint32_t depth = 0;
+	std::atomic<uint32_t> depth{0};
 
-	// Returns the info word of the subtree over prims [b, e).  Split: object median along the
-	// largest extent of the centroid bounds (balanced tree, depth = ceil(log2(n / max_leaf))).
-	int32_t build(size_t b, size_t e, uint32_t level)
+	size_t left_count(size_t n) const
 	{
-		depth = std::max(depth, level);
+		size_t half = n / 2;
+		if (n > (size_t)(2 * max_leaf))
+			half = ((half + max_leaf - 1) / max_leaf) * max_leaf; // keep leaves full
+		return half;
+	}
+	// pair records / leaf positions of the subtree over n primitives
+	void shape(size_t n, size_t& n_pairs, size_t& n_positions) const
+	{
+		if (n <= (size_t)max_leaf)
+		{
+			n_pairs = 0;
+			n_positions = n + (n & 1u);
+			return;
+		}
+		const size_t half = left_count(n);
+		size_t pl, ql, pr, qr;
+		shape(half, pl, ql);
+		shape(n - half, pr, qr);
+		n_pairs = 1 + pl + pr;
+		n_positions = ql + qr;
+	}
+	void allocate()
+	{
+		size_t np, nq;
+		shape(prims.size(), np, nq);
+		pairs.resize(np);
+		for (auto& r : pairs)
+			clear_rec(r);
+		order.assign(nq, -1);
+	}
+
+	// Returns the info word of the subtree over prims [b, e), whose records start at `rec` and whose
+	// leaves start at position `pos`.  Split: object median along the largest extent of the centroid
+	// bounds (balanced tree, depth = ceil(log2(n / max_leaf))).
+	int32_t build(size_t b, size_t e, uint32_t level, size_t rec, size_t pos)
+	{
+		uint32_t seen = depth.load(std::memory_order_relaxed);
+		while (level > seen && !depth.compare_exchange_weak(seen, level, std::memory_order_relaxed))
+		{
+		}
 		if (e - b <= (size_t)max_leaf)
 		{
-			const uint32_t first = (uint32_t)order.size();
 			for (size_t i = b; i < e; ++i)
-				order.push_back((int64_t)i);
-			if ((e - b) & 1u)
-				order.push_back(-1); // padding slot: leaves start at even positions
-			const uint32_t positions = (uint32_t)order.size() - first;
-			return ~(int32_t)((first << kLeafBits) | (positions - 1));
+				order[pos + (i - b)] = (int64_t)i; // an odd leaf keeps its padding slot (-1) at the end
+			const uint32_t positions = (uint32_t)((e - b) + ((e - b) & 1u));
+			return ~(int32_t)(((uint32_t)pos << kLeafBits) | (positions - 1));
 		}
 		double clo[3], chi[3];
 		for (int d = 0; d < 3; ++d)
@@ -364,20 +409,26 @@ struct Builder
 		for (int d = 1; d < 3; ++d)
 			if (chi[d] - clo[d] > chi[axis] - clo[axis])
 				axis = d;
-		// keep leaves full: the left half gets a multiple of max_leaf when possible
-		size_t half = (e - b) / 2;
-		if ((e - b) > (size_t)(2 * max_leaf))
-			half = ((half + max_leaf - 1) / max_leaf) * max_leaf;
+		const size_t half = left_count(e - b);
 		const size_t mid = b + half;
 		std::nth_element(prims.begin() + b, prims.begin() + mid, prims.begin() + e,
 						 [axis](const Prim& p, const Prim& q) {
 							 return p.c[axis] < q.c[axis] || (p.c[axis] == q.c[axis] && p.tri < q.tri);
 						 });
-		const size_t rec = pairs.size();
-		pairs.emplace_back();
-		clear_rec(pairs[rec]);
-		const int32_t il = build(b, mid, level + 1);
-		const int32_t ir = build(mid, e, level + 1);
+		size_t pl, ql;
+		shape(half, pl, ql);
+		int32_t il, ir;
+		if (level < 4 && e - b > 65536) // the top of a big tree: left half on its own thread
+		{
+			auto left = std::async(std::launch::async, [&]() { return build(b, mid, level + 1, rec + 1, pos); });
+			ir = build(mid, e, level + 1, rec + 1 + pl, pos + ql);
+			il = left.get();
+		}
+		else
+		{
+			il = build(b, mid, level + 1, rec + 1, pos);
+			ir = build(mid, e, level + 1, rec + 1 + pl, pos + ql);
+		}
 		put_side(pairs[rec], 0, bounds_of(&prims[b], mid - b, origin));
 		put_side(pairs[rec], 1, bounds_of(&prims[mid], e - mid, origin));
 		pairs[rec].info[0] = il;
@@ -401,8 +452,17 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	for (size_t i = 0; i < n_vertices; ++i)
 		V[i] = {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
 
+	const bool timing = std::getenv("DG_BUILD_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto tick = [&](const char* what) {
+		const auto now = std::chrono::steady_clock::now();
+		if (timing)
+			std::fprintf(stderr, "build_mesh: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+		t_last = now;
+	};
 	std::vector<D3> pn;
 	pseudonormals(V, tris, n_triangles, pn, out.not_watertight);
+	tick("pseudonormals");
 
 	Builder B;
 	B.max_leaf = max_leaf;
@@ -444,12 +504,13 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	for (int d = 0; d < 3; ++d)
 		out.origin[d] = 0.5 * (lo[d] + hi[d]);
 	B.origin = out.origin;
-	B.pairs.reserve(2 * n_triangles / max_leaf + 16);
-	B.order.reserve(n_triangles + n_triangles / 2 + 2);
-	out.root_info = B.build(0, n_triangles, 0);
+	tick("primitives");
+	B.allocate();
+	out.root_info = B.build(0, n_triangles, 0, 0, 0);
+	tick("tree");
 
 	out.pairs.swap(B.pairs);
-	out.depth = B.depth;
+	out.depth = B.depth.load();
 	// level-order cut of the tree into <= kSubtrees disjoint subtrees that cover it (heavy bricks are split
 	// over them): split the oldest inner node of the queue until kSubtrees pieces exist or only leaves remain
 	{
@@ -482,27 +543,44 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 		l1 = std::max(l1, std::fabs(V[i].x - out.origin[0]) + std::fabs(V[i].y - out.origin[1]) +
 							  std::fabs(V[i].z - out.origin[2]));
 	out.mesh_l1 = std::nextafterf(round_up(l1), std::numeric_limits<float>::infinity());
-	for (size_t k = 0; k < npos; ++k)
+	// packets, per-triangle boxes and pseudonormals in leaf order: independent per position pair
+	// (a padding slot copies its left neighbour, which is in the same pair)
+	auto fill = [&](size_t k0, size_t k1) {
+		for (size_t k = k0; k < k1; ++k)
+		{
+			if (B.order[k] < 0)
+			{
+				// padding slot: a copy of its left neighbour's packet that no bound test can select
+				out.tris[k] = out.tris[k - 1];
+				out.tris[k].tri_id = -1;
+				continue;
+			}
+			const Prim& P = B.prims[(size_t)B.order[k]];
+			const uint32_t t = P.tri;
+			make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
+						out.tris[k]);
+			put_side(out.tri_pairs[k / 2], (int)(k & 1), bounds_of(&P, 1, out.origin));
+			for (int s = 0; s < kPnSlots; ++s)
+			{
+				out.pn[(k * kPnSlots + s) * 3 + 0] = pn[t * kPnSlots + s].x;
+				out.pn[(k * kPnSlots + s) * 3 + 1] = pn[t * kPnSlots + s].y;
+				out.pn[(k * kPnSlots + s) * 3 + 2] = pn[t * kPnSlots + s].z;
+			}
+		}
+	};
+	const size_t n_threads = npos >= (1u << 16) ? std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+	if (n_threads <= 1)
+		fill(0, npos);
+	else
 	{
-		if (B.order[k] < 0)
-		{
-			// padding slot: a copy of its left neighbour's packet that no bound test can select
-			out.tris[k] = out.tris[k - 1];
-			out.tris[k].tri_id = -1;
-			continue;
-		}
-		const Prim& P = B.prims[(size_t)B.order[k]];
-		const uint32_t t = P.tri;
-		make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
-					out.tris[k]);
-		put_side(out.tri_pairs[k / 2], (int)(k & 1), bounds_of(&P, 1, out.origin));
-		for (int s = 0; s < kPnSlots; ++s)
-		{
-			out.pn[(k * kPnSlots + s) * 3 + 0] = pn[t * kPnSlots + s].x;
-			out.pn[(k * kPnSlots + s) * 3 + 1] = pn[t * kPnSlots + s].y;
-			out.pn[(k * kPnSlots + s) * 3 + 2] = pn[t * kPnSlots + s].z;
-		}
+		std::vector<std::thread> workers;
+		const size_t per = (((npos + n_threads - 1) / n_threads) + 1) & ~(size_t)1; // even: a pair stays in one chunk
+		for (size_t k0 = 0; k0 < npos; k0 += per)
+			workers.emplace_back(fill, k0, std::min(npos, k0 + per));
+		for (auto& w : workers)
+			w.join();
 	}
+	tick("packets");
 	return true;
 }
 
