@@ -6,32 +6,38 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the whole grid: every lattice node of a
-CubicLagrangeDiscreteGrid gets the signed distance to the mesh (the addFunction node loop),
-with the mesh/BVH already resident in HBM.  Workload (BASELINE.json configs[2], the one the
-metric is quoted on): synthetic class-I geodesic icosphere, nu = 71 -> 100 820 triangles,
-unit radius; grid 256^3 over the reference's default domain -> 118 425 857 nodes per GPU.
-For N > 1 (weak scaling, BASELINE configs[3]) the grid grows with N -- (256a, 256b, 256c),
-abc = N, i.e. 512^3 at N = 8 -- the lattice is dealt to the ranks in 4-plane slabs, every
-rank samples its shard, an RCCL all-gather assembles the packed shards on every GPU and an
-unpack kernel restores reference node order.  The gather is issued in --pieces C pieces
-(default 4): piece p of rank r is the shard of "virtual rank" p*N + r of a C*N-way deal, so
-the all-gather of piece p runs on RCCL's stream over xGMI while the kernel samples piece p+1
-and a third stream unpacks piece p-1 (C = 1 is the plain sample / gather / unpack sequence).
+CubicLagrangeDiscreteGrid gets the signed distance to the mesh (the addFunction node loop,
+cubic_lagrange_discrete_grid.cpp:806-831), with the mesh/BVH already resident in HBM and the result
+left in HBM.  Workload (BASELINE.json configs[2], the one the metric is quoted on): synthetic class-I
+geodesic icosphere, nu = 71 -> 100 820 triangles, unit radius; grid 256^3 over the reference's default
+domain -> 118 425 857 nodes per GPU.  For N > 1 (weak scaling, BASELINE configs[3]) the grid grows with
+N -- (256a, 256b, 256c), abc = N, i.e. 512^3 at N = 8 -- and one step is the library's
+dg_sdf_sample_allgather_device: the lattice is dealt to the ranks in 4-plane slabs, every rank samples
+its shards in --pieces C pieces, RCCL (inside libdiscregrid_hip.so, its own communicator) all-gathers
+piece p over xGMI while piece p+1 is sampled and piece p-1 is unpacked into reference node order.
 value = total nodes / time, max over ranks.
 
-Also on the JSON line:
-  roofline      achieved = ALGORITHMIC bytes of the reference traversal per launch
-                (B_alg = Vbar*72 + Lbar*84 + 8 bytes/node, SURVEY.md 8(d), frozen in
-                profiles/balg_icosphere71_256.json) / mean K1 kernel duration measured with
-                HIP events on the launch stream; peak = 8 TB/s HBM3E.  (The kernel is VALU-issue
-                bound, not HBM bound: `valu_busy` is the measured fraction of VALU issue slots in use.)
+On the JSON line besides the contract's keys:
+  roofline      K1 is bound by VALU issue, not by HBM: `frac` = fraction of the VALU issue cycles of the
+                1024 SIMDs that were busy (PMC), `hbm` = measured HBM traffic per launch / kernel time
+                against the 8 TB/s peak, next to the compulsory traffic (8 B/node) and a copy kernel's
+                bandwidth measured here.  Counter-derived numbers come from profiles/counters.json, which
+                profiles/collect.sh writes together with a hash of discregrid_amd/csrc: if the sources
+                changed since, they are null ("stale").  `algorithmic_gbs` (the reference traversal's
+                bytes, SURVEY.md 8(d), / kernel time) is informational and is NOT a fraction of anything.
+  value_with_d2h   Mnodes/s of dg_sdf_sample_nodes: kernels + D2H into the caller's host array.
+  addfunction_e2e  the C++ CubicLagrangeDiscreteGrid::addFunction(MeshSDF) call, wall time.
+  secondary     K2 (10 M queries, uniform and SPH-like shell, value / value+gradient) and K3 (density
+                map on the 256^3 SDF) at BASELINE configs[4] sizes.
   cpu_baseline  the unmodified reference (oracle/_ref, kind "reference") or this repo's CPU
                 restatement (kind "port") timed on this box's host cores on a bounded,
                 evenly spread sample of the same lattice (rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,6 +48,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMDS = 1024         # 256 CUs x 4
 
 
 def grid_for(n_gpus):
@@ -56,9 +63,30 @@ def grid_for(n_gpus):
     return dims
 
 
-def load_balg():
-    p = os.path.join(ROOT, "profiles", "balg_icosphere71_256.json")
+def csrc_hash():
+    """SHA-256 over the kernel / ABI sources: ties profiles/counters.json to the code it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "discregrid_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def load_counters():
+    p = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(p):
+        return None, "profiles/counters.json missing"
     with open(p) as f:
+        c = json.load(f)
+    if c.get("csrc_sha256") != csrc_hash():
+        return None, "stale: discregrid_amd/csrc changed since profiles/collect.sh ran"
+    return c, "profiles/counters.json (%s)" % c.get("collected", "?")
+
+
+def load_balg():
+    with open(os.path.join(ROOT, "profiles", "balg_icosphere71_256.json")) as f:
         return json.load(f)
 
 
@@ -91,9 +119,107 @@ def cpu_baseline(V, F, dom, res, budget_s):
     nodes = sum(min(n, s + per_chunk) - s for s in starts)
     return {
         "value": nodes / t / 1e6, "unit": "Mnodes/s", "cores": os.cpu_count(), "kind": kind,
+        "sample_nodes": nodes, "sample_fraction": nodes / n, "sample_seconds": t,
         "sample": "%d nodes = %d evenly spaced runs of %d consecutive lattice nodes of the same %s grid, "
                   "OpenMP schedule(static), %.1f s" % (nodes, n_chunks, per_chunk, "x".join(map(str, res)), t),
     }
+
+
+def timed(torch, stream, fn, reps):
+    """mean device time of fn() in ms, HIP events on the launch stream"""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
+    """The figures SURVEY.md 8(d) asks for beside the kernel rate (N = 1): D2H-inclusive rate, the C++
+    addFunction call end to end, a copy kernel's HBM bandwidth, K2 and K3 at BASELINE configs[4] sizes."""
+    out = {}
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    n_nodes = dg.n_nodes(grid)
+    # -- achievable HBM bandwidth: a device-to-device copy of 1 GiB (read + write counted)
+    src = torch.empty(1 << 27, dtype=torch.float64, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ms = timed(torch, stream, lambda: dst.copy_(src), 5)
+    out["hbm_copy_gbs"] = 2 * src.numel() * 8 / (ms * 1e-3) / 1e9
+    del src, dst
+    # -- K1 + D2H into a host array the caller owns (fresh memory every time, like addFunction's vector)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        host = mesh.sample_nodes(grid)
+        best = min(best, time.perf_counter() - t0)
+        assert host[0] > 0 and np.isfinite(host[::100003]).all()
+        del host
+    out["value_with_d2h"] = {"value": n_nodes / best / 1e6, "unit": "Mnodes/s", "ms": best * 1e3,
+                             "what": "dg_sdf_sample_nodes: K1 + D2H into a freshly allocated pageable host array (best of 3)"}
+    # -- the C++ API call a Discregrid user makes
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "unchanged_caller")
+    if os.path.exists(exe):
+        obj = "/tmp/dg_bench_ico71.obj"
+        T.write_obj(obj, V, F)
+        try:
+            j = json.loads(subprocess.check_output([exe, "addfunction", obj, " ".join(map(str, res)), "4"], timeout=300).decode())
+            calls = [c["total_s"] for c in j["calls"]]
+            out["addfunction_e2e"] = {
+                "value": n_nodes / min(calls[1:]) / 1e6, "unit": "Mnodes/s", "ms": min(calls[1:]) * 1e3, "first_call_ms": calls[0] * 1e3,
+                "ratio_to_kernel": min(calls[1:]) * 1e3 / kernel_ms,
+                "what": "CubicLagrangeDiscreteGrid::addFunction(MeshSDF) on a fresh grid, wall time of the call (C++, best of calls 2-4; "
+                        "the first call of a process also sets up streams and device buffers)"}
+        except Exception as e:  # noqa: BLE001  (a missing / failing driver must not void the headline number)
+            out["addfunction_e2e"] = {"error": str(e)[:200]}
+    else:
+        out["addfunction_e2e"] = None
+    # -- K2: batched interpolate, 10 M queries on the field just sampled (BASELINE configs[4])
+    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n_nodes)
+    nq = 10_000_000
+    P = torch.from_numpy(T.uniform_points(1234, nq, dom[:3], dom[3:])).cuda()
+    C = torch.from_numpy(T.uniform_points(4321, 26_000_000, dom[:3], dom[3:])).cuda()
+    phic = torch.empty(len(C), dtype=torch.float64, device="cuda")
+    fld.interpolate_device(C.data_ptr(), len(C), phic.data_ptr(), stream=s)
+    S = C[(phic.abs() < 0.2)][:nq].contiguous()
+    del C, phic
+    phi = torch.empty(nq, dtype=torch.float64, device="cuda")
+    grad = torch.empty(3 * nq, dtype=torch.float64, device="cuda")
+    k2 = {}
+    for name, Q in (("uniform", P), ("shell", S)):
+        if len(Q) < nq:
+            continue
+        for g in (False, True):
+            fn = (lambda Q=Q, g=g: fld.interpolate_device(Q.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
+            fn()
+            ms = timed(torch, stream, fn, 5)
+            bytes_q = 312 if g else 288
+            k2["%s_%s" % (name, "grad" if g else "value")] = {
+                "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "algorithmic_gbs": nq * bytes_q / (ms * 1e-3) / 1e9,
+                "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    k2["what"] = "10 M queries (std::mt19937_64 seed 1234 uniform; |phi| < 2h shell, h = 0.1) on the 256^3 field, device-resident, unordered input incl. the on-device binning"
+    out_secondary = {"k2_interpolate": k2}
+    del P, S, phi, grad
+    # -- K3: density map on the same SDF (GenerateDensityMap's node function), whole lattice
+    dens = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
+    fld.density_map_nodes_device(0.1, 1000.0, True, 0, min(n_nodes, 1 << 20), dens.data_ptr(), stream=s)   # code load
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fld.density_map_nodes_device(0.1, 1000.0, True, 0, n_nodes, dens.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    integrated = int(((dens != np.finfo(np.float64).max) & (dens != 0.0)).sum().item())
+    out_secondary["k3_density_map"] = {
+        "seconds": dt, "mnodes_s": n_nodes / dt / 1e6, "nodes_integrated": integrated,
+        "ginterpolations_s": integrated * 4097 / dt / 1e9,
+        "what": "dg_density_map_nodes_device, h = 0.1, band predicate, all %d nodes of the 256^3 SDF; an integrated node is 1 + 4096 "
+                "interpolations in the reference's count" % n_nodes}
+    out["secondary"] = out_secondary
+    fld.close()
+    return out
 
 
 def main():
@@ -102,11 +228,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--pcie", action="store_true", help="also report the PCIe-inclusive rate on stderr")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed K1 steps (profiling runs)")
     ap.add_argument("--pieces", type=int, default=4,
                     help="N > 1: issue the all-gather in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
-                    help="run the N > 1 protocol (RCCL init, shard, all_gather, unpack) even at N = 1 (self-test)")
+                    help="run the N > 1 protocol (communicator, shards, all-gather, unpack) even at N = 1 (self-test)")
+    ap.add_argument("--python-gather", action="store_true",
+                    help="N > 1: drive the pieces from here with torch.distributed's all_gather instead of the library's "
+                         "dg_sdf_sample_allgather_device (A/B, and the one-GPU self-test)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
@@ -123,6 +252,7 @@ def main():
     selftest = os.environ.get("DG_BENCH_SELFTEST_ONE_GPU") == "1"
     if selftest:
         local_rank = 0
+        args.python_gather = True
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -147,10 +277,9 @@ def main():
     s = stream.cuda_stream
 
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
+    comm = None
+    pieces = 1
     if sharded:
-        # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
-        # 4-plane slabs; all virtual ranks share one slot size, so `gathered` is exactly the buffer a
-        # single all-gather among pieces*world ranks would produce and the unpack kernel is unchanged
         pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
         vworld = pieces * world
         counts = []
@@ -158,32 +287,47 @@ def main():
         for p in range(pieces):
             c, stride = dg.shard_layout(grid, p * world + rank, vworld)
             counts.append(c)
-        gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
-        mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
         launch_nodes = sum(counts)
+        if args.python_gather:
+            # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
+            # 4-plane slabs; `gathered` is exactly the buffer a single all-gather among pieces*world ranks
+            # would produce and the unpack kernel is unchanged
+            gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
+            mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
+            unpack_stream = torch.cuda.Stream()
+        else:
+            # the library's own RCCL communicator: rank 0's unique id travels through torch.distributed
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(dg.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = dg.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
     else:
         launch_nodes = n_nodes
 
-    unpack_stream = torch.cuda.Stream() if sharded else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record(stream)
-        if sharded:
+        if sharded and comm is not None:
+            comm.sample_allgather_device(mesh, grid, field.data_ptr(), pieces=pieces, stream=s)
+            if i is not None:
+                ev[i][1].record(stream)    # the call makes `stream` wait for the last unpack
+        elif sharded:
             for p in range(pieces):
                 mp = mine[p * stride:(p + 1) * stride]
                 mesh.sample_shard_device(grid, p * world + rank, vworld, mp.data_ptr(), stream=s)
-                # RCCL's stream waits for the kernel just enqueued; this stream goes on with piece p+1
+                # the collective's stream waits for the kernel just enqueued; this stream goes on with piece p+1
                 work = dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp,
                                                    async_op=True)
                 with torch.cuda.stream(unpack_stream):
                     work.wait()          # unpack_stream waits for gather p, not the host
                     dg.unpack_shard_range_device(grid, vworld, gathered.data_ptr(), stride, p * world, (p + 1) * world,
                                                  field.data_ptr(), stream=unpack_stream.cuda_stream)
+            stream.wait_stream(unpack_stream)
             if i is not None:
                 ev[i][1].record(stream)
-            stream.wait_stream(unpack_stream)
         else:
             mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
             if i is not None:
@@ -220,9 +364,10 @@ def main():
 
     if rank == 0:
         balg = load_balg()
-        achieved = balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9
+        counters, counters_note = load_counters()
+        k1 = (counters or {}).get("k1") if world == 1 else None
         out = {
-            "metric": "Mnodes/s SDF sampling (256\u00b3 grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
+            "metric": "Mnodes/s SDF sampling (256³ grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
             "value": n_nodes * args.steps / elapsed / 1e6,
             "unit": "Mnodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,35 +379,44 @@ def main():
                             % ("x".join(map(str, res)), n_nodes),
                 "nodes_per_gpu_launch": launch_nodes,
                 "sharding": "none" if not sharded else
-                            "4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s)" % pieces,
+                            "4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
+                            % (pieces, "torch.distributed (python)" if comm is None else "dg_sdf_sample_allgather_device (RCCL inside the library)"),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": balg.get("measured_hbm_bytes_per_launch") if world == 1 else None,
-                # one dg_sdf_sample_*_device call = k_sample_nodes + the two heavy-brick kernels (4 % of it)
+                # K1's binding resource is VALU issue: frac = busy VALU cycles / (SIMDs x kernel cycles), from PMC
+                "bound": "valu_issue",
+                "achieved": k1["valu_busy"] if k1 else None, "peak": 1.0,
+                "unit": "fraction of the VALU issue cycles of the %d SIMDs" % N_SIMDS,
+                "frac": k1["valu_busy"] if k1 else None,
+                "traffic": k1["hbm_bytes_per_launch"] if k1 else None,
+                # one dg_sdf_sample_*_device call = k_sample_nodes + the two heavy-brick kernels (3 % of it)
                 "kernel": "k_sample_nodes (+ k_heavy_subtrees, k_heavy_finish)", "kernel_ms": kernel_ms,
-                # the resource that actually binds K1 (PMC, profiles/r01_pmc_summary.txt): VALU issue
-                "valu_busy": balg.get("measured_valu_busy") if world == 1 else None,
+                "hbm": {
+                    "bound_by_hbm": False,
+                    "achieved_gbs": (k1["hbm_bytes_per_launch"] / (k1["kernel_ms"] * 1e-3) / 1e9) if k1 else None,
+                    "peak_gbs": HBM_PEAK_GBS,
+                    "frac": (k1["hbm_bytes_per_launch"] / (k1["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1 else None,
+                    "compulsory_bytes_per_launch": 8 * launch_nodes,
+                    "kernel_ms_at_hbm_roof": 8 * launch_nodes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                },
+                "counters": counters_note,
+                "per_brick": k1.get("per_brick") if k1 else None,
+                # informational only: bytes the REFERENCE's traversal would move for these nodes / this kernel's time
                 "algorithmic_bytes_per_node": balg["bytes_per_node"],
+                "algorithmic_gbs": balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9,
             },
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and not args.no_extras:
+            out.update(extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms))
+            out["roofline"]["hbm"]["copy_kernel_gbs"] = out.pop("hbm_copy_gbs")
+        if world == 1 and args.cpu_seconds > 0 and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(V, F, dom, res, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        if args.pcie and world == 1:
-            host = torch.empty(n_nodes, dtype=torch.float64).pin_memory()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
-            host.copy_(field, non_blocking=True)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            print("PCIe-inclusive (kernel + D2H into pinned host memory): %.1f Mnodes/s" % (n_nodes / dt / 1e6),
-                  file=sys.stderr)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -67,6 +67,8 @@ SYMBOLS = {
     "dg_signed_distance": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _i32p, _i32p, _dp]),
     "dg_signed_distance_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "dg_signed_distance_point": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _dp]),
+    "dg_set_progress_callback": (None, [C.c_void_p, C.c_void_p]),
     "dg_shard_layout": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_int, C.POINTER(ShardInfo)]),
     "dg_sdf_sample_shard_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p]),
@@ -74,6 +76,12 @@ SYMBOLS = {
                                           C.c_void_p]),
     "dg_unpack_shard_range_device": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                                C.c_void_p, C.c_void_p]),
+    "dg_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dg_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dg_comm_adopt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dg_comm_destroy": (None, [C.c_void_p]),
+    "dg_sdf_sample_allgather_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p]),
     "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
                                   C.POINTER(C.c_void_p)]),
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -221,6 +229,16 @@ class Mesh:
                                             None if near is None else near.ctypes.data_as(_dp)))
         return (d, tri, ent, near) if full else d
 
+    def signed_distance_point(self, p, full=False):
+        """dg_signed_distance_point: one point, evaluated on the calling host thread."""
+        x = _f64(p).reshape(3)
+        d = C.c_double()
+        tri, ent = C.c_int32(), C.c_int32()
+        near = np.empty(3)
+        _check(self._lib.dg_signed_distance_point(self.handle, x.ctypes.data_as(_dp), C.byref(d), C.byref(tri),
+                                                  C.byref(ent), near.ctypes.data_as(_dp)))
+        return (d.value, tri.value, ent.value, near) if full else d.value
+
     # ---- device-pointer entry points (ints = device addresses, stream = hipStream_t address) ---
     def sample_nodes_device(self, grid, begin, end, d_out, invert=False, d_mask=None, stream=0):
         _check(self._lib.dg_sdf_sample_nodes_device(self.handle, C.byref(grid), int(invert), begin, end,
@@ -257,6 +275,35 @@ def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):
 def unpack_shard_range_device(grid, nranks, d_gathered, stride, rank_begin, rank_end, d_field, stream=0):
     _check(load_library().dg_unpack_shard_range_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
                                                        rank_begin, rank_end, C.c_void_p(d_field), C.c_void_p(stream)))
+
+
+class Comm:
+    """dg_comm handle: an RCCL communicator of one-process-per-GPU ranks, created inside the library."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(load_library().dg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, nranks):
+        self._lib = load_library()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(self._lib.dg_comm_create(buf, rank, nranks, C.byref(h)))
+        self.handle = h
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.dg_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def sample_allgather_device(self, mesh, grid, d_field, pieces=4, invert=False, stream=0):
+        _check(self._lib.dg_sdf_sample_allgather_device(mesh.handle, C.byref(grid), int(invert), self.handle, pieces,
+                                                        C.c_void_p(d_field), C.c_void_p(stream)))
 
 
 class Field:

@@ -1,0 +1,269 @@
+// GenerateSDFMultiGPU -- GenerateSDF over several GPUs of one node, one process per GPU (no reference
+// counterpart: the reference is a single OpenMP process; options as GenerateSDF, cmd/generate_sdf/main.cpp:33-40,
+// plus -g/--gpus N, --pieces C, --steps K).
+//
+// The parent forks N ranks before touching HIP.  Rank r makes device r current, uploads the mesh
+// (replicated), joins the RCCL communicator (rank 0 publishes the unique id through a file) and calls
+// dg_sdf_sample_allgather_device: its shards of the node lattice are sampled, all-gathered over xGMI and
+// unpacked, in pieces that overlap, so that EVERY rank holds the whole coefficient vector on its GPU
+// (ready for the batched interpolate / density-map kernels).  Rank 0 copies it to the host and writes the
+// same .cdf file GenerateSDF writes.  With --steps K the sampling step is repeated K times after one
+// warm-up and the parent prints one JSON line: whole-job Mnodes/s = nodes * K / max over ranks of the
+// time of the K steps (the figure bench.py reports for N GPUs).
+#include <Discregrid/All>
+
+#include <hip/hip_runtime_api.h>
+
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "discregrid_hip.h"
+
+namespace
+{
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Options
+{
+	std::array<unsigned int, 3> resolution = {{10, 10, 10}};
+	Eigen::AlignedBox3d domain;
+	bool invert = false;
+	int gpus = 1, pieces = 4, steps = 1;
+	std::string output, input;
+};
+
+[[noreturn]] void die(int rank, const std::string& what)
+{
+	std::cerr << "GenerateSDFMultiGPU rank " << rank << ": " << what << std::endl;
+	_exit(1);
+}
+void check(int rank, dg_status s, const char* what)
+{
+	if (s != DG_OK)
+		die(rank, std::string(what) + ": " + dg_last_error());
+}
+void check_hip(int rank, hipError_t e, const char* what)
+{
+	if (e != hipSuccess)
+		die(rank, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int run_rank(const Options& opt, int rank, const std::string& id_file, const std::string& time_file)
+{
+	int n_devices = 0;
+	check(rank, dg_device_count(&n_devices), "dg_device_count");
+	if (n_devices < 1)
+		die(rank, "no HIP device");
+	if (opt.gpus > n_devices)
+		die(rank, "asked for " + std::to_string(opt.gpus) + " GPUs, " + std::to_string(n_devices) + " visible");
+	check(rank, dg_set_device(rank), "dg_set_device");
+
+	Discregrid::TriangleMesh mesh(opt.input);
+	Eigen::AlignedBox3d domain = opt.domain;
+	if (domain.isEmpty())
+	{
+		for (auto const& x : mesh.vertices())
+			domain.extend(x);
+		domain.max() += 1.0e-3 * domain.diagonal().norm() * Eigen::Vector3d::Ones(); // main.cpp:83-91
+		domain.min() -= 1.0e-3 * domain.diagonal().norm() * Eigen::Vector3d::Ones();
+	}
+	Discregrid::TriangleMeshDistance md(mesh); // uploads BVH + packets to this rank's GPU
+	Discregrid::CubicLagrangeDiscreteGrid sdf(domain, opt.resolution);
+	dg_grid_desc grid;
+	std::memset(&grid, 0, sizeof(grid));
+	for (int d = 0; d < 3; ++d)
+	{
+		grid.domain_min[d] = domain.min()[d];
+		grid.domain_max[d] = domain.max()[d];
+		grid.resolution[d] = opt.resolution[d];
+		grid.cell_size[d] = sdf.cellSize()[d];
+		grid.inv_cell_size[d] = sdf.invCellSize()[d];
+	}
+	const uint64_t n_nodes = dg_grid_n_nodes(&grid);
+
+	// communicator: rank 0 publishes the RCCL unique id through a file (written whole, then renamed)
+	uint8_t id[DG_UNIQUE_ID_BYTES];
+	if (rank == 0)
+	{
+		check(rank, dg_comm_unique_id(id), "dg_comm_unique_id");
+		const std::string tmp = id_file + ".tmp";
+		std::ofstream(tmp, std::ios::binary).write(reinterpret_cast<const char*>(id), sizeof(id));
+		if (std::rename(tmp.c_str(), id_file.c_str()) != 0)
+			die(rank, "cannot publish the communicator id");
+	}
+	else
+	{
+		const double t0 = now();
+		while (true)
+		{
+			std::ifstream in(id_file, std::ios::binary);
+			if (in.good() && in.read(reinterpret_cast<char*>(id), sizeof(id)))
+				break;
+			if (now() - t0 > 120.0)
+				die(rank, "timed out waiting for the communicator id");
+			std::this_thread::sleep_for(std::chrono::milliseconds(20));
+		}
+	}
+	dg_comm* comm = nullptr;
+	check(rank, dg_comm_create(id, rank, opt.gpus, &comm), "dg_comm_create");
+
+	double* d_field = nullptr;
+	check_hip(rank, hipMalloc(reinterpret_cast<void**>(&d_field), n_nodes * sizeof(double)), "hipMalloc");
+	hipStream_t stream = nullptr;
+	check_hip(rank, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+	const dg_mesh* dmesh = static_cast<const dg_mesh*>(md.deviceMesh());
+
+	// one untimed step (first-use allocations, RCCL channel set-up), then the timed ones
+	check(rank, dg_sdf_sample_allgather_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, d_field, stream), "sample + all-gather");
+	check_hip(rank, hipStreamSynchronize(stream), "synchronize");
+	double seconds = 0.0;
+	if (opt.steps > 1 || !time_file.empty())
+	{
+		const double t0 = now();
+		for (int k = 0; k < opt.steps; ++k)
+			check(rank, dg_sdf_sample_allgather_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, d_field, stream), "sample + all-gather");
+		check_hip(rank, hipStreamSynchronize(stream), "synchronize");
+		seconds = now() - t0;
+	}
+	if (!time_file.empty())
+		std::ofstream(time_file) << seconds << "\n";
+
+	if (rank == 0 && !opt.output.empty())
+	{
+		Discregrid::FieldVector coeffs(n_nodes);
+		check_hip(rank, hipMemcpy(coeffs.data(), d_field, n_nodes * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy");
+		sdf.addNodeData(std::move(coeffs));
+		sdf.save(opt.output);
+	}
+	dg_comm_destroy(comm);
+	(void)hipFree(d_field);
+	(void)hipStreamDestroy(stream);
+	return 0;
+}
+} // namespace
+
+int main(int argc, char* argv[])
+{
+	Options opt;
+	opt.domain.setEmpty();
+	bool timing = false;
+	for (int i = 1; i < argc; ++i)
+	{
+		const std::string a = argv[i];
+		auto value = [&]() -> std::string {
+			if (i + 1 >= argc)
+			{
+				std::cout << "error parsing options: Option " << a << " is missing an argument" << std::endl;
+				exit(1);
+			}
+			return argv[++i];
+		};
+		if (a == "-h" || a == "--help")
+		{
+			std::cout << "Usage: " << argv[0]
+					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--steps k] [-o out.cdf] mesh.obj"
+					  << std::endl;
+			return 0;
+		}
+		else if (a == "-i" || a == "--invert")
+			opt.invert = true;
+		else if (a == "-r" || a == "--resolution")
+		{
+			std::istringstream s(value());
+			s >> opt.resolution[0] >> opt.resolution[1] >> opt.resolution[2];
+		}
+		else if (a == "-d" || a == "--domain")
+		{
+			std::istringstream s(value());
+			s >> opt.domain.min()[0] >> opt.domain.min()[1] >> opt.domain.min()[2] >> opt.domain.max()[0] >> opt.domain.max()[1] >>
+				opt.domain.max()[2];
+		}
+		else if (a == "-g" || a == "--gpus")
+			opt.gpus = std::atoi(value().c_str());
+		else if (a == "--pieces")
+			opt.pieces = std::atoi(value().c_str());
+		else if (a == "--steps")
+		{
+			opt.steps = std::atoi(value().c_str());
+			timing = true;
+		}
+		else if (a == "-o" || a == "--output")
+			opt.output = value();
+		else if (!a.empty() && a[0] == '-')
+		{
+			std::cout << "error parsing options: Option '" << a << "' does not exist" << std::endl;
+			return 1;
+		}
+		else if (opt.input.empty())
+			opt.input = a;
+	}
+	if (opt.input.empty() || !std::ifstream(opt.input).good())
+	{
+		std::cerr << "ERROR: Input file does not exist!" << std::endl;
+		return 1;
+	}
+	if (opt.gpus < 1 || opt.gpus > 64 || opt.steps < 1)
+	{
+		std::cerr << "ERROR: --gpus must be 1..64, --steps >= 1" << std::endl;
+		return 1;
+	}
+	const std::string base = "/tmp/dg_multi_gpu_" + std::to_string((long)getpid());
+	const std::string id_file = base + ".id";
+	std::vector<pid_t> kids;
+	for (int r = 0; r < opt.gpus; ++r)
+	{
+		const pid_t pid = fork(); // before any HIP call: every rank initialises its own runtime
+		if (pid < 0)
+		{
+			std::perror("fork");
+			return 1;
+		}
+		if (pid == 0)
+			_exit(run_rank(opt, r, id_file, timing ? base + ".t" + std::to_string(r) : std::string()));
+		kids.push_back(pid);
+	}
+	int failed = 0;
+	for (pid_t pid : kids)
+	{
+		int st = 0;
+		waitpid(pid, &st, 0);
+		failed += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+	}
+	std::remove(id_file.c_str());
+	double slowest = 0.0;
+	for (int r = 0; r < opt.gpus && timing; ++r)
+	{
+		const std::string f = base + ".t" + std::to_string(r);
+		double s = 0.0;
+		std::ifstream(f) >> s;
+		slowest = std::max(slowest, s);
+		std::remove(f.c_str());
+	}
+	if (failed)
+	{
+		std::cerr << "GenerateSDFMultiGPU: " << failed << " rank(s) failed" << std::endl;
+		return 1;
+	}
+	if (timing)
+	{
+		const uint64_t nx = opt.resolution[0], ny = opt.resolution[1], nz = opt.resolution[2];
+		const uint64_t n_nodes = (nx + 1) * (ny + 1) * (nz + 1) + 2 * (nx * (ny + 1) * (nz + 1) + (nx + 1) * ny * (nz + 1) + (nx + 1) * (ny + 1) * nz);
+		std::printf("{\"metric\": \"Mnodes/s SDF sampling, sample + all-gather + unpack\", \"value\": %.3f, \"unit\": \"Mnodes/s\", "
+					"\"n_gpus\": %d, \"steps\": %d, \"pieces\": %d, \"ms_per_step\": %.4f, \"nodes\": %llu}\n",
+					(double)n_nodes * opt.steps / slowest / 1e6, opt.gpus, opt.steps, opt.pieces, slowest / opt.steps * 1e3,
+					(unsigned long long)n_nodes);
+	}
+	return 0;
+}

@@ -17,6 +17,7 @@
 #pragma once
 
 #include "discrete_grid.hpp"
+#include "utility/field_allocator.hpp"
 
 #include <memory>
 
@@ -74,8 +75,14 @@ public:
 	unsigned int addDensityMap(unsigned int sdf_field, double support_radius, double rho0, bool band_predicate = true,
 							   bool verbose = false);
 
+	// Adopts a coefficient vector that was computed elsewhere for THIS grid's lattice (full, unreduced
+	// node order [V | X | Y | Z], nNodes() values) -- e.g. by dg_sdf_sample_allgather_device on several
+	// GPUs -- as a new field; returns its id.  Throws std::invalid_argument on a size mismatch.
+	unsigned int addNodeData(FieldVector coeffs);
+	unsigned int nNodes() const { return nNodesFull(); }
+
 	std::size_t nFields() const { return m_n_fields; }
-	std::vector<double> const& nodeData(unsigned int field_id) const { return m_nodes[field_id]; }
+	FieldVector const& nodeData(unsigned int field_id) const { return m_nodes[field_id]; }
 	// Seconds spent in the last addFunction call (whole call) and in its node-sampling stage.
 	double lastAddFunctionSeconds() const { return m_last_total_s; }
 	double lastSamplingSeconds() const { return m_last_sampling_s; }
@@ -89,7 +96,9 @@ private:
 	void invalidateDevice(unsigned int field_id) const;
 
 private:
-	std::vector<std::vector<double>> m_nodes;
+	// one FieldVector per field: a std::vector<double> whose allocator skips the zero fill and
+	// hands out huge-page-advised memory (utility/field_allocator.hpp)
+	std::vector<FieldVector> m_nodes;
 	// m_cells[f] / m_cell_map[f] are EMPTY while field f is unreduced (identity map, closed-form
 	// rows); they hold the reference's tables once the field has been reduced or loaded reduced.
 	std::vector<std::vector<std::array<unsigned int, 32>>> m_cells;

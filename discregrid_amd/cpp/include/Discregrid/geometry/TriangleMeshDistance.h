@@ -1,10 +1,12 @@
 // Discregrid::TriangleMeshDistance -- API-compatible with the reference's header-only class
 // (discregrid/include/Discregrid/geometry/TriangleMeshDistance.h:36-208).  Construction builds the
 // angle-weighted pseudonormals exactly like the reference and a flattened BVH of this
-// library's own design, and uploads both to the GPU (dg_mesh_create); every distance query
-// runs on the GPU.  Single-point calls keep the reference signatures (one tiny launch each --
-// correct but slow); use the batch overloads, or hand a MeshSDF to
-// CubicLagrangeDiscreteGrid::addFunction, for throughput.
+// library's own design, and uploads both to the GPU (dg_mesh_create).  Batches of points and whole
+// lattices (hand a MeshSDF to CubicLagrangeDiscreteGrid::addFunction) are evaluated on the GPU.  The
+// reference's single-point signed_distance / unsigned_distance keep their signatures and contract
+// (const, thread safe) and are evaluated on the calling thread against the same BVH with the same
+// arithmetic -- an unchanged caller such as the lambda of cmd/generate_sdf/main.cpp:97-101 works,
+// at host speed.
 //
 // Deviations from the reference, on purpose:
 //   * errors (query before construct(), empty triangle list) throw std::runtime_error after

@@ -18,6 +18,7 @@
 #include <limits>
 #include <numeric>
 #include <stdexcept>
+#include <string>
 
 #include "discregrid_hip.h"
 #include "dg_lattice.h"
@@ -223,6 +224,22 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 		// one GPU, or -- when the mesh has replicas on further devices (DG_DEVICES) -- all of them,
 		// each with its own copy pipeline writing into `coeffs`
 		auto const& all = sdf->distance->deviceMeshes();
+		// verbose: the reference's progress line, at most once per second and at the end (:819-829)
+		struct ProgressScope
+		{
+			explicit ProgressScope(bool on)
+			{
+				if (on)
+					dg_set_progress_callback(
+						[](uint64_t done, uint64_t total, void*) {
+							std::cout << "\r"
+									  << "Construction " << std::setw(20)
+									  << 100.0 * static_cast<double>(done) / static_cast<double>(total) << "%" << std::flush;
+						},
+						nullptr);
+			}
+			~ProgressScope() { dg_set_progress_callback(nullptr, nullptr); }
+		} progress_scope(verbose);
 		dg_status st;
 		if (all.size() > 1)
 			st = dg_sdf_sample_nodes_multi(reinterpret_cast<const dg_mesh* const*>(all.data()), (int)all.size(), &g,
@@ -232,9 +249,6 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 		if (st != DG_OK)
 			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addFunction (GPU): ") + dg_last_error());
 		m_last_used_gpu = true;
-		if (verbose)
-			std::cout << "\r"
-					  << "Construction " << std::setw(20) << 100.0 << "%";
 	}
 	else
 	{
@@ -281,6 +295,18 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 	return static_cast<unsigned int>(m_n_fields++);
 }
 
+unsigned int CubicLagrangeDiscreteGrid::addNodeData(FieldVector coeffs)
+{
+	if (coeffs.size() != nNodesFull())
+		throw std::invalid_argument("CubicLagrangeDiscreteGrid::addNodeData: expected " + std::to_string(nNodesFull()) +
+									" coefficients, got " + std::to_string(coeffs.size()));
+	m_nodes.push_back(std::move(coeffs));
+	m_cells.push_back({});
+	m_cell_map.push_back({});
+	m_dev->fields.resize(m_nodes.size(), nullptr);
+	return static_cast<unsigned int>(m_n_fields++);
+}
+
 unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, double support_radius, double rho0,
 													  bool band_predicate, bool verbose)
 {
@@ -302,7 +328,7 @@ unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, do
 							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
 			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
 	}
-	std::vector<double> coeffs(n_nodes);
+	FieldVector coeffs(n_nodes);
 	if (dg_density_map_nodes(f, support_radius, rho0, band_predicate ? 1 : 0, 0, n_nodes, nullptr, coeffs.data()) != DG_OK)
 		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
 	m_nodes.push_back(std::move(coeffs));
@@ -325,7 +351,7 @@ unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, do
 namespace
 {
 dg::FieldDev host_field(Eigen::AlignedBox3d const& dom, std::array<unsigned int, 3> const& res,
-						Eigen::Vector3d const& cell, Eigen::Vector3d const& inv, std::vector<double> const& coeffs,
+						Eigen::Vector3d const& cell, Eigen::Vector3d const& inv, FieldVector const& coeffs,
 						std::vector<std::array<unsigned int, 32>> const& cells, std::vector<unsigned int> const& map)
 {
 	dg::FieldDev F;
@@ -558,7 +584,7 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 
 	tick("sort");
 	std::vector<unsigned int> new_id(n, kNoCell);
-	std::vector<double> out(m);
+	FieldVector out(m);
 	for (std::size_t i = 0; i < m; ++i)
 	{
 		out[i] = coeffs[at[order[i]]];

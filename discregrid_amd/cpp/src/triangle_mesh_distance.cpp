@@ -1,5 +1,7 @@
-// TriangleMeshDistance: a thin owner of a dg_mesh handle (include/discregrid_hip.h).  All
-// distance queries run on the GPU; there is no host implementation of the query here.
+// TriangleMeshDistance: owner of a dg_mesh handle (include/discregrid_hip.h).  Batches of points and
+// whole lattices (MeshSDF) run on the GPU; the reference's single-point signed_distance /
+// unsigned_distance -- const, thread safe, called per node or per particle by user code -- are
+// evaluated on the calling thread by dg_signed_distance_point (same BVH, same arithmetic, same bits).
 #include <Discregrid/geometry/TriangleMeshDistance.h>
 
 #include <cstdlib>
@@ -126,10 +128,16 @@ void TriangleMeshDistance::signed_distance(const double* xyz, std::size_t n, dou
 
 Result TriangleMeshDistance::signed_distance(const std::array<double, 3>& point) const
 {
+	if (!m_impl)
+	{
+		std::cout << "DistanceTriangleMesh error: not constructed." << std::endl;
+		throw std::runtime_error("DistanceTriangleMesh error: not constructed.");
+	}
 	Result r;
-	int tri = -1, ent = 0;
+	int32_t tri = -1, ent = 0;
 	double np[3] = {0, 0, 0};
-	signed_distance(point.data(), 1, &r.distance, &tri, &ent, np);
+	if (dg_signed_distance_point(m_impl->mesh, point.data(), &r.distance, &tri, &ent, np) != DG_OK)
+		fail("TriangleMeshDistance::signed_distance");
 	r.triangle_id = tri;
 	r.nearest_entity = static_cast<NearestEntity>(ent);
 	r.nearest_point = Vec3d(np[0], np[1], np[2]);

@@ -240,6 +240,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->info.not_watertight = B.not_watertight;
 	m->info.device_bytes = nb + tb + pb + sb;
 	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
+	m->host = std::move(B);
 	*out = m;
 	return DG_OK;
 }
@@ -256,6 +257,7 @@ void dg_mesh_destroy(dg_mesh* m)
 {
 	if (!m)
 		return;
+	DeviceGuard guard(m->device);
 	if (m->d_pairs) (void)hipFree(m->d_pairs);
 	if (m->d_tri_pairs) (void)hipFree(m->d_tri_pairs);
 	if (m->d_tris) (void)hipFree(m->d_tris);
@@ -320,6 +322,8 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		return -1;
 	}
 	int idx = -1;
+	char* base = nullptr;
+	uint32_t laid_out_slots = 0;
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		for (size_t i = 0; i < mesh->scratch.size() && idx < 0; ++i)
@@ -346,10 +350,11 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		mesh->scratch[(size_t)idx].stream = stream;
 		mesh->scratch[(size_t)idx].serial = ++mesh->scratch_serial;
 		mesh->scratch[(size_t)idx].used_slots = slots;
+		base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
+		laid_out_slots = mesh->scratch[(size_t)idx].slots;
 	}
-	char* base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
 	size_t off[6];
-	dg::overflow_bytes(mesh->scratch[(size_t)idx].slots, off); // the layout the buffer was allocated with
+	dg::overflow_bytes(laid_out_slots, off); // the layout the buffer was allocated with
 	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
 	P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
 	P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
@@ -399,6 +404,7 @@ dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32
 	}
 	if (!mem)
 		return DG_OK;
+	DG_ON_DEVICE_OF(mesh);
 	DG_HIP(hipEventSynchronize(done));
 	uint32_t count = 0;
 	DG_HIP(hipMemcpy(&count, mem, sizeof(count), hipMemcpyDeviceToHost)); // the counter is the first word
@@ -428,6 +434,7 @@ dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* gr
 					(unsigned long long)node_end, (unsigned long long)total);
 	if (node_begin == node_end)
 		return DG_OK;
+	DG_ON_DEVICE_OF(mesh);
 
 	dg::SampleParams P;
 	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
@@ -446,6 +453,7 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 		return fail(DG_ERR_INVALID, "null argument");
 	if (n == 0)
 		return DG_OK;
+	DG_ON_DEVICE_OF(mesh);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	dg::SampleParams P;
 	const double zero[3] = {0.0, 0.0, 0.0};
@@ -520,6 +528,7 @@ dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* gr
 		return fail(DG_ERR_INVALID, "invalid grid");
 	if (nranks < 1 || nranks > dg::kMaxRanks || rank < 0 || rank >= nranks)
 		return fail(DG_ERR_INVALID, "rank %d / nranks %d out of range", rank, nranks);
+	DG_ON_DEVICE_OF(mesh);
 	dg::SampleParams P;
 	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
 	P.xcd_chunk = env_xcd_chunk();

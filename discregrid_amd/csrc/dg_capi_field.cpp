@@ -26,13 +26,16 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 	if (!out)
 		return fail(DG_ERR_INVALID, "out is null");
 	*out = nullptr;
-	if (!grid || !d_coeffs)
+	if (!grid || (!d_coeffs && n_coeffs != 0))
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))
 		return fail(DG_ERR_INVALID, "invalid grid");
-	if ((d_cells == nullptr) != (d_cell_map == nullptr))
+	// a field reduced to nothing (reduceField removed every cell) has an empty cell table and a cell map
+	// that marks every cell as removed: every query then returns DG_NO_VALUE, as in the reference (:992-994)
+	const bool reduced_to_nothing = d_cells == nullptr && d_cell_map != nullptr && n_cell_rows == 0;
+	if ((d_cells == nullptr) != (d_cell_map == nullptr) && !reduced_to_nothing)
 		return fail(DG_ERR_INVALID, "cells and cell_map must be given together");
-	if (!d_cells && n_coeffs != dg_grid_n_nodes(grid))
+	if (!d_cells && !d_cell_map && n_coeffs != dg_grid_n_nodes(grid))
 		return fail(DG_ERR_INVALID, "an unreduced field needs %llu coefficients, got %llu",
 					(unsigned long long)dg_grid_n_nodes(grid), (unsigned long long)n_coeffs);
 	(void)n_cell_rows;
@@ -46,7 +49,7 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 	f->dev.cell_major = nullptr;
 	f->grid = *grid;
 	f->n_coeffs = n_coeffs;
-	f->n_rows = d_cells ? n_cell_rows : dg_grid_n_cells(grid);
+	f->n_rows = (d_cells || d_cell_map) ? n_cell_rows : dg_grid_n_cells(grid);
 	(void)hipGetDevice(&f->device);
 	*out = f;
 	return DG_OK;
@@ -58,23 +61,36 @@ dg_status dg_field_create(const dg_grid_desc* grid, const double* coeffs, uint64
 	if (!out)
 		return fail(DG_ERR_INVALID, "out is null");
 	*out = nullptr;
-	if (!grid || !coeffs)
+	if (!grid || (!coeffs && n_coeffs != 0))
 		return fail(DG_ERR_INVALID, "null argument");
-	if ((cells == nullptr) != (cell_map == nullptr))
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	const uint64_t ncell = dg_grid_n_cells(grid);
+	if (n_cell_rows == 0 && cell_map != nullptr)
+	{
+		// reduced to nothing: the (possibly null) table has no rows, so the map may only hold "removed"
+		for (uint64_t i = 0; i < ncell; ++i)
+			if (cell_map[i] != 0xffffffffu)
+				return fail(DG_ERR_INVALID, "cell_map[%llu] refers to a row of an empty cell table", (unsigned long long)i);
+		cells = nullptr;
+	}
+	else if ((cells == nullptr) != (cell_map == nullptr))
 		return fail(DG_ERR_INVALID, "cells and cell_map must be given together");
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
 	void *d_c = nullptr, *d_cells = nullptr, *d_map = nullptr;
-	const uint64_t ncell = dg_grid_n_cells(grid);
-	hipError_t e = hipMalloc(&d_c, n_coeffs * sizeof(double));
-	if (e == hipSuccess) e = hipMemcpy(d_c, coeffs, n_coeffs * sizeof(double), hipMemcpyHostToDevice);
+	hipError_t e = hipMalloc(&d_c, std::max<uint64_t>(n_coeffs, 1) * sizeof(double));
+	if (e == hipSuccess && n_coeffs) e = hipMemcpy(d_c, coeffs, n_coeffs * sizeof(double), hipMemcpyHostToDevice);
 	if (e == hipSuccess && cells)
 	{
-		e = hipMalloc(&d_cells, std::max<uint64_t>(n_cell_rows, 1) * 32 * sizeof(uint32_t));
-		if (e == hipSuccess && n_cell_rows)
+		e = hipMalloc(&d_cells, n_cell_rows * 32 * sizeof(uint32_t));
+		if (e == hipSuccess)
 			e = hipMemcpy(d_cells, cells, n_cell_rows * 32 * sizeof(uint32_t), hipMemcpyHostToDevice);
-		if (e == hipSuccess) e = hipMalloc(&d_map, ncell * sizeof(uint32_t));
+	}
+	if (e == hipSuccess && cell_map)
+	{
+		e = hipMalloc(&d_map, ncell * sizeof(uint32_t));
 		if (e == hipSuccess) e = hipMemcpy(d_map, cell_map, ncell * sizeof(uint32_t), hipMemcpyHostToDevice);
 	}
 	dg_status st = DG_OK;
@@ -100,16 +116,16 @@ void dg_field_destroy(dg_field* f)
 {
 	if (!f)
 		return;
+	DeviceGuard guard(f->device);
 	for (void* p : f->owned)
 		if (p)
 			(void)hipFree(p);
 	if (f->d_cell_major)
 		(void)hipFree(f->d_cell_major);
-	if (f->d_wtab)
-		(void)hipFree(f->d_wtab);
-	if (f->d_unsafe)
-		(void)hipFree(f->d_unsafe);
+	for (auto& kv : f->wtabs)
+		(void)hipFree(kv.second);
 	f->scratch.destroy();
+	f->flag_scratch.destroy();
 	if (f->bin_flag_host) (void)hipHostFree(f->bin_flag_host);
 	delete f;
 }
@@ -122,6 +138,7 @@ dg_status dg_field_build_cell_major(dg_field* field, void* stream)
 		return DG_OK;
 	if (field->n_rows == 0)
 		return DG_OK;
+	DG_ON_DEVICE_OF(field);
 	void* p = nullptr;
 	hipError_t e = hipMalloc(&p, field->n_rows * 32 * sizeof(double));
 	if (e != hipSuccess)
@@ -144,6 +161,7 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (field->d_cell_major)
 	{
+		DG_ON_DEVICE_OF(field);
 		DG_HIP(hipDeviceSynchronize());
 		(void)hipFree(field->d_cell_major);
 		field->d_cell_major = nullptr;
@@ -166,18 +184,31 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		return fail(DG_ERR_INVALID, "node range outside the lattice");
 	if (node_begin == node_end)
 		return DG_OK;
+	DG_ON_DEVICE_OF(sdf);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	dg::DensityParams P;
 	std::vector<double> w;
 	dg::init_density_params(P, support_radius, rho0, sdf->grid.cell_size, band_predicate, w);
-	if (sdf->wtab_h != support_radius)
+	// One immutable device table of kernel values per support radius: uploaded (blocking) before the
+	// first launch that uses it and never written again, so launches on other streams or threads that
+	// are still reading a table cannot see it change.
 	{
-		if (!sdf->d_wtab)
-			DG_HIP(hipMalloc(&sdf->d_wtab, 4096 * sizeof(double)));
-		DG_HIP(hipMemcpy(sdf->d_wtab, w.data(), 4096 * sizeof(double), hipMemcpyHostToDevice));
-		sdf->wtab_h = support_radius;
+		std::lock_guard<std::mutex> lock(sdf->wtab_mutex);
+		auto it = sdf->wtabs.find(support_radius);
+		if (it == sdf->wtabs.end())
+		{
+			void* d_w = nullptr;
+			DG_HIP(hipMalloc(&d_w, 4096 * sizeof(double)));
+			const hipError_t e = hipMemcpy(d_w, w.data(), 4096 * sizeof(double), hipMemcpyHostToDevice);
+			if (e != hipSuccess)
+			{
+				(void)hipFree(d_w);
+				return fail(DG_ERR_HIP, "kernel table upload: %s", hipGetErrorString(e));
+			}
+			it = sdf->wtabs.emplace(support_radius, d_w).first;
+		}
+		P.wtab = static_cast<const double*>(it->second);
 	}
-	P.wtab = static_cast<const double*>(sdf->d_wtab);
 	// K1's lattice decomposition: one wave per 4x4x4 brick of nodes
 	dg::SampleParams L;
 	dg::MeshDev none;
@@ -186,17 +217,21 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
 	L.mask = d_pred_mask;
 	L.out = d_out;
-	P.wtab = static_cast<const double*>(sdf->d_wtab);
 	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
 	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
+	int flag_idx = -1; // the flag k_field_check writes belongs to this launch (stream-ordered scratch)
 	if (env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12)
 	{
-		if (!sdf->d_unsafe)
-			DG_HIP(hipMalloc(&sdf->d_unsafe, sizeof(uint32_t)));
+		void* d_flag = nullptr;
+		flag_idx = sdf->flag_scratch.acquire(256, st, &d_flag);
+		if (flag_idx < 0)
+			return fail(DG_ERR_ALLOC, "device allocation failed");
 		P.skip_mode = 2;
-		P.unsafe = static_cast<const uint32_t*>(sdf->d_unsafe);
+		P.unsafe = static_cast<const uint32_t*>(d_flag);
 	}
-	DG_HIP(dg::launch_density_bricks(L, sdf->dev, sdf->n_coeffs, P, st));
+	const hipError_t e = dg::launch_density_bricks(L, sdf->dev, sdf->n_coeffs, P, st);
+	sdf->flag_scratch.release(flag_idx, st);
+	DG_HIP(e);
 	return DG_OK;
 }
 
@@ -205,6 +240,9 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 {
 	if (!field || (n && (!d_xyz || !d_phi)))
 		return fail(DG_ERR_INVALID, "null argument");
+	if (n == 0)
+		return DG_OK;
+	DG_ON_DEVICE_OF(field);
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and

@@ -1,12 +1,17 @@
 // dg_capi_host.cpp -- the host-pointer entry points of include/discregrid_hip.h.  The caller's arrays
-// are ordinary pageable memory; every call is cut into chunks that run through one pipeline: host
-// threads stage the inputs in pinned memory, the compute stream uploads them and runs the device entry
-// point, the copy stream brings the outputs back, host threads move them into the caller's arrays --
-// while the GPU is already busy with the next chunk.
+// are ordinary pageable memory; every call is cut into chunks that run through a pipeline.  Two forms:
+//   * direct (K1 results into memory nobody has touched yet, e.g. the freshly allocated coefficient
+//     vector of addFunction): the pages are faulted in as huge pages by a few host threads and pinned
+//     (hipHostRegister) while the first chunk is already being sampled, and the copy engine then writes
+//     every chunk straight into the caller's array while the next one is computed;
+//   * staged (everything else): host threads stage the inputs in pinned memory, the compute stream
+//     uploads them and runs the device entry point, the copy stream brings the outputs back into pinned
+//     memory, host threads move them into the caller's arrays -- while the GPU is busy with the next chunk.
 #include "dg_capi_internal.h"
 
-extern "C"
-{
+#include <sys/mman.h>
+#include <unistd.h>
+
 
 // ---- host-pointer K1: device buffers, kernel and the copy back to pageable memory, pipelined --------------
 // The caller's array is ordinary pageable memory (a std::vector in the C++ API), which the runtime
@@ -19,61 +24,261 @@ namespace
 {
 struct HostPipe
 {
-	std::mutex mutex; // one host-pointer launch at a time uses the staging buffers
+	std::mutex mutex; // one host-pointer call at a time uses a pipe (see lease_pipe())
 	int device = -1;
-	size_t chunk_bytes = 0;
+	size_t chunk_bytes = 0, staging_bytes = 0;
 	void* d_buf[2] = {nullptr, nullptr};
-	void* h_buf[2] = {nullptr, nullptr};
+	void* h_buf[2] = {nullptr, nullptr}; // pinned staging memory: allocated only when the staged form runs
 	hipStream_t compute = nullptr, copy = nullptr;
 	hipEvent_t k_begin[2] = {nullptr, nullptr}, k_end[2] = {nullptr, nullptr}, c_end[2] = {nullptr, nullptr};
+	std::vector<hipEvent_t> ev; // direct form: three events per chunk (kernel begin, kernel end, copy end)
 
-	void release()
+	void release_staging()
 	{
 		for (int i = 0; i < 2; ++i)
 		{
-			if (d_buf[i]) (void)hipFree(d_buf[i]);
 			if (h_buf[i]) (void)hipHostFree(h_buf[i]);
+			h_buf[i] = nullptr;
+		}
+		staging_bytes = 0;
+	}
+	void release()
+	{
+		release_staging();
+		for (int i = 0; i < 2; ++i)
+		{
+			if (d_buf[i]) (void)hipFree(d_buf[i]);
 			if (k_begin[i]) (void)hipEventDestroy(k_begin[i]);
 			if (k_end[i]) (void)hipEventDestroy(k_end[i]);
 			if (c_end[i]) (void)hipEventDestroy(c_end[i]);
-			d_buf[i] = h_buf[i] = nullptr;
+			d_buf[i] = nullptr;
 			k_begin[i] = k_end[i] = c_end[i] = nullptr;
 		}
+		for (hipEvent_t e : ev)
+			(void)hipEventDestroy(e);
+		ev.clear();
 		if (compute) (void)hipStreamDestroy(compute);
 		if (copy) (void)hipStreamDestroy(copy);
 		compute = copy = nullptr;
 		chunk_bytes = 0;
 		device = -1;
 	}
-	hipError_t prepare(size_t bytes)
+	// device buffers, streams and events for chunks of `bytes`; pinned staging buffers only if `staging`
+	hipError_t prepare(size_t bytes, bool staging)
 	{
 		int dev = 0;
 		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess)
 			return e;
-		if (dev == device && bytes <= chunk_bytes)
-			return hipSuccess;
-		release();
-		device = dev;
-		e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
-		if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
-		for (int i = 0; i < 2 && e == hipSuccess; ++i)
+		if (dev != device || bytes > chunk_bytes)
 		{
-			e = hipMalloc(&d_buf[i], bytes);
-			if (e == hipSuccess) e = hipHostMalloc(&h_buf[i], bytes, hipHostMallocDefault);
-			if (e == hipSuccess) e = hipEventCreate(&k_begin[i]);
-			if (e == hipSuccess) e = hipEventCreate(&k_end[i]);
-			if (e == hipSuccess) e = hipEventCreateWithFlags(&c_end[i], hipEventDisableTiming);
+			release();
+			device = dev;
+			e = hipStreamCreateWithFlags(&compute, hipStreamNonBlocking);
+			if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+			for (int i = 0; i < 2 && e == hipSuccess; ++i)
+			{
+				e = hipMalloc(&d_buf[i], bytes);
+				if (e == hipSuccess) e = hipEventCreate(&k_begin[i]);
+				if (e == hipSuccess) e = hipEventCreate(&k_end[i]);
+				if (e == hipSuccess) e = hipEventCreateWithFlags(&c_end[i], hipEventDisableTiming);
+			}
+			if (e == hipSuccess)
+				chunk_bytes = bytes;
 		}
-		if (e == hipSuccess)
-			chunk_bytes = bytes;
-		else
+		if (e == hipSuccess && staging && bytes > staging_bytes)
+		{
+			release_staging();
+			for (int i = 0; i < 2 && e == hipSuccess; ++i)
+				e = hipHostMalloc(&h_buf[i], chunk_bytes, hipHostMallocDefault);
+			if (e == hipSuccess)
+				staging_bytes = chunk_bytes;
+		}
+		if (e != hipSuccess)
 			release();
 		return e;
 	}
+	hipError_t events(size_t n)
+	{
+		while (ev.size() < n)
+		{
+			hipEvent_t e = nullptr;
+			const hipError_t err = hipEventCreate(&e);
+			if (err != hipSuccess)
+				return err;
+			ev.push_back(e);
+		}
+		return hipSuccess;
+	}
 };
 const int kMaxPipes = 16;
-HostPipe g_pipes[kMaxPipes]; // [0]: single-mesh calls; [i]: worker i of dg_sdf_sample_nodes_multi
+HostPipe g_pipes[kMaxPipes];
+
+// dg_set_progress_callback: per calling thread
+thread_local dg_progress_fn t_progress = nullptr;
+thread_local void* t_progress_user = nullptr;
+struct Progress
+{
+	dg_progress_fn cb;
+	void* user;
+	uint64_t total;
+	std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+	void report(uint64_t done)
+	{
+		if (!cb)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		if (done >= total || now - last > std::chrono::milliseconds(1000))
+		{
+			last = now;
+			cb(done, total, user);
+		}
+	}
+};
+
+// A pipe for the calling thread: an idle one already set up for `device` if there is one, else any idle
+// one; concurrent callers therefore run side by side (up to kMaxPipes of them), and only when every
+// pipe is busy does a caller wait.
+struct PipeLease
+{
+	HostPipe* pipe = nullptr;
+	std::unique_lock<std::mutex> lock;
+};
+PipeLease lease_pipe(int device)
+{
+	PipeLease L;
+	for (int pass = 0; pass < 3; ++pass)
+		for (int i = 0; i < kMaxPipes; ++i)
+		{
+			std::unique_lock<std::mutex> lk(g_pipes[i].mutex, std::try_to_lock);
+			if (!lk.owns_lock())
+				continue;
+			const int d = g_pipes[i].device;
+			if ((pass == 0 && d != device) || (pass == 1 && d != -1))
+				continue;
+			L.pipe = &g_pipes[i];
+			L.lock = std::move(lk);
+			return L;
+		}
+	const size_t slot = std::hash<std::thread::id>()(std::this_thread::get_id()) % kMaxPipes;
+	L.pipe = &g_pipes[slot];
+	L.lock = std::unique_lock<std::mutex>(g_pipes[slot].mutex);
+	return L;
+}
+
+// ---- the caller's output array as a DMA target ----------------------------------------------------------------
+// Pinning 0.95 GB that already sits in 4 KiB pages costs 40+ ms, more than the staged pipeline loses;
+// pinning memory that was faulted in as 2 MiB pages costs 3 ms, and faulting it in with 16 threads 5 ms
+// [MI355X host, tests/perf/probes/host_mem_probe.cpp].  So the direct form is taken when the array is
+// (a) already pinned by the caller, (b) still untouched -- then this code decides how it is faulted in --
+// or (c) an array this code has faulted in itself on an earlier call.
+struct PreparedRanges
+{
+	std::mutex mutex;
+	std::vector<std::pair<uintptr_t, size_t>> ranges;
+	bool contains(const void* p, size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (auto const& r : ranges)
+			if ((uintptr_t)p >= r.first && (uintptr_t)p + bytes <= r.first + r.second)
+				return true;
+		return false;
+	}
+	void add(const void* p, size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		if (ranges.size() >= 64)
+			ranges.erase(ranges.begin());
+		ranges.emplace_back((uintptr_t)p, bytes);
+	}
+} g_prepared;
+
+// fraction of (sampled) pages of [p, p + bytes) that are resident
+double resident_fraction(const void* p, size_t bytes)
+{
+	const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+	const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)(page - 1);
+	const size_t pages = ((uintptr_t)p + bytes - lo + page - 1) / page;
+	const size_t samples = std::min<size_t>(pages, 128);
+	size_t resident = 0, seen = 0;
+	for (size_t i = 0; i < samples; ++i)
+	{
+		unsigned char v = 0;
+		const uintptr_t at = lo + (pages * i / samples) * page;
+		if (mincore(reinterpret_cast<void*>(at), page, &v) == 0)
+		{
+			++seen;
+			resident += v & 1u;
+		}
+	}
+	return seen ? (double)resident / (double)seen : 1.0;
+}
+
+struct HostTarget // RAII: the registration ends with the call
+{
+	void* base = nullptr;
+	bool registered = false;
+	~HostTarget()
+	{
+		if (registered)
+			(void)hipHostUnregister(base);
+	}
+};
+// Makes [out, out + bytes) -- an array this call overwrites completely -- a DMA target.  Returns false if
+// the staged form should run instead (array already resident in pages of unknown size, registration
+// refused, or switched off with DG_HOST_DIRECT=0; =2 takes the direct form whatever the state of the pages).
+bool prepare_host_target(void* out, size_t bytes, HostTarget& T)
+{
+	const int mode = env_int("DG_HOST_DIRECT", 1, 0, 2);
+	if (mode == 0 || (mode != 2 && bytes < (1u << 22)))
+		return false;
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, out) == hipSuccess)
+	{
+		if (attr.type == hipMemoryTypeHost)
+			return true; // pinned or registered by the caller
+		if (attr.type != hipMemoryTypeUnregistered)
+			return false;
+	}
+	else
+		(void)hipGetLastError(); // ordinary memory the runtime has never seen
+	const bool fresh = resident_fraction(out, bytes) < 0.1;
+	if (mode != 2 && !fresh && !g_prepared.contains(out, bytes))
+		return false;
+	if (fresh)
+	{
+		// huge pages for the 2 MiB-aligned interior, then first touch from several threads (every byte of
+		// the range is overwritten by this call, so writing to it is safe)
+		const uintptr_t a = ((uintptr_t)out + (1u << 21) - 1) & ~(uintptr_t)((1u << 21) - 1);
+		const uintptr_t b = ((uintptr_t)out + bytes) & ~(uintptr_t)((1u << 21) - 1);
+		if (b > a)
+			(void)madvise(reinterpret_cast<void*>(a), b - a, MADV_HUGEPAGE);
+		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+		const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, bytes >> 24));
+		const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+		std::vector<std::thread> th;
+		volatile char* c = static_cast<volatile char*>(out);
+		for (unsigned t = 0; t < nt; ++t)
+			th.emplace_back([=]() {
+				const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+				for (size_t o = lo; o < hi; o += 4096)
+					c[o] = 0;
+				if (hi > lo)
+					c[hi - 1] = 0;
+			});
+		for (auto& t : th)
+			t.join();
+		g_prepared.add(out, bytes);
+	}
+	if (hipHostRegister(out, bytes, hipHostRegisterPortable) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return false;
+	}
+	T.base = out;
+	T.registered = true;
+	return true;
+}
 
 // dst <- src with a few threads (one thread tops out near 10 GB/s, the PCIe link delivers 50+)
 void parallel_copy(void* dst, const void* src, size_t bytes)
@@ -114,6 +319,38 @@ void chunk_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end, u
 	}
 	cuts.push_back(node_end);
 }
+// [node_begin, node_end) cut at slab boundaries into chunks whose sizes follow `fractions` (of the whole
+// range) as closely as the slabs allow.  The direct form wants few chunks -- every chunk ends with a
+// kernel tail of ~0.4 ms -- and a small LAST one, whose copy is the only one nothing overlaps.
+void schedule_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end, const std::vector<double>& fractions,
+				   std::vector<uint64_t>& cuts)
+{
+	dg::ClassGeom cg[4];
+	dg::class_geometry(res, cg);
+	std::vector<uint64_t> cand;
+	for (int c = 0; c < 4; ++c)
+	{
+		const uint64_t slab = (uint64_t)dg::kSlabPlanes * cg[c].D[0] * cg[c].D[1];
+		for (uint64_t at = cg[c].off; at < cg[c].off + cg[c].size; at += slab)
+			if (at > node_begin && at < node_end)
+				cand.push_back(at);
+	}
+	std::sort(cand.begin(), cand.end());
+	cuts.assign(1, node_begin);
+	const double n = (double)(node_end - node_begin);
+	double acc = 0.0;
+	for (size_t i = 0; i + 1 < fractions.size(); ++i)
+	{
+		acc += fractions[i];
+		const uint64_t want = node_begin + (uint64_t)(acc * n);
+		auto it = std::lower_bound(cand.begin(), cand.end(), want);
+		if (it != cand.begin() && (it == cand.end() || *it - want > want - *(it - 1)))
+			--it;
+		if (it != cand.end() && *it > cuts.back())
+			cuts.push_back(*it);
+	}
+	cuts.push_back(node_end);
+}
 } // namespace
 
 // One array of a pipelined host-pointer call: read from the host (`in`) or written back to it (`out`),
@@ -149,7 +386,7 @@ static dg_status run_pipeline(HostPipe& pipe, const std::vector<uint64_t>& cuts,
 		const bool present = arrays[i].in != nullptr || arrays[i].out != nullptr;
 		off[i + 1] = off[i] + (present ? ((longest * arrays[i].item_bytes + 255) & ~(size_t)255) : 0);
 	}
-	hipError_t e = pipe.prepare(off.back());
+	hipError_t e = pipe.prepare(off.back(), true);
 	dg_status st = DG_OK;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto drain = [&](size_t k, int b) -> hipError_t { // chunk k: wait for its copies, move the outputs into the caller's arrays
@@ -234,6 +471,98 @@ static dg_status run_k1_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 	return run_pipeline(pipe, cuts, first, stride, arrays, launch, "dg_sdf_sample_nodes", kernel_ms, t_wait, t_copy);
 }
 
+// K1, direct form: `out` is a DMA target (prepare_host_target()).  Everything is enqueued up front -- the
+// compute stream samples chunk i into device buffer i & 1 as soon as the copy of chunk i - 2 has left
+// it, the copy stream writes chunk i into the caller's array as soon as it is sampled -- and the host
+// only waits for the last copy.  `host_ready` runs on the host after the first two chunks are enqueued
+// (the GPU is busy by then) and before the first copy is: it makes `out` a DMA target, or says no.
+static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_desc* grid, int invert,
+							   const std::vector<uint64_t>& cuts, size_t first, size_t stride, const uint8_t* pred_mask, double* out,
+							   const std::function<bool()>& host_ready, bool* went_direct, double* kernel_ms, Progress* progress = nullptr)
+{
+	*went_direct = true;
+	const size_t n_chunks = cuts.size() - 1;
+	std::vector<size_t> mine;
+	uint64_t longest = 0;
+	for (size_t k = first; k < n_chunks; k += stride)
+	{
+		mine.push_back(k);
+		longest = std::max(longest, cuts[k + 1] - cuts[k]);
+	}
+	if (longest == 0)
+		return DG_OK;
+	const size_t out_bytes = (longest * sizeof(double) + 255) & ~(size_t)255;
+	const size_t mask_bytes = pred_mask ? ((longest + 255) & ~(size_t)255) : 0;
+	hipError_t e = pipe.prepare(out_bytes + mask_bytes, false);
+	if (e == hipSuccess) e = pipe.events(3 * mine.size());
+	dg_status st = DG_OK;
+	auto enqueue_kernel = [&](size_t i) {
+		const size_t k = mine[i];
+		const int b = (int)(i & 1);
+		const uint64_t cn = cuts[k + 1] - cuts[k];
+		double* d_out = static_cast<double*>(pipe.d_buf[b]);
+		uint8_t* d_mask = pred_mask ? reinterpret_cast<uint8_t*>(static_cast<char*>(pipe.d_buf[b]) + out_bytes) : nullptr;
+		if (i >= 2)
+			e = hipStreamWaitEvent(pipe.compute, pipe.ev[3 * (i - 2) + 2], 0);
+		if (e == hipSuccess) e = hipEventRecord(pipe.ev[3 * i], pipe.compute);
+		if (e == hipSuccess && pred_mask)
+			e = hipMemcpyAsync(d_mask, pred_mask + (cuts[k] - cuts[0]), cn, hipMemcpyHostToDevice, pipe.compute);
+		if (e == hipSuccess)
+			st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask, d_out, pipe.compute);
+		if (e == hipSuccess && st == DG_OK) e = hipEventRecord(pipe.ev[3 * i + 1], pipe.compute);
+	};
+	auto enqueue_copy = [&](size_t i) {
+		const size_t k = mine[i];
+		const uint64_t cn = cuts[k + 1] - cuts[k];
+		e = hipStreamWaitEvent(pipe.copy, pipe.ev[3 * i + 1], 0);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(out + (cuts[k] - cuts[0]), pipe.d_buf[i & 1], cn * sizeof(double), hipMemcpyDeviceToHost, pipe.copy);
+		if (e == hipSuccess) e = hipEventRecord(pipe.ev[3 * i + 2], pipe.copy);
+	};
+	const size_t head = std::min<size_t>(2, mine.size());
+	for (size_t i = 0; i < head && e == hipSuccess && st == DG_OK; ++i)
+		enqueue_kernel(i);
+	if (e == hipSuccess && st == DG_OK && !host_ready())
+	{
+		(void)hipStreamSynchronize(pipe.compute); // the two chunks already in flight are simply sampled again
+		*went_direct = false;
+		return DG_OK;
+	}
+	for (size_t i = 0; i < head && e == hipSuccess && st == DG_OK; ++i)
+		enqueue_copy(i);
+	for (size_t i = head; i < mine.size() && e == hipSuccess && st == DG_OK; ++i)
+	{
+		enqueue_kernel(i);
+		if (e == hipSuccess && st == DG_OK)
+			enqueue_copy(i);
+	}
+	if (progress && progress->cb && e == hipSuccess && st == DG_OK)
+	{
+		uint64_t done = 0;
+		for (size_t i = 0; i < mine.size(); ++i)
+		{
+			if (hipEventSynchronize(pipe.ev[3 * i + 2]) != hipSuccess)
+				break;
+			done += cuts[mine[i] + 1] - cuts[mine[i]];
+			progress->report(done);
+		}
+	}
+	const hipError_t e1 = hipStreamSynchronize(pipe.compute), e2 = hipStreamSynchronize(pipe.copy);
+	if (st != DG_OK)
+		return st;
+	if (e == hipSuccess) e = e1;
+	if (e == hipSuccess) e = e2;
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_sdf_sample_nodes (direct): %s", hipGetErrorString(e));
+	for (size_t i = 0; i < mine.size(); ++i)
+	{
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pipe.ev[3 * i], pipe.ev[3 * i + 1]) == hipSuccess)
+			*kernel_ms += ms;
+	}
+	return DG_OK;
+}
+
 // items [0, n) in uniform chunks (K1p, K2): big enough to amortise the launches, small enough to overlap
 static void uniform_cuts(uint64_t n, int default_chunk, std::vector<uint64_t>& cuts)
 {
@@ -256,6 +585,9 @@ static dg_status check_host_range(const dg_grid_desc* grid, uint64_t node_begin,
 	return DG_OK;
 }
 
+extern "C"
+{
+
 dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 							  uint64_t node_end, const uint8_t* pred_mask, double* out)
 {
@@ -273,18 +605,48 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	// ~10 chunks per call (every chunk costs a kernel tail, ~0.4 ms), 32..256 MiB of results each
 	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
 	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
-	std::vector<uint64_t> cuts;
+	std::vector<uint64_t> cuts, direct_cuts;
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
+	// direct form: seven chunks, the first two big enough to cover the preparation of the caller's array,
+	// the last one small (DG_HOST_CHUNK_NODES set: the uniform chunks above, as in the staged form)
+	if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
+		direct_cuts = cuts;
+	else
+		schedule_cuts(grid->resolution, node_begin, node_end, {0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, direct_cuts);
 	double kernel_ms = 0, t_wait = 0, t_copy = 0;
-	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
-	s = run_k1_chunks(g_pipes[0], mesh, grid, invert, cuts, 0, 1, pred_mask, out, &kernel_ms, &t_wait, &t_copy);
+	DG_ON_DEVICE_OF(mesh);
+	PipeLease lease = lease_pipe(mesh->device);
+	HostTarget host_target;
+	bool direct = false;
+	double t_prepare = 0;
+	Progress progress{t_progress, t_progress_user, n};
+	s = run_k1_direct(*lease.pipe, mesh, grid, invert, direct_cuts, 0, 1, pred_mask, out,
+					  [&]() {
+						  const auto t0 = std::chrono::steady_clock::now();
+						  const bool ok = prepare_host_target(out, n * sizeof(double), host_target);
+						  t_prepare = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+						  return ok;
+					  },
+					  &direct, &kernel_ms, &progress);
+	if (s == DG_OK && !direct)
+	{
+		kernel_ms = 0;
+		s = run_k1_chunks(*lease.pipe, mesh, grid, invert, cuts, 0, 1, pred_mask, out, &kernel_ms, &t_wait, &t_copy);
+	}
 	if (s != DG_OK)
 		return s;
+	progress.report(n);
 	g_last_ms = kernel_ms;
 	if (std::getenv("DG_HOST_DEBUG"))
-		std::fprintf(stderr, "dg_sdf_sample_nodes: %zu chunks, kernels %.1f ms, host waited %.1f ms, host copies %.1f ms\n",
-					 cuts.size() - 1, kernel_ms, t_wait * 1e3, t_copy * 1e3);
+		std::fprintf(stderr, "dg_sdf_sample_nodes: %s, %zu chunks, kernels %.1f ms, host prepared the array in %.1f ms, waited %.1f ms, copied %.1f ms\n",
+					 direct ? "direct" : "staged", (direct ? direct_cuts : cuts).size() - 1, kernel_ms, t_prepare * 1e3, t_wait * 1e3, t_copy * 1e3);
 	return DG_OK;
+}
+
+void dg_set_progress_callback(dg_progress_fn cb, void* user)
+{
+	t_progress = cb;
+	t_progress_user = user;
 }
 
 dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, const dg_grid_desc* grid, int invert,
@@ -313,30 +675,39 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 	std::vector<std::string> message((size_t)n_meshes);
 	std::vector<double> kernel_ms((size_t)n_meshes, 0.0);
 	std::vector<std::thread> workers;
-	int caller_device = 0;
-	(void)hipGetDevice(&caller_device);
+	// the array becomes a DMA target once, for all devices, before the workers start (3-8 ms; the staged
+	// form runs if it cannot)
+	HostTarget host_target;
+	const bool direct = prepare_host_target(out, n * sizeof(double), host_target);
 	for (int i = 0; i < n_meshes; ++i)
 		workers.emplace_back([&, i]() {
-			if (hipSetDevice(meshes[i]->device) != hipSuccess)
+			DeviceGuard guard(meshes[i]->device);
+			if (guard.err != hipSuccess)
 			{
 				status[(size_t)i] = DG_ERR_HIP;
 				message[(size_t)i] = "hipSetDevice failed";
 				return;
 			}
 			double t_wait = 0, t_copy = 0;
-			std::lock_guard<std::mutex> lock(g_pipes[i].mutex);
-			status[(size_t)i] = run_k1_chunks(g_pipes[i], meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
-											  &kernel_ms[(size_t)i], &t_wait, &t_copy);
+			PipeLease lease = lease_pipe(meshes[i]->device);
+			bool went = false;
+			if (direct)
+				status[(size_t)i] = run_k1_direct(*lease.pipe, meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
+												  []() { return true; }, &went, &kernel_ms[(size_t)i]);
+			else
+				status[(size_t)i] = run_k1_chunks(*lease.pipe, meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
+												  &kernel_ms[(size_t)i], &t_wait, &t_copy);
 			if (status[(size_t)i] != DG_OK)
 				message[(size_t)i] = dg_last_error(); // thread-local: carry it to the caller
 		});
 	for (auto& w : workers)
 		w.join();
-	(void)hipSetDevice(caller_device);
 	for (int i = 0; i < n_meshes; ++i)
 		if (status[(size_t)i] != DG_OK)
 			return fail(status[(size_t)i], "mesh %d (device %d): %s", i, meshes[i]->device, message[(size_t)i].c_str());
 	g_last_ms = *std::max_element(kernel_ms.begin(), kernel_ms.end());
+	if (t_progress)
+		t_progress(n, n, t_progress_user);
 	return DG_OK;
 }
 
@@ -362,8 +733,9 @@ dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n,
 										 static_cast<int32_t*>(d[2]), static_cast<int32_t*>(d[3]), static_cast<double*>(d[4]), stream);
 	};
 	double kernel_ms = 0, t_wait = 0, t_copy = 0;
-	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
-	s = run_pipeline(g_pipes[0], cuts, 0, 1, arrays, launch, "dg_signed_distance", &kernel_ms, &t_wait, &t_copy);
+	DG_ON_DEVICE_OF(mesh);
+	PipeLease lease = lease_pipe(mesh->device);
+	s = run_pipeline(*lease.pipe, cuts, 0, 1, arrays, launch, "dg_signed_distance", &kernel_ms, &t_wait, &t_copy);
 	if (s == DG_OK)
 		g_last_ms = kernel_ms;
 	return s;
@@ -382,6 +754,7 @@ dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0
 	dg_status s = require_device();
 	if (s != DG_OK)
 		return s;
+	DG_ON_DEVICE_OF(sdf);
 	HostCall call;
 	double* d_out = call.device<double>(n);
 	uint8_t* d_mask = call.device<uint8_t>(n, pred_mask != nullptr);
@@ -416,8 +789,9 @@ dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_
 										   static_cast<double*>(d[2]), stream);
 	};
 	double kernel_ms = 0, t_wait = 0, t_copy = 0;
-	std::lock_guard<std::mutex> lock(g_pipes[0].mutex);
-	s = run_pipeline(g_pipes[0], cuts, 0, 1, arrays, launch, "dg_interpolate_batch", &kernel_ms, &t_wait, &t_copy);
+	DG_ON_DEVICE_OF(field);
+	PipeLease lease = lease_pipe(field->device);
+	s = run_pipeline(*lease.pipe, cuts, 0, 1, arrays, launch, "dg_interpolate_batch", &kernel_ms, &t_wait, &t_copy);
 	if (s == DG_OK)
 		g_last_ms = kernel_ms;
 	return s;

@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -108,12 +110,13 @@ struct dg_mesh
 	int device = -1;
 	dg_mesh_info info;
 	mutable std::mutex scratch_mutex;
-	mutable std::vector<HeavyScratch> scratch;
+	mutable std::deque<HeavyScratch> scratch; // deque: a push_back never moves the entries other launches hold
 	mutable uint64_t scratch_serial = 0;
 	mutable uint64_t unsplit_serial = 0; // serial of the last launch that ran without the split path
 	mutable ScratchPool bin_scratch;     // K1p point binning
 	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	double bbox_lo[3], bbox_hi[3];       // of the vertices
+	dg::MeshBuild host;                  // the arrays that were uploaded, kept for dg_signed_distance_point (immutable)
 };
 
 struct dg_field
@@ -123,15 +126,46 @@ struct dg_field
 	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_cell_major = nullptr;
-	void* d_wtab = nullptr;    // K3: 4096 kernel values for support radius wtab_h
-	void* d_unsafe = nullptr;  // K3: flag written by k_field_check
-	double wtab_h = -1.0;
+	mutable ScratchPool flag_scratch;     // K3: the flag word k_field_check writes, one per launch in flight
+	std::mutex wtab_mutex;
+	std::map<double, void*> wtabs;        // K3: support radius -> immutable device table of 4096 kernel values
 	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
 	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)
 	int device = -1;
 };
 
+
+// Every entry point that takes a handle runs on the handle's device, whatever device is current on the
+// calling thread (the HIP current device is per thread and starts at 0: an OpenMP worker or any thread
+// other than the one that called dg_set_device() would otherwise launch on device 0 with pointers into
+// the handle's device).  The caller's current device is restored on return.
+struct DeviceGuard
+{
+	int prev = -1;
+	bool changed = false;
+	hipError_t err = hipSuccess;
+	explicit DeviceGuard(int want)
+	{
+		err = hipGetDevice(&prev);
+		if (err == hipSuccess && want >= 0 && want != prev)
+		{
+			err = hipSetDevice(want);
+			changed = err == hipSuccess;
+		}
+	}
+	~DeviceGuard()
+	{
+		if (changed)
+			(void)hipSetDevice(prev);
+	}
+	DeviceGuard(const DeviceGuard&) = delete;
+	DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define DG_ON_DEVICE_OF(handle)                                                                       \
+	DeviceGuard device_guard_((handle)->device);                                                      \
+	if (device_guard_.err != hipSuccess)                                                              \
+		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))
 
 // ---- shared internals (defined in dg_capi.cpp) ---------------------------------------------------------------
 extern thread_local std::string g_error;  // dg_last_error()

@@ -14,16 +14,18 @@
  *   dg_signed_distance[_device]
  *                             TriangleMeshDistance::signed_distance for a batch of points
  *                             TriangleMeshDistance.h:269-314
+ *   dg_signed_distance_point  the same for one point, on the calling host thread (:188-208, 269-328)
  *   dg_field_create / dg_field_attach_device
  *                             the per-field storage m_nodes / m_cells / m_cell_map
  *                             discregrid/include/Discregrid/cubic_lagrange_discrete_grid.hpp:69-71
  *   dg_interpolate_batch[_device]
  *                             CubicLagrangeDiscreteGrid::interpolate(field_id, x, gradient*)
  *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063 (shape functions :339-580)
- *   dg_shard_* / dg_unpack_shards_device
+ *   dg_shard_* / dg_unpack_shards_device, dg_comm_*, dg_sdf_sample_allgather_device
  *                             no counterpart (the reference is single-process OpenMP): lattice sharding
- *                             for one-process-per-GPU runs, the exchange itself is one RCCL all-gather
- *                             issued by the caller.
+ *                             for one-process-per-GPU runs; the exchange is one logical RCCL all-gather,
+ *                             issued either by the caller (dg_sdf_sample_shard_device + dg_unpack_*) or
+ *                             by the library itself (dg_sdf_sample_allgather_device).
  *
  * Conventions: plain pointers and sizes only; every function returns a dg_status (0 = ok)
  * and never throws or exits; dg_last_error() gives a thread-local message.  Functions
@@ -141,6 +143,16 @@ dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n,
 dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
 									int32_t* d_tri, int32_t* d_entity, double* d_nearest, void* stream);
 
+/* ONE point, evaluated on the calling thread (no launch): TriangleMeshDistance::signed_distance(point)
+ * as user code calls it per node or per particle (TriangleMeshDistance.h:188-208, 269-328;
+ * cmd/generate_sdf/main.cpp:97-101).  Walks the host copy of the very arrays dg_mesh_create uploaded with
+ * the same per-triangle arithmetic as the kernels, so `dist` has the bits dg_signed_distance returns for
+ * the point (of exactly equidistant triangles either may be named).  Const and lock-free: any number of
+ * threads may call it on one mesh.  tri / entity / nearest may be NULL.  Batches belong on the GPU
+ * (dg_signed_distance, dg_sdf_sample_nodes): this is the per-point evaluator, not a CPU path for them. */
+dg_status dg_signed_distance_point(const dg_mesh* mesh, const double xyz[3], double* dist, int32_t* tri,
+								   int32_t* entity, double* nearest);
+
 /* ---- multi-GPU sharding of the node lattice (one process per GPU) -------------------------- */
 /* The lattice of each of the four node classes [V | X | Y | Z] is cut into slabs of 4 planes
  * along its slowest-varying index (k, k, i, j -- i.e. Z-slabs for V and X) and the slabs are
@@ -160,6 +172,26 @@ dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const do
  * base of the whole buffer): lets a pieced gather unpack piece p while piece p+1 is in flight. */
 dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 									   int rank_begin, int rank_end, double* d_field, void* stream);
+
+/* The exchange step behind the ABI.  A dg_comm wraps an RCCL communicator of one-process-per-GPU ranks
+ * (RCCL is loaded on the first dg_comm_* call; single-GPU users never load it):
+ *   rank 0 calls dg_comm_unique_id() and hands the 128 bytes to the other ranks out of band (a file, MPI,
+ *   a TCP store); every rank then calls dg_comm_create() with its device current (collective:
+ *   ncclCommInitRank).  dg_comm_adopt() wraps an existing ncclComm_t of the same RCCL instance instead.
+ * dg_sdf_sample_allgather_device() is the whole multi-GPU node-sampling step (collective, asynchronous):
+ * this rank samples its shards of the lattice in `pieces` pieces, each piece is all-gathered over xGMI
+ * while the next one is sampled and unpacked into reference node order while the one after is gathered;
+ * when the work enqueued on `stream` has run, d_field (dg_grid_n_nodes doubles, device memory) holds the
+ * WHOLE coefficient vector on every rank -- bit for bit what dg_sdf_sample_nodes_device writes on one GPU.
+ * pieces is clamped to 64 / nranks; 4 is a good value.  No reference counterpart (single process). */
+#define DG_UNIQUE_ID_BYTES 128
+typedef struct dg_comm dg_comm;
+dg_status dg_comm_unique_id(uint8_t id[DG_UNIQUE_ID_BYTES]);
+dg_status dg_comm_create(const uint8_t id[DG_UNIQUE_ID_BYTES], int rank, int nranks, dg_comm** out);
+dg_status dg_comm_adopt(void* nccl_comm, int rank, int nranks, dg_comm** out); /* does not take ownership */
+void dg_comm_destroy(dg_comm* comm);
+dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm,
+										 int pieces, double* d_field, void* stream);
 
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both
@@ -201,6 +233,13 @@ dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0
 dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
 									  double* d_out, void* stream);
+
+/* Progress of the HOST-pointer node-sampling calls issued by the calling thread (dg_sdf_sample_nodes,
+ * dg_sdf_sample_nodes_multi): `cb(done, total, user)` is called on that thread as chunks of nodes
+ * arrive in the caller's array, at most once per second and once at the end -- what
+ * addFunction(verbose) prints (cubic_lagrange_discrete_grid.cpp:819-829).  NULL switches it off. */
+typedef void (*dg_progress_fn)(uint64_t done, uint64_t total, void* user);
+void dg_set_progress_callback(dg_progress_fn cb, void* user);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* Device time (HIP events on the launch stream) of the most recent K1 / K2 kernel launch issued

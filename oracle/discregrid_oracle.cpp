@@ -27,6 +27,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <random>
 #include <unordered_map>
 #include <vector>
 
@@ -1175,6 +1176,21 @@ size_t dgo_write_cdf(const char* path, const double domain[6], const unsigned re
 	size_t w = std::fwrite(b.data(), 1, b.size(), fp);
 	std::fclose(fp);
 	return w;
+}
+
+// Query points of BASELINE config 5: n points uniform in the box [lo, hi], drawn with
+// std::mt19937_64 + std::uniform_real_distribution<double> (x, y, z per point, in that order).  The
+// same libstdc++ runs on the build container and on the GPU box, so both sides see the same points.
+void dgo_uniform_points(uint64_t seed, size_t n, const double lo[3], const double hi[3], double* out)
+{
+	std::mt19937_64 gen(seed);
+	std::uniform_real_distribution<double> ux(lo[0], hi[0]), uy(lo[1], hi[1]), uz(lo[2], hi[2]);
+	for (size_t i = 0; i < n; ++i)
+	{
+		out[3 * i] = ux(gen);
+		out[3 * i + 1] = uy(gen);
+		out[3 * i + 2] = uz(gen);
+	}
 }
 
 } // extern "C"

@@ -3,7 +3,7 @@
 // C entry points over the UNMODIFIED reference sources under /root/reference,
 // compiled in place by oracle/Makefile (target `ref`) into
 // oracle/_ref/libdiscregrid_ref.so against the stand-in Eigen header in
-// oracle/eigen_shim.  Nothing from the reference is copied into this repo: this
+// discregrid_amd/cpp/third_party/eigen_min.  Nothing from the reference is copied into this repo: this
 // file only *includes* its public headers and calls its public API the way
 // cmd/generate_sdf/main.cpp:70-120 does.
 //

@@ -1,25 +1,39 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for the K1 numbers on the GPU box (run through gpurun):
-#   profiles/collect.sh <tag> [kt|pmc|all]
-# kernel trace + stats of the default bench, and the PMC passes (own runs, counters only) from which
-# profiles/<tag>_pmc_summary.txt is derived.  Raw databases stay under gpurun_out/ (scratch).
+# Collects the rocprofv3 evidence on the GPU box (run through gpurun) and turns it into the committed
+# summaries:
+#   profiles/collect.sh <tag> [k1|k2|k3|u|all]
+# Per workload: one --kernel-trace --stats run (kernel durations) and the PMC passes (own runs, counters
+# only -- never combined with a trace).  K1 = the default bench (python bench.py, 256^3 icosphere);
+# K2 / K3 / U = profiles/pmc_workloads.py at BASELINE configs[4] sizes.  Raw databases stay under
+# gpurun_out/ (scratch); profiles/summarize_pmc.py writes profiles/<tag>_pmc_summary.txt,
+# profiles/<tag>_kernel_stats.txt and the machine-readable profiles/counters.json that bench.py reads
+# (keyed by a hash of discregrid_amd/csrc, so that stale counters are never reported).
 set -u
-TAG=${1:-r01}; WHAT=${2:-all}
+TAG=${1:-r02}; WHAT=${2:-all}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
-if [ $WHAT = kt ] || [ $WHAT = all ]; then
-  rocprofv3 --kernel-trace --stats -d $OUT -o kt -- python bench.py --steps 10 --warmup 2 --cpu-seconds 0 > $OUT/bench_kt.log 2>&1
-  python profiles/summarize_rocpd.py $OUT/kt_results.db $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-seconds 0, 1x MI355X" > /dev/null
-fi
-if [ $WHAT = pmc ] || [ $WHAT = all ]; then
-  i=0
-  for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
-             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
-             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_ANY" \
-             "SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_LDS_BANK_CONFLICT"; do
+GROUPS_BASE=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
+             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum")
+GROUPS_K1=("SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_LDS_BANK_CONFLICT")
+run_set () {  # name, command..., then the counter groups come from the global array GRP
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $OUT -o ${name}_kt -- "$@" > $OUT/${name}_kt.log 2>&1
+  local i=0
+  for grp in "${GRP[@]}"; do
     i=$((i+1))
-    rocprofv3 --pmc $grp -d $OUT -o pmc$i -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $OUT/bench_pmc$i.log 2>&1
-    python profiles/summarize_rocpd.py $OUT/pmc${i}_results.db $OUT/pmc$i.txt "pass $i: $grp" > /dev/null
+    rocprofv3 --pmc $grp -d $OUT -o ${name}_pmc$i -- "$@" > $OUT/${name}_pmc$i.log 2>&1
   done
+}
+if [ $WHAT = k1 ] || [ $WHAT = all ]; then
+  GRP=("${GROUPS_BASE[@]}" "${GROUPS_K1[@]}")
+  run_set k1 python bench.py --steps 10 --warmup 2 --no-extras
 fi
-ls $OUT
+for w in k2 k3 u; do
+  if [ $WHAT = $w ] || [ $WHAT = all ]; then
+    GRP=("${GROUPS_BASE[@]}")
+    run_set $w python profiles/pmc_workloads.py $w
+  fi
+done
+python profiles/summarize_pmc.py $OUT $TAG
+ls $OUT | head -50

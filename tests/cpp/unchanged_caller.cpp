@@ -1,0 +1,149 @@
+// tests/cpp/unchanged_caller.cpp -- TEST TOOLING.  A caller written against the REFERENCE, compiled
+// unchanged against this repository's headers:
+//
+//   unchanged_caller lambda   mesh.obj "rx ry rz" out.bin
+//       the body of the reference's GenerateSDF (cmd/generate_sdf/main.cpp:70-105): TriangleMesh,
+//       TriangleMeshDistance, default domain, and addFunction with the reference's OWN lambda
+//           [&md](Eigen::Vector3d const& xi) { return md.signed_distance(xi).distance; }
+//       (:97-101) -- an opaque std::function, so the grid runs its host loop and every node costs one
+//       single-point signed_distance on the calling OpenMP thread.  Then the same grid through the typed
+//       MeshSDF functor (GPU).  out.bin = [n_nodes, lambda seconds, MeshSDF seconds, mismatching nodes,
+//       lambda coefficients...].
+//   unchanged_caller threads  mesh.obj n_threads n_points out.bin
+//       n_threads std::threads call md.signed_distance(point) on one const object at once
+//       (TriangleMeshDistance.h:188,199: "Thread safe"); out.bin = [mismatches vs the batched GPU query].
+//   unchanged_caller addfunction mesh.obj "rx ry rz" repeats
+//       prints the wall time of CubicLagrangeDiscreteGrid::addFunction(MeshSDF) per call, as JSON
+//       (bench.py's addfunction_e2e leg).
+#include <Discregrid/All>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace Discregrid;
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static Eigen::AlignedBox3d default_domain(TriangleMesh const& mesh)
+{
+	Eigen::AlignedBox3d domain;
+	domain.setEmpty();
+	for (auto const& x : mesh.vertices())
+		domain.extend(x);
+	domain.max() += 1.0e-3 * domain.diagonal().norm() * Eigen::Vector3d::Ones();
+	domain.min() -= 1.0e-3 * domain.diagonal().norm() * Eigen::Vector3d::Ones();
+	return domain;
+}
+static std::array<unsigned int, 3> parse_res(const char* s)
+{
+	std::array<unsigned int, 3> r;
+	std::istringstream in(s);
+	in >> r[0] >> r[1] >> r[2];
+	return r;
+}
+static void write_doubles(const std::string& p, const std::vector<double>& v)
+{
+	std::ofstream out(p, std::ios::binary);
+	out.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(double)));
+}
+
+int main(int argc, char** argv)
+{
+	if (argc < 2)
+		return 2;
+	const std::string cmd = argv[1];
+	if (cmd == "lambda" && argc == 5)
+	{
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		const auto domain = default_domain(mesh);
+		const auto resolution = parse_res(argv[3]);
+		CubicLagrangeDiscreteGrid sdf(domain, resolution);
+		auto func = DiscreteGrid::ContinuousFunction{};
+		func = [&md](Eigen::Vector3d const& xi) { return md.signed_distance(xi).distance; }; // main.cpp:97-101, verbatim
+		double t0 = now();
+		sdf.addFunction(func, false);
+		double t_lambda = now() - t0;
+		if (sdf.lastAddFunctionUsedGpu())
+			return 3; // an opaque callable cannot have taken the GPU path
+		{
+			// once more on a second grid: the first call also started the OpenMP team of this process
+			CubicLagrangeDiscreteGrid again(domain, resolution);
+			t0 = now();
+			again.addFunction(func, false);
+			t_lambda = std::min(t_lambda, now() - t0);
+		}
+		t0 = now();
+		sdf.addFunction(MeshSDF{&md, false}, false);
+		const double t_typed = now() - t0;
+		if (!sdf.lastAddFunctionUsedGpu())
+			return 4;
+		auto const& a = sdf.nodeData(0);
+		auto const& b = sdf.nodeData(1);
+		size_t bad = a.size() != b.size();
+		for (size_t i = 0; i < a.size() && i < b.size(); ++i)
+			bad += !(a[i] == b[i]);
+		std::vector<double> out = {(double)a.size(), t_lambda, t_typed, (double)bad};
+		out.insert(out.end(), a.begin(), a.end());
+		write_doubles(argv[4], out);
+		return 0;
+	}
+	if (cmd == "threads" && argc == 6)
+	{
+		TriangleMesh mesh{std::string(argv[2])};
+		const TriangleMeshDistance md(mesh);
+		const int nt = std::atoi(argv[3]);
+		const size_t n = (size_t)std::atoll(argv[4]);
+		const auto dom = default_domain(mesh);
+		std::mt19937_64 gen(7);
+		std::vector<double> pts(3 * n);
+		for (size_t i = 0; i < n; ++i)
+			for (int d = 0; d < 3; ++d)
+				pts[3 * i + d] = std::uniform_real_distribution<double>(dom.min()[d], dom.max()[d])(gen);
+		std::vector<double> want(n), got(n, 0.0);
+		md.signed_distance(pts.data(), n, want.data()); // batched, on the GPU
+		std::vector<std::thread> th;
+		for (int t = 0; t < nt; ++t)
+			th.emplace_back([&, t]() {
+				for (size_t i = (size_t)t; i < n; i += (size_t)nt) // interleaved: all threads are inside the call at once
+					got[i] = md.signed_distance(Eigen::Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])).distance;
+			});
+		for (auto& t : th)
+			t.join();
+		size_t bad = 0;
+		for (size_t i = 0; i < n; ++i)
+			bad += !(got[i] == want[i]);
+		write_doubles(argv[5], {(double)bad});
+		return 0;
+	}
+	if (cmd == "addfunction" && argc == 5)
+	{
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		const auto domain = default_domain(mesh);
+		const auto resolution = parse_res(argv[3]);
+		const int repeats = std::atoi(argv[4]);
+		std::printf("{\"calls\": [");
+		for (int r = 0; r < repeats; ++r)
+		{
+			CubicLagrangeDiscreteGrid sdf(domain, resolution); // a fresh grid per call, like the tool
+			const double t0 = now();
+			sdf.addFunction(MeshSDF{&md, false}, false);
+			const double dt = now() - t0;
+			if (!sdf.lastAddFunctionUsedGpu())
+				return 4;
+			std::printf("%s{\"total_s\": %.6f, \"sampling_s\": %.6f}", r ? ", " : "", dt, sdf.lastSamplingSeconds());
+		}
+		std::printf("], \"cells\": %zu}\n", CubicLagrangeDiscreteGrid(domain, resolution).nCells());
+		return 0;
+	}
+	return 2;
+}

@@ -216,6 +216,7 @@ def oracle_lib():
         L.dgo_density_map_nodes.restype = C.c_double
         L.dgo_density_map_nodes.argtypes = [c_dp, c_up, c_dp, c_up, c_up, C.c_double, C.c_double, C.c_int, c_dp, c_dp,
                                             C.c_uint, C.c_uint, c_dp]
+        L.dgo_uniform_points.argtypes = [C.c_uint64, C.c_size_t, c_dp, c_dp, c_dp]
         L.dgo_write_cdf.restype = C.c_size_t
         L.dgo_write_cdf.argtypes = [C.c_char_p, c_dp, c_up, C.POINTER(c_dp), C.c_size_t]
         _oracle = L
@@ -274,6 +275,41 @@ class OracleMesh:
         return dict(pn_tri=pt, pn_edge=pe, pn_vert=pv, spheres=sp, children=ch)
 
 
+def oracle_point_triangle(V, F, tri, P):
+    """Squared distance point <-> triangle with the reference's arithmetic (TriangleMeshDistance.h:564-820)
+    for explicit pairs: tri and P may be one index / point (returns a float) or arrays (returns an array).
+    Two triangles that are 'exactly tied' for a point give the same double here."""
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    F = np.asarray(F)
+    scalar = np.ndim(tri) == 0
+    tri = np.atleast_1d(np.asarray(tri, dtype=np.int64))
+    P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 3))
+    v0 = np.ascontiguousarray(V[F[tri, 0]])
+    v1 = np.ascontiguousarray(V[F[tri, 1]])
+    v2 = np.ascontiguousarray(V[F[tri, 2]])
+    d2 = np.empty(len(tri))
+    oracle_lib().dgo_point_triangle(dp(P), dp(v0), dp(v1), dp(v2), len(tri), dp(d2), None, None, None)
+    return float(d2[0]) if scalar else d2
+
+
+def assert_exact_ties(V, F, P, tri_a, tri_b):
+    """Every pair of differing triangle ids names two triangles that are tied for the point under the
+    reference's own acceptance rule.  The reference accepts a triangle only if its d^2 is below the SQUARE
+    OF THE STORED sqrt of the best so far (TriangleMeshDistance.h:528-531), so two triangles are
+    interchangeable exactly when their distances -- the correctly rounded sqrt of the reference's d^2 --
+    are the same double (their d^2 may then differ in the last bit; which one is kept depends on the
+    visiting order, and the stored distance is the same either way)."""
+    diff = np.flatnonzero(np.asarray(tri_a) != np.asarray(tri_b))
+    if len(diff) == 0:
+        return 0
+    P = np.asarray(P).reshape(-1, 3)
+    a = oracle_point_triangle(V, F, np.asarray(tri_a)[diff], P[diff])
+    b = oracle_point_triangle(V, F, np.asarray(tri_b)[diff], P[diff])
+    bad = np.flatnonzero(np.sqrt(a) != np.sqrt(b))
+    assert len(bad) == 0, "triangle ids differ without an exact tie at %s" % diff[bad][:8]
+    return len(diff)
+
+
 def oracle_default_domain(V):
     V = np.ascontiguousarray(V, dtype=np.float64)
     out = np.empty(6)
@@ -323,6 +359,32 @@ def oracle_interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=
                                         dp(phi), dp(g))
     oracle_interpolate.last_seconds = secs
     return (phi, g) if grad else phi
+
+
+def uniform_points(seed, n, lo, hi):
+    """n points uniform in [lo, hi] from std::mt19937_64(seed) (BASELINE config 5's query generator)."""
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    out = np.empty((n, 3))
+    oracle_lib().dgo_uniform_points(seed, n, dp(lo), dp(hi), dp(out))
+    return out
+
+
+def block_digests(a, block=1 << 20):
+    """SHA-256 (first 16 bytes) of the raw bytes of every `block` consecutive items of a (rows of a 2-D
+    array count as items): the committed lattice / query digests of tests/golden/make_digests.py."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    a = np.ascontiguousarray(a)
+    n = a.shape[0]
+    out = np.empty(((n + block - 1) // block, 16), dtype=np.uint8)
+
+    def one(i):
+        out[i] = np.frombuffer(hashlib.sha256(memoryview(a[i * block:(i + 1) * block]).cast("B")).digest()[:16], dtype=np.uint8)
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:   # hashlib releases the GIL on large buffers
+        list(ex.map(one, range(len(out))))
+    return out
 
 
 def gauss_rule_p30():

@@ -36,6 +36,7 @@ def lib():
         L.emu_subtree_triangles.argtypes = [C.c_void_p]
         L.emu_subtree_triangles.restype = C.c_longlong
         L.emu_signed_distance.argtypes = [C.c_void_p, T.c_dp, C.c_uint64, T.c_dp, T.c_ip, T.c_ip, T.c_dp]
+        L.emu_host_signed_distance.argtypes = [C.c_void_p, T.c_dp, C.c_uint64, C.c_int, T.c_dp, T.c_ip, T.c_ip, T.c_dp]
         L.emu_shard_count.restype = C.c_uint64
         L.emu_shard_count.argtypes = [T.c_up, C.c_int, C.c_int]
         L.emu_unpack.argtypes = [T.c_up, C.c_int, T.c_dp, C.c_uint64, T.c_dp]
@@ -124,6 +125,17 @@ class EmuMesh:
         ent = np.empty(n, dtype=np.int32)
         near = np.empty((n, 3))
         self.L.emu_signed_distance(self.h, T.dp(P), n, T.dp(d), T.ip(tri), T.ip(ent), T.dp(near))
+        return (d, tri, ent, near) if full else d
+
+    def host_signed_distance(self, P, full=False, threads=8):
+        """The product's single-point host evaluator (dg_host_query.h), `threads` concurrent callers."""
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+        n = len(P)
+        d = np.empty(n)
+        tri = np.empty(n, dtype=np.int32)
+        ent = np.empty(n, dtype=np.int32)
+        near = np.empty((n, 3))
+        self.L.emu_host_signed_distance(self.h, T.dp(P), n, threads, T.dp(d), T.ip(tri), T.ip(ent), T.dp(near))
         return (d, tri, ent, near) if full else d
 
 

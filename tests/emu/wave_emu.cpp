@@ -18,6 +18,7 @@
 #include "../../discregrid_amd/csrc/dg_build.h"
 #include "../../discregrid_amd/csrc/dg_kernels.h"
 #include "../../discregrid_amd/csrc/dg_layout.h"
+#include "../../discregrid_amd/csrc/dg_host_query.h"
 
 
 
@@ -558,6 +559,31 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		stats[11] = st.heavy_bricks;
 	}
 	return err;
+}
+
+// the product's single-point host evaluator (dg_host_query.h), called from `threads` OpenMP threads at once
+void emu_host_signed_distance(void* h, const double* xyz, uint64_t n, int threads, double* dist, int32_t* tri, int32_t* entity,
+							  double* nearest)
+{
+	auto m = static_cast<HostMesh*>(h);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+	for (long long i = 0; i < (long long)n; ++i)
+	{
+		LaneResult r;
+		if (!dg::host::signed_distance_point(m->B, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], r))
+		{
+			dist[i] = 1.7976931348623157e308;
+			if (tri) tri[i] = -1;
+			if (entity) entity[i] = -1;
+			continue;
+		}
+		dist[i] = r.signed_dist;
+		if (tri) tri[i] = r.tri_id;
+		if (entity) entity[i] = r.entity;
+		if (nearest)
+			for (int d = 0; d < 3; ++d)
+				nearest[3 * i + d] = r.nearest[d];
+	}
 }
 
 void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, int32_t* tri, int32_t* entity,

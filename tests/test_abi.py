@@ -102,11 +102,19 @@ def test_no_device_fails_loudly(dg):
 def test_product_does_not_reference_oracle():
     """The product tree must not import/link/execute anything under oracle/ or tests/."""
     bad = []
-    for root, _, files in os.walk(os.path.join(T.ROOT, "discregrid_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")):
-                txt = open(os.path.join(root, f), errors="ignore").read()
-                if re.search(r"oracle/|libdiscregrid_oracle|libdiscregrid_ref|wave_emu|dgtest", txt):
+    for top in (os.path.join(T.ROOT, "discregrid_amd"), os.path.join(T.ROOT, "include")):
+        for root, dirs, files in os.walk(top):
+            dirs[:] = [d for d in dirs if d not in ("build", "variants", "__pycache__")]
+            for f in files:
+                txt = None
+                if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")) or f in ("All", "Dense", "Core"):
+                    txt = open(os.path.join(root, f), errors="ignore").read()
+                    pattern = r"oracle/|libdiscregrid_oracle|libdiscregrid_ref|wave_emu|dgtest"
+                elif f.endswith((".mk", ".sh", ".cmake")) or f in ("Makefile", "CMakeLists.txt"):
+                    # build recipes must not even mention the test trees
+                    txt = open(os.path.join(root, f), errors="ignore").read()
+                    pattern = r"oracle|tests/|wave_emu|dgtest"
+                if txt is not None and re.search(pattern, txt):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
     out = subprocess.check_output(["ldd", os.path.join(T.ROOT, "discregrid_amd", "libdiscregrid_hip.so")]).decode()

@@ -222,3 +222,49 @@ def test_config3_planes_bit_exact():
     plane = 257 * 257
     for b, e in ((127 * plane, 128 * plane + 1000), (257 ** 3 + 2 * 256 * 257 * 100, 257 ** 3 + 2 * 256 * 257 * 100 + 70000)):
         np.testing.assert_array_equal(em.sample_range(dom, res, b, e), om.sample_nodes(dom, res, b, e))
+
+
+# ---- the single-point host evaluator of the product (dg_host_query.h) ------------------------------------
+@pytest.mark.parametrize("mesh", ["box", "ico8", "torus", "bunny"])
+def test_host_point_query_matches_oracle_bitwise(mesh):
+    """dg_signed_distance_point's walk (near-first DFS over the product's BVH, conservative float
+    bounds, reference arithmetic per triangle) gives the oracle's signed distance bit for bit; where the
+    triangle differs the two triangles are exactly tied (nearest point and d^2 identical)."""
+    V, F = {"box": T.box_mesh, "ico8": lambda: T.icosphere(8), "torus": T.torus, "bunny": T.bunny_mesh}[mesh]()
+    rng = np.random.default_rng(11)
+    lo, hi = V.min(0), V.max(0)
+    P = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), size=(6000, 3))
+    P[:200] = V[rng.integers(0, len(V), 200)]                      # on vertices: many exact ties
+    P[200:400] = 0.5 * (V[F[rng.integers(0, len(F), 200), 0]] + V[F[rng.integers(0, len(F), 200), 1]])
+    P[400] = 0.5 * (lo + hi)
+    om = T.OracleMesh(V, F)
+    wd, wtri, went, wnear = om.signed_distance(P, full=True)
+    em = emu.EmuMesh(V, F)
+    d, tri, ent, near = em.host_signed_distance(P, full=True, threads=8)
+    same = tri == wtri
+    # the distance is the minimum of bit-exact d^2 values: identical whatever triangle attains it
+    assert np.array_equal(d, wd)
+    assert np.array_equal(ent[same], went[same])
+    assert np.array_equal(near[same], wnear[same])
+    # a different triangle must be an exact tie: the oracle's d^2 of both triangles is the same double
+    T.assert_exact_ties(V, F, P, tri, wtri)
+
+
+def test_host_point_query_concurrent_callers():
+    """64 threads query one mesh at once (the reference declares signed_distance const + thread safe,
+    TriangleMeshDistance.h:188,199): results equal the single-threaded ones."""
+    V, F = T.icosphere(12)
+    rng = np.random.default_rng(5)
+    P = rng.uniform(-1.4, 1.4, size=(20000, 3))
+    em = emu.EmuMesh(V, F)
+    one = em.host_signed_distance(P, full=True, threads=1)
+    many = em.host_signed_distance(P, full=True, threads=64)
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b)
+
+
+def test_host_point_query_nan_point():
+    V, F = T.box_mesh()
+    em = emu.EmuMesh(V, F)
+    d, tri, ent, _ = em.host_signed_distance(np.array([[np.nan, 0.0, 0.0], [0.0, 0.0, 0.0]]), full=True)
+    assert d[0] == np.finfo(np.float64).max and tri[0] == -1 and d[1] == -1.0

@@ -13,11 +13,13 @@ import dgtest as T
 pytestmark = pytest.mark.gpu
 DBL_MAX = np.finfo(np.float64).max
 BUILD = os.path.join(T.ROOT, "discregrid_amd", "cpp", "build")
+TEST_BUILD = os.path.join(T.ROOT, "tests", "cpp", "build")
 
 
 def _need(path):
     if not os.path.exists(path):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(BUILD)])
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(TEST_BUILD)])
     return path
 
 
@@ -80,7 +82,7 @@ def test_generate_sdf_cli_explicit_domain(tmp_path):
 
 
 def test_host_api_gpu_driver(tmp_path):
-    exe = _need(os.path.join(BUILD, "host_api_driver"))
+    exe = _need(os.path.join(TEST_BUILD, "host_api_driver"))
     obj = str(tmp_path / "torus.obj")
     V, F = T.torus()
     T.write_obj(obj, V, F)
@@ -104,6 +106,67 @@ def test_host_api_gpu_driver(tmp_path):
     np.testing.assert_array_equal(f1, np.where(pos[:, 2] > 0.0, -1.0 * want, DBL_MAX))
     np.testing.assert_array_equal(d, om.signed_distance(P))
     np.testing.assert_array_equal(phi, T.oracle_interpolate(dom, res, want, P))
+
+
+def test_unchanged_reference_caller(tmp_path):
+    """The reference's own idiom -- addFunction with the lambda of cmd/generate_sdf/main.cpp:97-101, an
+    opaque std::function -- compiled unchanged against this repository's headers: the grid takes its host
+    loop and every node is one TriangleMeshDistance::signed_distance(point) on the calling OpenMP thread
+    (dg_signed_distance_point).  Same coefficients as the typed MeshSDF path (GPU) and as the oracle, and
+    not slower than the unmodified reference on the same host cores (bunny 32^3, BASELINE config 1's size)."""
+    exe = _need(os.path.join(TEST_BUILD, "unchanged_caller"))
+    V, F = T.bunny_mesh()
+    obj = str(tmp_path / "bunny.obj")
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, "lambda", obj, "32 32 32", out])
+    got = np.fromfile(out)
+    n = int(got[0])
+    t_lambda, t_typed, bad = got[1], got[2], got[3]
+    assert n == T.n_nodes([32, 32, 32]) and bad == 0.0
+    dom = T.oracle_default_domain(V)
+    om = T.OracleMesh(V, F)
+    want = om.sample_nodes(dom, [32, 32, 32])
+    np.testing.assert_array_equal(got[4:], want)
+    if T.ref_available():
+        g = T.RefGrid(V, F, dom, [32, 32, 32])
+        g.sample_nodes(0, n)
+        g.sample_nodes(0, n)                # timed with the OpenMP team already running, like the caller
+        t_ref = g.last_seconds
+        print("bunny 32^3: unchanged lambda caller %.3f s, reference node loop %.3f s, MeshSDF (GPU) %.4f s"
+              % (t_lambda, t_ref, t_typed))
+        assert t_lambda <= 1.5 * t_ref      # same league as the reference (measured: several times faster)
+
+
+def test_dg_devices_all_spreads_addfunction(tmp_path):
+    """DG_DEVICES=all: the C++ addFunction deals the lattice to every visible GPU (dg_sdf_sample_nodes_multi,
+    one copy pipeline per device writing into the one host array).  Needs two or more devices."""
+    import discregrid_amd as dg
+    dg.load_library()
+    if dg.device_count() < 2:
+        pytest.skip("one GPU visible")
+    exe = _need(os.path.join(BUILD, "GenerateSDF"))
+    V, F = T.torus()
+    obj = str(tmp_path / "torus.obj")
+    T.write_obj(obj, V, F)
+    outs = []
+    for env in (dict(os.environ), dict(os.environ, DG_DEVICES="all")):
+        out = str(tmp_path / ("o%d.cdf" % len(outs)))
+        subprocess.check_call([exe, "-r", "40 36 30", "-o", out, obj], env=env, stdout=subprocess.DEVNULL)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+
+
+def test_concurrent_single_point_callers(tmp_path):
+    """64 threads call signed_distance(point) on one const TriangleMeshDistance at once (declared thread
+    safe in the reference, TriangleMeshDistance.h:188,199); every result equals the batched GPU query."""
+    exe = _need(os.path.join(TEST_BUILD, "unchanged_caller"))
+    V, F = T.icosphere(12)
+    obj = str(tmp_path / "ico.obj")
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, "threads", obj, "64", "20000", out])
+    assert np.fromfile(out)[0] == 0.0
 
 
 def _bitmap_cases():

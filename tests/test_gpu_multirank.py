@@ -22,6 +22,40 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def test_library_allgather_one_rank():
+    """The N > 1 step of bench.py as the driver runs it -- dg_sdf_sample_allgather_device: the library's own
+    RCCL communicator (dg_comm_create), shards, pieced all-gather, range unpacks -- with a world of one
+    rank on the one GPU of this box; bench.py asserts field == direct launch, bit for bit."""
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--force-shard-path", "--steps", "2", "--warmup", "1",
+           "--no-extras", "--pieces", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "dg_sdf_sample_allgather_device" in rec["config"]["sharding"] and rec["value"] > 0
+
+
+def test_cpp_multi_gpu_tool_one_rank(tmp_path):
+    """GenerateSDFMultiGPU (C++, one process per GPU, ncclCommInitRank through dg_comm_create, device-resident
+    field on every rank) with one rank writes the file GenerateSDF writes, byte for byte; with --steps it
+    prints the whole-job rate.  With two or more GPUs visible the same comparison runs on all of them."""
+    import discregrid_amd as dg
+    build = os.path.join(T.ROOT, "discregrid_amd", "cpp", "build")
+    V, F = T.torus()
+    obj = str(tmp_path / "torus.obj")
+    T.write_obj(obj, V, F)
+    ref = str(tmp_path / "ref.cdf")
+    subprocess.check_call([os.path.join(build, "GenerateSDF"), "-r", "24 20 22", "-o", ref, obj], stdout=subprocess.DEVNULL)
+    dg.load_library()
+    for gpus in sorted({1, min(dg.device_count(), 8)}):
+        out = str(tmp_path / ("multi%d.cdf" % gpus))
+        txt = subprocess.check_output([os.path.join(build, "GenerateSDFMultiGPU"), "-g", str(gpus), "-r", "24 20 22", "--steps", "3",
+                                       "--pieces", "2", "-o", out, obj], timeout=600).decode()
+        rec = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+        assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["nodes"] == T.n_nodes([24, 20, 22])
+        assert open(out, "rb").read() == open(ref, "rb").read()
+
+
 @pytest.mark.parametrize("world,pieces", [(2, 4), (4, 2)])
 def test_sharded_protocol_with_several_ranks_on_one_gpu(world, pieces):
     env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1")

@@ -11,7 +11,7 @@ import dgtest as T
 
 DBL_MAX = np.finfo(np.float64).max
 CPP = os.path.join(T.ROOT, "discregrid_amd", "cpp")
-DRIVER = os.path.join(CPP, "build", "host_api_driver")
+DRIVER = os.path.join(T.ROOT, "tests", "cpp", "build", "host_api_driver")
 
 
 @pytest.fixture(scope="module")
@@ -19,6 +19,7 @@ def driver():
     from discregrid_amd.build import build
     build()
     subprocess.check_call(["make", "-s", "-C", CPP])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(T.ROOT, "tests", "cpp")])
     return DRIVER
 
 
@@ -122,4 +123,4 @@ def test_headers_compile_standalone(tmp_path):
         src = tmp_path / "t.cpp"
         src.write_text("#include <%s>\nint main() { return 0; }\n" % h)
         subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + inc,
-                               "-I" + os.path.join(T.ROOT, "oracle", "eigen_shim"), str(src)])
+                               "-I" + os.path.join(CPP, "third_party", "eigen_min"), str(src)])
