@@ -92,6 +92,11 @@ SYMBOLS = {
     "dg_interpolate_batch": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _dp]),
     "dg_interpolate_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
+    "dg_reduce_field": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, C.c_int, C.c_double, C.c_double, C.c_double,
+                                  C.POINTER(C.c_void_p)]),
+    "dg_reduction_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dg_reduction_fetch": (C.c_int, [C.c_void_p, _dp, _u32p, _u32p]),
+    "dg_reduction_destroy": (None, [C.c_void_p]),
     "dg_density_map_nodes": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64, _u8p, _dp]),
     "dg_density_map_nodes_device": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -166,6 +171,10 @@ def default_domain(verts):
 
 def n_nodes(grid):
     return int(load_library().dg_grid_n_nodes(C.byref(grid)))
+
+
+def n_cells(grid):
+    return int(load_library().dg_grid_n_cells(C.byref(grid)))
 
 
 def shard_layout(grid, rank, nranks):
@@ -275,6 +284,26 @@ def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):
 def unpack_shard_range_device(grid, nranks, d_gathered, stride, rank_begin, rank_end, d_field, stream=0):
     _check(load_library().dg_unpack_shard_range_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
                                                        rank_begin, rank_end, C.c_void_p(d_field), C.c_void_p(stream)))
+
+
+def reduce_field(grid, coeffs, lo, hi, offset=0.0, closed=False):
+    """dg_reduce_field: returns (coeffs, cells[rows, 32], cell_map, tied_keys); the arrays are None when tied."""
+    lib = load_library()
+    c = _f64(coeffs)
+    h = C.c_void_p()
+    _check(lib.dg_reduce_field(C.byref(grid), c.ctypes.data_as(_dp), len(c), int(closed), lo, hi, offset, C.byref(h)))
+    try:
+        m, rows, tied = C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(lib.dg_reduction_info(h, C.byref(m), C.byref(rows), C.byref(tied)))
+        if tied.value:
+            return None, None, None, True
+        out = np.empty(m.value)
+        cells = np.empty((rows.value, 32), dtype=np.uint32)
+        cmap = np.empty(n_cells(grid), dtype=np.uint32)
+        _check(lib.dg_reduction_fetch(h, out.ctypes.data_as(_dp), cells.ctypes.data_as(_u32p), cmap.ctypes.data_as(_u32p)))
+        return out, cells, cmap, False
+    finally:
+        lib.dg_reduction_destroy(h)
 
 
 class Comm:

@@ -94,8 +94,9 @@ int main(int argc, char* argv[])
 	if (!no_reduction)
 	{
 		std::cout << "Reduce discrete fields...";
-		sdf->reduceField(0u, [&](const Eigen::Vector3d&, double v) { return -6.0 * h < v + cell_diag && v - cell_diag < 2.0 * h; });
-		sdf->reduceField(1u, [&](const Eigen::Vector3d&, double v) { return 0.0 <= v && v <= 3.0 * rho0; });
+		// the reference's two lambdas (main.cpp:138-145) as typed predicates: same arithmetic, evaluated on the GPU
+		sdf->reduceField(0u, Discregrid::ValuePredicate::band(-6.0 * h, 2.0 * h, cell_diag));
+		sdf->reduceField(1u, Discregrid::ValuePredicate::range(0.0, 3.0 * rho0));
 		std::cout << "DONE" << std::endl;
 	}
 

@@ -24,6 +24,24 @@
 namespace Discregrid
 {
 
+// A reduceField predicate on the node value alone, of the two forms the reference's GenerateDensityMap
+// uses (cmd/generate_density_map/main.cpp:138-145):
+//     band(lo, hi, offset):  lo < v + offset && v - offset < hi          range(lo, hi):  lo <= v && v <= hi
+// It is an ordinary callable -- it converts to DiscreteGrid::Predicate and behaves like the lambda it
+// replaces -- but CubicLagrangeDiscreteGrid::reduceField recognises it (pred.target<ValuePredicate>()) and
+// then runs the selection, compaction and Morton renumbering on the GPU.
+struct ValuePredicate
+{
+	double lo = 0.0, hi = 0.0, offset = 0.0;
+	bool closed = false;
+	static ValuePredicate band(double lo, double hi, double offset) { return ValuePredicate{lo, hi, offset, false}; }
+	static ValuePredicate range(double lo, double hi) { return ValuePredicate{lo, hi, 0.0, true}; }
+	bool operator()(Eigen::Vector3d const&, double v) const
+	{
+		return closed ? (lo <= v && v <= hi) : (lo < v + offset && v - offset < hi);
+	}
+};
+
 class CubicLagrangeDiscreteGrid : public DiscreteGrid
 {
 public:
@@ -87,6 +105,7 @@ public:
 	double lastAddFunctionSeconds() const { return m_last_total_s; }
 	double lastSamplingSeconds() const { return m_last_sampling_s; }
 	bool lastAddFunctionUsedGpu() const { return m_last_used_gpu; }
+	bool lastReduceFieldUsedGpu() const { return m_last_reduce_used_gpu; }
 
 private:
 	Eigen::Vector3d indexToNodePosition(unsigned int l) const;
@@ -108,6 +127,8 @@ private:
 	mutable std::unique_ptr<DeviceCache> m_dev;
 	double m_last_total_s = 0.0, m_last_sampling_s = 0.0;
 	bool m_last_used_gpu = false;
+	bool m_last_reduce_used_gpu = false;
+	bool reduceFieldOnDevice(unsigned int field_id, ValuePredicate const& pred);
 };
 
 } // namespace Discregrid

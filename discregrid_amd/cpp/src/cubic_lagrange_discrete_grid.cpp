@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -67,35 +68,9 @@ dg_grid_desc make_desc(Eigen::AlignedBox3d const& dom, std::array<unsigned int, 
 	return g;
 }
 
-// Morton key of the reference's zValue()/morton_lut() (cubic_lagrange_discrete_grid.cpp:583-601,
-// src/data/z_sort_table.hpp:119-134).  The reference shifts its partial result by 48 and then by
-// 24 bits, which pushes the contribution of the top byte out of the 64-bit word: only the low
-// 16 bits of each biased coordinate end up in the key.  Reproduced as is (the node order of
-// reduced fields, and with it the .cdm files, depend on it).
-inline uint64_t spread3(uint32_t byte)
-{
-	uint64_t r = 0;
-	for (int b = 0; b < 8; ++b)
-		r |= (uint64_t)((byte >> b) & 1u) << (3 * b);
-	return r;
-}
-inline uint64_t z_value(const double x[3], double inv_cell)
-{
-	uint32_t p[3];
-	for (int d = 0; d < 3; ++d)
-	{
-		int key = (x[d] >= 0.0) ? static_cast<int>(inv_cell * x[d]) : static_cast<int>(inv_cell * x[d]) - 1;
-		p[d] = static_cast<uint32_t>(static_cast<int64_t>(key) - (std::numeric_limits<int>::lowest() + 1));
-	}
-	auto level = [&](int shift) {
-		return spread3((p[0] >> shift) & 0xFFu) | (spread3((p[1] >> shift) & 0xFFu) << 1) |
-			   (spread3((p[2] >> shift) & 0xFFu) << 2);
-	};
-	uint64_t a = level(16);
-	a = (a << 48) | level(8);
-	a = (a << 24) | level(0);
-	return a;
-}
+// Morton key of the reference's zValue()/morton_lut(): dg::reference_z_value (dg_lattice.h), shared with
+// the device version of reduceField.
+inline uint64_t z_value(const double x[3], double inv_cell) { return dg::reference_z_value(x, inv_cell); }
 } // namespace
 
 // device-side mirrors of the fields, created lazily by the batched interpolate
@@ -503,8 +478,50 @@ double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vect
 // ---------------------------------------------------------------------------------------------
 // reduceField (:1065-1174)
 // ---------------------------------------------------------------------------------------------
+// The device version (dg_reduce_field) for an unreduced field and a value predicate.  Returns false -- and
+// leaves the field untouched -- when two surviving nodes share a Morton key: the reference's numbering is
+// then whatever libstdc++'s unstable sort makes of the tie, which only the host algorithm below reproduces.
+bool CubicLagrangeDiscreteGrid::reduceFieldOnDevice(unsigned int field_id, ValuePredicate const& pred)
+{
+	const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+	dg_reduction* red = nullptr;
+	if (dg_reduce_field(&g, m_nodes[field_id].data(), m_nodes[field_id].size(), pred.closed ? 1 : 0, pred.lo, pred.hi, pred.offset,
+						&red) != DG_OK)
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::reduceField (GPU): ") + dg_last_error());
+	struct Guard
+	{
+		dg_reduction* r;
+		~Guard() { dg_reduction_destroy(r); }
+	} guard{red};
+	uint64_t m = 0, rows = 0;
+	int tied = 0;
+	dg_reduction_info(red, &m, &rows, &tied);
+	if (tied)
+		return false;
+	FieldVector out(m);
+	std::vector<std::array<unsigned int, 32>> cells(rows);
+	std::vector<unsigned int> map(m_n_cells);
+	static_assert(sizeof(std::array<unsigned int, 32>) == 32 * sizeof(uint32_t), "cell rows must be packed");
+	if (dg_reduction_fetch(red, out.data(), rows ? reinterpret_cast<uint32_t*>(cells[0].data()) : nullptr,
+						   reinterpret_cast<uint32_t*>(map.data())) != DG_OK)
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::reduceField (GPU): ") + dg_last_error());
+	invalidateDevice(field_id);
+	m_nodes[field_id].swap(out);
+	m_cells[field_id].swap(cells);
+	m_cell_map[field_id].swap(map);
+	return true;
+}
+
 void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pred)
 {
+	m_last_reduce_used_gpu = false;
+	if (ValuePredicate const* vp = pred.target<ValuePredicate>())
+		if (m_cells[field_id].empty() && m_cell_map[field_id].empty() && m_nodes[field_id].size() == nNodesFull() &&
+			std::getenv("DG_REDUCE_ON_HOST") == nullptr && reduceFieldOnDevice(field_id, *vp))
+		{
+			m_last_reduce_used_gpu = true;
+			return;
+		}
 	using clock = std::chrono::steady_clock;
 	const bool timing = std::getenv("DG_REDUCE_TIMING") != nullptr;
 	auto tick = [&](const char* what) {

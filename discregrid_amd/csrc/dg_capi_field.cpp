@@ -122,6 +122,8 @@ void dg_field_destroy(dg_field* f)
 			(void)hipFree(p);
 	if (f->d_cell_major)
 		(void)hipFree(f->d_cell_major);
+	if (f->cell_major_ready)
+		(void)hipEventDestroy(f->cell_major_ready);
 	for (auto& kv : f->wtabs)
 		(void)hipFree(kv.second);
 	f->scratch.destroy();
@@ -144,7 +146,12 @@ dg_status dg_field_build_cell_major(dg_field* field, void* stream)
 	if (e != hipSuccess)
 		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "cell-major allocation of %llu bytes: %s",
 					(unsigned long long)(field->n_rows * 256), hipGetErrorString(e));
-	e = dg::launch_expand_cells(field->dev, field->n_rows, static_cast<double*>(p), static_cast<hipStream_t>(stream));
+	if (!field->cell_major_ready)
+		e = hipEventCreateWithFlags(&field->cell_major_ready, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = dg::launch_expand_cells(field->dev, field->n_rows, static_cast<double*>(p), static_cast<hipStream_t>(stream));
+	if (e == hipSuccess)
+		e = hipEventRecord(field->cell_major_ready, static_cast<hipStream_t>(stream));
 	if (e != hipSuccess)
 	{
 		(void)hipFree(p);
@@ -170,6 +177,97 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 	return DG_OK;
 }
 
+// ---- reduceField -------------------------------------------------------------------------------------------
+} // extern "C"
+struct dg_reduction
+{
+	dg::ReduceResult r;
+	uint64_t n_cells = 0;
+	int device = -1;
+};
+extern "C"
+{
+
+dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, int closed, double lo,
+						  double hi, double offset, dg_reduction** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!grid || !coeffs)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (n_coeffs != dg_grid_n_nodes(grid))
+		return fail(DG_ERR_INVALID, "dg_reduce_field needs an unreduced field: %llu coefficients, got %llu",
+					(unsigned long long)dg_grid_n_nodes(grid), (unsigned long long)n_coeffs);
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	dg_reduction* red = new (std::nothrow) dg_reduction;
+	if (!red)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	red->n_cells = dg_grid_n_cells(grid);
+	(void)hipGetDevice(&red->device);
+	void* d_c = nullptr;
+	hipError_t e = hipMalloc(&d_c, n_coeffs * sizeof(double));
+	if (e == hipSuccess) e = hipMemcpy(d_c, coeffs, n_coeffs * sizeof(double), hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+	{
+		dg::ReducePredicate P;
+		P.lo = lo;
+		P.hi = hi;
+		P.offset = offset;
+		P.closed = closed ? 1 : 0;
+		e = dg::reduce_field_device(grid->resolution, grid->domain_min, grid->cell_size, grid->inv_cell_size,
+									static_cast<const double*>(d_c), n_coeffs, P, red->r, nullptr);
+	}
+	if (d_c) (void)hipFree(d_c);
+	if (e != hipSuccess)
+	{
+		dg_reduction_destroy(red);
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_reduce_field: %s", hipGetErrorString(e));
+	}
+	*out = red;
+	return DG_OK;
+}
+
+dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys)
+{
+	if (!r)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (n_coeffs_out) *n_coeffs_out = r->r.n_nodes_out;
+	if (n_cell_rows) *n_cell_rows = r->r.n_rows;
+	if (tied_keys) *tied_keys = r->r.tied_keys;
+	return DG_OK;
+}
+
+dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* cells, uint32_t* cell_map)
+{
+	if (!r || !cell_map || (r->r.n_nodes_out && !coeffs) || (r->r.n_rows && !cells))
+		return fail(DG_ERR_INVALID, "null argument");
+	if (r->r.tied_keys)
+		return fail(DG_ERR_INVALID, "tied Morton keys: the node order is not unique, run the host algorithm");
+	DG_ON_DEVICE_OF(r);
+	if (r->r.n_nodes_out)
+		DG_HIP(hipMemcpy(coeffs, r->r.d_coeffs, r->r.n_nodes_out * sizeof(double), hipMemcpyDeviceToHost));
+	if (r->r.n_rows)
+		DG_HIP(hipMemcpy(cells, r->r.d_cells, r->r.n_rows * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	DG_HIP(hipMemcpy(cell_map, r->r.d_cell_map, r->n_cells * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return DG_OK;
+}
+
+void dg_reduction_destroy(dg_reduction* r)
+{
+	if (!r)
+		return;
+	DeviceGuard guard(r->device);
+	if (r->r.d_coeffs) (void)hipFree(r->r.d_coeffs);
+	if (r->r.d_cells) (void)hipFree(r->r.d_cells);
+	if (r->r.d_cell_map) (void)hipFree(r->r.d_cell_map);
+	delete r;
+}
+
 // ---- K3 ---------------------------------------------------------------------------------------------------
 dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
@@ -186,6 +284,8 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		return DG_OK;
 	DG_ON_DEVICE_OF(sdf);
 	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (sdf->d_cell_major && sdf->cell_major_ready)
+		DG_HIP(hipStreamWaitEvent(st, sdf->cell_major_ready, 0));
 	dg::DensityParams P;
 	std::vector<double> w;
 	dg::init_density_params(P, support_radius, rho0, sdf->grid.cell_size, band_predicate, w);
@@ -244,6 +344,8 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 		return DG_OK;
 	DG_ON_DEVICE_OF(field);
 	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (field->d_cell_major && field->cell_major_ready) // the copy may still be being built on another stream
+		DG_HIP(hipStreamWaitEvent(st, field->cell_major_ready, 0));
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and
 	// run as they are).  DG_K2_BINNING=0 switches it off, =2 forces it for any size.

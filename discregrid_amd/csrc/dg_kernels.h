@@ -296,6 +296,27 @@ inline TileGrid point_tiles(const double lo[3], const double hi[3], uint64_t n)
 	}
 	return g;
 }
+// ---- reduceField on the device (cubic_lagrange_discrete_grid.cpp:1065-1174) for value predicates ------------
+// keep(v) = closed ? (lo <= v && v <= hi) : (lo < v + offset && v - offset < hi), and v != DBL_MAX: the two
+// predicates of the reference's GenerateDensityMap (cmd/generate_density_map/main.cpp:138-145).
+struct ReducePredicate
+{
+	double lo, hi, offset;
+	int closed;
+};
+struct ReduceResult // device arrays owned by the caller of reduce_field_device(); host counts
+{
+	uint64_t n_nodes_out = 0; // m: nodes referenced by a surviving cell
+	uint64_t n_rows = 0;      // surviving cells
+	int tied_keys = 0;        // two survivors share a Morton key: the reference's order is then libstdc++'s business
+	void* d_coeffs = nullptr;   // [m] f64, Morton order
+	void* d_cells = nullptr;    // [n_rows][32] u32, renumbered
+	void* d_cell_map = nullptr; // [n_cells] u32, row or 0xffffffff
+};
+// Unreduced field (closed-form cell rows) with n = all lattice nodes.  Synchronises with `stream`.
+hipError_t reduce_field_device(const uint32_t res[3], const double dmin[3], const double cell[3], const double inv_cell[3],
+							   const double* d_coeffs, uint64_t n, const ReducePredicate& pred, ReduceResult& out, hipStream_t stream);
+
 size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles); // rocPRIM's requirement for n pairs
 inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[6])
 {

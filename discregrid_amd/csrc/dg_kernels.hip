@@ -35,6 +35,9 @@
 // Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <stdint.h>
 #include <algorithm>
 #include "dg_kernels.h"
@@ -444,11 +447,43 @@ __global__ __launch_bounds__(256) void k_unpack_shards(const UnpackParams P)
 // evaluation is per-lane; the 32 coefficients are fetched as 16 x 16-byte pairs (closed-form
 // rows) with all loads issued before the first use.
 // ------------------------------------------------------------------------------------------------
+// XCD-aware block order for K2: the hardware deals consecutive workgroups to the 8 XCDs in turn, so eight
+// neighbouring blocks of queries -- which, in tile order, gather from the same coefficient lines -- would
+// each pull those lines into a different L2.  Chunks of kK2XcdChunk consecutive LOGICAL blocks (one
+// chunk = what an XCD holds in flight) go to one XCD instead.  Returns false for padding blocks.
+#ifndef DG_K2_XCD_CHUNK
+#define DG_K2_XCD_CHUNK 256
+#endif
+static const uint32_t kK2XcdChunk = DG_K2_XCD_CHUNK;
+__device__ __forceinline__ bool k2_logical_block(uint32_t block_idx, uint32_t n_blocks, uint32_t* blk)
+{
+	if (kK2XcdChunk == 0)
+	{
+		*blk = block_idx;
+		return block_idx < n_blocks;
+	}
+	const uint32_t xcd = block_idx & 7u, within = block_idx >> 3;
+	const uint32_t b = ((within / kK2XcdChunk) * 8u + xcd) * kK2XcdChunk + within % kK2XcdChunk;
+	*blk = b;
+	return b < n_blocks;
+}
+static uint32_t k2_grid(uint64_t n)
+{
+	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	if (kK2XcdChunk == 0)
+		return blocks;
+	const uint32_t round = 8u * kK2XcdChunk;
+	return (blocks + round - 1) / round * round;
+}
+
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
 													  double* __restrict__ phi_out, double* __restrict__ grad_out)
 {
-	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t blk;
+	if (!k2_logical_block(blockIdx.x, (uint32_t)((n + 255) / 256), &blk))
+		return;
+	const uint64_t gid = (uint64_t)blk * blockDim.x + threadIdx.x;
 	if (gid >= n)
 		return;
 	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
@@ -508,7 +543,10 @@ template <bool GRAD>
 __global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
 															 double* __restrict__ phi_out, double* __restrict__ grad_out, BinScratch S)
 {
-	uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t blk;
+	if (!k2_logical_block(blockIdx.x, (uint32_t)((n + 255) / 256), &blk))
+		return;
+	uint64_t gid = (uint64_t)blk * blockDim.x + threadIdx.x;
 	if (gid >= n)
 		return;
 	if (S.sort_launched != 0 && S.flag[0] != 0)
@@ -606,6 +644,217 @@ __global__ __launch_bounds__(256) void k_field_check(const double* __restrict__ 
 		atomicOr(unsafe, 1u);
 }
 
+// ---- reduceField (dg_kernels.h: reduce_field_device) --------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_keep(const double* __restrict__ v, uint64_t n, const ReducePredicate P, uint8_t* __restrict__ keep,
+													  uint8_t* __restrict__ used)
+{
+	for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n; l += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const double x = v[l];
+		const bool ok = P.closed ? (P.lo <= x && x <= P.hi) : (P.lo < x + P.offset && x - P.offset < P.hi);
+		keep[l] = (ok && x != 1.7976931348623157e308) ? 1 : 0;
+		used[l] = 0;
+	}
+}
+// a cell survives if any of its 32 nodes is kept (:1091-1098)
+__global__ __launch_bounds__(256) void k_reduce_cell_flags(const uint32_t rx, const uint32_t ry, const uint32_t rz, const uint8_t* __restrict__ keep,
+															uint32_t* __restrict__ flag)
+{
+	const uint64_t n_cells = (uint64_t)rx * ry * rz;
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cells)
+		return;
+	const uint32_t res[3] = {rx, ry, rz};
+	const uint32_t n01 = rx * ry;
+	const uint32_t k = (uint32_t)(c / n01), r = (uint32_t)(c % n01);
+	uint32_t idx[32];
+	cell_node_indices(r % rx, r / rx, k, res, idx);
+	bool any = false;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		any = any || keep[idx[j]] != 0;
+	flag[c] = any ? 1u : 0u;
+}
+// cell map + the nodes the surviving cells reference (:1099-1128)
+__global__ __launch_bounds__(256) void k_reduce_cell_map(const uint32_t rx, const uint32_t ry, const uint32_t rz, const uint32_t* __restrict__ flag,
+														  const uint32_t* __restrict__ row, uint32_t* __restrict__ cell_map, uint8_t* __restrict__ used)
+{
+	const uint64_t n_cells = (uint64_t)rx * ry * rz;
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cells)
+		return;
+	if (flag[c] == 0u)
+	{
+		cell_map[c] = 0xffffffffu;
+		return;
+	}
+	cell_map[c] = row[c];
+	const uint32_t res[3] = {rx, ry, rz};
+	const uint32_t n01 = rx * ry;
+	const uint32_t k = (uint32_t)(c / n01), r = (uint32_t)(c % n01);
+	uint32_t idx[32];
+	cell_node_indices(r % rx, r / rx, k, res, idx);
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		used[idx[j]] = 1; // same value from every writer
+}
+struct ReduceGeom
+{
+	uint32_t res[3];
+	double dmin[3], cell[3];
+	double zscale;
+};
+// Morton keys of the surviving nodes, with the reference's arithmetic (:1110-1115)
+__global__ __launch_bounds__(256) void k_reduce_keys(const ReduceGeom G, const uint32_t* __restrict__ node, uint64_t m, uint64_t* __restrict__ keys)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
+	{
+		double x[3];
+		node_position_flat(node[i], G.res, G.dmin, G.cell, x);
+		keys[i] = reference_z_value(x, G.zscale);
+	}
+}
+// after the sort: new numbering, coefficients in the new order, and whether two survivors share a key
+__global__ __launch_bounds__(256) void k_reduce_renumber(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ node, uint64_t m,
+														  const double* __restrict__ v, uint32_t* __restrict__ new_id, double* __restrict__ out,
+														  uint32_t* __restrict__ tied)
+{
+	bool tie = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const uint32_t l = node[i];
+		new_id[l] = (uint32_t)i;
+		out[i] = v[l];
+		tie = tie || (i + 1 < m && keys[i] == keys[i + 1]);
+	}
+	if (__ballot(tie) != 0ull && (threadIdx.x & 63u) == 0u)
+		atomicOr(tied, 1u);
+}
+// rows of the surviving cells with the new node numbers (:1161-1173)
+__global__ __launch_bounds__(256) void k_reduce_rows(const uint32_t rx, const uint32_t ry, const uint32_t rz, const uint32_t* __restrict__ cell_map,
+													  const uint32_t* __restrict__ new_id, uint32_t* __restrict__ rows)
+{
+	const uint64_t n_cells = (uint64_t)rx * ry * rz;
+	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_cells)
+		return;
+	const uint32_t row = cell_map[c];
+	if (row == 0xffffffffu)
+		return;
+	const uint32_t res[3] = {rx, ry, rz};
+	const uint32_t n01 = rx * ry;
+	const uint32_t k = (uint32_t)(c / n01), r = (uint32_t)(c % n01);
+	uint32_t idx[32];
+	cell_node_indices(r % rx, r / rx, k, res, idx);
+	uint32_t* o = rows + 32 * (size_t)row;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		o[j] = new_id[idx[j]];
+}
+
+} // namespace
+
+hipError_t reduce_field_device(const uint32_t res[3], const double dmin[3], const double cell[3], const double inv_cell[3],
+							   const double* d_coeffs, uint64_t n, const ReducePredicate& pred, ReduceResult& out, hipStream_t stream)
+{
+	const uint64_t n_cells = (uint64_t)res[0] * res[1] * res[2];
+	struct Scratch
+	{
+		std::vector<void*> p;
+		~Scratch()
+		{
+			for (void* q : p)
+				(void)hipFree(q);
+		}
+		hipError_t get(void** q, size_t bytes)
+		{
+			const hipError_t e = hipMalloc(q, bytes ? bytes : 8);
+			if (e == hipSuccess)
+				p.push_back(*q);
+			return e;
+		}
+	} S;
+#define DG_TRY(x)                \
+	do                           \
+	{                            \
+		const hipError_t e_ = (x); \
+		if (e_ != hipSuccess)    \
+			return e_;           \
+	} while (0)
+	uint8_t *keep = nullptr, *used = nullptr;
+	uint32_t *flag = nullptr, *row = nullptr, *cell_map = nullptr, *node = nullptr, *node_sorted = nullptr, *new_id = nullptr, *counts = nullptr;
+	DG_TRY(S.get((void**)&keep, n));
+	DG_TRY(S.get((void**)&used, n));
+	DG_TRY(S.get((void**)&flag, n_cells * 4));
+	DG_TRY(S.get((void**)&row, n_cells * 4));
+	DG_TRY(S.get((void**)&counts, 16));
+	DG_TRY(hipMalloc((void**)&cell_map, n_cells * 4));
+	out.d_cell_map = cell_map; // results are freed by the caller (also on failure: it owns `out`)
+	DG_TRY(hipMemsetAsync(counts, 0, 16, stream));
+	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
+	const uint32_t cgrid = (uint32_t)((n_cells + 255) / 256);
+	hipLaunchKernelGGL(k_reduce_keep, dim3(wide), dim3(256), 0, stream, d_coeffs, n, pred, keep, used);
+	hipLaunchKernelGGL(k_reduce_cell_flags, dim3(cgrid), dim3(256), 0, stream, res[0], res[1], res[2], keep, flag);
+	size_t tmp_bytes = 0, b2 = 0;
+	DG_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, flag, row, 0u, (size_t)n_cells, rocprim::plus<uint32_t>(), stream));
+	DG_TRY(rocprim::select(nullptr, b2, rocprim::counting_iterator<uint32_t>(0u), used, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, stream));
+	tmp_bytes = std::max(tmp_bytes, b2);
+	void* tmp = nullptr;
+	DG_TRY(S.get(&tmp, tmp_bytes));
+	size_t tb = tmp_bytes;
+	DG_TRY(rocprim::exclusive_scan(tmp, tb, flag, row, 0u, (size_t)n_cells, rocprim::plus<uint32_t>(), stream));
+	hipLaunchKernelGGL(k_reduce_cell_map, dim3(cgrid), dim3(256), 0, stream, res[0], res[1], res[2], flag, row, cell_map, used);
+	DG_TRY(S.get((void**)&node, n * 4)); // survivors in node order (at most n)
+	tb = tmp_bytes;
+	DG_TRY(rocprim::select(tmp, tb, rocprim::counting_iterator<uint32_t>(0u), used, node, counts, (size_t)n, stream));
+	DG_TRY(hipGetLastError());
+	// sizes: surviving nodes, surviving cells
+	uint32_t h_m = 0, h_last_row = 0, h_last_flag = 0;
+	DG_TRY(hipMemcpyAsync(&h_m, counts, 4, hipMemcpyDeviceToHost, stream));
+	DG_TRY(hipMemcpyAsync(&h_last_row, row + (n_cells - 1), 4, hipMemcpyDeviceToHost, stream));
+	DG_TRY(hipMemcpyAsync(&h_last_flag, flag + (n_cells - 1), 4, hipMemcpyDeviceToHost, stream));
+	DG_TRY(hipStreamSynchronize(stream));
+	const uint64_t m = h_m, rows = (uint64_t)h_last_row + h_last_flag;
+	out.n_nodes_out = m;
+	out.n_rows = rows;
+	DG_TRY(hipMalloc(&out.d_coeffs, std::max<uint64_t>(m, 1) * sizeof(double)));
+	DG_TRY(hipMalloc(&out.d_cells, std::max<uint64_t>(rows, 1) * 32 * sizeof(uint32_t)));
+	if (m == 0)
+		return hipSuccess;
+	uint64_t *keys = nullptr, *keys_sorted = nullptr;
+	DG_TRY(S.get((void**)&keys, m * 8));
+	DG_TRY(S.get((void**)&keys_sorted, m * 8));
+	DG_TRY(S.get((void**)&node_sorted, m * 4));
+	DG_TRY(S.get((void**)&new_id, n * 4));
+	ReduceGeom G;
+	for (int d = 0; d < 3; ++d)
+	{
+		G.res[d] = res[d];
+		G.dmin[d] = dmin[d];
+		G.cell[d] = cell[d];
+	}
+	G.zscale = 4.0 * std::min(std::min(inv_cell[0], inv_cell[1]), inv_cell[2]); // :1112
+	const uint32_t mwide = (uint32_t)std::min<uint64_t>((m + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_reduce_keys, dim3(mwide), dim3(256), 0, stream, G, node, m, keys);
+	size_t sort_bytes = 0;
+	DG_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, node, node_sorted, (size_t)m, 0u, (unsigned)kReferenceZBits, stream));
+	void* sort_tmp = nullptr;
+	DG_TRY(S.get(&sort_tmp, sort_bytes));
+	DG_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys, keys_sorted, node, node_sorted, (size_t)m, 0u, (unsigned)kReferenceZBits, stream));
+	hipLaunchKernelGGL(k_reduce_renumber, dim3(mwide), dim3(256), 0, stream, keys_sorted, node_sorted, m, d_coeffs, new_id,
+					   static_cast<double*>(out.d_coeffs), counts + 1);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(cgrid), dim3(256), 0, stream, res[0], res[1], res[2], cell_map, new_id, static_cast<uint32_t*>(out.d_cells));
+	DG_TRY(hipGetLastError());
+	uint32_t h_tied = 0;
+	DG_TRY(hipMemcpyAsync(&h_tied, counts + 1, 4, hipMemcpyDeviceToHost, stream));
+	DG_TRY(hipStreamSynchronize(stream));
+	out.tied_keys = (int)h_tied;
+#undef DG_TRY
+	return hipSuccess;
+}
+
+namespace
+{
 } // namespace
 
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, uint64_t n_coeffs, const DensityParams& p,
@@ -730,7 +979,7 @@ hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n
 {
 	if (n == 0)
 		return hipSuccess;
-	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	const uint32_t grid = k2_grid(n);
 	if (d_grad)
 		hipLaunchKernelGGL(k_interpolate<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
 	else
@@ -747,7 +996,7 @@ hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uin
 	const hipError_t e = launch_binning(field_tiles(f), field_tiles(f, kSortCells), d_xyz, n, S, 4u, stream);
 	if (e != hipSuccess)
 		return e;
-	const uint32_t grid = (uint32_t)((n + 255) / 256);
+	const uint32_t grid = k2_grid(n);
 	if (d_grad)
 		hipLaunchKernelGGL(k_interpolate_binned<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
 	else

@@ -314,6 +314,40 @@ DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3]
 	return phi;
 }
 
+// Morton key of the reference's zValue() / morton_lut() for a node position
+// (cubic_lagrange_discrete_grid.cpp:583-601, src/data/z_sort_table.hpp:119-134).  The reference shifts its
+// partial result by 48 and then by 24 bits, which pushes the contribution of the top byte out of the
+// 64-bit word: only the low 16 bits of each biased coordinate end up in the key (48 significant bits).
+// Reproduced as is: the node order of reduced fields, and with it the .cdm files, depend on it.
+DG_HD uint64_t morton_spread3(uint32_t byte)
+{
+	uint64_t r = 0;
+	for (int b = 0; b < 8; ++b)
+		r |= (uint64_t)((byte >> b) & 1u) << (3 * b);
+	return r;
+}
+DG_HD uint64_t reference_z_value(const double x[3], double inv_cell)
+{
+	uint32_t p[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		const int key = (x[d] >= 0.0) ? (int)(inv_cell * x[d]) : (int)(inv_cell * x[d]) - 1;
+		p[d] = (uint32_t)((int64_t)key - (int64_t)(-2147483647)); // key - (INT_MIN + 1)
+	}
+	uint64_t lv[3];
+	for (int s = 0; s < 3; ++s)
+	{
+		const int shift = 8 * s;
+		lv[s] = morton_spread3((p[0] >> shift) & 0xFFu) | (morton_spread3((p[1] >> shift) & 0xFFu) << 1) |
+				(morton_spread3((p[2] >> shift) & 0xFFu) << 2);
+	}
+	uint64_t a = lv[2];
+	a = (a << 48) | lv[1];
+	a = (a << 24) | lv[0];
+	return a;
+}
+static const int kReferenceZBits = 48;
+
 // flat node index -> position (the inverse of the class decomposition; used where nodes are
 // addressed individually rather than as bricks)
 DG_HD void node_position_flat(uint64_t l, const uint32_t res[3], const double dmin[3], const double cell[3], double x[3])

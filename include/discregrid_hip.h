@@ -21,6 +21,8 @@
  *   dg_interpolate_batch[_device]
  *                             CubicLagrangeDiscreteGrid::interpolate(field_id, x, gradient*)
  *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063 (shape functions :339-580)
+ *   dg_reduce_field           CubicLagrangeDiscreteGrid::reduceField for value predicates
+ *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:1065-1174, zValue :583-601
  *   dg_shard_* / dg_unpack_shards_device, dg_comm_*, dg_sdf_sample_allgather_device
  *                             no counterpart (the reference is single-process OpenMP): lattice sharding
  *                             for one-process-per-GPU runs; the exchange is one logical RCCL all-gather,
@@ -219,6 +221,25 @@ dg_status dg_field_drop_cell_major(dg_field* field);
 dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad);
 dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
 									  double* d_grad, void* stream);
+
+/* ---- reduceField (sparsification of a field) on the device ------------------------------------------ */
+/* CubicLagrangeDiscreteGrid::reduceField (cubic_lagrange_discrete_grid.cpp:1065-1174) for an UNREDUCED field
+ * (n_coeffs == dg_grid_n_nodes) and a predicate on the node value of one of the two forms the reference's
+ * GenerateDensityMap uses (cmd/generate_density_map/main.cpp:138-145):
+ *     closed == 0:  lo < v + offset && v - offset < hi        closed != 0:  lo <= v && v <= hi
+ * (a node whose value is DG_NO_VALUE never passes, :1090).  On the device: node flags, surviving cells (any of
+ * their 32 nodes passes), the nodes those cells reference, their Morton keys with the reference's own
+ * arithmetic (zValue :583-601), a radix sort, renumbering of the cell rows.  The reference orders nodes
+ * with an unstable std::sort; the result is unique -- and this function reproduces it -- unless two
+ * surviving nodes share a key (possible on strongly anisotropic lattices only): then *tied_keys is set, no
+ * result can be fetched, and the caller must run the host algorithm (the C++ class does).
+ * dg_reduction_fetch copies: coeffs[n_coeffs_out], cells[32 * n_cell_rows], cell_map[dg_grid_n_cells]. */
+typedef struct dg_reduction dg_reduction;
+dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, int closed, double lo,
+						  double hi, double offset, dg_reduction** out);
+dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys);
+dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* cells, uint32_t* cell_map);
+void dg_reduction_destroy(dg_reduction* r);
 
 /* ---- K3: SPH boundary density map (next row of the path: GenerateDensityMap) ------------------ */
 /* out[l - node_begin] = density_func(indexToNodePosition(l)) of cmd/generate_density_map/main.cpp:96-112

@@ -5,13 +5,13 @@
 # Per workload: one --kernel-trace --stats run (kernel durations) and the PMC passes (own runs, counters
 # only -- never combined with a trace).  K1 = the default bench (python bench.py, 256^3 icosphere);
 # K2 / K3 / U = profiles/pmc_workloads.py at BASELINE configs[4] sizes.  Raw databases stay under
-# gpurun_out/ (scratch); profiles/summarize_pmc.py writes profiles/<tag>_pmc_summary.txt,
+# /tmp on the box (too big to travel); profiles/summarize_pmc.py writes profiles/<tag>_pmc_summary.txt,
 # profiles/<tag>_kernel_stats.txt and the machine-readable profiles/counters.json that bench.py reads
 # (keyed by a hash of discregrid_amd/csrc, so that stale counters are never reported).
 set -u
 TAG=${1:-r02}; WHAT=${2:-all}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
+OUT=/tmp/prof_$TAG; mkdir -p $OUT gpurun_out/prof_$TAG   # raw databases (100+ MB) stay on the box; summaries travel
 GROUPS_BASE=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
              "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum")
 GROUPS_K1=("SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_ANY" \
@@ -36,4 +36,5 @@ for w in k2 k3 u; do
   fi
 done
 python profiles/summarize_pmc.py $OUT $TAG
-ls $OUT | head -50
+cp profiles/counters.json profiles/${TAG}_pmc_summary.txt profiles/${TAG}_kernel_stats.txt gpurun_out/prof_$TAG/
+cp $OUT/*.log gpurun_out/prof_$TAG/ 2>/dev/null

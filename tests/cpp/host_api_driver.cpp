@@ -5,6 +5,7 @@
 //   host_api_driver roundtrip  in.cdf out.cdf            load -> save
 //   host_api_driver poly       out.cdf                    generic (host callback) addFunction
 //   host_api_driver reduce     in.cdf bound out.cdf       load -> reduceField(|v| < bound) -> save
+//   host_api_driver reduceband in.cdf lo hi out.cdf gpu|host  the same through the typed ValuePredicate (GPU path)
 //   host_api_driver eval       in.cdf pts.bin out.bin     scalar interpolate (value + gradient)
 //   host_api_driver evalsplit  in.cdf pts.bin out.bin     determineShapeFunctions + split interpolate
 //   host_api_driver gpu        mesh.obj pts.bin out.bin   GPU: MeshSDF addFunction (with a predicate
@@ -14,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -68,6 +70,19 @@ int main(int argc, char** argv)
 		const double bound = std::stod(argv[3]);
 		g.reduceField(0u, [bound](Eigen::Vector3d const&, double v) { return std::abs(v) < bound; });
 		g.save(argv[4]);
+		return 0;
+	}
+	if (cmd == "reduceband" && argc == 7)
+	{
+		// typed predicate |v| < bound as band(-bound, bound, 0): GPU path where the node order is unique;
+		// prints which path ran.  argv[6] = "host" forces the host algorithm through the same typed predicate.
+		CubicLagrangeDiscreteGrid g{std::string(argv[2])};
+		const double lo = std::stod(argv[3]), hi = std::stod(argv[4]);
+		if (std::string(argv[6]) == "host")
+			setenv("DG_REDUCE_ON_HOST", "1", 1);
+		g.reduceField(0u, ValuePredicate::band(lo, hi, 0.0));
+		std::printf("%s\n", g.lastReduceFieldUsedGpu() ? "gpu" : "host");
+		g.save(argv[5]);
 		return 0;
 	}
 	if ((cmd == "eval" || cmd == "evalsplit") && argc == 5)

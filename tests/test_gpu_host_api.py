@@ -108,6 +108,76 @@ def test_host_api_gpu_driver(tmp_path):
     np.testing.assert_array_equal(phi, T.oracle_interpolate(dom, res, want, P))
 
 
+@pytest.mark.parametrize("src,bound,golden", [("box.cdf", 0.25, "box_reduced_0p25.cdf"),
+                                               ("torus_9_14_6.cdf", 0.08, "torus_9_14_6_reduced_0p08.cdf")])
+def test_reduce_field_on_device_matches_reference_file(tmp_path, src, bound, golden):
+    """reduceField with a typed ValuePredicate runs on the GPU (node flags, surviving cells, compaction,
+    Morton keys with the reference's arithmetic, radix sort, renumbering) and reproduces the file the
+    REFERENCE wrote for the same reduction, byte for byte; dg_reduce_field through ctypes gives the same
+    arrays."""
+    import discregrid_amd as dg
+    exe = _need(os.path.join(TEST_BUILD, "host_api_driver"))
+    out = str(tmp_path / "red.cdf")
+    path = subprocess.check_output([exe, "reduceband", os.path.join(T.GOLDEN, src), str(-bound), str(bound), out, "gpu"]).decode().strip()
+    assert open(out, "rb").read() == open(os.path.join(T.GOLDEN, golden), "rb").read()
+    full, want = T.read_cdf(os.path.join(T.GOLDEN, src)), T.read_cdf(os.path.join(T.GOLDEN, golden))
+    dg.load_library()
+    g = dg.grid_desc(full["domain"][:3], full["domain"][3:], full["res"])
+    coeffs, cells, cmap, tied = dg.reduce_field(g, full["nodes"][0], -bound, bound)
+    # the torus lattice (9 x 14 x 6 over an oblong box) is anisotropic enough for tied Morton keys: the
+    # device says so and the class runs the host algorithm; the cube's lattice has unique keys
+    assert tied == (src == "torus_9_14_6.cdf") and path == ("host" if tied else "gpu")
+    if tied:
+        return
+    np.testing.assert_array_equal(coeffs, want["nodes"][0])
+    np.testing.assert_array_equal(cells, want["cells"][0].reshape(-1, 32))
+    np.testing.assert_array_equal(cmap, want["cell_map"][0])
+
+
+def test_reduce_field_on_device_random_fields_and_ties(tmp_path):
+    """Device reduceField == host reduceField (which reproduces the reference's files) on random fields incl.
+    DBL_MAX nodes, closed-range predicates, everything / nothing removed; on a strongly anisotropic lattice
+    the Morton keys tie, the device reports it and the C++ class runs the host algorithm."""
+    import discregrid_amd as dg
+    exe = _need(os.path.join(TEST_BUILD, "host_api_driver"))
+    dg.load_library()
+    rng = np.random.default_rng(31)
+    cases = [([7, 9, 6], [-1.0, -0.5, 0.0, 1.5, 0.75, 2.0], False), ([12, 12, 12], [0.0, 0.0, 0.0, 1.0, 1.0, 1.0], False),
+             ([40, 3, 3], [0.0, 0.0, 0.0, 1.0, 1.0, 1.0], True)]
+    for res, dom, expect_tie in cases:
+        dom = np.array(dom)
+        n = T.n_nodes(res)
+        coeffs = rng.normal(size=n)
+        coeffs[rng.integers(0, n, n // 50)] = DBL_MAX
+        src = str(tmp_path / "src.cdf")
+        T.oracle_write_cdf(src, dom, res, [coeffs])
+        for lo, hi in ((-0.3, 0.2), (-100.0, 100.0), (5.0, 6.0)):
+            outs = {}
+            for mode in ("gpu", "host"):
+                out = str(tmp_path / (mode + ".cdf"))
+                path = subprocess.check_output([exe, "reduceband", src, str(lo), str(hi), out, mode]).decode().strip()
+                outs[mode] = (path, open(out, "rb").read())
+            assert outs["host"][0] == "host"
+            g = dg.grid_desc(dom[:3], dom[3:], res)
+            _, _, _, tied = dg.reduce_field(g, coeffs, lo, hi)
+            assert outs["gpu"][0] == ("host" if tied else "gpu")
+            assert outs["gpu"][1] == outs["host"][1]
+            if expect_tie and lo < 0:
+                assert tied
+        # closed range through the C ABI vs a numpy restatement of the node / cell selection
+        c2, cells, cmap, tied = dg.reduce_field(g, coeffs, -0.25, 0.5, closed=True)
+        if not tied:
+            keep = (coeffs >= -0.25) & (coeffs <= 0.5) & (coeffs != DBL_MAX)
+            table = T.oracle_cell_table(res)
+            alive = keep[table].any(axis=1)
+            assert len(cells) == alive.sum() and ((cmap != 0xFFFFFFFF) == alive).all()
+            used = np.zeros(n, dtype=bool)
+            used[table[alive].ravel()] = True
+            assert len(c2) == used.sum()
+            np.testing.assert_array_equal(np.sort(c2), np.sort(coeffs[used]))
+            np.testing.assert_array_equal(c2[cells[cmap[alive]]], coeffs[table[alive]])
+
+
 def test_unchanged_reference_caller(tmp_path):
     """The reference's own idiom -- addFunction with the lambda of cmd/generate_sdf/main.cpp:97-101, an
     opaque std::function -- compiled unchanged against this repository's headers: the grid takes its host

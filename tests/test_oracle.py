@@ -186,3 +186,31 @@ def test_against_live_reference(name):
     b, gb = T.oracle_interpolate(dom, res, coeffs, P, grad=True)
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(ga, gb)
+
+
+def test_lattice_digests_pin_the_oracle():
+    """tests/golden/lattice_digests.npz (SHA-256 per 2^20-node block of the REFERENCE's coefficients for the
+    judged configurations, make_digests.py) against the oracle on a few blocks: heavy-brick region of the
+    256^3 icosphere lattice, a bunny block, the last (ragged) block of the 512^3 lattice."""
+    import os
+    gold = dict(np.load(os.path.join(T.GOLDEN, "lattice_digests.npz")))
+    B = int(gold["block"])
+    assert B == 1 << 20
+    for name, mesh, res, blocks in (("bunny128", T.bunny_mesh(), [128] * 3, [3]),
+                                    ("ico71_256", T.icosphere(71), [256] * 3, [8]),
+                                    ("ico71_512", T.icosphere(71), [512] * 3, [-1])):
+        V, F = mesh
+        dom = gold[name + "_domain"]
+        np.testing.assert_array_equal(dom, T.oracle_default_domain(V))
+        n = T.n_nodes(res)
+        assert n == int(gold[name + "_nodes"]) and len(gold[name + "_digest"]) == (n + B - 1) // B
+        om = T.OracleMesh(V, F)
+        for b in blocks:
+            b = b % len(gold[name + "_digest"])
+            e = min(n, (b + 1) * B)
+            got = T.block_digests(om.sample_nodes(dom, res, b * B, e), B)
+            np.testing.assert_array_equal(got[0], gold[name + "_digest"][b])
+    # config 5 keys are present and sized for 10 M queries
+    nq = int(gold["c5_n_queries"])
+    for k in ("c5_uniform_phi", "c5_uniform_phi_g", "c5_uniform_grad", "c5_shell_points", "c5_shell_phi", "c5_shell_phi_g", "c5_shell_grad"):
+        assert len(gold[k]) == (nq + B - 1) // B
