@@ -538,6 +538,8 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	out.tri_pairs.resize(npos / 2);
 	for (auto& r : out.tri_pairs)
 		clear_rec(r);
+	out.tri_approx.resize(npos / 2);
+	std::memset(out.tri_approx.data(), 0, out.tri_approx.size() * sizeof(TriApproxPair)); // padding slots: valid = 0
 	double l1 = 0.0;
 	for (size_t i = 0; i < n_vertices; ++i)
 		l1 = std::max(l1, std::fabs(V[i].x - out.origin[0]) + std::fabs(V[i].y - out.origin[1]) +
@@ -560,6 +562,8 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 			make_packet(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], (int32_t)t,
 						out.tris[k]);
 			put_side(out.tri_pairs[k / 2], (int)(k & 1), bounds_of(&P, 1, out.origin));
+			make_tri_approx(verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2], out.origin,
+							out.tri_approx[k / 2], (int)(k & 1));
 			for (int s = 0; s < kPnSlots; ++s)
 			{
 				out.pn[(k * kPnSlots + s) * 3 + 0] = pn[t * kPnSlots + s].x;

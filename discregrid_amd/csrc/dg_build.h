@@ -19,6 +19,7 @@ struct MeshBuild
 	std::vector<PairRec> pairs;     // node pairs; an inner node's record holds its two children
 	std::vector<PairRec> tri_pairs; // triangle bound pairs: position t -> tri_pairs[t / 2], side t & 1
 	std::vector<TriPacket> tris;    // one per position (leaf order; padding slots have tri_id = -1)
+	std::vector<TriApproxPair> tri_approx; // float filter data of the triangles: position t -> tri_approx[t / 2], side t & 1
 	std::vector<double> pn;         // kPnSlots * 3 doubles per position
 	int32_t root_info = 0;          // info word of the root (dg_geom.h)
 	std::vector<int32_t> sub_roots; // info words of <= kSubtrees disjoint subtrees covering the tree (level-order cut)

@@ -195,11 +195,14 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	const size_t sb = B.tri_pairs.size() * sizeof(dg::PairRec);
 	const size_t tb = B.tris.size() * sizeof(dg::TriPacket);
 	const size_t pb = B.pn.size() * sizeof(double);
+	const size_t ab = B.tri_approx.size() * sizeof(dg::TriApproxPair);
 	hipError_t e = hipGetDevice(&m->device);
 	if (e == hipSuccess) e = hipMalloc(&m->d_pairs, std::max<size_t>(nb, 128));
 	if (e == hipSuccess) e = hipMalloc(&m->d_tri_pairs, sb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_tris, tb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_pn, pb);
+	if (e == hipSuccess) e = hipMalloc(&m->d_tri_approx, ab);
+	if (e == hipSuccess) e = hipMemcpy(m->d_tri_approx, B.tri_approx.data(), ab, hipMemcpyHostToDevice);
 	if (e == hipSuccess && nb) e = hipMemcpy(m->d_pairs, B.pairs.data(), nb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_tri_pairs, B.tri_pairs.data(), sb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_tris, B.tris.data(), tb, hipMemcpyHostToDevice);
@@ -213,6 +216,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->dev.pairs = static_cast<const dg::PairRec*>(m->d_pairs);
 	m->dev.tri_pairs = static_cast<const dg::PairRec*>(m->d_tri_pairs);
 	m->dev.tris = static_cast<const dg::TriPacket*>(m->d_tris);
+	m->dev.tri_approx = static_cast<const dg::TriApproxPair*>(m->d_tri_approx);
 	m->dev.pn = static_cast<const double*>(m->d_pn);
 	m->dev.root_info = B.root_info;
 	m->dev.n_positions = (int32_t)B.tris.size();
@@ -238,7 +242,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->info.n_bvh_nodes = 2 * B.pairs.size() + 1;
 	m->info.bvh_depth = B.depth;
 	m->info.not_watertight = B.not_watertight;
-	m->info.device_bytes = nb + tb + pb + sb;
+	m->info.device_bytes = nb + tb + pb + sb + ab;
 	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
 	m->host = std::move(B);
 	*out = m;
@@ -260,6 +264,7 @@ void dg_mesh_destroy(dg_mesh* m)
 	DeviceGuard guard(m->device);
 	if (m->d_pairs) (void)hipFree(m->d_pairs);
 	if (m->d_tri_pairs) (void)hipFree(m->d_tri_pairs);
+	if (m->d_tri_approx) (void)hipFree(m->d_tri_approx);
 	if (m->d_tris) (void)hipFree(m->d_tris);
 	if (m->d_pn) (void)hipFree(m->d_pn);
 	for (HeavyScratch& h : m->scratch)
@@ -314,30 +319,37 @@ extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, co
 extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
-	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
-	if (slots == 0 || mesh->dev.n_sub < 2)
+	uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
+	if (mesh->dev.n_sub < 2)
+		slots = 0; // a tree of one leaf cannot be split
+	// the filtered kernel (DG_K1_FAST=0: exact kernel only) needs a list with room for every brick of the launch
+	const bool fast = env_int("DG_K1_FAST", 0, 0, 1) != 0 && DG_OBB != 0 && P.total_bricks < 0xffffffffull;
+	const uint32_t redo_cap = fast ? (uint32_t)P.total_bricks : 0u;
+	if (slots == 0)
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		mesh->unsplit_serial = ++mesh->scratch_serial;
-		return -1;
+		if (!fast)
+			return -1;
 	}
 	int idx = -1;
 	char* base = nullptr;
-	uint32_t laid_out_slots = 0;
+	uint32_t laid_out_slots = 0, laid_out_redo = 0;
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		for (size_t i = 0; i < mesh->scratch.size() && idx < 0; ++i)
 		{
 			HeavyScratch& h = mesh->scratch[i];
-			if (!h.busy && h.slots >= slots && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
+			if (!h.busy && h.slots >= slots && h.redo_cap >= redo_cap && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
 				idx = (int)i;
 		}
 		if (idx < 0)
 		{
 			HeavyScratch h;
 			h.slots = slots;
-			size_t unused[6];
-			if (hipMalloc(&h.mem, dg::overflow_bytes(slots, unused)) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
+			h.redo_cap = redo_cap;
+			size_t unused[8];
+			if (hipMalloc(&h.mem, dg::overflow_bytes(slots, redo_cap, unused)) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
 			{
 				(void)hipGetLastError();
 				if (h.mem) (void)hipFree(h.mem);
@@ -348,22 +360,33 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		}
 		mesh->scratch[(size_t)idx].busy = true;
 		mesh->scratch[(size_t)idx].stream = stream;
-		mesh->scratch[(size_t)idx].serial = ++mesh->scratch_serial;
+		mesh->scratch[(size_t)idx].serial = slots ? ++mesh->scratch_serial : mesh->scratch[(size_t)idx].serial;
 		mesh->scratch[(size_t)idx].used_slots = slots;
 		base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
 		laid_out_slots = mesh->scratch[(size_t)idx].slots;
+		laid_out_redo = mesh->scratch[(size_t)idx].redo_cap;
 	}
-	size_t off[6];
-	dg::overflow_bytes(laid_out_slots, off); // the layout the buffer was allocated with
-	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
-	P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
-	P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
-	P.ovf.saved_tri = reinterpret_cast<int32_t*>(base + off[3]);
-	P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
-	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
-	P.ovf.slots = slots;
-	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
-	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
+	size_t off[8];
+	dg::overflow_bytes(laid_out_slots, laid_out_redo, off); // the layout the buffer was allocated with
+	uint32_t* counters = reinterpret_cast<uint32_t*>(base + off[0]);
+	if (slots)
+	{
+		P.ovf.count = counters;
+		P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
+		P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
+		P.ovf.saved_tri = reinterpret_cast<int32_t*>(base + off[3]);
+		P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
+		P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
+		P.ovf.slots = slots;
+		P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
+	}
+	if (fast)
+	{
+		P.ovf.redo_count = counters + 1;
+		P.ovf.redo = reinterpret_cast<uint32_t*>(base + off[6]);
+		P.ovf.redo_cap = redo_cap;
+	}
+	if (hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), stream) != hipSuccess)
 	{
 		(void)hipGetLastError();
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);

@@ -426,6 +426,231 @@ DG_HD float best_as_float(double d2)
 	return b * 1.0000019073486328125f; // * (1 + 2^-19)
 }
 
+// ---- float filter for the point/triangle test --------------------------------------------------------------
+// The traversal needs, per lane, only (a) an UPPER bound of its minimum squared distance to prune
+// with and (b) the set of triangles that can attain the minimum.  Both follow from an evaluation of
+// the point/triangle distance in float whose error is bounded rigorously: the exact double test with
+// the reference's operation order (tri_closest) then runs only on each lane's own short list of
+// candidates, once, after the traversal -- instead of on every triangle any lane of the wave is
+// interested in.
+//
+// Formulation (chosen for its error analysis, not for minimal arithmetic): the triangle carries an
+// orthonormal frame (u along v0->v1, w in the plane towards v2, n the normal).  With d = p - v0:
+// x = u.d, y = w.d, h = n.d, and dist^2 = h^2 + r^2 with r the distance of (x, y) to the 2-D
+// triangle A = (0,0), B = (l0,0), C: r = 0 inside, otherwise the minimum over the three sides of the
+// point/segment distance sqrt(perp_i^2 + excess_i^2) (perp_i: signed distance to the side's line,
+// positive inside; excess_i: how far the foot of the perpendicular lies beyond the segment's ends).
+//
+// Error bound.  eps = 2^-24.  Inputs: p - origin and v0 - origin rounded to float (componentwise
+// relative eps); the frame vectors, side directions and lengths rounded to float.  With
+// R = |p - origin|_1 + mesh_l1 (>= |p-origin|_inf + |v0-origin|_inf, >= |d|_inf, >= l/2):
+//   * each of x, y, h carries an absolute error <= 11 eps R (input rounding 2 sqrt(3) eps R, frame
+//     rounding and the three roundings of the dot product 4 eps |d|_2 <= 4 sqrt(3) eps R);
+//   * every side's segment distance is 1-Lipschitz in the point and in its end points, its float
+//     evaluation adds <= 5 eps l + 3 eps |X|: absolute error of r <= 29 eps R; the clamped parameter
+//     need not be accurate (any parameter in [0,1] yields a point of the segment; an error du costs
+//     3 l^2 du^2, second order);
+//   * the inside/outside decision uses the margin em >= 23 eps R on min(perp_i): "strictly inside"
+//     (r taken as 0 for the UPPER value) only if every perp_i >= em, "possibly inside" (r taken as 0
+//     for the LOWER value) if every perp_i >= -em.  A needle-shaped triangle, where a point beyond the
+//     sharp corner is within em of two side lines, therefore gets a valid (if loose) pair of values.
+// Hence |dist_float - dist| <= sqrt(29^2 + 11^2) eps R < E := 2^-19 R, and in squares
+//   dist^2 in [dL2 - err(dL2), dU2 + err(dU2)],  err(q) = 2 sqrt(q) E + E^2 + 8 eps q.
+// sqrt is avoided by 2 sqrt(q) E <= q E / d0 + E d0 for ANY d0 > 0 (tight at q = d0^2): the caller
+// passes theta = E / d0 + 2^-20 and kappa = E d0 + E^2 (+ an absolute floor against float
+// underflow), with d0 the lane's current estimate of its distance.  The double value the reference
+// computes differs from the true dist^2 by ~1e-15 |p - v0|^2 <= 4e-15 R^2 << E^2 = 3.6e-12 R^2, so the
+// interval also contains the reference's value: the triangle whose DOUBLE d^2 is smallest is never lost.
+//
+// Degenerate triangles (zero-length side, area below 1e-7 of the longest side squared, non-finite
+// data) get big = +inf: lower value -inf, upper value +inf -- always a candidate, never a bound.
+struct alignas(64) TriApproxPair
+{
+	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 1/l0; 14,15 direction of side B->C;
+	// 16 l1; 17 1/l1; 18,19 direction of side A->C; 20 l2; 21 1/l2; 22 big: 0, or +inf for a degenerate triangle (all else 0)
+	float f[23][2];
+	int32_t valid[2]; // 0: padding slot of an odd leaf (never tested)
+};
+static_assert(sizeof(TriApproxPair) == 192, "TriApproxPair must be 192 bytes");
+static const int kApproxFloats = 46;
+
+// host: fill one side of a record from the triangle's vertices (double, absolute coordinates)
+inline void make_tri_approx(const double v0[3], const double v1[3], const double v2[3], const double origin[3],
+							TriApproxPair& rec, int side)
+{
+	float* f = &rec.f[0][0];
+	auto put = [&](int k, double v) { f[2 * k + side] = (float)v; };
+	for (int k = 0; k < 23; ++k)
+		put(k, 0.0);
+	rec.valid[side] = 1;
+	double e0[3], e1[3], e2[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		e0[d] = v1[d] - v0[d];
+		e1[d] = v2[d] - v0[d];
+		e2[d] = v2[d] - v1[d];
+	}
+	const double n[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+	const double l0 = __builtin_sqrt(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2]);
+	const double l2 = __builtin_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+	const double l1 = __builtin_sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+	const double area2 = __builtin_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+	const double lmax = l0 > l1 ? (l0 > l2 ? l0 : l2) : (l1 > l2 ? l1 : l2);
+	const double lmin = l0 < l1 ? (l0 < l2 ? l0 : l2) : (l1 < l2 ? l1 : l2);
+	bool ok = lmin > 1.0e-15 && lmax < 1.0e15 && area2 > 1.0e-7 * lmax * lmax; // (false for NaN)
+	for (int d = 0; d < 3; ++d)
+		ok = ok && __builtin_fabs(v0[d] - origin[d]) < 1.0e15;
+	if (!ok)
+	{
+		put(22, __builtin_inf()); // degenerate: every lane keeps it as a candidate, it never bounds anything
+		return;
+	}
+	double u[3], w[3], nn[3];
+	for (int d = 0; d < 3; ++d)
+	{
+		u[d] = e0[d] / l0;
+		nn[d] = n[d] / area2;
+	}
+	w[0] = nn[1] * u[2] - nn[2] * u[1];
+	w[1] = nn[2] * u[0] - nn[0] * u[2];
+	w[2] = nn[0] * u[1] - nn[1] * u[0];
+	const double cx = e1[0] * u[0] + e1[1] * u[1] + e1[2] * u[2];
+	const double cy = e1[0] * w[0] + e1[1] * w[1] + e1[2] * w[2]; // > 0
+	for (int d = 0; d < 3; ++d)
+	{
+		put(d, v0[d] - origin[d]);
+		put(3 + d, u[d]);
+		put(6 + d, w[d]);
+		put(9 + d, nn[d]);
+	}
+	put(12, l0);
+	put(13, 1.0 / l0);
+	put(14, (cx - l0) / l1);
+	put(15, cy / l1);
+	put(16, l1);
+	put(17, 1.0 / l1);
+	put(18, cx / l2);
+	put(19, cy / l2);
+	put(20, l2);
+	put(21, 1.0 / l2);
+}
+
+// per-lane constants of the filter
+struct ApproxLane
+{
+	float x[3]; // p - origin, rounded
+	float E;    // 2^-19 (|p - origin|_1 + mesh_l1): bound of |dist_float - dist|; +inf => the lane cannot use the filter
+};
+DG_HD ApproxLane make_approx_lane(double rx, double ry, double rz, float mesh_l1)
+{
+	ApproxLane a;
+	a.x[0] = (float)rx;
+	a.x[1] = (float)ry;
+	a.x[2] = (float)rz;
+	const float s = (__builtin_fabsf(a.x[0]) + __builtin_fabsf(a.x[1])) + __builtin_fabsf(a.x[2]) + mesh_l1;
+	// 2^-19 s, rounded up a little; coordinates beyond 1e15 (or NaN) leave the range in which the
+	// squares stay finite floats
+	a.E = (s < 1.0e15f) ? s * 1.9073505e-06f + 1.0e-30f : __builtin_inff();
+	return a;
+}
+// err(q) = q theta + kappa for a lane whose distance is about d0 (any d0 > 0 is valid, d0 = the lane's
+// distance is tight): the float filter's value q of a triangle brackets dist^2 as [q - err(q), q + err(q)].
+// kappa carries 5 E^2 instead of E^2: 4 E^2 for points within the margin of a side (see tri_approx_pair).
+// The same two numbers turn an upper bound U of dist^2 into the threshold the BOUND tests of the traversal
+// may prune with, U (1 + theta) + kappa >= (sqrt(U) + sqrt(3) es)^2 (1 + 2^-19): es <= E / 2 is the error of
+// one slab projection (FPoint::es), which the fast bound test leaves out of its three slabs, and 2^-19
+// covers the float rounding of the bound's own arithmetic.
+DG_HD void approx_err_terms(float E, float d0, float inv_d0 /* ~ 1 / d0, 1 ulp */, float* theta, float* kappa)
+{
+	*theta = (E * inv_d0) * 1.001f + 3.814697265625e-06f; // + 2^-18
+	*kappa = (E * d0 + 5.0f * (E * E)) * 1.001f + 1.0e-30f;
+}
+// d0 for approx_err_terms from a squared distance estimate: clamped to [E, 1e18] (also for NaN / negative input)
+DG_HD float approx_d0(float E, float d0sq)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	float d0 = __builtin_amdgcn_sqrtf(d0sq); // v_sqrt_f32, 1 ulp: any d0 > 0 is valid
+#else
+	float d0 = __builtin_sqrtf(d0sq);
+#endif
+	d0 = (d0 > E) ? d0 : E;
+	return (d0 < 1.0e18f) ? d0 : 1.0e18f;
+}
+DG_HD float fmin2(float a, float b) { return __builtin_fminf(a, b); }
+DG_HD float fmin_sel(float a, float b) { return b < a ? b : a; } // a if b is NaN
+DG_HD float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+#if defined(__HIP_DEVICE_COMPILE__)
+DG_HD float sat01(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 1.0f); }
+DG_HD float fmed3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); } // lo <= hi, no NaN
+#else
+DG_HD float sat01(float a) { return __builtin_fminf(__builtin_fmaxf(a, 0.0f), 1.0f); }
+DG_HD float fmed3(float a, float lo, float hi) { return __builtin_fmaxf(__builtin_fminf(a, hi), lo); }
+#endif
+DG_HD f2 f2_sat01(f2 a) { return f2_make(sat01(a.x), sat01(a.y)); }
+DG_HD f2 f2_neg(f2 a) { return f2_make(-a.x, -a.y); }
+// Both triangles of a record for one lane: the float value q of dist^2 (BEFORE the error terms; the
+// caller forms q -+ err(q)).  A point counts as inside (r = 0) only if it is inside by the margin
+// p.E >= 23 eps R; a point that is inside by less gets the distance to the nearest side, which is then
+// below 2 E: an upper value all the same, and as a lower value too high by at most 4 E^2 (in kappa).
+DG_HD f2 tri_approx_pair(const float* r, const ApproxLane& p)
+{
+#define DG_R(k) f2_make(r[2 * (k)], r[2 * (k) + 1])
+	const f2 dx = f2_splat(p.x[0]) - DG_R(0);
+	const f2 dy = f2_splat(p.x[1]) - DG_R(1);
+	const f2 dz = f2_splat(p.x[2]) - DG_R(2);
+	const f2 x = f2_fma(DG_R(3), dx, f2_fma(DG_R(4), dy, DG_R(5) * dz));
+	const f2 y = f2_fma(DG_R(6), dx, f2_fma(DG_R(7), dy, DG_R(8) * dz));
+	const f2 h = f2_fma(DG_R(9), dx, f2_fma(DG_R(10), dy, DG_R(11) * dz));
+	// side A->B: along = x, perp = y
+	const f2 l0 = DG_R(12);
+	const f2 uc0 = f2_make(sat01(x.x * r[26]), sat01(x.y * r[27]));
+	const f2 ex0 = f2_fma(uc0, f2_neg(l0), x);
+	const f2 t0 = f2_fma(ex0, ex0, y * y);
+	// side B->C: relative to B; interior on the left
+	const f2 xm = x - l0;
+	const f2 t1x = DG_R(14), t1y = DG_R(15), l1 = DG_R(16);
+	const f2 al1 = f2_fma(t1x, xm, t1y * y);
+	const f2 pp1 = f2_fma(t1x, y, f2_neg(t1y * xm));
+	const f2 uc1 = f2_make(sat01(al1.x * r[34]), sat01(al1.y * r[35]));
+	const f2 ex1 = f2_fma(uc1, f2_neg(l1), al1);
+	const f2 t1 = f2_fma(ex1, ex1, pp1 * pp1);
+	// side A->C: relative to A; interior on the right
+	const f2 t2x = DG_R(18), t2y = DG_R(19), l2 = DG_R(20);
+	const f2 al2 = f2_fma(t2x, x, t2y * y);
+	const f2 pp2 = f2_fma(t2y, x, f2_neg(t2x * y));
+	const f2 uc2 = f2_make(sat01(al2.x * r[42]), sat01(al2.y * r[43]));
+	const f2 ex2 = f2_fma(uc2, f2_neg(l2), al2);
+	const f2 t2 = f2_fma(ex2, ex2, pp2 * pp2);
+#undef DG_R
+	const float m0 = fmin3(y.x, pp1.x, pp2.x), m1 = fmin3(y.y, pp1.y, pp2.y);
+	const float tm0 = fmin3(t0.x, t1.x, t2.x), tm1 = fmin3(t0.y, t1.y, t2.y);
+	return f2_fma(h, h, f2_make(m0 >= p.E ? 0.0f : tm0, m1 >= p.E ? 0.0f : tm1));
+}
+
+#if DG_OBB
+// The bound test of the filtered traversal: pair_lb2 without the per-slab error term (the caller's
+// threshold carries it, approx_err_terms) and with the slab excess as t - median(t, -half, half).
+// Node pairs only (no empty sides: an inner node has two children).
+DG_HD f2 pair_lb2_fast(const float* r, const float* x)
+{
+	const f2 dx = f2_splat(x[0]) - f2_make(r[0], r[1]);
+	const f2 dy = f2_splat(x[1]) - f2_make(r[2], r[3]);
+	const f2 dz = f2_splat(x[2]) - f2_make(r[4], r[5]);
+	f2 acc = f2_splat(0.0f);
+	for (int a = 0; a < 3; ++a)
+	{
+		const float* q = r + 6 + 6 * a;
+		f2 t = f2_make(q[4], q[5]) * dz;
+		t = f2_fma(f2_make(q[2], q[3]), dy, t);
+		t = f2_fma(f2_make(q[0], q[1]), dx, t);
+		const float h0 = r[24 + 2 * a], h1 = r[25 + 2 * a];
+		const f2 e = t - f2_make(fmed3(t.x, -h0, h0), fmed3(t.y, -h1, h1));
+		acc = f2_fma(e, e, acc);
+	}
+	return acc;
+}
+#endif
+
 // ---- per-lane query state and epilogue ------------------------------------------------------------------
 struct LaneQuery
 {
@@ -453,7 +678,7 @@ DG_HD void offer(LaneQuery& q, double d2, int packet_index)
 	{
 		q.best_d2 = d2;
 		q.best_tri = packet_index;
-		q.bestf = best_as_float(d2);
+		q.bestf = fmin2(q.bestf, best_as_float(d2)); // (min: bestf may have been seeded with a tighter upper bound)
 	}
 }
 

@@ -335,6 +335,28 @@ __device__ __forceinline__ void write_result(const SampleParams& P, const LaneTa
 // ------------------------------------------------------------------------------------------------
 // K1 / K1p: one wave per 4x4x4 brick of one node class, or per 64 points.
 // ------------------------------------------------------------------------------------------------
+// the exact traversal of one brick by one wave (double test on every triangle some lane may need)
+template <bool POINTS>
+__device__ __forceinline__ void sample_brick_exact(const SampleParams& P, uint64_t brick, int lane, float* lds_lb)
+{
+	const LaneTask t = lane_task<POINTS>(P, brick, lane);
+	LaneQuery q;
+	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	if (__ballot(t.sample) != 0ull)
+	{
+		const int slot = traverse(P.mesh, q, lds_lb, P.mesh.root_info, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		if (slot >= 0) // heavy brick: park the running bests, k_heavy_subtrees / k_heavy_finish take over
+		{
+			if (lane == 0)
+				P.ovf.brick[slot] = (uint32_t)brick;
+			P.ovf.saved_d2[slot * 64 + lane] = q.best_d2;
+			P.ovf.saved_tri[slot * 64 + lane] = q.best_tri;
+			return;
+		}
+	}
+	write_result<POINTS>(P, t, q);
+}
+
 template <bool POINTS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample_nodes(const SampleParams P)
 {
@@ -346,22 +368,231 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 	const uint64_t brick = (uint64_t)blk * (uint64_t)kWavesPerBlock + (uint64_t)wave;
 	if (brick >= P.total_bricks)
 		return;
-	const LaneTask t = lane_task<POINTS>(P, brick, lane);
-
 	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [waves][stack_levels][64]
-	LaneQuery q;
-	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
-	if (__ballot(t.sample) != 0ull)
+	sample_brick_exact<POINTS>(P, brick, lane, lds_lb + wave * (P.mesh.stack_levels * 64));
+}
+
+// the exact kernel over the bricks the filtered kernel handed back (their number is only known on the device)
+template <bool POINTS>
+__global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_redo(const SampleParams P)
+{
+	const uint32_t n = min(*P.ovf.redo_count, P.ovf.redo_cap);
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[];
+	for (uint32_t i = blockIdx.x; i < n; i += gridDim.x)
+		sample_brick_exact<POINTS>(P, (uint64_t)P.ovf.redo[i], (int)threadIdx.x, lds_lb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 / K1p, filtered: the same packet traversal, but a visited leaf's triangles go through the FLOAT
+// filter (dg_geom.h: tri_approx_pair, two triangles per record with packed math) instead of a bound
+// test plus the double test.  Every lane keeps an upper bound U of its minimum d^2 (what the traversal
+// prunes with) and, in LDS, the list of triangles whose interval [q - err, q + err] reaches below U:
+// the only ones that can attain the lane's minimum.  After the traversal each lane runs the double
+// test on ITS OWN candidates (typically 1-2, six around a mesh vertex) -- instead of the whole wave
+// running it on every triangle any of its lanes was interested in (29 of 36 per brick improved some
+// lane, hardly ever more than a few lanes each).  Bit-exactness: the triangle with the smallest double
+// d^2 is always among the lane's candidates (error analysis in dg_geom.h), and the winner among the
+// candidates is found with the double test in list order (strict <), as before.
+// A wave hands its brick back to the exact kernel (k_sample_redo) if a lane fills its list or lies
+// outside the filter's range, and parks it as a heavy brick when the work budget runs out.
+// ------------------------------------------------------------------------------------------------
+struct FastLane
+{
+	ApproxLane a;
+	float U;      // upper bound of the lane's minimum d^2; -inf: lane inactive
+	float Uprune; // what bound tests compare with: U (1 + theta) + kappa
+	float Lmin;   // smallest lower value among the listed candidates
+	int cnt;      // listed candidates (<= kFastListCap; == kFastListCap: the list may have overflowed)
+};
+// returns -1 (searched to the end) or the heavy slot the wave claimed
+__device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, float* lds_lb, int* lds_list, uint32_t* ovf_count,
+											 uint32_t ovf_slots, int heavy_work)
+{
+	const int lane_id = (int)__lane_id();
+	int stackv = 0;
+	int sp = 0;
+	int cur = M.root_info;
+	float lbcur = 0.0f;
+	int work = 0;
+	int budget = ovf_count ? heavy_work : 0x7fffffff;
+	while (true)
 	{
-		const int slot = traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64), P.mesh.root_info,
-								  P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
-		if (slot >= 0) // heavy brick: park the running bests, k_heavy_subtrees / k_heavy_finish take over
+		if (work > budget)
+		{
+			int slot = 0;
+			if (lane_id == 0)
+				slot = (int)atomicAdd(ovf_count, 1u);
+			slot = uniform(slot);
+			if ((unsigned)slot < ovf_slots)
+				return slot;
+			budget = 0x7fffffff;
+		}
+		++work;
+		if (cur < 0)
+		{
+			const unsigned code = ~(unsigned)cur;
+			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
+			// error terms for this leaf's triangles around the lane's current distance estimate (its upper
+			// bound, or the leaf's own bound while no triangle has been seen); they are valid for any estimate
+			float theta, kappa;
+			{
+				const float d0 = approx_d0(f.a.E, f.U < __builtin_inff() ? f.U : lbcur);
+				approx_err_terms(f.a.E, d0, __builtin_amdgcn_rcpf(d0), &theta, &kappa);
+			}
+			for (int g = 0; g < cnt; g += 2)
+			{
+				const char* base = (const char*)(M.tri_approx + ((first + g) >> 1));
+				const v16i a = sload16(base);
+				const v16i b = sload16(base + 64);
+				const v16i c = sload16(base + 128);
+				float r[kApproxFloats];
+#pragma unroll
+				for (int i = 0; i < 16; ++i)
+				{
+					r[i] = __int_as_float(a[i]);
+					r[16 + i] = __int_as_float(b[i]);
+				}
+#pragma unroll
+				for (int i = 0; i < kApproxFloats - 32; ++i)
+					r[32 + i] = __int_as_float(c[i]);
+				const int valid0 = c[14], valid1 = c[15]; // 0: padding slot of an odd leaf
+				const f2 q = tri_approx_pair(r, f.a);
+				const f2 err = f2_fma(q, f2_splat(theta), f2_splat(kappa)) + f2_make(r[44], r[45]); // + big (0, or +inf for a degenerate triangle)
+				const f2 up = q + err, lo = q - err;
+				++work;
+#pragma unroll
+				for (int side = 0; side < 2; ++side)
+				{
+					if ((side == 0 ? valid0 : valid1) == 0) // wave-uniform
+						continue;
+					// (a degenerate triangle has lo = -inf, up = +inf: always a candidate, bounds nothing)
+					const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
+					if (lo_s <= f.U)
+					{
+						// a candidate; if even its upper value is below every listed lower value, the list is obsolete
+						const bool reset = up_s < f.Lmin;
+						f.cnt = reset ? 0 : f.cnt;
+						lds_list[f.cnt * 64 + lane_id] = first + g + side;
+						f.cnt = min(f.cnt + 1, kFastListCap);
+						f.Lmin = fmin_sel(reset ? __builtin_inff() : f.Lmin, lo_s);
+					}
+					f.U = fmin_sel(f.U, up_s);
+				}
+			}
+			// the threshold the bound tests compare with (dg_geom.h: approx_err_terms)
+			f.Uprune = __builtin_fmaf(f.U, 1.0f + theta, kappa);
+		}
+		else
+		{
+			const SPair pr = load_pair(M.pairs, cur);
+			const f2 lb = pair_lb2_fast(pr.r, f.a.x);
+			const bool hl = lb.x <= f.Uprune, hr = lb.y <= f.Uprune;
+			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
+			if ((bl | br) != 0ull)
+			{
+				bool left = bl != 0ull;
+				if (bl != 0ull && br != 0ull)
+				{
+					const unsigned long long pref = __ballot(lb.x <= lb.y) & (bl | br);
+					left = 2 * __popcll(pref) >= __popcll(bl | br);
+					if (sp < M.stack_levels)
+					{
+						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
+						lds_lb[sp * 64 + lane_id] = left ? lb.y : lb.x;
+						++sp;
+					}
+				}
+				cur = left ? pr.info0 : pr.info1;
+				lbcur = left ? lb.x : lb.y;
+				continue;
+			}
+		}
+		bool found = false;
+		while (sp > 0)
+		{
+			--sp;
+			lbcur = lds_lb[sp * 64 + lane_id];
+			if (__ballot(lbcur <= f.Uprune) != 0ull)
+			{
+				cur = __builtin_amdgcn_readlane(stackv, sp);
+				found = true;
+				break;
+			}
+		}
+		if (!found)
+			break;
+	}
+	return -1;
+}
+
+__device__ __forceinline__ void push_redo(const SampleParams& P, uint64_t brick, int lane)
+{
+	if (lane == 0)
+	{
+		const uint32_t at = atomicAdd(P.ovf.redo_count, 1u);
+		if (at < P.ovf.redo_cap) // always: the list has room for every brick of the launch
+			P.ovf.redo[at] = (uint32_t)brick;
+	}
+}
+
+template <bool POINTS>
+__global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const SampleParams P)
+{
+	uint32_t blk;
+	if (!logical_block(P, blockIdx.x, &blk))
+		return;
+	const int lane = (int)threadIdx.x;
+	const uint64_t brick = (uint64_t)blk;
+	if (brick >= P.total_bricks)
+		return;
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [stack_levels][64] bounds, then [kFastListCap + 1][64] candidates
+	int* lds_list = (int*)(lds_lb + P.mesh.stack_levels * 64);
+	FastLane f;
+	bool sample;
+	{
+		const LaneTask t = lane_task<POINTS>(P, brick, lane);
+		sample = t.sample;
+		f.a = make_approx_lane(t.x0 - P.mesh.origin[0], t.x1 - P.mesh.origin[1], t.x2 - P.mesh.origin[2], P.mesh.mesh_l1);
+	}
+	if (__ballot(sample && !(f.a.E < __builtin_inff())) != 0ull) // a lane outside the filter's range (or NaN)
+	{
+		push_redo(P, brick, lane);
+		return;
+	}
+	f.U = sample ? __builtin_inff() : -__builtin_inff();
+	f.Uprune = f.U;
+	f.Lmin = __builtin_inff();
+	f.cnt = 0;
+	if (__ballot(sample) != 0ull)
+	{
+		const int slot = traverse_fast(P.mesh, f, lds_lb, lds_list, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		if (slot >= 0) // heavy brick: park the lanes' upper bounds as seeds, k_heavy_subtrees / k_heavy_finish take over
 		{
 			if (lane == 0)
 				P.ovf.brick[slot] = (uint32_t)brick;
-			P.ovf.saved_d2[slot * 64 + lane] = q.best_d2;
-			P.ovf.saved_tri[slot * 64 + lane] = q.best_tri;
+			P.ovf.saved_d2[slot * 64 + lane] = (double)f.U;
+			P.ovf.saved_tri[slot * 64 + lane] = kSeedOnly;
 			return;
+		}
+		if (__ballot(sample && f.cnt >= kFastListCap) != 0ull)
+		{
+			push_redo(P, brick, lane);
+			return;
+		}
+	}
+	if (!sample)
+		f.cnt = 0;
+	// each lane: the double test on its own candidates, in list (= traversal) order
+	const LaneTask t = lane_task<POINTS>(P, brick, lane);
+	LaneQuery q;
+	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	for (int k = 0; __ballot(k < f.cnt) != 0ull; ++k)
+	{
+		if (k < f.cnt)
+		{
+			const int tri = lds_list[k * 64 + lane];
+			const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
+			offer(q, h.d2, tri);
 		}
 	}
 	write_result<POINTS>(P, t, q);
@@ -387,6 +618,8 @@ __global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
 		const int tri = P.ovf.saved_tri[slot * 64 + lane];
 		if (t.sample && tri >= 0)
 			offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
+		else if (t.sample && tri == kSeedOnly) // parked by the filtered kernel: an upper bound, no triangle yet
+			q.bestf = fmin2(q.bestf, best_as_float(P.ovf.saved_d2[slot * 64 + lane]));
 		traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
 		const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
 		P.ovf.cand_d2[at] = q.best_d2;
@@ -893,7 +1126,16 @@ static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 		return hipSuccess;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
 	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
-	hipLaunchKernelGGL(k_sample_nodes<POINTS>, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
+	if (p.ovf.redo_count != nullptr)
+	{
+		static_assert(kWavesPerBlock == 1, "k_sample_fast assumes one brick per block");
+		const size_t lds_fast = (size_t)(p.mesh.stack_levels + kFastListCap + 1) * 64 * sizeof(float);
+		hipLaunchKernelGGL(k_sample_fast<POINTS>, dim3(grid), dim3(64), lds_fast, stream, p);
+		const uint32_t redo_blocks = (uint32_t)std::min<uint64_t>(p.total_bricks, 8192);
+		hipLaunchKernelGGL(k_sample_redo<POINTS>, dim3(redo_blocks), dim3(64), (size_t)p.mesh.stack_levels * 64 * sizeof(float), stream, p);
+	}
+	else
+		hipLaunchKernelGGL(k_sample_nodes<POINTS>, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);
 	if (p.ovf.count != nullptr)
 	{
 		const size_t lds1 = (size_t)p.mesh.stack_levels * 64 * sizeof(float);

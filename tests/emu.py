@@ -194,6 +194,22 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     return (phi, g) if grad else phi
 
 
+def set_fast(on=1):
+    """Filtered K1 kernel (float filter + per-lane candidate lists) in the emulated launches; 0 = exact kernel
+    only (DG_K1_FAST=0).  Resets the counters of fast_stats()."""
+    lib().emu_set_fast(int(on))
+
+
+def fast_stats():
+    st = np.zeros(28, dtype=np.uint64)
+    lib().emu_fast_stats(st.ctypes.data_as(T.c_u64p))
+    names = ("bricks", "pair_steps", "leaf_visits", "tri_pairs", "appends", "resets", "redo_bricks", "sum_max_list",
+             "sum_list", "lanes", "parked")
+    d = dict(zip(names, st[:11].tolist()))
+    d["hist"] = st[11:].tolist()
+    return d
+
+
 def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
     slots = 0 disables the split; the defaults size slots and budget as the product does."""

@@ -183,6 +183,163 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 	return -1;
 }
 
+
+// ---- filtered traversal: mirrors traverse_fast() / k_sample_fast of dg_kernels.hip ----------------------
+struct FastStats
+{
+	uint64_t bricks = 0, pair_steps = 0, leaf_visits = 0, tri_pairs = 0, appends = 0, resets = 0, redo_bricks = 0,
+			 sum_max_list = 0, sum_list = 0, lanes = 0, parked = 0, hist[17] = {0};
+	void add(const FastStats& o)
+	{
+		bricks += o.bricks; pair_steps += o.pair_steps; leaf_visits += o.leaf_visits; tri_pairs += o.tri_pairs;
+		appends += o.appends; resets += o.resets; redo_bricks += o.redo_bricks; sum_max_list += o.sum_max_list;
+		sum_list += o.sum_list; lanes += o.lanes; parked += o.parked;
+		for (int k = 0; k < 17; ++k) hist[k] += o.hist[k];
+	}
+};
+int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_K1_FAST=0)
+FastStats g_fs;
+
+struct FastLane
+{
+	ApproxLane a;
+	float U, Uprune, Lmin;
+	int cnt;
+	int list[kFastListCap + 1];
+};
+int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowBuf* ovf)
+{
+	int stack_info[kStackDepth];
+	static thread_local float stack_lb[kStackDepth][64];
+	int sp = 0;
+	int cur = M.root_info;
+	float lbcur[64];
+	for (int k = 0; k < 64; ++k)
+		lbcur[k] = 0.0f;
+	int work = 0;
+	int budget = (ovf && ovf->count) ? ovf->heavy_work : 0x7fffffff;
+	while (true)
+	{
+		if (work > budget)
+		{
+			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
+			if (slot < ovf->slots)
+				return (int)slot;
+			budget = 0x7fffffff;
+		}
+		++work;
+		bool descended = false;
+		if (cur < 0)
+		{
+			st.leaf_visits++;
+			const unsigned code = ~(unsigned)cur;
+			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
+			float theta[64], kappa[64];
+			for (int l = 0; l < 64; ++l)
+			{
+				const float d0 = approx_d0(fl[l].a.E, fl[l].U < __builtin_inff() ? fl[l].U : lbcur[l]);
+				approx_err_terms(fl[l].a.E, d0, 1.0f / d0, &theta[l], &kappa[l]);
+			}
+			for (int g = 0; g < cnt; g += 2)
+			{
+				const TriApproxPair& rec = M.tri_approx[(first + g) >> 1];
+				const float* r = &rec.f[0][0];
+				st.tri_pairs++;
+				++work;
+				for (int l = 0; l < 64; ++l)
+				{
+					FastLane& f = fl[l];
+					const f2 q = tri_approx_pair(r, f.a);
+					const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l])) + f2_make(r[44], r[45]);
+					const f2 up = q + err, lo = q - err;
+					for (int side = 0; side < 2; ++side)
+					{
+						if (rec.valid[side] == 0)
+							continue;
+						const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
+						if (lo_s <= f.U)
+						{
+							const bool reset = up_s < f.Lmin;
+							st.resets += reset && f.cnt > 0;
+							f.cnt = reset ? 0 : f.cnt;
+							f.list[f.cnt] = first + g + side;
+							f.cnt = f.cnt + 1 < kFastListCap ? f.cnt + 1 : kFastListCap;
+							f.Lmin = fmin_sel(reset ? __builtin_inff() : f.Lmin, lo_s);
+							st.appends++;
+						}
+						f.U = fmin_sel(f.U, up_s);
+					}
+				}
+			}
+			for (int l = 0; l < 64; ++l)
+				fl[l].Uprune = __builtin_fmaf(fl[l].U, 1.0f + theta[l], kappa[l]);
+		}
+		else
+		{
+			const PairRec& pr = M.pairs[cur];
+			st.pair_steps++;
+			float lbl[64], lbr[64];
+			bool anyl = false, anyr = false;
+			int pref = 0, act = 0;
+			for (int k = 0; k < 64; ++k)
+			{
+				const f2 lb = pair_lb2_fast(&pr.f[0][0], fl[k].a.x);
+				lbl[k] = lb.x;
+				lbr[k] = lb.y;
+				const bool hl = lb.x <= fl[k].Uprune, hr = lb.y <= fl[k].Uprune;
+				anyl = anyl || hl;
+				anyr = anyr || hr;
+				if (hl || hr)
+				{
+					act++;
+					pref += (lb.x <= lb.y);
+				}
+			}
+			if (anyl || anyr)
+			{
+				bool left = anyl;
+				if (anyl && anyr)
+				{
+					left = 2 * pref >= act;
+					if (sp < M.stack_levels)
+					{
+						stack_info[sp] = left ? pr.info[1] : pr.info[0];
+						for (int k = 0; k < 64; ++k)
+							stack_lb[sp][k] = left ? lbr[k] : lbl[k];
+						++sp;
+					}
+				}
+				cur = left ? pr.info[0] : pr.info[1];
+				for (int k = 0; k < 64; ++k)
+					lbcur[k] = left ? lbl[k] : lbr[k];
+				descended = true;
+			}
+		}
+		if (descended)
+			continue;
+		bool found = false;
+		while (sp > 0)
+		{
+			--sp;
+			bool any = false;
+			for (int k = 0; k < 64; ++k)
+			{
+				lbcur[k] = stack_lb[sp][k];
+				any = any || (lbcur[k] <= fl[k].Uprune);
+			}
+			if (any)
+			{
+				cur = stack_info[sp];
+				found = true;
+				break;
+			}
+		}
+		if (!found)
+			break;
+	}
+	return -1;
+}
+
 // heavy-brick settings of the emulated launches (defaults = the product's)
 const uint32_t kAutoSlots = 0xffffffffu; // slots chosen per launch as dg_capi.cpp does
 uint32_t g_heavy_slots = kAutoSlots;
@@ -210,6 +367,7 @@ void* emu_mesh_create(const double* verts, size_t nv, const uint32_t* tris, size
 	m->dev.pairs = m->B.pairs.data();
 	m->dev.tri_pairs = m->B.tri_pairs.data();
 	m->dev.tris = m->B.tris.data();
+	m->dev.tri_approx = m->B.tri_approx.data();
 	m->dev.pn = m->B.pn.data();
 	m->dev.mesh_l1 = m->B.mesh_l1;
 	m->dev.root_info = m->B.root_info;
@@ -228,6 +386,18 @@ void emu_set_heavy(uint32_t slots, int work)
 {
 	g_heavy_slots = slots == kAutoSlots ? kAutoSlots : (slots < (uint32_t)kOverflowSlots ? slots : (uint32_t)kOverflowSlots);
 	g_heavy_work = work;
+}
+void emu_set_fast(int on)
+{
+	g_fast = on;
+	g_fs = FastStats();
+}
+void emu_fast_stats(uint64_t* out /*28*/)
+{
+	out[0] = g_fs.bricks; out[1] = g_fs.pair_steps; out[2] = g_fs.leaf_visits; out[3] = g_fs.tri_pairs;
+	out[4] = g_fs.appends; out[5] = g_fs.resets; out[6] = g_fs.redo_bricks; out[7] = g_fs.sum_max_list;
+	out[8] = g_fs.sum_list; out[9] = g_fs.lanes; out[10] = g_fs.parked;
+	for (int k = 0; k < 17; ++k) out[11 + k] = g_fs.hist[k];
 }
 int emu_n_subtrees(void* h) { return static_cast<HostMesh*>(h)->dev.n_sub; }
 // number of triangles reachable from the subtree roots; -1 if a triangle is reachable twice
@@ -405,9 +575,9 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 	P.out = out;
 	Stats st;
 	int err = 0;
-	// heavy-brick scratch exactly as dg_capi.cpp attaches it
-	uint32_t ovf_count = 0;
-	std::unique_ptr<uint32_t[]> ovf_brick;
+	// heavy-brick scratch and redo list exactly as dg_capi.cpp attaches them
+	uint32_t ovf_count = 0, redo_count = 0;
+	std::unique_ptr<uint32_t[]> ovf_brick, redo_list;
 	std::unique_ptr<double[]> saved_d2, cand_d2; // uninitialised on purpose: only parked slots are ever touched
 	std::unique_ptr<int32_t[]> saved_tri, cand_tri;
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
@@ -427,6 +597,13 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		P.ovf.cand_tri = cand_tri.get();
 		P.ovf.slots = slots;
 		P.ovf.heavy_work = g_heavy_work > 0 ? g_heavy_work : heavy_work_for(P.mesh.n_positions);
+	}
+	if (g_fast && DG_OBB)
+	{
+		redo_list.reset(new uint32_t[P.total_bricks]);
+		P.ovf.redo_count = &redo_count;
+		P.ovf.redo = redo_list.get();
+		P.ovf.redo_cap = (uint32_t)P.total_bricks;
 	}
 	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
 		for (int l = 0; l < 64; ++l)
@@ -480,6 +657,73 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			const bool any = init_wave(brick, ln, sample, w);
 			ls.bricks++;
 			int slot = -1;
+			if (any && P.ovf.redo_count)
+			{
+				// k_sample_fast
+				FastLane fl[64];
+				FastStats fs;
+				fs.bricks = 1;
+				bool out_of_range = false;
+				for (int l = 0; l < 64; ++l)
+				{
+					fl[l].a = make_approx_lane(w.q[l].px - P.mesh.origin[0], w.q[l].py - P.mesh.origin[1],
+											   w.q[l].pz - P.mesh.origin[2], P.mesh.mesh_l1);
+					out_of_range = out_of_range || (sample[l] && !(fl[l].a.E < __builtin_inff()));
+					fl[l].U = sample[l] ? __builtin_inff() : -__builtin_inff();
+					fl[l].Uprune = fl[l].U;
+					fl[l].Lmin = __builtin_inff();
+					fl[l].cnt = 0;
+				}
+				bool redo = out_of_range;
+				if (!redo)
+				{
+					slot = traverse_fast(P.mesh, fl, fs, &P.ovf);
+					if (slot >= 0) // parked as a heavy brick with the upper bounds as seeds
+					{
+						fs.parked = 1;
+						P.ovf.brick[slot] = (uint32_t)brick;
+						for (int l = 0; l < 64; ++l)
+						{
+							P.ovf.saved_d2[slot * 64 + l] = (double)fl[l].U;
+							P.ovf.saved_tri[slot * 64 + l] = kSeedOnly;
+						}
+					}
+					else
+						for (int l = 0; l < 64; ++l)
+							redo = redo || (sample[l] && fl[l].cnt >= kFastListCap);
+				}
+				if (redo)
+				{
+					fs.redo_bricks = 1;
+					const uint32_t at = __atomic_fetch_add(P.ovf.redo_count, 1u, __ATOMIC_RELAXED);
+					if (at < P.ovf.redo_cap)
+						P.ovf.redo[at] = (uint32_t)brick;
+				}
+				else if (slot < 0)
+				{
+					int mx = 0;
+					for (int l = 0; l < 64; ++l)
+					{
+						if (!sample[l])
+							continue;
+						fs.lanes++;
+						fs.sum_list += fl[l].cnt;
+						fs.hist[fl[l].cnt]++;
+						mx = fl[l].cnt > mx ? fl[l].cnt : mx;
+						for (int k = 0; k < fl[l].cnt; ++k)
+						{
+							const int t = fl[l].list[k];
+							const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
+							offer(w.q[l], h.d2, t);
+						}
+					}
+					fs.sum_max_list += mx;
+					write_nodes(ln, sample, w);
+				}
+#pragma omp critical
+				g_fs.add(fs);
+				continue;
+			}
 			if (any)
 				slot = traverse(P.mesh, w, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
 			if (slot >= 0) // k_sample_nodes parks the wave
@@ -509,6 +753,29 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.stale_pops += ls.stale_pops;
 		}
 	}
+	// k_sample_redo: the exact traversal for the bricks the filtered kernel handed back
+	for (uint32_t i = 0; i < std::min(redo_count, P.ovf.redo_cap); ++i)
+	{
+		const uint64_t brick = P.ovf.redo[i];
+		Wave w;
+		LaneNode ln[64];
+		bool sample[64];
+		const bool any = init_wave(brick, ln, sample, w);
+		int slot = -1;
+		if (any)
+			slot = traverse(P.mesh, w, st, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
+		if (slot >= 0)
+		{
+			P.ovf.brick[slot] = (uint32_t)brick;
+			for (int l = 0; l < 64; ++l)
+			{
+				P.ovf.saved_d2[slot * 64 + l] = w.q[l].best_d2;
+				P.ovf.saved_tri[slot * 64 + l] = w.q[l].best_tri;
+			}
+			continue;
+		}
+		write_nodes(ln, sample, w);
+	}
 	// k_heavy_subtrees, k_heavy_finish
 	const uint32_t parked = P.ovf.count ? std::min(ovf_count, P.ovf.slots) : 0u;
 	st.heavy_bricks = parked;
@@ -521,8 +788,12 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			Wave w;
 			init_wave(P.ovf.brick[slot], ln, sample, w);
 			for (int l = 0; l < 64; ++l)
+			{
 				if (sample[l] && P.ovf.saved_tri[slot * 64 + l] >= 0)
 					offer(w.q[l], P.ovf.saved_d2[slot * 64 + l], P.ovf.saved_tri[slot * 64 + l]);
+				else if (sample[l] && P.ovf.saved_tri[slot * 64 + l] == kSeedOnly)
+					w.q[l].bestf = fmin2(w.q[l].bestf, best_as_float(P.ovf.saved_d2[slot * 64 + l]));
+			}
 			traverse(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
 			for (int l = 0; l < 64; ++l)
 			{
