@@ -319,37 +319,32 @@ extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, co
 extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
-	uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
-	if (mesh->dev.n_sub < 2)
-		slots = 0; // a tree of one leaf cannot be split
-	// the filtered kernel (DG_K1_FAST=0: exact kernel only) needs a list with room for every brick of the launch
-	const bool fast = env_int("DG_K1_FAST", 0, 0, 1) != 0 && DG_OBB != 0 && P.total_bricks < 0xffffffffull;
-	const uint32_t redo_cap = fast ? (uint32_t)P.total_bricks : 0u;
-	if (slots == 0)
+	// the filtered kernel (dg_kernels.hip: k_sample_fast) unless DG_K1_FAST=0 asks for the exact kernel only
+	P.filtered = (env_int("DG_K1_FAST", 1, 0, 1) != 0 && DG_OBB != 0) ? 1 : 0;
+	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
+	if (slots == 0 || mesh->dev.n_sub < 2)
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		mesh->unsplit_serial = ++mesh->scratch_serial;
-		if (!fast)
-			return -1;
+		return -1;
 	}
 	int idx = -1;
 	char* base = nullptr;
-	uint32_t laid_out_slots = 0, laid_out_redo = 0;
+	uint32_t laid_out_slots = 0;
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		for (size_t i = 0; i < mesh->scratch.size() && idx < 0; ++i)
 		{
 			HeavyScratch& h = mesh->scratch[i];
-			if (!h.busy && h.slots >= slots && h.redo_cap >= redo_cap && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
+			if (!h.busy && h.slots >= slots && (h.stream == stream || hipEventQuery(h.done) == hipSuccess))
 				idx = (int)i;
 		}
 		if (idx < 0)
 		{
 			HeavyScratch h;
 			h.slots = slots;
-			h.redo_cap = redo_cap;
-			size_t unused[8];
-			if (hipMalloc(&h.mem, dg::overflow_bytes(slots, redo_cap, unused)) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
+			size_t unused[6];
+			if (hipMalloc(&h.mem, dg::overflow_bytes(slots, unused)) != hipSuccess || hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess)
 			{
 				(void)hipGetLastError();
 				if (h.mem) (void)hipFree(h.mem);
@@ -360,33 +355,22 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		}
 		mesh->scratch[(size_t)idx].busy = true;
 		mesh->scratch[(size_t)idx].stream = stream;
-		mesh->scratch[(size_t)idx].serial = slots ? ++mesh->scratch_serial : mesh->scratch[(size_t)idx].serial;
+		mesh->scratch[(size_t)idx].serial = ++mesh->scratch_serial;
 		mesh->scratch[(size_t)idx].used_slots = slots;
 		base = static_cast<char*>(mesh->scratch[(size_t)idx].mem);
 		laid_out_slots = mesh->scratch[(size_t)idx].slots;
-		laid_out_redo = mesh->scratch[(size_t)idx].redo_cap;
 	}
-	size_t off[8];
-	dg::overflow_bytes(laid_out_slots, laid_out_redo, off); // the layout the buffer was allocated with
-	uint32_t* counters = reinterpret_cast<uint32_t*>(base + off[0]);
-	if (slots)
-	{
-		P.ovf.count = counters;
-		P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
-		P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
-		P.ovf.saved_tri = reinterpret_cast<int32_t*>(base + off[3]);
-		P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
-		P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
-		P.ovf.slots = slots;
-		P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
-	}
-	if (fast)
-	{
-		P.ovf.redo_count = counters + 1;
-		P.ovf.redo = reinterpret_cast<uint32_t*>(base + off[6]);
-		P.ovf.redo_cap = redo_cap;
-	}
-	if (hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), stream) != hipSuccess)
+	size_t off[6];
+	dg::overflow_bytes(laid_out_slots, off); // the layout the buffer was allocated with
+	P.ovf.count = reinterpret_cast<uint32_t*>(base + off[0]);
+	P.ovf.brick = reinterpret_cast<uint32_t*>(base + off[1]);
+	P.ovf.saved_d2 = reinterpret_cast<double*>(base + off[2]);
+	P.ovf.saved_tri = reinterpret_cast<int32_t*>(base + off[3]);
+	P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
+	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
+	P.ovf.slots = slots;
+	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
+	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
 	{
 		(void)hipGetLastError();
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);

@@ -95,7 +95,6 @@ struct HeavyScratch
 	hipEvent_t done = nullptr;
 	hipStream_t stream = nullptr;
 	uint32_t slots = 0;      // capacity the buffer was laid out for
-	uint32_t redo_cap = 0;   // ... and the length of its redo list (filtered K1)
 	uint32_t used_slots = 0; // slots the most recent launch was given
 	bool busy = false; // between acquire and the event record
 	uint64_t serial = 0; // order of use

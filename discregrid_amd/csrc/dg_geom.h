@@ -467,9 +467,10 @@ DG_HD float best_as_float(double d2)
 struct alignas(64) TriApproxPair
 {
 	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 1/l0; 14,15 direction of side B->C;
-	// 16 l1; 17 1/l1; 18,19 direction of side A->C; 20 l2; 21 1/l2; 22 big: 0, or +inf for a degenerate triangle (all else 0)
+	// 16 l1; 17 1/l1; 18,19 direction of side A->C; 20 l2; 21 1/l2; 22 unused
 	float f[23][2];
-	int32_t valid[2]; // 0: padding slot of an odd leaf (never tested)
+	int32_t valid[2]; // 1: triangle; 0: padding slot of an odd leaf (never tested); 2: degenerate triangle (floats all 0):
+	                  // a wave that meets one hands its brick to the exact kernel
 };
 static_assert(sizeof(TriApproxPair) == 192, "TriApproxPair must be 192 bytes");
 static const int kApproxFloats = 46;
@@ -502,7 +503,7 @@ inline void make_tri_approx(const double v0[3], const double v1[3], const double
 		ok = ok && __builtin_fabs(v0[d] - origin[d]) < 1.0e15;
 	if (!ok)
 	{
-		put(22, __builtin_inf()); // degenerate: every lane keeps it as a candidate, it never bounds anything
+		rec.valid[side] = 2; // degenerate: the float filter says nothing about it
 		return;
 	}
 	double u[3], w[3], nn[3];
@@ -550,34 +551,45 @@ DG_HD ApproxLane make_approx_lane(double rx, double ry, double rz, float mesh_l1
 	const float s = (__builtin_fabsf(a.x[0]) + __builtin_fabsf(a.x[1])) + __builtin_fabsf(a.x[2]) + mesh_l1;
 	// 2^-19 s, rounded up a little; coordinates beyond 1e15 (or NaN) leave the range in which the
 	// squares stay finite floats
-	a.E = (s < 1.0e15f) ? s * 1.9073505e-06f + 1.0e-30f : __builtin_inff();
+	a.E = (s < 1.0e15f) ? s * 1.9092579e-06f + 1.0e-30f : __builtin_inff(); // 2^-19 x 1.001
 	return a;
 }
-// err(q) = q theta + kappa for a lane whose distance is about d0 (any d0 > 0 is valid, d0 = the lane's
-// distance is tight): the float filter's value q of a triangle brackets dist^2 as [q - err(q), q + err(q)].
-// kappa carries 5 E^2 instead of E^2: 4 E^2 for points within the margin of a side (see tri_approx_pair).
+// err(q) = q theta + kappa: the float filter's value q of a triangle brackets dist^2 as
+// [q - err(q), q + err(q)].  From err(q) >= 2 sqrt(q) E + 5 E^2 + 2^-18 q (5 E^2 instead of E^2: 4 E^2 for
+// points within the margin of a side, see tri_approx_pair) and 2 sqrt(q) <= q a + b for ANY a, b > 0 with
+// a b >= 1:  theta = E a + 2^-18,  kappa = E b + 5 E^2.  The bound is tight where q = b / a, so b should be
+// near the lane's distance: b = sqrt(d0sq) and a = 1 / b to a few percent, from integer arithmetic on the
+// float bits (halved exponent; magic-constant reciprocal, whose product with b lies in [0.9494, 1.0506] for
+// every float b -- checked exhaustively over a binade -- hence a b >= 1.006 after the factor 1.06).
 // The same two numbers turn an upper bound U of dist^2 into the threshold the BOUND tests of the traversal
 // may prune with, U (1 + theta) + kappa >= (sqrt(U) + sqrt(3) es)^2 (1 + 2^-19): es <= E / 2 is the error of
 // one slab projection (FPoint::es), which the fast bound test leaves out of its three slabs, and 2^-19
 // covers the float rounding of the bound's own arithmetic.
-DG_HD void approx_err_terms(float E, float d0, float inv_d0 /* ~ 1 / d0, 1 ulp */, float* theta, float* kappa)
+// d0sq: any float (a negative, infinite or NaN value only makes the terms loose, b >= E always).
+DG_HD void approx_err_terms(float E, float d0sq, float* theta, float* kappa)
 {
-	*theta = (E * inv_d0) * 1.001f + 3.814697265625e-06f; // + 2^-18
-	*kappa = (E * d0 + 5.0f * (E * E)) * 1.001f + 1.0e-30f;
-}
-// d0 for approx_err_terms from a squared distance estimate: clamped to [E, 1e18] (also for NaN / negative input)
-DG_HD float approx_d0(float E, float d0sq)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-	float d0 = __builtin_amdgcn_sqrtf(d0sq); // v_sqrt_f32, 1 ulp: any d0 > 0 is valid
-#else
-	float d0 = __builtin_sqrtf(d0sq);
-#endif
-	d0 = (d0 > E) ? d0 : E;
-	return (d0 < 1.0e18f) ? d0 : 1.0e18f;
+	union { float f; int32_t i; } u;
+	u.f = d0sq;
+	u.i = (u.i >> 1) + 0x1fbd1df5; // ~ sqrt(d0sq) within 4.5 %
+	const float b = __builtin_fmaxf(u.f, E); // (NaN -> E)
+	u.f = b;
+	u.i = 0x7ef311c7 - u.i; // ~ 1 / b within 5.1 %
+	const float a = u.f * 1.06f;
+	*theta = __builtin_fmaf(E, a, 3.814697265625e-06f);
+	*kappa = __builtin_fmaf(E, __builtin_fmaf(5.0f, E, b), 1.0e-30f);
 }
 DG_HD float fmin2(float a, float b) { return __builtin_fminf(a, b); }
-DG_HD float fmin_sel(float a, float b) { return b < a ? b : a; } // a if b is NaN
+// min of two non-NaN floats in ONE instruction (fminf() costs two more to quiet signalling NaNs)
+#if defined(__HIP_DEVICE_COMPILE__)
+DG_HD float fmin_sel(float a, float b)
+{
+	float r;
+	__asm__("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+#else
+DG_HD float fmin_sel(float a, float b) { return b < a ? b : a; }
+#endif
 DG_HD float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 #if defined(__HIP_DEVICE_COMPILE__)
 DG_HD float sat01(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 1.0f); }

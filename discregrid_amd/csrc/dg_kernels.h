@@ -54,26 +54,19 @@ struct OverflowBuf // device scratch of one K1 launch (null count: splitting dis
 	int32_t* cand_tri;   // [slots][kSubtrees][64]
 	uint32_t slots;      // <= kOverflowSlots
 	int32_t heavy_work;  // work budget of a brick
-	// filtered K1 (k_sample_fast): bricks it hands back to the exact kernel (a lane's candidate list
-	// overflowed, or a lane's coordinates are outside the float filter's range)
-	uint32_t* redo_count; // null: the launch runs the exact kernel only
-	uint32_t* redo;       // [redo_cap] brick ids
-	uint32_t redo_cap;    // >= bricks of the launch
 };
-static const int kFastListCap = 8;  // candidate triangles a lane can hold (a lane that fills its list sends the brick to the exact kernel)
+static const int kFastListCap = 10; // candidate triangles a lane can hold (a lane that fills its list gets the exact traversal)
 static const int32_t kSeedOnly = -2; // OverflowBuf::saved_tri: saved_d2 is an upper bound of the lane's d^2, no triangle yet
-inline size_t overflow_bytes(uint32_t slots, uint32_t redo_cap, size_t off[8])
+inline size_t overflow_bytes(uint32_t slots, size_t off[6])
 {
 	size_t o = 0;
 	auto take = [&](size_t n) { const size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
-	off[0] = take(2 * sizeof(uint32_t)); // [0] heavy slots claimed, [1] redo entries
+	off[0] = take(sizeof(uint32_t));
 	off[1] = take(sizeof(uint32_t) * slots);
 	off[2] = take(sizeof(double) * 64 * slots);
 	off[3] = take(sizeof(int32_t) * 64 * slots);
 	off[4] = take(sizeof(double) * 64 * kSubtrees * slots);
 	off[5] = take(sizeof(int32_t) * 64 * kSubtrees * slots);
-	off[6] = take(sizeof(uint32_t) * redo_cap);
-	off[7] = o;
 	return o;
 }
 
@@ -137,6 +130,7 @@ struct SampleParams
 	const uint8_t* mask;     // indexed like out; nullable
 	double* out;
 	OverflowBuf ovf;
+	int32_t filtered;        // K1 / K1p: 1 = the filtered kernel (k_sample_fast), 0 = the exact kernel only
 	PointsDesc pts;          // K1p: "brick" b = the 64 points (in processing order) b*64 .. b*64+63
 };
 

@@ -165,7 +165,16 @@ __device__ __forceinline__ int test_leaf(const MeshDev& M, int first, int cnt, f
 // overflow slot and returns the slot number at once -- the caller parks the lanes' running
 // bests there (dg_kernels.h, "Heavy bricks").  If all slots are taken the wave simply carries on.
 // Returns -1 when the subtree was searched to the end.
-__device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, float* lds_lb /* [M.stack_levels][64] of this wave */,
+// The parked bounds live in LDS either as floats or -- in the filtered kernel, whose LDS also holds the
+// candidate lists -- as the upper 16 bits of the float (truncation = a lower bound of a non-negative value,
+// relative loss < 2^-7): LDS per wave decides how many waves a CU holds.
+__device__ __forceinline__ void park_bound(float* p, int i, float lb) { p[i] = lb; }
+__device__ __forceinline__ float parked_bound(const float* p, int i) { return p[i]; }
+__device__ __forceinline__ void park_bound(uint16_t* p, int i, float lb) { p[i] = (uint16_t)(__float_as_uint(lb) >> 16); }
+__device__ __forceinline__ float parked_bound(const uint16_t* p, int i) { return __uint_as_float((uint32_t)p[i] << 16); }
+
+template <class StackT>
+__device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* lds_lb /* [M.stack_levels][64] of this wave */,
 										int start, uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
 {
 	const int lane_id = (int)__lane_id();
@@ -211,7 +220,7 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, float* l
 					if (sp < M.stack_levels) // always true: one push per tree level at most
 					{
 						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-						lds_lb[sp * 64 + lane_id] = left ? lb.y : lb.x;
+						park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
 						++sp;
 					}
 				}
@@ -225,7 +234,7 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, float* l
 		while (sp > 0)
 		{
 			--sp;
-			lbcur = lds_lb[sp * 64 + lane_id];
+			lbcur = parked_bound(lds_lb, sp * 64 + lane_id);
 			if (__ballot(lbcur < q.bestf) != 0ull)
 			{
 				cur = __builtin_amdgcn_readlane(stackv, sp);
@@ -372,16 +381,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 	sample_brick_exact<POINTS>(P, brick, lane, lds_lb + wave * (P.mesh.stack_levels * 64));
 }
 
-// the exact kernel over the bricks the filtered kernel handed back (their number is only known on the device)
-template <bool POINTS>
-__global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_redo(const SampleParams P)
-{
-	const uint32_t n = min(*P.ovf.redo_count, P.ovf.redo_cap);
-	extern __shared__ __attribute__((aligned(16))) float lds_lb[];
-	for (uint32_t i = blockIdx.x; i < n; i += gridDim.x)
-		sample_brick_exact<POINTS>(P, (uint64_t)P.ovf.redo[i], (int)threadIdx.x, lds_lb);
-}
-
 // ------------------------------------------------------------------------------------------------
 // K1 / K1p, filtered: the same packet traversal, but a visited leaf's triangles go through the FLOAT
 // filter (dg_geom.h: tri_approx_pair, two triangles per record with packed math) instead of a bound
@@ -393,8 +392,9 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_redo(const Sampl
 // lane, hardly ever more than a few lanes each).  Bit-exactness: the triangle with the smallest double
 // d^2 is always among the lane's candidates (error analysis in dg_geom.h), and the winner among the
 // candidates is found with the double test in list order (strict <), as before.
-// A wave hands its brick back to the exact kernel (k_sample_redo) if a lane fills its list or lies
-// outside the filter's range, and parks it as a heavy brick when the work budget runs out.
+// Lanes the filter cannot serve (list full, coordinates outside the filter's range, a degenerate triangle
+// met) get the exact traversal in the same wave, pruned from the start by their upper bounds; a brick whose
+// work budget runs out is parked as a heavy brick with the upper bounds as seeds.
 // ------------------------------------------------------------------------------------------------
 struct FastLane
 {
@@ -404,8 +404,9 @@ struct FastLane
 	float Lmin;   // smallest lower value among the listed candidates
 	int cnt;      // listed candidates (<= kFastListCap; == kFastListCap: the list may have overflowed)
 };
-// returns -1 (searched to the end) or the heavy slot the wave claimed
-__device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, float* lds_lb, int* lds_list, uint32_t* ovf_count,
+// returns -1 (searched to the end), -2 (searched to the end, but a degenerate triangle was met: the lists are
+// incomplete) or the heavy slot the wave claimed
+__device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint16_t* lds_lb, int* lds_list, uint32_t* ovf_count,
 											 uint32_t ovf_slots, int heavy_work)
 {
 	const int lane_id = (int)__lane_id();
@@ -415,6 +416,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 	float lbcur = 0.0f;
 	int work = 0;
 	int budget = ovf_count ? heavy_work : 0x7fffffff;
+	bool degenerate = false; // wave-uniform: a degenerate triangle was met
 	while (true)
 	{
 		if (work > budget)
@@ -435,10 +437,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 			// error terms for this leaf's triangles around the lane's current distance estimate (its upper
 			// bound, or the leaf's own bound while no triangle has been seen); they are valid for any estimate
 			float theta, kappa;
-			{
-				const float d0 = approx_d0(f.a.E, f.U < __builtin_inff() ? f.U : lbcur);
-				approx_err_terms(f.a.E, d0, __builtin_amdgcn_rcpf(d0), &theta, &kappa);
-			}
+			approx_err_terms(f.a.E, f.U < __builtin_inff() ? f.U : lbcur, &theta, &kappa);
 			for (int g = 0; g < cnt; g += 2)
 			{
 				const char* base = (const char*)(M.tri_approx + ((first + g) >> 1));
@@ -455,17 +454,20 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 #pragma unroll
 				for (int i = 0; i < kApproxFloats - 32; ++i)
 					r[32 + i] = __int_as_float(c[i]);
-				const int valid0 = c[14], valid1 = c[15]; // 0: padding slot of an odd leaf
+				const int valid0 = c[14], valid1 = c[15]; // 1: triangle, 0: padding slot of an odd leaf, 2: degenerate triangle
 				const f2 q = tri_approx_pair(r, f.a);
-				const f2 err = f2_fma(q, f2_splat(theta), f2_splat(kappa)) + f2_make(r[44], r[45]); // + big (0, or +inf for a degenerate triangle)
+				const f2 err = f2_fma(q, f2_splat(theta), f2_splat(kappa));
 				const f2 up = q + err, lo = q - err;
 				++work;
 #pragma unroll
 				for (int side = 0; side < 2; ++side)
 				{
-					if ((side == 0 ? valid0 : valid1) == 0) // wave-uniform
+					const int valid = side == 0 ? valid0 : valid1; // wave-uniform
+					if (valid != 1)
+					{
+						degenerate = degenerate || valid == 2;
 						continue;
-					// (a degenerate triangle has lo = -inf, up = +inf: always a candidate, bounds nothing)
+					}
 					const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
 					if (lo_s <= f.U)
 					{
@@ -498,7 +500,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 					if (sp < M.stack_levels)
 					{
 						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-						lds_lb[sp * 64 + lane_id] = left ? lb.y : lb.x;
+						park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
 						++sp;
 					}
 				}
@@ -511,7 +513,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 		while (sp > 0)
 		{
 			--sp;
-			lbcur = lds_lb[sp * 64 + lane_id];
+			lbcur = parked_bound(lds_lb, sp * 64 + lane_id);
 			if (__ballot(lbcur <= f.Uprune) != 0ull)
 			{
 				cur = __builtin_amdgcn_readlane(stackv, sp);
@@ -522,17 +524,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, floa
 		if (!found)
 			break;
 	}
-	return -1;
-}
-
-__device__ __forceinline__ void push_redo(const SampleParams& P, uint64_t brick, int lane)
-{
-	if (lane == 0)
-	{
-		const uint32_t at = atomicAdd(P.ovf.redo_count, 1u);
-		if (at < P.ovf.redo_cap) // always: the list has room for every brick of the launch
-			P.ovf.redo[at] = (uint32_t)brick;
-	}
+	return degenerate ? -2 : -1;
 }
 
 template <bool POINTS>
@@ -545,8 +537,9 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	const uint64_t brick = (uint64_t)blk;
 	if (brick >= P.total_bricks)
 		return;
-	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [stack_levels][64] bounds, then [kFastListCap + 1][64] candidates
-	int* lds_list = (int*)(lds_lb + P.mesh.stack_levels * 64);
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // (one extern array per module: the same name in every kernel)
+	uint16_t* lds_lb16 = (uint16_t*)lds_lb;                     // [stack_levels][64] bounds (16 bit), then [kFastListCap + 1][64] candidates
+	int* lds_list = (int*)(lds_lb16 + P.mesh.stack_levels * 64);
 	FastLane f;
 	bool sample;
 	{
@@ -554,46 +547,65 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 		sample = t.sample;
 		f.a = make_approx_lane(t.x0 - P.mesh.origin[0], t.x1 - P.mesh.origin[1], t.x2 - P.mesh.origin[2], P.mesh.mesh_l1);
 	}
-	if (__ballot(sample && !(f.a.E < __builtin_inff())) != 0ull) // a lane outside the filter's range (or NaN)
-	{
-		push_redo(P, brick, lane);
-		return;
-	}
-	f.U = sample ? __builtin_inff() : -__builtin_inff();
+	// `exact`: lanes the filter cannot serve -- outside its range (or NaN) from the start, later those
+	// whose list filled up -- get the exact traversal below, in this wave, with only them active
+	bool exact = sample && !(f.a.E < __builtin_inff());
+	f.U = (sample && !exact) ? __builtin_inff() : -__builtin_inff();
 	f.Uprune = f.U;
 	f.Lmin = __builtin_inff();
 	f.cnt = 0;
-	if (__ballot(sample) != 0ull)
+	if (__ballot(sample && !exact) != 0ull)
 	{
-		const int slot = traverse_fast(P.mesh, f, lds_lb, lds_list, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		const int slot = traverse_fast(P.mesh, f, lds_lb16, lds_list, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
 		if (slot >= 0) // heavy brick: park the lanes' upper bounds as seeds, k_heavy_subtrees / k_heavy_finish take over
 		{
 			if (lane == 0)
 				P.ovf.brick[slot] = (uint32_t)brick;
-			P.ovf.saved_d2[slot * 64 + lane] = (double)f.U;
+			P.ovf.saved_d2[slot * 64 + lane] = exact ? 1.7976931348623157e308 : (double)f.U;
 			P.ovf.saved_tri[slot * 64 + lane] = kSeedOnly;
 			return;
 		}
-		if (__ballot(sample && f.cnt >= kFastListCap) != 0ull)
+		// a degenerate triangle was met: nobody's list is complete
+		exact = exact || (sample && (slot == -2 || f.cnt >= kFastListCap));
+	}
+	const LaneTask t = lane_task<POINTS>(P, brick, lane);
+	LaneQuery q;
+	if (__ballot(exact) != 0ull)
+	{
+		// Exact traversal for the few lanes that need it, pruned from the start by their upper bounds (so it
+		// only meets what lies within those lanes' distance); the fast traversal's bound stack is free by now.
+		init_query(P.mesh.origin, P.mesh.mesh_l1, exact, t.x0, t.x1, t.x2, q);
+		if (exact && f.U > 0.0f) // (U > 0 always for a lane that went through the filter; -inf if it did not)
+			q.bestf = best_as_float((double)f.U);
+		const int slot = traverse(P.mesh, q, lds_lb16, P.mesh.root_info, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		if (slot >= 0) // over budget after all: the heavy-brick kernels redo every lane, seeded with what is known
 		{
-			push_redo(P, brick, lane);
+			if (lane == 0)
+				P.ovf.brick[slot] = (uint32_t)brick;
+			const bool have = exact && q.best_tri >= 0;
+			P.ovf.saved_d2[slot * 64 + lane] = have ? q.best_d2 : (exact ? 1.7976931348623157e308 : (double)f.U);
+			P.ovf.saved_tri[slot * 64 + lane] = have ? q.best_tri : kSeedOnly;
 			return;
 		}
 	}
-	if (!sample)
-		f.cnt = 0;
-	// each lane: the double test on its own candidates, in list (= traversal) order
-	const LaneTask t = lane_task<POINTS>(P, brick, lane);
-	LaneQuery q;
+	const double ex_d2 = q.best_d2;
+	const int ex_tri = q.best_tri;
+	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
-	for (int k = 0; __ballot(k < f.cnt) != 0ull; ++k)
+	const int n_cand = (sample && !exact) ? f.cnt : 0;
+	for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
 	{
-		if (k < f.cnt)
+		if (k < n_cand)
 		{
 			const int tri = lds_list[k * 64 + lane];
 			const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
 			offer(q, h.d2, tri);
 		}
+	}
+	if (exact)
+	{
+		q.best_d2 = ex_d2;
+		q.best_tri = ex_tri;
 	}
 	write_result<POINTS>(P, t, q);
 }
@@ -1126,13 +1138,11 @@ static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 		return hipSuccess;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
 	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
-	if (p.ovf.redo_count != nullptr)
+	if (p.filtered != 0)
 	{
 		static_assert(kWavesPerBlock == 1, "k_sample_fast assumes one brick per block");
-		const size_t lds_fast = (size_t)(p.mesh.stack_levels + kFastListCap + 1) * 64 * sizeof(float);
+		const size_t lds_fast = (size_t)p.mesh.stack_levels * 64 * sizeof(uint16_t) + (size_t)(kFastListCap + 1) * 64 * sizeof(int);
 		hipLaunchKernelGGL(k_sample_fast<POINTS>, dim3(grid), dim3(64), lds_fast, stream, p);
-		const uint32_t redo_blocks = (uint32_t)std::min<uint64_t>(p.total_bricks, 8192);
-		hipLaunchKernelGGL(k_sample_redo<POINTS>, dim3(redo_blocks), dim3(64), (size_t)p.mesh.stack_levels * 64 * sizeof(float), stream, p);
 	}
 	else
 		hipLaunchKernelGGL(k_sample_nodes<POINTS>, dim3(grid), dim3(64 * kWavesPerBlock), lds, stream, p);

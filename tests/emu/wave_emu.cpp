@@ -10,6 +10,8 @@
 // the brick decomposition cover every node exactly once?) is checked here on CPU before GPU
 // minutes are spent.  The product never links this file and has no CPU path.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -87,7 +89,15 @@ int test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per 
 // mirrors traverse() of dg_kernels.hip: near-first packet traversal, wave-shared stack of info
 // words, per-lane bounds of postponed subtrees parked per level
 // (including the work budget / overflow-slot claim of the heavy-brick path)
-int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf)
+float truncate16(float v) // park_bound / parked_bound of the 16-bit stack
+{
+	uint32_t bits;
+	std::memcpy(&bits, &v, 4);
+	bits &= 0xffff0000u;
+	std::memcpy(&v, &bits, 4);
+	return v;
+}
+int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf, bool stack16 = false)
 {
 	int stack_info[kStackDepth];
 	static thread_local float stack_lb[kStackDepth][64];
@@ -146,7 +156,7 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 					{
 						stack_info[sp] = left ? pr.info[1] : pr.info[0];
 						for (int k = 0; k < 64; ++k)
-							stack_lb[sp][k] = left ? lbr[k] : lbl[k];
+							stack_lb[sp][k] = stack16 ? truncate16(left ? lbr[k] : lbl[k]) : (left ? lbr[k] : lbl[k]);
 						++sp;
 					}
 				}
@@ -218,6 +228,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 		lbcur[k] = 0.0f;
 	int work = 0;
 	int budget = (ovf && ovf->count) ? ovf->heavy_work : 0x7fffffff;
+	bool degenerate = false;
 	while (true)
 	{
 		if (work > budget)
@@ -237,8 +248,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 			float theta[64], kappa[64];
 			for (int l = 0; l < 64; ++l)
 			{
-				const float d0 = approx_d0(fl[l].a.E, fl[l].U < __builtin_inff() ? fl[l].U : lbcur[l]);
-				approx_err_terms(fl[l].a.E, d0, 1.0f / d0, &theta[l], &kappa[l]);
+				approx_err_terms(fl[l].a.E, fl[l].U < __builtin_inff() ? fl[l].U : lbcur[l], &theta[l], &kappa[l]);
 			}
 			for (int g = 0; g < cnt; g += 2)
 			{
@@ -250,12 +260,15 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 				{
 					FastLane& f = fl[l];
 					const f2 q = tri_approx_pair(r, f.a);
-					const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l])) + f2_make(r[44], r[45]);
+					const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l]));
 					const f2 up = q + err, lo = q - err;
 					for (int side = 0; side < 2; ++side)
 					{
-						if (rec.valid[side] == 0)
+						if (rec.valid[side] != 1)
+						{
+							degenerate = degenerate || rec.valid[side] == 2;
 							continue;
+						}
 						const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
 						if (lo_s <= f.U)
 						{
@@ -305,7 +318,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 					{
 						stack_info[sp] = left ? pr.info[1] : pr.info[0];
 						for (int k = 0; k < 64; ++k)
-							stack_lb[sp][k] = left ? lbr[k] : lbl[k];
+							stack_lb[sp][k] = truncate16(left ? lbr[k] : lbl[k]);
 						++sp;
 					}
 				}
@@ -337,7 +350,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 		if (!found)
 			break;
 	}
-	return -1;
+	return degenerate ? -2 : -1;
 }
 
 // heavy-brick settings of the emulated launches (defaults = the product's)
@@ -575,9 +588,9 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 	P.out = out;
 	Stats st;
 	int err = 0;
-	// heavy-brick scratch and redo list exactly as dg_capi.cpp attaches them
-	uint32_t ovf_count = 0, redo_count = 0;
-	std::unique_ptr<uint32_t[]> ovf_brick, redo_list;
+	// heavy-brick scratch exactly as dg_capi.cpp attaches it
+	uint32_t ovf_count = 0;
+	std::unique_ptr<uint32_t[]> ovf_brick;
 	std::unique_ptr<double[]> saved_d2, cand_d2; // uninitialised on purpose: only parked slots are ever touched
 	std::unique_ptr<int32_t[]> saved_tri, cand_tri;
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
@@ -598,13 +611,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		P.ovf.slots = slots;
 		P.ovf.heavy_work = g_heavy_work > 0 ? g_heavy_work : heavy_work_for(P.mesh.n_positions);
 	}
-	if (g_fast && DG_OBB)
-	{
-		redo_list.reset(new uint32_t[P.total_bricks]);
-		P.ovf.redo_count = &redo_count;
-		P.ovf.redo = redo_list.get();
-		P.ovf.redo_cap = (uint32_t)P.total_bricks;
-	}
+	P.filtered = (g_fast && DG_OBB) ? 1 : 0;
 	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
 		for (int l = 0; l < 64; ++l)
 		{
@@ -657,25 +664,26 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			const bool any = init_wave(brick, ln, sample, w);
 			ls.bricks++;
 			int slot = -1;
-			if (any && P.ovf.redo_count)
+			if (any && P.filtered)
 			{
 				// k_sample_fast
 				FastLane fl[64];
 				FastStats fs;
 				fs.bricks = 1;
-				bool out_of_range = false;
+				bool exact[64];
+				bool any_fast = false, any_exact = false;
 				for (int l = 0; l < 64; ++l)
 				{
 					fl[l].a = make_approx_lane(w.q[l].px - P.mesh.origin[0], w.q[l].py - P.mesh.origin[1],
 											   w.q[l].pz - P.mesh.origin[2], P.mesh.mesh_l1);
-					out_of_range = out_of_range || (sample[l] && !(fl[l].a.E < __builtin_inff()));
-					fl[l].U = sample[l] ? __builtin_inff() : -__builtin_inff();
+					exact[l] = sample[l] && !(fl[l].a.E < __builtin_inff());
+					fl[l].U = (sample[l] && !exact[l]) ? __builtin_inff() : -__builtin_inff();
 					fl[l].Uprune = fl[l].U;
 					fl[l].Lmin = __builtin_inff();
 					fl[l].cnt = 0;
+					any_fast = any_fast || (sample[l] && !exact[l]);
 				}
-				bool redo = out_of_range;
-				if (!redo)
+				if (any_fast)
 				{
 					slot = traverse_fast(P.mesh, fl, fs, &P.ovf);
 					if (slot >= 0) // parked as a heavy brick with the upper bounds as seeds
@@ -684,41 +692,69 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 						P.ovf.brick[slot] = (uint32_t)brick;
 						for (int l = 0; l < 64; ++l)
 						{
-							P.ovf.saved_d2[slot * 64 + l] = (double)fl[l].U;
+							P.ovf.saved_d2[slot * 64 + l] = exact[l] ? 1.7976931348623157e308 : (double)fl[l].U;
 							P.ovf.saved_tri[slot * 64 + l] = kSeedOnly;
 						}
 					}
 					else
 						for (int l = 0; l < 64; ++l)
-							redo = redo || (sample[l] && fl[l].cnt >= kFastListCap);
+							exact[l] = exact[l] || (sample[l] && (slot == -2 || fl[l].cnt >= kFastListCap));
 				}
-				if (redo)
+				if (slot < 0)
 				{
-					fs.redo_bricks = 1;
-					const uint32_t at = __atomic_fetch_add(P.ovf.redo_count, 1u, __ATOMIC_RELAXED);
-					if (at < P.ovf.redo_cap)
-						P.ovf.redo[at] = (uint32_t)brick;
-				}
-				else if (slot < 0)
-				{
-					int mx = 0;
 					for (int l = 0; l < 64; ++l)
+						any_exact = any_exact || exact[l];
+					Wave wx; // the exact traversal of the lanes the filter could not serve
+					int slot2 = -1;
+					if (any_exact)
 					{
-						if (!sample[l])
-							continue;
-						fs.lanes++;
-						fs.sum_list += fl[l].cnt;
-						fs.hist[fl[l].cnt]++;
-						mx = fl[l].cnt > mx ? fl[l].cnt : mx;
-						for (int k = 0; k < fl[l].cnt; ++k)
+						fs.redo_bricks = 1;
+						for (int l = 0; l < 64; ++l)
 						{
-							const int t = fl[l].list[k];
-							const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
-							offer(w.q[l], h.d2, t);
+							init_query(P.mesh.origin, P.mesh.mesh_l1, exact[l], w.q[l].px, w.q[l].py, w.q[l].pz, wx.q[l]);
+							if (exact[l] && fl[l].U > 0.0f)
+								wx.q[l].bestf = best_as_float((double)fl[l].U);
+						}
+						slot2 = traverse(P.mesh, wx, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr, true);
+					}
+					if (slot2 >= 0)
+					{
+						fs.parked = 1;
+						P.ovf.brick[slot2] = (uint32_t)brick;
+						for (int l = 0; l < 64; ++l)
+						{
+							const bool have = exact[l] && wx.q[l].best_tri >= 0;
+							P.ovf.saved_d2[slot2 * 64 + l] = have ? wx.q[l].best_d2 : (exact[l] ? 1.7976931348623157e308 : (double)fl[l].U);
+							P.ovf.saved_tri[slot2 * 64 + l] = have ? wx.q[l].best_tri : kSeedOnly;
 						}
 					}
-					fs.sum_max_list += mx;
-					write_nodes(ln, sample, w);
+					else
+					{
+						int mx = 0;
+						for (int l = 0; l < 64; ++l)
+						{
+							if (!sample[l])
+								continue;
+							if (exact[l])
+							{
+								w.q[l].best_d2 = wx.q[l].best_d2;
+								w.q[l].best_tri = wx.q[l].best_tri;
+								continue;
+							}
+							fs.lanes++;
+							fs.sum_list += fl[l].cnt;
+							fs.hist[fl[l].cnt]++;
+							mx = fl[l].cnt > mx ? fl[l].cnt : mx;
+							for (int k = 0; k < fl[l].cnt; ++k)
+							{
+								const int t = fl[l].list[k];
+								const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
+								offer(w.q[l], h.d2, t);
+							}
+						}
+						fs.sum_max_list += mx;
+						write_nodes(ln, sample, w);
+					}
 				}
 #pragma omp critical
 				g_fs.add(fs);
@@ -752,29 +788,6 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			st.pops += ls.pops;
 			st.stale_pops += ls.stale_pops;
 		}
-	}
-	// k_sample_redo: the exact traversal for the bricks the filtered kernel handed back
-	for (uint32_t i = 0; i < std::min(redo_count, P.ovf.redo_cap); ++i)
-	{
-		const uint64_t brick = P.ovf.redo[i];
-		Wave w;
-		LaneNode ln[64];
-		bool sample[64];
-		const bool any = init_wave(brick, ln, sample, w);
-		int slot = -1;
-		if (any)
-			slot = traverse(P.mesh, w, st, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
-		if (slot >= 0)
-		{
-			P.ovf.brick[slot] = (uint32_t)brick;
-			for (int l = 0; l < 64; ++l)
-			{
-				P.ovf.saved_d2[slot * 64 + l] = w.q[l].best_d2;
-				P.ovf.saved_tri[slot * 64 + l] = w.q[l].best_tri;
-			}
-			continue;
-		}
-		write_nodes(ln, sample, w);
 	}
 	// k_heavy_subtrees, k_heavy_finish
 	const uint32_t parked = P.ovf.count ? std::min(ovf_count, P.ovf.slots) : 0u;

@@ -54,5 +54,5 @@ print("        overflow bricks %d (%.3f%%)  mean list %.2f  mean max-list/brick 
     tot["redo_bricks"], 100.0 * tot["redo_bricks"] / B, tot["sum_list"] / max(1, tot["lanes"]), tot["sum_max_list"] / max(1, B - tot["redo_bricks"])))
 print("        list length histogram:", (tot["hist"] / max(1, tot["hist"].sum())).round(4).tolist())
 cur = 40 * tot["x_node_visits"] / 2 / tot["x_bricks"] + 34 * tot["x_leaf_groups"] / tot["x_bricks"] + 71 * tot["x_tri_tests"] / tot["x_bricks"]
-new = 34 * tot["pair_steps"] / B + 54 * tot["tri_pairs"] / B + 90 * tot["sum_max_list"] / max(1, B) + 13 * tot["leaf_visits"] / B
+new = 30 * tot["pair_steps"] / B + 64 * tot["tri_pairs"] / B + 90 * tot["sum_max_list"] / max(1, B) + 15 * tot["leaf_visits"] / B
 print("VALU model per brick: exact %.0f  fast %.0f  (ratio %.2f)" % (cur, new, new / cur))
