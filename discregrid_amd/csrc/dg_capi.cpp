@@ -320,7 +320,9 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
 	// the filtered kernel (dg_kernels.hip: k_sample_fast) unless DG_K1_FAST=0 asks for the exact kernel only
-	P.filtered = (env_int("DG_K1_FAST", 1, 0, 1) != 0 && DG_OBB != 0) ? 1 : 0;
+	// (DG_K1_FAST=1 forces it for small meshes too, which by default keep the exact kernel)
+	const int fast_default = mesh->info.n_triangles >= dg::kFastMinTriangles ? 1 : 0;
+	P.filtered = (env_int("DG_K1_FAST", fast_default, 0, 1) != 0 && DG_OBB != 0 && mesh->dev.n_positions < (1 << 26)) ? 1 : 0;
 	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
 	if (slots == 0 || mesh->dev.n_sub < 2)
 	{

@@ -432,7 +432,7 @@ DG_HD float best_as_float(double d2)
 // the point/triangle distance in float whose error is bounded rigorously: the exact double test with
 // the reference's operation order (tri_closest) then runs only on each lane's own short list of
 // candidates, once, after the traversal -- instead of on every triangle any lane of the wave is
-// interested in.
+// interested in (dg_kernels.hip: k_sample_fast).
 //
 // Formulation (chosen for its error analysis, not for minimal arithmetic): the triangle carries an
 // orthonormal frame (u along v0->v1, w in the plane towards v2, n the normal).  With d = p - v0:
@@ -450,20 +450,24 @@ DG_HD float best_as_float(double d2)
 //     evaluation adds <= 5 eps l + 3 eps |X|: absolute error of r <= 29 eps R; the clamped parameter
 //     need not be accurate (any parameter in [0,1] yields a point of the segment; an error du costs
 //     3 l^2 du^2, second order);
-//   * the inside/outside decision uses the margin em >= 23 eps R on min(perp_i): "strictly inside"
-//     (r taken as 0 for the UPPER value) only if every perp_i >= em, "possibly inside" (r taken as 0
-//     for the LOWER value) if every perp_i >= -em.  A needle-shaped triangle, where a point beyond the
-//     sharp corner is within em of two side lines, therefore gets a valid (if loose) pair of values.
+//   * a point counts as inside (r = 0) only if min(perp_i) >= E, E >= 23 eps R the error of a perp_i: then
+//     it IS inside.  A point that is inside by less gets the distance to its nearest side, which is below
+//     2 E: still an upper value, and as a lower value too high by at most 4 E^2 (carried by kappa below).
+//     A needle-shaped triangle, where a point beyond the sharp corner is within E of two side lines,
+//     therefore gets a valid (if loose) interval.
 // Hence |dist_float - dist| <= sqrt(29^2 + 11^2) eps R < E := 2^-19 R, and in squares
-//   dist^2 in [dL2 - err(dL2), dU2 + err(dU2)],  err(q) = 2 sqrt(q) E + E^2 + 8 eps q.
-// sqrt is avoided by 2 sqrt(q) E <= q E / d0 + E d0 for ANY d0 > 0 (tight at q = d0^2): the caller
-// passes theta = E / d0 + 2^-20 and kappa = E d0 + E^2 (+ an absolute floor against float
-// underflow), with d0 the lane's current estimate of its distance.  The double value the reference
-// computes differs from the true dist^2 by ~1e-15 |p - v0|^2 <= 4e-15 R^2 << E^2 = 3.6e-12 R^2, so the
-// interval also contains the reference's value: the triangle whose DOUBLE d^2 is smallest is never lost.
+//   dist^2 in [q - err(q), q + err(q)],  err(q) >= 2 sqrt(q) E + 5 E^2 + 2^-18 q   (approx_err_terms).
 //
-// Degenerate triangles (zero-length side, area below 1e-7 of the longest side squared, non-finite
-// data) get big = +inf: lower value -inf, upper value +inf -- always a candidate, never a bound.
+// What has to lie in that interval is the DOUBLE value the reference computes (the minimum is taken over
+// those), not the true distance.  For a well-shaped triangle the two differ by ~1e-15 |p - v0|^2 <= 4e-15 R^2,
+// far below the 1.8e-14 R^2 of slack in 5 E^2 x 1.001.  For a sliver they do not: the reference solves
+// the 2x2 system with det = a00 a11 - a01^2, whose cancellation leaves (s, t) with an error of
+// ~1e-16 (l^2 / area)^2 and the value with l^2 times its square -- 3e-9 instead of 5e-15 was seen for
+// area / l^2 = 5e-7.  Triangles with area below 1e-4 of the longest side squared (reference error
+// <= 1e-16 l^2), with a zero-length side or with non-finite data are therefore DEGENERATE for the filter
+// (valid = 2): a wave that meets one gives all its lanes the exact traversal.
+// tests/test_emu.py::test_float_filter_interval_contains_the_double_value checks the interval on 36 M
+// random and adversarial (triangle, point) pairs: no violation, largest |q - d2| / err = 0.14.
 struct alignas(64) TriApproxPair
 {
 	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 1/l0; 14,15 direction of side B->C;
@@ -498,7 +502,7 @@ inline void make_tri_approx(const double v0[3], const double v1[3], const double
 	const double area2 = __builtin_sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
 	const double lmax = l0 > l1 ? (l0 > l2 ? l0 : l2) : (l1 > l2 ? l1 : l2);
 	const double lmin = l0 < l1 ? (l0 < l2 ? l0 : l2) : (l1 < l2 ? l1 : l2);
-	bool ok = lmin > 1.0e-15 && lmax < 1.0e15 && area2 > 1.0e-7 * lmax * lmax; // (false for NaN)
+	bool ok = lmin > 1.0e-15 && lmax < 1.0e15 && area2 > 1.0e-4 * lmax * lmax; // (false for NaN)
 	for (int d = 0; d < 3; ++d)
 		ok = ok && __builtin_fabs(v0[d] - origin[d]) < 1.0e15;
 	if (!ok)

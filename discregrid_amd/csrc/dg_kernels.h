@@ -40,8 +40,10 @@ inline int heavy_work_for(int32_t n_positions)
 // slots a launch of `bricks` bricks gets: heavy bricks are a small, slowly growing fraction of a launch
 inline uint32_t overflow_slots_for(uint64_t bricks)
 {
-	const uint64_t want = bricks / 2048;
-	return (uint32_t)(want < 256 ? 256 : (want > (uint64_t)kOverflowSlots ? (uint64_t)kOverflowSlots : want));
+	uint64_t want = bricks / 2048;
+	want = want < 1024 ? 1024 : want;   // (197 KB of scratch per slot)
+	want = want > bricks ? bricks : want;
+	return (uint32_t)(want > (uint64_t)kOverflowSlots ? (uint64_t)kOverflowSlots : want);
 }
 
 struct OverflowBuf // device scratch of one K1 launch (null count: splitting disabled)
@@ -56,6 +58,15 @@ struct OverflowBuf // device scratch of one K1 launch (null count: splitting dis
 	int32_t heavy_work;  // work budget of a brick
 };
 static const int kFastListCap = 10; // candidate triangles a lane can hold (a lane that fills its list gets the exact traversal)
+// The filtered traversal counts node steps + triangle PAIRS (the exact one: node steps + exact tests): about the
+// same cost per unit, but ~1.7 x as many bricks pass the budget (632 against 381 at 256^3 on the icosphere).
+// A factor 2 on the budget brings the count back down and was measured SLOWER on small launches (a 64^3
+// lattice ends with the un-parked near-heavy waves running alone: 2.8 against 1.5 ms), so the budget stays and
+// the launches get more slots instead (overflow_slots_for).
+static const int kFastWorkFactor = 1;
+// meshes below this triangle count run the exact kernel: with a few hundred triangles a brick's exact tests
+// are fewer than its filter tests + per-lane candidates (box 256^3: 2.6 vs 4.6 ms, 57 600-triangle torus 18.4 vs 17.2)
+static const uint64_t kFastMinTriangles = 8192;
 static const int32_t kSeedOnly = -2; // OverflowBuf::saved_tri: saved_d2 is an upper bound of the lane's d^2, no triangle yet
 inline size_t overflow_bytes(uint32_t slots, size_t off[6])
 {

@@ -415,7 +415,7 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 	int cur = M.root_info;
 	float lbcur = 0.0f;
 	int work = 0;
-	int budget = ovf_count ? heavy_work : 0x7fffffff;
+	int budget = ovf_count ? kFastWorkFactor * heavy_work : 0x7fffffff;
 	bool degenerate = false; // wave-uniform: a degenerate triangle was met
 	while (true)
 	{

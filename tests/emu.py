@@ -210,6 +210,43 @@ def fast_stats():
     return d
 
 
+def filter_interval_check(rng, n_tri=2000, n_pts=64):
+    """Random + adversarial (triangle, point) sets through emu_filter_check; returns the totals."""
+    L = lib()
+    L.emu_filter_check.restype = C.c_uint64
+    L.emu_filter_check.argtypes = [T.c_dp, C.c_size_t, T.c_dp, C.c_size_t, T.c_dp, T.c_dp, T.c_u64p]
+    tot = dict(violations=0, checked=0, worst=0.0)
+    for case in range(12):
+        scale = 10.0 ** rng.integers(-3, 4)
+        shift = rng.uniform(-1, 1, size=3) * scale * (0.0 if case % 3 == 0 else 10.0 ** rng.integers(0, 4))
+        tri = rng.uniform(-1, 1, size=(n_tri, 3, 3)) * scale
+        k = n_tri // 4
+        tri[:k, 2] = tri[:k, 0] + (tri[:k, 1] - tri[:k, 0]) * rng.uniform(-0.5, 1.5, size=(k, 1)) + \
+            rng.normal(size=(k, 3)) * scale * 10.0 ** rng.uniform(-6, -1, size=(k, 1))      # slivers / needles
+        tri[k:2 * k, 1] = tri[k:2 * k, 0] + rng.normal(size=(k, 3)) * scale * 1e-4              # one very short side
+        tri += shift
+        origin = 0.5 * (tri.reshape(-1, 3).min(0) + tri.reshape(-1, 3).max(0))
+        for t0 in range(0, n_tri, 2 * 250):
+            sub = np.ascontiguousarray(tri[t0:t0 + 500]).reshape(-1, 9)
+            base = sub.reshape(-1, 3, 3)
+            w = rng.dirichlet([0.3, 0.3, 0.3], size=n_pts)                                     # near vertices / sides
+            on = np.einsum("pk,pkd->pd", w, base[rng.integers(0, len(base), n_pts)])
+            pts = np.concatenate([
+                on + rng.normal(size=(n_pts, 3)) * scale * 10.0 ** rng.uniform(-9, 0, size=(n_pts, 1)),
+                rng.uniform(-3, 3, size=(n_pts // 2, 3)) * scale + shift,
+                rng.uniform(-1, 1, size=(n_pts // 4, 3)) * scale * 1e3 + shift,
+            ])
+            pts = np.ascontiguousarray(pts)
+            worst = C.c_double(0.0)
+            checked = C.c_uint64(0)
+            bad = L.emu_filter_check(T.dp(sub), len(sub), T.dp(pts), len(pts), T.dp(np.ascontiguousarray(origin)),
+                                     C.byref(worst), C.byref(checked))
+            tot["violations"] += int(bad)
+            tot["checked"] += int(checked.value)
+            tot["worst"] = max(tot["worst"], worst.value)
+    return tot
+
+
 def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
     slots = 0 disables the split; the defaults size slots and budget as the product does."""

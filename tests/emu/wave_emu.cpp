@@ -227,7 +227,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 	for (int k = 0; k < 64; ++k)
 		lbcur[k] = 0.0f;
 	int work = 0;
-	int budget = (ovf && ovf->count) ? ovf->heavy_work : 0x7fffffff;
+	int budget = (ovf && ovf->count) ? kFastWorkFactor * ovf->heavy_work : 0x7fffffff;
 	bool degenerate = false;
 	while (true)
 	{
@@ -351,6 +351,64 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 			break;
 	}
 	return degenerate ? -2 : -1;
+}
+
+
+// k_sample_fast for one wave without heavy-brick parking (K1p emulation): w.q[l] end up with the lanes'
+// winners exactly as the kernel's epilogue leaves them
+void fast_wave_unparked(const MeshDev& M, Wave& w, const bool* sample, FastStats& fs, Stats& ls)
+{
+	FastLane fl[64];
+	bool exact[64];
+	bool any_fast = false, any_exact = false;
+	for (int l = 0; l < 64; ++l)
+	{
+		fl[l].a = make_approx_lane(w.q[l].px - M.origin[0], w.q[l].py - M.origin[1], w.q[l].pz - M.origin[2], M.mesh_l1);
+		exact[l] = sample[l] && !(fl[l].a.E < __builtin_inff());
+		fl[l].U = (sample[l] && !exact[l]) ? __builtin_inff() : -__builtin_inff();
+		fl[l].Uprune = fl[l].U;
+		fl[l].Lmin = __builtin_inff();
+		fl[l].cnt = 0;
+		any_fast = any_fast || (sample[l] && !exact[l]);
+	}
+	fs.bricks++;
+	if (any_fast)
+	{
+		const int r = traverse_fast(M, fl, fs, nullptr);
+		for (int l = 0; l < 64; ++l)
+			exact[l] = exact[l] || (sample[l] && (r == -2 || fl[l].cnt >= kFastListCap));
+	}
+	for (int l = 0; l < 64; ++l)
+		any_exact = any_exact || exact[l];
+	Wave wx;
+	if (any_exact)
+	{
+		fs.redo_bricks++;
+		for (int l = 0; l < 64; ++l)
+		{
+			init_query(M.origin, M.mesh_l1, exact[l], w.q[l].px, w.q[l].py, w.q[l].pz, wx.q[l]);
+			if (exact[l] && fl[l].U > 0.0f)
+				wx.q[l].bestf = best_as_float((double)fl[l].U);
+		}
+		traverse(M, wx, ls, M.root_info, nullptr, true);
+	}
+	for (int l = 0; l < 64; ++l)
+	{
+		if (!sample[l])
+			continue;
+		if (exact[l])
+		{
+			w.q[l].best_d2 = wx.q[l].best_d2;
+			w.q[l].best_tri = wx.q[l].best_tri;
+			continue;
+		}
+		for (int k = 0; k < fl[l].cnt; ++k)
+		{
+			const int t = fl[l].list[k];
+			const Hit h = tri_closest<false>(M.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
+			offer(w.q[l], h.d2, t);
+		}
+	}
 }
 
 // heavy-brick settings of the emulated launches (defaults = the product's)
@@ -756,6 +814,12 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 						write_nodes(ln, sample, w);
 					}
 				}
+				if (getenv("EMU_COST_DEBUG"))
+				{
+					const double rx = w.q[21].px - P.mesh.origin[0], ry = w.q[21].py - P.mesh.origin[1], rz = w.q[21].pz - P.mesh.origin[2];
+#pragma omp critical
+					fprintf(stderr, "cost %.4f %llu %llu %llu %llu\n", sqrt(rx*rx+ry*ry+rz*rz), (unsigned long long)fs.pair_steps, (unsigned long long)fs.tri_pairs, (unsigned long long)fs.sum_max_list, (unsigned long long)fs.parked);
+				}
 #pragma omp critical
 				g_fs.add(fs);
 				continue;
@@ -880,14 +944,24 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 	{
 		Wave w;
 		Stats st;
+		bool act[64];
 		for (int l = 0; l < 64; ++l)
 		{
 			const uint64_t gid = (uint64_t)wv * 64 + l;
 			const bool valid = gid < n;
 			const uint64_t g = valid ? gid : n - 1;
 			init_query(m->dev.origin, m->dev.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
+			act[l] = valid;
 		}
-		traverse(m->dev, w, st, m->dev.root_info, nullptr);
+		if (g_fast && DG_OBB)
+		{
+			FastStats fs;
+			fast_wave_unparked(m->dev, w, act, fs, st);
+#pragma omp critical
+			g_fs.add(fs);
+		}
+		else
+			traverse(m->dev, w, st, m->dev.root_info, nullptr);
 		for (int l = 0; l < 64; ++l)
 		{
 			const uint64_t gid = (uint64_t)wv * 64 + l;
@@ -938,6 +1012,80 @@ void emu_points_work(void* h, const double* xyz, uint64_t n, uint64_t* stats /*4
 	stats[1] = nv;
 	stats[2] = tt;
 	stats[3] = lg;
+}
+
+// Float filter vs the double test: for every (triangle, point) the interval [q - err, q + err] the filtered
+// kernel would form (error terms around the TRUE distance as d0 and around a 100 x larger one) must contain
+// tri_closest's double value.  origin = the mesh origin the records are relative to; mesh_l1 as dg_build
+// computes it.  Returns the number of violations; worst = max of (|q - d2| / err) seen.
+uint64_t emu_filter_check(const double* tri /* n_tri x 9 */, size_t n_tri, const double* pts /* n_pts x 3 */, size_t n_pts,
+						  const double origin[3], double* worst, uint64_t* checked)
+{
+	float l1 = 0.0f;
+	for (size_t t = 0; t < n_tri; ++t)
+		for (int k = 0; k < 3; ++k)
+		{
+			const double* v = tri + 9 * t + 3 * k;
+			const double a = std::fabs(v[0] - origin[0]) + std::fabs(v[1] - origin[1]) + std::fabs(v[2] - origin[2]);
+			l1 = std::max(l1, std::nextafterf((float)a, INFINITY));
+		}
+	uint64_t bad = 0, n = 0;
+	double w = 0.0;
+	for (size_t t = 0; t + 1 < n_tri; t += 2)
+	{
+		TriApproxPair rec;
+		std::memset(&rec, 0, sizeof(rec));
+		TriPacket pk[2];
+		for (int side = 0; side < 2; ++side)
+		{
+			const double* v = tri + 9 * (t + side);
+			make_tri_approx(v, v + 3, v + 6, origin, rec, side);
+			make_packet(v, v + 3, v + 6, (int32_t)(t + side), pk[side]);
+		}
+		for (size_t i = 0; i < n_pts; ++i)
+		{
+			const double* p = pts + 3 * i;
+			const ApproxLane a = make_approx_lane(p[0] - origin[0], p[1] - origin[1], p[2] - origin[2], l1);
+			if (!(a.E < __builtin_inff()))
+				continue;
+			const f2 q = tri_approx_pair(&rec.f[0][0], a);
+			for (int side = 0; side < 2; ++side)
+			{
+				if (rec.valid[side] != 1)
+					continue;
+				const double d2 = tri_closest<false>(pk[side], p[0], p[1], p[2]).d2;
+				const float qs = side ? q.y : q.x;
+				for (double scale : {1.0, 100.0, 0.01})
+				{
+					float theta, kappa;
+					approx_err_terms(a.E, (float)(d2 * scale * scale), &theta, &kappa);
+					const float err = __builtin_fmaf(qs, theta, kappa);
+					const float lo = qs - err, up = qs + err;
+					++n;
+					if (!((double)lo <= d2 && d2 <= (double)up))
+					{
+						++bad;
+						if (getenv("EMU_FILTER_DEBUG") && scale == 1.0)
+						{
+							const double* v = tri + 9 * (t + side);
+							double e0[3], e1[3], e2[3];
+							for (int d = 0; d < 3; ++d) { e0[d] = v[3+d]-v[d]; e1[d] = v[6+d]-v[d]; e2[d] = v[6+d]-v[3+d]; }
+							auto len = [](const double* e) { return std::sqrt(e[0]*e[0]+e[1]*e[1]+e[2]*e[2]); };
+							const double n0 = e0[1]*e1[2]-e0[2]*e1[1], n1 = e0[2]*e1[0]-e0[0]*e1[2], n2 = e0[0]*e1[1]-e0[1]*e1[0];
+							const double area2 = std::sqrt(n0*n0+n1*n1+n2*n2);
+							fprintf(stderr, "viol q %.9g d2 %.17g err %.3g E %.3g sides %.3g %.3g %.3g area2/lmax^2 %.3g |p-o| %.3g\n", (double)qs, d2, (double)err, (double)a.E,
+									len(e0), len(e1), len(e2), area2 / std::pow(std::max(len(e0), std::max(len(e1), len(e2))), 2), std::fabs(p[0]-origin[0])+std::fabs(p[1]-origin[1])+std::fabs(p[2]-origin[2]));
+						}
+					}
+					if (scale == 1.0)
+						w = std::max(w, std::fabs((double)qs - d2) / (double)err);
+				}
+			}
+		}
+	}
+	*worst = w;
+	*checked = n;
+	return bad;
 }
 
 uint64_t emu_shard_count(const uint32_t res[3], int rank, int nranks) { return shard_count(res, rank, nranks); }

@@ -268,3 +268,71 @@ def test_host_point_query_nan_point():
     em = emu.EmuMesh(V, F)
     d, tri, ent, _ = em.host_signed_distance(np.array([[np.nan, 0.0, 0.0], [0.0, 0.0, 0.0]]), full=True)
     assert d[0] == np.finfo(np.float64).max and tri[0] == -1 and d[1] == -1.0
+
+
+# ---- filtered K1 kernel (k_sample_fast): float filter + per-lane candidates + in-wave exact fallback ------------
+def test_filtered_kernel_equals_exact_kernel_and_counts_its_paths():
+    """Same bits with and without the filtered kernel, on lattices (heavy bricks parked with seed bounds
+    included) and on point batches; the statistics show that the float filter really carried the work."""
+    V, F = T.icosphere(12)
+    dom = T.oracle_default_domain(V)
+    res = [21, 18, 24]
+    em = emu.EmuMesh(V, F)
+    try:
+        emu.set_fast(0)
+        a = em.sample_range(dom, res)
+        emu.set_fast(1)
+        b = em.sample_range(dom, res)
+        st = emu.fast_stats()
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(b, T.OracleMesh(V, F).sample_nodes(dom, res))
+        assert st["bricks"] > 0 and st["tri_pairs"] > 0 and st["lanes"] > 0.9 * len(a) * 0.9
+        assert st["sum_list"] >= st["lanes"]          # every lane ends with at least one candidate
+        emu.set_heavy(256, 3)                          # almost every brick is parked: seeds, not triangles
+        emu.set_fast(1)
+        c = em.sample_range(dom, res)
+        assert emu.fast_stats()["parked"] > 0
+        np.testing.assert_array_equal(a, c)
+    finally:
+        emu.set_heavy()
+        emu.set_fast(1)
+
+
+def test_filtered_kernel_fallbacks_degenerate_triangles_and_far_points():
+    """What the float filter cannot serve gets the exact traversal in the same wave: degenerate triangles
+    (zero area, duplicated vertices), points whose coordinates leave the filter's range (1e20) next to
+    ordinary points, NaN points."""
+    V, F = T.icosphere(5)
+    V = np.vstack([V, V[3] + [0, 0, 0.25], V[3] + [0, 0, 0.5]])
+    n = len(V)
+    F2 = np.vstack([F, [[3, n - 2, n - 1]], [[7, 7, 9]], [[n - 1, n - 2, 3]]]).astype(np.uint32)  # collinear, duplicate vertex
+    om, em = T.OracleMesh(V, F2), emu.EmuMesh(V, F2)
+    rng = np.random.default_rng(9)
+    P = rng.uniform(-1.6, 1.6, size=(1500, 3))
+    P[::97] *= 1.0e20
+    emu.set_fast(1)
+    got = em.signed_distance(P)
+    st = emu.fast_stats()
+    want = om.signed_distance(P)
+    np.testing.assert_array_equal(np.abs(got), np.abs(want))
+    assert st["redo_bricks"] > 0                       # the fallback ran
+    dom = T.oracle_default_domain(V)
+    emu.set_fast(1)
+    np.testing.assert_array_equal(np.abs(em.sample_range(dom, [9, 11, 8])), np.abs(om.sample_nodes(dom, [9, 11, 8])))
+    assert emu.fast_stats()["redo_bricks"] > 0
+    Q = P[:130].copy()
+    Q[5] = np.nan
+    emu.set_fast(1)
+    d = em.signed_distance(Q)
+    assert d[5] == DBL_MAX
+    np.testing.assert_array_equal(np.abs(np.delete(d, 5)), np.abs(np.delete(want[:130], 5)))
+
+
+def test_float_filter_interval_contains_the_double_value():
+    """The error analysis of dg_geom.h on random and adversarial inputs: needles, slivers, points near
+    sides / vertices, far points, large offsets from the origin -- checked with the product's own code
+    through the emulator (a violated interval would make the filtered kernel drop the true winner)."""
+    rng = np.random.default_rng(21)
+    worst = emu.filter_interval_check(rng, n_tri=4000, n_pts=64)
+    assert worst["violations"] == 0, worst
+    assert worst["checked"] > 200000

@@ -7,8 +7,11 @@ import pytest
 import dgtest as T
 from test_edge_cases import meshes
 
+from conftest import k1_variant_fixture
+
 pytestmark = pytest.mark.gpu
 DBL_MAX = np.finfo(np.float64).max
+k1_variant = k1_variant_fixture()
 
 
 @pytest.fixture(scope="module")

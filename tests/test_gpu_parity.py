@@ -13,9 +13,12 @@ import pytest
 
 import dgtest as T
 
+from conftest import k1_variant_fixture
+
 pytestmark = pytest.mark.gpu
 DBL_MAX = np.finfo(np.float64).max
 TOL = 1e-10
+k1_variant = k1_variant_fixture()
 MESHES = {"box": T.box_mesh, "ico8": lambda: T.icosphere(8), "torus": T.torus, "bunny": T.bunny_mesh}
 
 

@@ -42,7 +42,8 @@ for i in (1, 2, 3):
         if q:
             for r in c.execute(q):
                 if "k_sample" in str(r[0]) or "k_heavy" in str(r[0]):
-                    print("%-40s %-28s %16.6g %4d" % (str(r[0]).split("::")[-1][:40], r[1], r[2], r[3]))
+                    nm = "k_sample_fast" if "k_sample_fast" in str(r[0]) else ("k_heavy_subtrees" if "subtrees" in str(r[0]) else ("k_heavy_finish" if "finish" in str(r[0]) else "k_sample_nodes"))
+                    print("%-20s %-28s %16.6g %4d" % (nm, r[1], r[2], r[3]))
         else:
             print("# tables:", tabs)
 PY
