@@ -89,6 +89,8 @@ SYMBOLS = {
     "dg_field_destroy": (None, [C.c_void_p]),
     "dg_field_build_cell_major": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_field_drop_cell_major": (C.c_int, [C.c_void_p]),
+    "dg_field_build_tile_major": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dg_field_drop_tile_major": (C.c_int, [C.c_void_p]),
     "dg_interpolate_batch": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _dp]),
     "dg_interpolate_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
@@ -368,6 +370,12 @@ class Field:
 
     def drop_cell_major(self):
         _check(self._lib.dg_field_drop_cell_major(self.handle))
+
+    def build_tile_major(self, stream=0):
+        _check(self._lib.dg_field_build_tile_major(self.handle, C.c_void_p(stream)))
+
+    def drop_tile_major(self):
+        _check(self._lib.dg_field_drop_tile_major(self.handle))
 
     def interpolate(self, points, grad=False):
         P = _f64(points).reshape(-1, 3)

@@ -342,6 +342,8 @@ dg::FieldDev host_field(Eigen::AlignedBox3d const& dom, std::array<unsigned int,
 	F.cells = cells.empty() ? nullptr : cells[0].data();
 	F.cell_map = map.empty() ? nullptr : map.data();
 	F.cell_major = nullptr;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
 	return F;
 }
 } // namespace

@@ -47,6 +47,9 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 	f->dev.cells = d_cells;
 	f->dev.cell_map = d_cell_map;
 	f->dev.cell_major = nullptr;
+	f->dev.tile_major = nullptr;
+	for (int d = 0; d < 3; ++d)
+		f->dev.ntile[d] = (f->dev.res[d] + dg::kTmCells - 1) / dg::kTmCells;
 	f->grid = *grid;
 	f->n_coeffs = n_coeffs;
 	f->n_rows = (d_cells || d_cell_map) ? n_cell_rows : dg_grid_n_cells(grid);
@@ -122,12 +125,15 @@ void dg_field_destroy(dg_field* f)
 			(void)hipFree(p);
 	if (f->d_cell_major)
 		(void)hipFree(f->d_cell_major);
+	if (f->d_tile_major)
+		(void)hipFree(f->d_tile_major);
 	if (f->cell_major_ready)
 		(void)hipEventDestroy(f->cell_major_ready);
 	for (auto& kv : f->wtabs)
 		(void)hipFree(kv.second);
 	f->scratch.destroy();
 	f->flag_scratch.destroy();
+	f->tile_scratch.destroy();
 	if (f->bin_flag_host) (void)hipHostFree(f->bin_flag_host);
 	delete f;
 }
@@ -159,6 +165,52 @@ dg_status dg_field_build_cell_major(dg_field* field, void* stream)
 	}
 	field->d_cell_major = p;
 	field->dev.cell_major = static_cast<const double*>(p);
+	return DG_OK;
+}
+
+dg_status dg_field_build_tile_major(dg_field* field, void* stream)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (field->d_tile_major)
+		return DG_OK;
+	if (field->dev.cells != nullptr || field->dev.cell_map != nullptr)
+		return fail(DG_ERR_INVALID, "the tile-major copy exists for unreduced fields only");
+	DG_ON_DEVICE_OF(field);
+	const uint64_t n_tiles = (uint64_t)field->dev.ntile[0] * field->dev.ntile[1] * field->dev.ntile[2];
+	void* p = nullptr;
+	hipError_t e = hipMalloc(&p, n_tiles * dg::kTmNodes * sizeof(double));
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "tile-major allocation of %llu bytes: %s",
+					(unsigned long long)(n_tiles * dg::kTmNodes * sizeof(double)), hipGetErrorString(e));
+	if (!field->cell_major_ready)
+		e = hipEventCreateWithFlags(&field->cell_major_ready, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = dg::launch_expand_tiles(field->dev, n_tiles, static_cast<double*>(p), static_cast<hipStream_t>(stream));
+	if (e == hipSuccess)
+		e = hipEventRecord(field->cell_major_ready, static_cast<hipStream_t>(stream)); // (one event serves both copies: launches wait for the later build)
+	if (e != hipSuccess)
+	{
+		(void)hipFree(p);
+		return fail(DG_ERR_HIP, "k_expand_tiles: %s", hipGetErrorString(e));
+	}
+	field->d_tile_major = p;
+	field->dev.tile_major = static_cast<const double*>(p);
+	return DG_OK;
+}
+
+dg_status dg_field_drop_tile_major(dg_field* field)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (field->d_tile_major)
+	{
+		DG_ON_DEVICE_OF(field);
+		DG_HIP(hipDeviceSynchronize());
+		(void)hipFree(field->d_tile_major);
+		field->d_tile_major = nullptr;
+		field->dev.tile_major = nullptr;
+	}
 	return DG_OK;
 }
 
@@ -284,7 +336,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		return DG_OK;
 	DG_ON_DEVICE_OF(sdf);
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	if (sdf->d_cell_major && sdf->cell_major_ready)
+	if ((sdf->d_cell_major || sdf->d_tile_major) && sdf->cell_major_ready)
 		DG_HIP(hipStreamWaitEvent(st, sdf->cell_major_ready, 0));
 	dg::DensityParams P;
 	std::vector<double> w;
@@ -329,7 +381,29 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		P.skip_mode = 2;
 		P.unsafe = static_cast<const uint32_t*>(d_flag);
 	}
-	const hipError_t e = dg::launch_density_bricks(L, sdf->dev, sdf->n_coeffs, P, st);
+	// Unreduced field without a tile-major copy: build one for this launch (stream-ordered scratch, built from
+	// the coefficients as they are NOW -- an attached device array may have changed since the last call).  One
+	// pass over the field against 1 + 4096 interpolations per integrated node: 128^3 161 -> 135 ms
+	// (DG_K3_TILES=0: off).  Launches over a small part of the lattice are not worth the pass.
+	dg::FieldDev dev = sdf->dev;
+	int tile_idx = -1;
+	if (dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
+		env_int("DG_K3_TILES", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
+	{
+		const uint64_t n_tiles = (uint64_t)dev.ntile[0] * dev.ntile[1] * dev.ntile[2];
+		void* d_tiles = nullptr;
+		tile_idx = sdf->tile_scratch.acquire(n_tiles * dg::kTmNodes * sizeof(double), st, &d_tiles);
+		if (tile_idx >= 0)
+		{
+			const hipError_t te = dg::launch_expand_tiles(dev, n_tiles, static_cast<double*>(d_tiles), st);
+			if (te == hipSuccess)
+				dev.tile_major = static_cast<const double*>(d_tiles);
+			else
+				(void)hipGetLastError(); // without the copy then
+		}
+	}
+	const hipError_t e = dg::launch_density_bricks(L, dev, sdf->n_coeffs, P, st);
+	sdf->tile_scratch.release(tile_idx, st);
 	sdf->flag_scratch.release(flag_idx, st);
 	DG_HIP(e);
 	return DG_OK;
@@ -344,7 +418,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 		return DG_OK;
 	DG_ON_DEVICE_OF(field);
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	if (field->d_cell_major && field->cell_major_ready) // the copy may still be being built on another stream
+	if ((field->d_cell_major || field->d_tile_major) && field->cell_major_ready) // the copy may still be being built on another stream
 		DG_HIP(hipStreamWaitEvent(st, field->cell_major_ready, 0));
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and

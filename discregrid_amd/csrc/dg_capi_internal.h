@@ -124,8 +124,10 @@ struct dg_field
 {
 	dg::FieldDev dev;
 	mutable ScratchPool scratch; // K2 query binning
+	mutable ScratchPool tile_scratch; // K3: per-launch tile-major copy of an unreduced field
 	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	void* owned[3] = {nullptr, nullptr, nullptr};
+	void* d_tile_major = nullptr;
 	void* d_cell_major = nullptr;
 	hipEvent_t cell_major_ready = nullptr; // recorded behind k_expand_cells: launches on other streams wait for it
 	mutable ScratchPool flag_scratch;     // K3: the flag word k_field_check writes, one per launch in flight

@@ -136,7 +136,7 @@ DG_HD Axis1D axis_eval(const FieldDev& F, int d, double y)
 // the reference's i, j, k order (gauss_quadrature.cpp:5941-5958).  Unreduced fields take the
 // staged path (per-axis work hoisted out of the inner loops); reduced fields go through
 // interpolate_point().  Both produce the same bits (tests/test_density_map.py).
-template <bool STAGED>
+template <bool STAGED, int MODE>
 DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const double x[3])
 {
 	const double NOVAL = 1.7976931348623157e308;
@@ -176,29 +176,7 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 					{
 						const uint32_t ci = F.res[1] * F.res[0] * az.mi + F.res[0] * ay.mi + ax.mi;
 						double cf[32];
-						if (F.cell_major)
-						{
-							const double* row = F.cell_major + 32 * (size_t)ci;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-							for (int q = 0; q < 32; ++q)
-								cf[q] = row[q];
-						}
-						else
-						{
-							uint32_t idx[32];
-							cell_node_indices(ax.mi, ay.mi, az.mi, F.res, idx);
-#if defined(__HIP__)
-#pragma unroll
-#endif
-							for (int q = 0; q < 32; q += 2)
-							{
-								const double* pr = F.coeffs + idx[q]; // adjacent pair: one 16-byte load
-								cf[q] = pr[0];
-								cf[q + 1] = pr[1];
-							}
-						}
+						fetch_cell<MODE>(F, ax.mi, ay.mi, az.mi, ci, cf);
 						const double mz = az.m, pz = az.p;
 						const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
 						// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
@@ -255,7 +233,7 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 				else
 				{
 					const double y[3] = {yx, yy, yz};
-					d = interpolate_point<false>(F, y, g);
+					d = interpolate_point_mode<false, MODE>(F, y, g);
 				}
 				const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
 				res += wijk * (gamma * P.wtab[(i * 16 + j) * 16 + k]);
@@ -265,11 +243,17 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 	res *= P.c0prod;
 	return P.rho0 * res;
 }
+// runtime dispatch (emulator); the kernels are instantiated per (staged, mode)
 DG_HD double density_integral(const FieldDev& F, const DensityParams& P, const double x[3])
 {
-	if ((F.cells == nullptr) && (F.cell_map == nullptr))
-		return density_integral_t<true>(F, P, x);
-	return density_integral_t<false>(F, P, x);
+	const bool unreduced = (F.cells == nullptr) && (F.cell_map == nullptr);
+	switch (field_mode(F))
+	{
+	case kFieldTileMajor: return density_integral_t<true, kFieldTileMajor>(F, P, x); // (unreduced fields only)
+	case kFieldCellMajor: return unreduced ? density_integral_t<true, kFieldCellMajor>(F, P, x) : density_integral_t<false, kFieldCellMajor>(F, P, x);
+	case kFieldTable: return density_integral_t<false, kFieldTable>(F, P, x);
+	default: return unreduced ? density_integral_t<true, kFieldClosed>(F, P, x) : density_integral_t<false, kFieldClosed>(F, P, x);
+	}
 }
 
 } // namespace dg

@@ -241,6 +241,8 @@ hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream);
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, uint64_t n_coeffs, const DensityParams& p,
 								 hipStream_t stream);
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
+// f.ntile must be set; d_out: n_tiles * kTmNodes doubles
+hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_out, hipStream_t stream);
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 							  hipStream_t stream);
 
@@ -257,6 +259,46 @@ struct TileGrid // uniform grid of tiles the points are binned into (points outs
 	uint32_t dims[3];
 };
 inline uint32_t tile_count(const TileGrid& g) { return g.dims[0] * g.dims[1] * g.dims[2]; }
+// Sort key of a tile.  DG_SORT_MORTON=1 (default): the bits of the three tile coordinates interleaved (each axis
+// contributes as many bits as its extent needs), so that consecutive keys are spatial neighbours at every
+// scale -- tiles that follow each other in the processing order share coefficient lines in y and z as well
+// as in x; 0: row-major (x fastest), the first design.
+#ifndef DG_SORT_MORTON
+#define DG_SORT_MORTON 1
+#endif
+inline uint32_t axis_bits(uint32_t dim)
+{
+	uint32_t b = 0;
+	while (b < 31 && (1u << b) < dim)
+		++b;
+	return b;
+}
+// number of significant key bits (what the radix sort has to look at)
+inline uint32_t tile_key_bits(const TileGrid& g)
+{
+#if DG_SORT_MORTON
+	const uint32_t b = axis_bits(g.dims[0]) + axis_bits(g.dims[1]) + axis_bits(g.dims[2]);
+#else
+	const uint32_t b = axis_bits(tile_count(g));
+#endif
+	return b < 1 ? 1 : (b > 32 ? 32 : b);
+}
+DG_HD uint32_t tile_key(const uint32_t dims[3], const uint32_t t[3])
+{
+#if DG_SORT_MORTON
+	uint32_t key = 0, pos = 0;
+	for (uint32_t b = 0; b < 11; ++b) // at most 2^11 tiles per axis fit 32 key bits with three full axes; fewer bits on short axes
+		for (int d = 0; d < 3; ++d)
+			if ((dims[d] - 1u) >> b) // axis d still has bit b
+			{
+				key |= ((t[d] >> b) & 1u) << (pos & 31u);
+				++pos;
+			}
+	return key;
+#else
+	return (t[2] * dims[1] + t[1]) * dims[0] + t[0];
+#endif
+}
 // The points are ordered by a radix sort of (tile, index) pairs (rocPRIM).  Two decisions are
 // involved: whether the batch is unordered at all -- taken exactly, on the device, by a probe of the
 // first points (flag) -- and whether the sort is launched, which only the host can decide and which it

@@ -721,8 +721,14 @@ static uint32_t k2_grid(uint64_t n)
 	return (blocks + round - 1) / round * round;
 }
 
-template <bool GRAD>
-__global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+// Occupancy matters more than anything else for this gather-latency bound kernel: left alone the compiler keeps all
+// 32 coefficients AND all 32 shape functions in registers (132 / 154 VGPRs, 3 waves per SIMD); asked for more
+// waves it forms the shape functions where they are consumed.
+#ifndef DG_K2_WAVES
+#define DG_K2_WAVES 3
+#endif
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
 													  double* __restrict__ phi_out, double* __restrict__ grad_out)
 {
 	uint32_t blk;
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(256) void k_interpolate(const FieldDev F, const dou
 		return;
 	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
 	double g[3];
-	phi_out[gid] = interpolate_point<GRAD>(F, x, g);
+	phi_out[gid] = interpolate_point_mode<GRAD, MODE>(F, x, g);
 	if (GRAD)
 	{
 		grad_out[3 * gid] = g[0];
@@ -753,7 +759,7 @@ __device__ __forceinline__ uint32_t tile_of(const TileGrid& G, const double* __r
 		uint32_t c = u > 0.0 ? (uint32_t)(u < 4.0e9 ? u : 4.0e9) : 0u; // NaN -> 0
 		t[d] = c < G.dims[d] ? c : G.dims[d] - 1;
 	}
-	return (t[2] * G.dims[1] + t[1]) * G.dims[0] + t[0];
+	return tile_key(G.dims, t);
 }
 // one block: how often do consecutive queries (among the first 4096) change tile?
 __global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S, uint32_t one_in)
@@ -784,8 +790,8 @@ __global__ __launch_bounds__(256) void k_bin_keys(const TileGrid F, const double
 		S.vals[i] = (uint32_t)i;
 	}
 }
-template <bool GRAD>
-__global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
 															 double* __restrict__ phi_out, double* __restrict__ grad_out, BinScratch S)
 {
 	uint32_t blk;
@@ -798,7 +804,7 @@ __global__ __launch_bounds__(256) void k_interpolate_binned(const FieldDev F, co
 		gid = S.perm[gid];
 	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
 	double g[3];
-	phi_out[gid] = interpolate_point<GRAD>(F, x, g);
+	phi_out[gid] = interpolate_point_mode<GRAD, MODE>(F, x, g);
 	if (GRAD)
 	{
 		grad_out[3 * gid] = g[0];
@@ -832,12 +838,29 @@ __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t
 		o[j] = F.coeffs[idx[j]];
 }
 
+// Builds the tile-major copy of an unreduced field (dg_lattice.h): one thread per slot, one block row per tile;
+// reads are gathers from the reference layout (each node is read by at most 8 tiles), writes are contiguous.
+__global__ __launch_bounds__(256) void k_expand_tiles(const FieldDev F, uint64_t n_tiles, double* __restrict__ out)
+{
+	const uint64_t total = n_tiles * kTmNodes;
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const uint64_t tile = e / kTmNodes;
+		const uint32_t slot = (uint32_t)(e - tile * kTmNodes);
+		const uint32_t ti = (uint32_t)(tile % F.ntile[0]);
+		const uint32_t tj = (uint32_t)((tile / F.ntile[0]) % F.ntile[1]);
+		const uint32_t tk = (uint32_t)(tile / ((uint64_t)F.ntile[0] * F.ntile[1]));
+		const uint32_t node = tile_slot_node(slot, ti, tj, tk, F.res);
+		out[e] = node == 0xffffffffu ? 0.0 : F.coeffs[node];
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: SPH boundary density map (GenerateDensityMap).  One wave = one 4x4x4 brick of lattice nodes
 // (K1's decomposition), so the 64 lanes evaluate the SDF in a 3x3x3-cell neighbourhood at every
 // quadrature step and the 256-byte coefficient rows they read stay in L1.  Lanes whose node is
 // rejected or beyond 2h idle; waves without an active lane exit at once.
-template <bool STAGED>
+template <bool STAGED, int MODE>
 __global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const SampleParams L, const FieldDev F, const DensityParams P)
 {
 	uint32_t blk;
@@ -855,7 +878,7 @@ __global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const Sample
 		double x[3];
 		node_position(ln.cls, ln.a, ln.b, ln.s, L.dmin, L.cell, x);
 		if (density_prefilter(F, P, x, &v))
-			v = density_integral_t<STAGED>(F, P, x);
+			v = density_integral_t<STAGED, MODE>(F, P, x);
 	}
 	L.out[ln.out_idx] = v;
 }
@@ -1116,10 +1139,30 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 		hipLaunchKernelGGL(k_field_check, dim3(blocks), dim3(256), 0, stream, f.coeffs, n_coeffs, const_cast<uint32_t*>(p.unsafe));
 	}
 	static_assert(kWavesPerBlock == 1, "k_density_bricks assumes one brick per block");
-	if (f.cells == nullptr && f.cell_map == nullptr) // unreduced field: staged evaluator
-		hipLaunchKernelGGL(k_density_bricks<true>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
-	else
-		hipLaunchKernelGGL(k_density_bricks<false>, dim3(layout.blocks_per_xcd * 8u), dim3(64), 0, stream, layout, f, p);
+	const dim3 grid(layout.blocks_per_xcd * 8u), block(64);
+	const bool unreduced = f.cells == nullptr && f.cell_map == nullptr; // staged evaluator
+	switch (field_mode(f))
+	{
+	case kFieldTileMajor: hipLaunchKernelGGL((k_density_bricks<true, kFieldTileMajor>), grid, block, 0, stream, layout, f, p); break;
+	case kFieldCellMajor:
+		if (unreduced) hipLaunchKernelGGL((k_density_bricks<true, kFieldCellMajor>), grid, block, 0, stream, layout, f, p);
+		else hipLaunchKernelGGL((k_density_bricks<false, kFieldCellMajor>), grid, block, 0, stream, layout, f, p);
+		break;
+	case kFieldTable: hipLaunchKernelGGL((k_density_bricks<false, kFieldTable>), grid, block, 0, stream, layout, f, p); break;
+	default:
+		if (unreduced) hipLaunchKernelGGL((k_density_bricks<true, kFieldClosed>), grid, block, 0, stream, layout, f, p);
+		else hipLaunchKernelGGL((k_density_bricks<false, kFieldClosed>), grid, block, 0, stream, layout, f, p);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_out, hipStream_t stream)
+{
+	if (n_tiles == 0)
+		return hipSuccess;
+	const uint64_t total = n_tiles * kTmNodes;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_expand_tiles, dim3(blocks), dim3(256), 0, stream, f, n_tiles, d_out);
 	return hipGetLastError();
 }
 
@@ -1170,7 +1213,7 @@ size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles)
 {
 	size_t bytes = 0;
 	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-									(uint32_t*)nullptr, (size_t)n, 0u, key_bits(n_tiles), (hipStream_t) nullptr);
+									(uint32_t*)nullptr, (size_t)n, 0u, 32u, (hipStream_t) nullptr); // (all 32 bits: an upper bound for any key width)
 	return bytes;
 }
 // the binning passes shared by K2 and K1p: probe (always), and -- if the host predicts an unordered batch
@@ -1184,7 +1227,7 @@ static hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& ti
 	hipLaunchKernelGGL(k_bin_keys, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
 	size_t bytes = S.sort_tmp_bytes;
 	const hipError_t e = rocprim::radix_sort_pairs(S.sort_tmp, bytes, (const uint32_t*)S.keys, S.keys_out, (const uint32_t*)S.vals, S.perm,
-												  (size_t)n, 0u, key_bits(tile_count(tiles)), stream);
+												  (size_t)n, 0u, tile_key_bits(tiles), stream);
 	return e != hipSuccess ? e : hipGetLastError();
 }
 
@@ -1232,10 +1275,19 @@ hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n
 	if (n == 0)
 		return hipSuccess;
 	const uint32_t grid = k2_grid(n);
-	if (d_grad)
-		hipLaunchKernelGGL(k_interpolate<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
-	else
-		hipLaunchKernelGGL(k_interpolate<false>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+#define DG_K2_LAUNCH(MODE)                                                                                                  \
+	if (d_grad)                                                                                                             \
+		hipLaunchKernelGGL((k_interpolate<true, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);      \
+	else                                                                                                                    \
+		hipLaunchKernelGGL((k_interpolate<false, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	switch (field_mode(f))
+	{
+	case kFieldTileMajor: DG_K2_LAUNCH(kFieldTileMajor) break;
+	case kFieldCellMajor: DG_K2_LAUNCH(kFieldCellMajor) break;
+	case kFieldTable: DG_K2_LAUNCH(kFieldTable) break;
+	default: DG_K2_LAUNCH(kFieldClosed)
+	}
+#undef DG_K2_LAUNCH
 	return hipGetLastError();
 }
 
@@ -1249,10 +1301,19 @@ hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uin
 	if (e != hipSuccess)
 		return e;
 	const uint32_t grid = k2_grid(n);
-	if (d_grad)
-		hipLaunchKernelGGL(k_interpolate_binned<true>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
-	else
-		hipLaunchKernelGGL(k_interpolate_binned<false>, dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
+#define DG_K2_LAUNCH(MODE)                                                                                                        \
+	if (d_grad)                                                                                                                   \
+		hipLaunchKernelGGL((k_interpolate_binned<true, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);  \
+	else                                                                                                                          \
+		hipLaunchKernelGGL((k_interpolate_binned<false, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
+	switch (field_mode(f))
+	{
+	case kFieldTileMajor: DG_K2_LAUNCH(kFieldTileMajor) break;
+	case kFieldCellMajor: DG_K2_LAUNCH(kFieldCellMajor) break;
+	case kFieldTable: DG_K2_LAUNCH(kFieldTable) break;
+	default: DG_K2_LAUNCH(kFieldClosed)
+	}
+#undef DG_K2_LAUNCH
 	return hipGetLastError();
 }
 

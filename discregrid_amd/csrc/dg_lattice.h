@@ -201,6 +201,92 @@ DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t 
 		out[m + 1] = out[m] + 1;
 }
 
+// ---- tile-major copy of an unreduced field ------------------------------------------------------------------------
+// The reference's coefficient vector is [V | X | Y | Z] with a different fastest axis per class: the 32
+// coefficients of a cell sit in 16 different cache lines, megabytes apart, and an evaluator that gathers from
+// it pulls a whole 128-byte line into L1 for every 16 bytes it uses (measured: K2 on cell-SORTED queries ran
+// at 0.78 ms per 10 M, bound by L1 fills, not by HBM).  The tile-major copy stores, for every tile of 4x4x4
+// cells, ALL nodes the tile's cells reference -- 5^3 vertex nodes and 3 x 4 x 5 x 5 edges of two nodes = 725
+// doubles, padded to 736 = 46 lines -- contiguously: the queries of one wave, which lie in one or two tiles
+// once a batch is in tile order, hit the same few dozen lines.  Nodes on tile faces are stored once per
+// adjacent tile (1.64 x the field's memory; the cell-major layout costs 4.6 x).  Same values, same
+// arithmetic: bit-identical results.
+static const uint32_t kTmCells = 4;     // tile edge in cells
+static const uint32_t kTmNodes = 736;   // doubles per tile (725 used)
+static const uint32_t kTmX = 125, kTmY = 325, kTmZ = 525; // first slot of the X / Y / Z edge nodes of a tile
+// slots (tile-local) of the 32 nodes of the cell with tile-local coordinates (li, lj, lk), in the order of
+// cell_node_indices(); pairs (2m, 2m+1) are adjacent as there
+DG_HD void tile_node_slots(uint32_t li, uint32_t lj, uint32_t lk, uint32_t out[32])
+{
+	const uint32_t v0 = (lk * 5 + lj) * 5 + li;
+	out[0] = v0;
+	out[2] = v0 + 5;
+	out[4] = v0 + 25;
+	out[6] = v0 + 30;
+	for (int m = 0; m < 8; m += 2)
+		out[m + 1] = out[m] + 1;
+	// X edges (along x, at (j, k)): slot kTmX + 2 ((k 5 + j) 4 + i)
+	out[8] = kTmX + 2 * ((lk * 5 + lj) * 4 + li);
+	out[10] = kTmX + 2 * (((lk + 1) * 5 + lj) * 4 + li);
+	out[12] = kTmX + 2 * ((lk * 5 + lj + 1) * 4 + li);
+	out[14] = kTmX + 2 * (((lk + 1) * 5 + lj + 1) * 4 + li);
+	// Y edges (along y, at (i, k)): slot kTmY + 2 ((i 5 + k) 4 + j)
+	out[16] = kTmY + 2 * ((li * 5 + lk) * 4 + lj);
+	out[18] = kTmY + 2 * (((li + 1) * 5 + lk) * 4 + lj);
+	out[20] = kTmY + 2 * ((li * 5 + lk + 1) * 4 + lj);
+	out[22] = kTmY + 2 * (((li + 1) * 5 + lk + 1) * 4 + lj);
+	// Z edges (along z, at (j, i)): slot kTmZ + 2 ((j 5 + i) 4 + k)
+	out[24] = kTmZ + 2 * ((lj * 5 + li) * 4 + lk);
+	out[26] = kTmZ + 2 * (((lj + 1) * 5 + li) * 4 + lk);
+	out[28] = kTmZ + 2 * ((lj * 5 + li + 1) * 4 + lk);
+	out[30] = kTmZ + 2 * (((lj + 1) * 5 + li + 1) * 4 + lk);
+	for (int m = 8; m < 32; m += 2)
+		out[m + 1] = out[m] + 1;
+}
+// global node index (reference order) stored in slot `slot` of tile (ti, tj, tk); 0xffffffff for padding slots
+// and for nodes beyond the lattice (tiles that stick out of a resolution that is no multiple of 4)
+DG_HD uint32_t tile_slot_node(uint32_t slot, uint32_t ti, uint32_t tj, uint32_t tk, const uint32_t res[3])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	const uint32_t i0 = ti * kTmCells, j0 = tj * kTmCells, k0 = tk * kTmCells;
+	if (slot < kTmX)
+	{
+		const uint32_t a = slot % 5, b = (slot / 5) % 5, c = slot / 25;
+		const uint32_t i = i0 + a, j = j0 + b, k = k0 + c;
+		if (i > nx || j > ny || k > nz)
+			return 0xffffffffu;
+		return (nx + 1) * (ny + 1) * k + (nx + 1) * j + i;
+	}
+	if (slot >= 725)
+		return 0xffffffffu;
+	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
+	const uint32_t nex = nx * (ny + 1) * (nz + 1);
+	const uint32_t ney = (nx + 1) * ny * (nz + 1);
+	const uint32_t cls = slot < kTmY ? 0u : (slot < kTmZ ? 1u : 2u);
+	const uint32_t e = (slot - (cls == 0 ? kTmX : (cls == 1 ? kTmY : kTmZ)));
+	const uint32_t sub = e & 1u, q = e >> 1; // q = (s2 5 + s1) 4 + s0
+	const uint32_t s0 = q % 4, s1 = (q / 4) % 5, s2 = q / 20;
+	if (cls == 0) // X: s0 = i, s1 = j, s2 = k
+	{
+		const uint32_t i = i0 + s0, j = j0 + s1, k = k0 + s2;
+		if (i >= nx || j > ny || k > nz)
+			return 0xffffffffu;
+		return nv + 2 * (nx * (ny + 1) * k + nx * j + i) + sub;
+	}
+	if (cls == 1) // Y: s0 = j, s1 = k, s2 = i
+	{
+		const uint32_t j = j0 + s0, k = k0 + s1, i = i0 + s2;
+		if (i > nx || j >= ny || k > nz)
+			return 0xffffffffu;
+		return nv + 2 * nex + 2 * (ny * (nz + 1) * i + ny * k + j) + sub;
+	}
+	// Z: s0 = k, s1 = i, s2 = j
+	const uint32_t k = k0 + s0, i = i0 + s1, j = j0 + s2;
+	if (i > nx || j > ny || k >= nz)
+		return 0xffffffffu;
+	return nv + 2 * nex + 2 * ney + 2 * (nz * (nx + 1) * j + nz * i + k) + sub;
+}
+
 // ---- K2 per-query body -------------------------------------------------------------------------------
 // Host or device arrays, same code (the C++ host API evaluates single points with it).
 struct FieldDev
@@ -216,15 +302,75 @@ struct FieldDev
 	// for a gather-free evaluator: one query reads 256 contiguous bytes instead of 16 scattered
 	// 16-byte segments in 16 different lines.
 	const double* cell_major;
+	// Optional tile-major copy of an UNREDUCED field (see above): kTmNodes doubles per tile of 4^3 cells,
+	// tiles in x-fastest order, ntile[d] = ceil(res[d] / 4).
+	const double* tile_major;
+	uint32_t ntile[3];
 };
+// Where the 32 coefficients of a cell come from (FieldDev): the kernels are instantiated per mode, so that each
+// has ONE load sequence (a runtime switch makes the compiler merge the variants into 32 separate 8-byte loads).
+enum FieldMode : int
+{
+	kFieldClosed = 0,    // unreduced field, closed-form node indices into the reference layout: 16 x 16-byte pairs
+	kFieldTable = 1,     // cell table (reduced / loaded fields): 32 indexed 8-byte loads
+	kFieldCellMajor = 2, // cell-major copy: 256 contiguous bytes
+	kFieldTileMajor = 3, // tile-major copy (unreduced fields): 16 x 16-byte pairs within one 5.9 KB tile
+};
+DG_HD int field_mode(const FieldDev& F)
+{
+	return F.tile_major ? kFieldTileMajor : (F.cell_major ? kFieldCellMajor : (F.cells ? kFieldTable : kFieldClosed));
+}
+template <int MODE>
+DG_HD void fetch_cell(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k, uint32_t row, double cf[32])
+{
+	if (MODE == kFieldCellMajor)
+	{
+		const double* r = F.cell_major + 32 * (size_t)row;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int q = 0; q < 32; ++q)
+			cf[q] = r[q];
+	}
+	else if (MODE == kFieldTable)
+	{
+		const uint32_t* r = F.cells + 32 * (size_t)row;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int q = 0; q < 32; ++q)
+			cf[q] = F.coeffs[r[q]];
+	}
+	else
+	{
+		uint32_t idx[32];
+		const double* base = F.coeffs;
+		if (MODE == kFieldTileMajor)
+		{
+			tile_node_slots(i & 3u, j & 3u, k & 3u, idx);
+			base = F.tile_major + (size_t)kTmNodes * ((size_t)((k >> 2) * F.ntile[1] + (j >> 2)) * F.ntile[0] + (i >> 2));
+		}
+		else
+			cell_node_indices(i, j, k, F.res, idx);
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int m = 0; m < 32; m += 2)
+		{
+			const double* pr = base + idx[m]; // adjacent pair: one 16-byte load
+			cf[m] = pr[0];
+			cf[m + 1] = pr[1];
+		}
+	}
+}
 
 // Per-query body of K2 = CubicLagrangeDiscreteGrid::interpolate(field, x, gradient*)
 // (discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063).  The 32-term sum runs in j order
 // (parity), the 32 coefficients are fetched as 16 adjacent pairs for unreduced fields.  Returns
 // DBL_MAX ("no value") outside the domain, in removed cells, or if a coefficient is DBL_MAX;
 // the gradient is zero in those cases.
-template <bool GRAD>
-DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
+template <bool GRAD, int MODE>
+DG_HD double interpolate_point_mode(const FieldDev& F, const double x[3], double g[3])
 {
 	const double NOVAL = 1.7976931348623157e308;
 	g[0] = g[1] = g[2] = 0.0;
@@ -253,38 +399,7 @@ DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3]
 		xi[d] = c0[d] * x[d] - c1;
 	}
 	double cf[32];
-	if (F.cell_major)
-	{
-		const double* row = F.cell_major + 32 * (size_t)cm;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int j = 0; j < 32; ++j)
-			cf[j] = row[j];
-	}
-	else if (F.cells)
-	{
-		const uint32_t* row = F.cells + 32 * (size_t)cm;
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int j = 0; j < 32; ++j)
-			cf[j] = F.coeffs[row[j]];
-	}
-	else
-	{
-		uint32_t idx[32];
-		cell_node_indices(mi[0], mi[1], mi[2], F.res, idx);
-#if defined(__HIP__)
-#pragma unroll
-#endif
-		for (int m = 0; m < 32; m += 2)
-		{
-			const double* pr = F.coeffs + idx[m]; // adjacent pair: one 16-byte load
-			cf[m] = pr[0];
-			cf[m + 1] = pr[1];
-		}
-	}
+	fetch_cell<MODE>(F, mi[0], mi[1], mi[2], cm, cf);
 	double N[32], dNx[32], dNy[32], dNz[32];
 	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
 	bool ok = true;
@@ -312,6 +427,18 @@ DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3]
 		g[2] = gz * c0[2];
 	}
 	return phi;
+}
+// runtime dispatch (host scalar API, emulator)
+template <bool GRAD>
+DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])
+{
+	switch (field_mode(F))
+	{
+	case kFieldTileMajor: return interpolate_point_mode<GRAD, kFieldTileMajor>(F, x, g);
+	case kFieldCellMajor: return interpolate_point_mode<GRAD, kFieldCellMajor>(F, x, g);
+	case kFieldTable: return interpolate_point_mode<GRAD, kFieldTable>(F, x, g);
+	default: return interpolate_point_mode<GRAD, kFieldClosed>(F, x, g);
+	}
 }
 
 // Morton key of the reference's zValue() / morton_lut() for a node position

@@ -247,6 +247,11 @@ def filter_interval_check(rng, n_tri=2000, n_pts=64):
     return tot
 
 
+def set_tile_major(on=1):
+    """K2 / K3 bodies read unreduced fields through a tile-major copy (dg_lattice.h) built as k_expand_tiles does."""
+    lib().emu_set_tile_major(int(on))
+
+
 def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
     slots = 0 disables the split; the defaults size slots and budget as the product does."""

@@ -1112,6 +1112,25 @@ void emu_unpack_ranks(const uint32_t res[3], int nranks, const double* gathered,
 			field[unpack_dest(U, (uint32_t)r, off)] = gathered[(uint64_t)r * stride + off];
 }
 
+int g_emu_tiles = 0; // 1: emu_interpolate / emu_density_map read an (unreduced) field through a tile-major copy
+void emu_set_tile_major(int on) { g_emu_tiles = on; }
+// the tile-major copy exactly as k_expand_tiles builds it
+static std::vector<double> build_tiles(FieldDev& F)
+{
+	for (int d = 0; d < 3; ++d)
+		F.ntile[d] = (F.res[d] + kTmCells - 1) / kTmCells;
+	const uint64_t n_tiles = (uint64_t)F.ntile[0] * F.ntile[1] * F.ntile[2];
+	std::vector<double> t(n_tiles * kTmNodes);
+	for (uint64_t e = 0; e < t.size(); ++e)
+	{
+		const uint64_t tile = e / kTmNodes;
+		const uint32_t slot = (uint32_t)(e - tile * kTmNodes);
+		const uint32_t node = tile_slot_node(slot, (uint32_t)(tile % F.ntile[0]), (uint32_t)((tile / F.ntile[0]) % F.ntile[1]),
+											 (uint32_t)(tile / ((uint64_t)F.ntile[0] * F.ntile[1])), F.res);
+		t[e] = node == 0xffffffffu ? 0.0 : F.coeffs[node];
+	}
+	return t;
+}
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)
@@ -1129,6 +1148,14 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	F.cells = cells;
 	F.cell_map = cell_map;
 	F.cell_major = nullptr;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
+	std::vector<double> tiles;
+	if (g_emu_tiles && !cells && !cell_map)
+	{
+		tiles = build_tiles(F);
+		F.tile_major = tiles.data();
+	}
 #pragma omp parallel for schedule(static)
 	for (long long q = 0; q < (long long)n; ++q)
 	{
@@ -1160,6 +1187,14 @@ void emu_density_map(const double domain[6], const double cell[3], const double 
 	F.cells = cells;
 	F.cell_map = cell_map;
 	F.cell_major = nullptr;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
+	std::vector<double> tiles;
+	if (g_emu_tiles && !cells && !cell_map)
+	{
+		tiles = build_tiles(F);
+		F.tile_major = tiles.data();
+	}
 	DensityParams P;
 	std::vector<double> w;
 	init_density_params(P, h, rho0, cell, band, w);

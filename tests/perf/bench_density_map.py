@@ -39,8 +39,11 @@ def main():
     out = torch.empty(n, dtype=torch.float64, device="cuda")
     h, rho0 = 0.1, 1000.0
     results = {}
-    for layout in ("node-order", "cell-major"):
+    for layout in ("node-order", "tile-major", "cell-major"):
+        if layout == "tile-major":
+            field.build_tile_major(s)
         if layout == "cell-major":
+            field.drop_tile_major()
             field.build_cell_major(s)
         field.density_map_nodes_device(h, rho0, True, 0, n, out.data_ptr(), stream=s)
         torch.cuda.synchronize()

@@ -64,8 +64,15 @@ def main():
     grad = torch.empty((m, 3), dtype=torch.float64, device="cuda")
 
     cases = []
-    for layout in ("node-order gather", "cell-major"):
+    for layout in ("node-order gather", "tile-major", "cell-major"):
+      if layout == "tile-major":
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        field.build_tile_major(s)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
       if layout == "cell-major":
+        field.drop_tile_major()
         t0 = time.perf_counter()
         field.build_cell_major(s)
         torch.cuda.synchronize()
@@ -92,6 +99,9 @@ def main():
             if layout == "cell-major":
                 out["cell_major_build_ms"] = build_ms
                 out["cell_major_bytes"] = 256 * int(np.prod(res))
+            if layout == "tile-major":
+                out["tile_major_build_ms"] = build_ms
+                out["tile_major_bytes"] = 736 * 8 * int(np.prod([(r + 3) // 4 for r in res]))
             cases.append((out, pts, with_grad))
     # parity spot check + CPU baseline on a bounded sample
     coeffs = None

@@ -336,3 +336,33 @@ def test_float_filter_interval_contains_the_double_value():
     worst = emu.filter_interval_check(rng, n_tri=4000, n_pts=64)
     assert worst["violations"] == 0, worst
     assert worst["checked"] > 200000
+
+
+def test_tile_major_copy_is_the_same_field(golden):
+    """The tile-major layout (4^3-cell tiles, 736 doubles each; dg_lattice.h) addresses exactly the reference's
+    nodes: K2 and K3 bodies give the same bits through it, on resolutions that are no multiples of 4 too."""
+    rng = np.random.default_rng(3)
+    try:
+        for res in ([4, 4, 4], [5, 7, 3], [9, 2, 6], [1, 1, 1]):
+            dom = np.array([-1.0, -0.5, 0.0, 1.5, 1.0, 2.0])
+            coeffs = rng.normal(size=T.n_nodes(res))
+            P = rng.uniform(dom[:3] - 0.1, dom[3:] + 0.1, size=(3000, 3))
+            emu.set_tile_major(0)
+            a, ga = emu.interpolate(dom, res, coeffs, P, grad=True)
+            emu.set_tile_major(1)
+            b, gb = emu.interpolate(dom, res, coeffs, P, grad=True)
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(ga, gb)
+            wa, wg = T.oracle_interpolate(dom, res, coeffs, P, grad=True)
+            np.testing.assert_array_equal(b, wa)
+            inside = b != DBL_MAX   # (the oracle leaves the gradient of "no value" queries untouched)
+            np.testing.assert_array_equal(gb[inside], wg[inside])
+        dom, res = golden["ico8_domain"], golden["ico8_res"]
+        coeffs = golden["ico8_coeffs"]
+        emu.set_tile_major(0)
+        d0 = emu.density_map(dom, res, coeffs, 0.1, 1000.0, begin=0, end=600)
+        emu.set_tile_major(1)
+        d1 = emu.density_map(dom, res, coeffs, 0.1, 1000.0, begin=0, end=600)
+        np.testing.assert_array_equal(d0, d1)
+    finally:
+        emu.set_tile_major(0)

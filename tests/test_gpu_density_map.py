@@ -24,7 +24,7 @@ def dg():
 
 @pytest.mark.parametrize("name,res,h,key", [("torus_9_14_6.cdf", [9, 14, 6], 0.15, "torus_density_h015"),
                                              ("torus_16_16_6.cdf", [16, 16, 6], 0.1, "torus16_density_h01")])
-def test_density_map_vs_reference_golden(dg, golden, name, res, h, key):
+def test_density_map_vs_reference_golden(dg, golden, monkeypatch, name, res, h, key):
     g = T.read_cdf(os.path.join(T.GOLDEN, name))
     grid = dg.grid_desc(g["domain"][:3], g["domain"][3:], res)
     f = dg.Field(grid, g["nodes"][0])
@@ -44,6 +44,14 @@ def test_density_map_vs_reference_golden(dg, golden, name, res, h, key):
     assert (m[mask == 0] == DBL_MAX).all()
     f.build_cell_major()
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
+    f.drop_cell_major()
+    f.build_tile_major()     # explicit tile-major copy (the plain launches above built one per launch)
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 777, 2500), want[777:2500])
+    f.drop_tile_major()
+    monkeypatch.setenv("DG_K3_TILES", "0")   # and without any copy
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
+    monkeypatch.delenv("DG_K3_TILES")
     if key == "torus_density_h015":
         np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False), golden["torus_density_h015_nopred"])
 

@@ -213,6 +213,16 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     f.drop_cell_major()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    # tile-major device copy (4^3-cell tiles of 736 doubles): bit-identical results, takes precedence over cell-major
+    f.build_tile_major()
+    phi3, grad3 = f.interpolate(P, grad=True)
+    np.testing.assert_array_equal(phi3, phi)
+    np.testing.assert_array_equal(grad3, grad)
+    f.build_cell_major()
+    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    f.drop_tile_major()
+    f.drop_cell_major()
+    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     # table mode, removed cells, DBL_MAX coefficients
     cells = T.oracle_cell_table(res)
     cmap = np.arange(len(cells), dtype=np.uint32)
@@ -230,6 +240,8 @@ def test_interpolate_vs_golden(dg, golden, name):
     a2, ga2 = f2.interpolate(P, grad=True)
     np.testing.assert_array_equal(a2, a)
     np.testing.assert_array_equal(ga2, ga)
+    with pytest.raises(dg.DiscregridError):
+        f2.build_tile_major()   # unreduced fields only
 
 
 @pytest.mark.parametrize("n_meshes", [1, 2, 3])
