@@ -201,6 +201,34 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "algorithmic_gbs": nq * bytes_q / (ms * 1e-3) / 1e9,
                 "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     k2["what"] = "10 M queries (std::mt19937_64 seed 1234 uniform; |phi| < 2h shell, h = 0.1) on the 256^3 field, device-resident, unordered input incl. the on-device binning"
+    # the same with the optional tile-major copy of the field (dg_field_build_tile_major: 1.5 GB, built once per field)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fld.build_tile_major(s)
+    torch.cuda.synchronize()
+    k2["tile_major_build_ms"] = (time.perf_counter() - t0) * 1e3
+    for name, Q in (("uniform", P), ("shell", S)):
+        if len(Q) < nq:
+            continue
+        fn = (lambda Q=Q: fld.interpolate_device(Q.data_ptr(), nq, phi.data_ptr(), 0, stream=s))
+        fn()
+        ms = timed(torch, stream, fn, 5)
+        k2["%s_value_tile_major" % name] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "hbm_frac_algorithmic": nq * 288 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # queries that arrive sorted by cell (what a caller with spatially sorted particles hands over), plain layout
+    fld.drop_tile_major()
+    h3 = torch.tensor((dom[3:] - dom[:3]) / np.array(res, dtype=np.float64), device="cuda")
+    cell = ((P - torch.tensor(dom[:3], device="cuda")) / h3).floor().clamp(0, res[0] - 1).long()
+    Ps = P[torch.argsort((cell[:, 2] * res[1] + cell[:, 1]) * res[0] + cell[:, 0])].contiguous()
+    del cell
+    for g in (False, True):
+        fn = (lambda g=g: fld.interpolate_device(Ps.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
+        fn()
+        fn()   # (the second call sees the probe's "ordered" verdict of the first and launches no sort)
+        ms = timed(torch, stream, fn, 5)
+        bytes_q = 312 if g else 288
+        k2["uniform_sorted_%s" % ("grad" if g else "value")] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms,
+                                                                "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del Ps
     out_secondary = {"k2_interpolate": k2}
     del P, S, phi, grad
     # -- K3: density map on the same SDF (GenerateDensityMap's node function), whole lattice
@@ -390,8 +418,11 @@ def main():
                 "unit": "fraction of the VALU issue cycles of the %d SIMDs" % N_SIMDS,
                 "frac": k1["valu_busy"] if k1 else None,
                 "traffic": k1["hbm_bytes_per_launch"] if k1 else None,
-                # one dg_sdf_sample_*_device call = k_sample_nodes + the two heavy-brick kernels (3 % of it)
-                "kernel": "k_sample_nodes (+ k_heavy_subtrees, k_heavy_finish)", "kernel_ms": kernel_ms,
+                # one dg_sdf_sample_*_device call = k_sample_fast (the filtered K1 kernel; k_sample_nodes with DG_K1_FAST=0)
+                # + the two heavy-brick kernels (4 % of it); kernel_ms: HIP events around the call, in the timed region
+                "kernel": "%s (+ k_heavy_subtrees, k_heavy_finish)" % ((k1 or {}).get("kernel") or
+                          ("k_sample_nodes" if os.environ.get("DG_K1_FAST") == "0" else "k_sample_fast")),
+                "kernel_ms": kernel_ms,
                 "hbm": {
                     "bound_by_hbm": False,
                     "achieved_gbs": (k1["hbm_bytes_per_launch"] / (k1["kernel_ms"] * 1e-3) / 1e9) if k1 else None,

@@ -322,9 +322,12 @@ struct BinScratch
 #endif
 static const uint32_t kTileCells = DG_TILE_CELLS;
 #ifndef DG_SORT_CELLS
-#define DG_SORT_CELLS 4
+#define DG_SORT_CELLS 1
 #endif
-static const uint32_t kSortCells = DG_SORT_CELLS; // K2 sorts by tiles of kSortCells^3 cells (the probe looks at kTileCells^3)
+// K2 sorts by tiles of kSortCells^3 cells (the probe looks at kTileCells^3).  With Morton keys the finest key costs
+// no extra radix pass up to 256^3 (24 bits = 3 passes, as 18): 10 M uniform queries 7.5 (4^3 tiles) -> 7.9 Gq/s
+// (single cells), shell 8.7 -> 9.4; row-major 4^3 tiles were the round-1 choice (profiles/r02_k2_sort_layout_ab.txt).
+static const uint32_t kSortCells = DG_SORT_CELLS;
 // K2: tiles of cells^3 grid cells
 inline TileGrid field_tiles(const FieldDev& f, uint32_t cells = kTileCells)
 {

@@ -19,7 +19,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["k_sample_nodes", "k_heavy_subtrees", "k_heavy_finish", "k_interpolate_binned", "k_interpolate", "k_bin_probe",
+KERNELS = ["k_sample_fast", "k_sample_nodes", "k_heavy_subtrees", "k_expand_tiles", "k_heavy_finish", "k_interpolate_binned", "k_interpolate", "k_bin_probe",
            "k_bin_keys", "k_density_bricks", "k_field_check", "k_unpack_shards", "k_unpack_ranks", "k_expand_cells"]
 
 
@@ -135,11 +135,13 @@ def main():
             derived.setdefault(w, {})[k] = e
     k1 = None
     if "k1" in derived:
-        for k, e in derived["k1"].items():
-            if k.startswith("k_sample_nodes"):
-                k1 = dict(e)
-                k1["kernel"] = k
-                k1["per_brick"] = e.get("per_wave")
+        # the dominant kernel of a K1 launch: the filtered kernel by default, the exact one with DG_K1_FAST=0
+        for want in ("k_sample_fast", "k_sample_nodes"):
+            for k, e in derived["k1"].items():
+                if k1 is None and k.startswith(want):
+                    k1 = dict(e)
+                    k1["kernel"] = k
+                    k1["per_brick"] = e.get("per_wave")
     out = {"csrc_sha256": csrc_hash(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"), "tag": tag,
            "method": "rocprofv3 --pmc (separate passes) via profiles/collect.sh; HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; "
                      "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 * GRBM_GUI_ACTIVE/8)",
