@@ -503,6 +503,16 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	}
 	for (int d = 0; d < 3; ++d)
 		out.origin[d] = 0.5 * (lo[d] + hi[d]);
+	{
+		double area = 0.0;
+		for (size_t t = 0; t < n_triangles; ++t)
+		{
+			const Prim& p = B.prims[t];
+			const double a = 0.5 * std::sqrt(p.an[0] * p.an[0] + p.an[1] * p.an[1] + p.an[2] * p.an[2]);
+			area += std::isfinite(a) ? a : 0.0;
+		}
+		out.mean_edge = std::sqrt(area / (double)n_triangles * (4.0 / 1.7320508075688772));
+	}
 	B.origin = out.origin;
 	tick("primitives");
 	B.allocate();

@@ -25,6 +25,7 @@ struct MeshBuild
 	std::vector<int32_t> sub_roots; // info words of <= kSubtrees disjoint subtrees covering the tree (level-order cut)
 	double origin[3];               // bounds are relative to this point
 	float mesh_l1 = 0;              // max over vertices of |v - origin|_1, rounded up
+	double mean_edge = 0;           // edge of the equilateral triangle with the mesh's mean triangle area (kernel choice, dg_capi.cpp)
 	uint32_t depth = 0;
 	uint32_t not_watertight = 0;    // bit0 single edge, bit1 edge shared by > 2 faces
 	uint64_t n_vertices = 0, n_triangles = 0;

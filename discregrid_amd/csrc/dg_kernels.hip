@@ -402,14 +402,17 @@ struct FastLane
 	float U;      // upper bound of the lane's minimum d^2; -inf: lane inactive
 	float Uprune; // what bound tests compare with: U (1 + theta) + kappa
 	float Lmin;   // smallest lower value among the listed candidates
-	int cnt;      // listed candidates (<= kFastListCap; == kFastListCap: the list may have overflowed)
+	uint32_t slot; // LDS byte address of the lane's next list entry: base + 256 * listed candidates, capped at
+	               // base + 256 * kFastListCap (a list that reaches the cap may have overflowed)
 };
 // returns -1 (searched to the end), -2 (searched to the end, but a degenerate triangle was met: the lists are
 // incomplete) or the heavy slot the wave claimed
-__device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint16_t* lds_lb, int* lds_list, uint32_t* ovf_count,
-											 uint32_t ovf_slots, int heavy_work)
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint16_t* lds_lb, uint32_t list_base /* f.slot of an empty list */,
+											 uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
 {
 	const int lane_id = (int)__lane_id();
+	const uint32_t list_limit = list_base + 256u * (uint32_t)kFastListCap;
 	int stackv = 0;
 	int sp = 0;
 	int cur = M.root_info;
@@ -473,9 +476,9 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 					{
 						// a candidate; if even its upper value is below every listed lower value, the list is obsolete
 						const bool reset = up_s < f.Lmin;
-						f.cnt = reset ? 0 : f.cnt;
-						lds_list[f.cnt * 64 + lane_id] = first + g + side;
-						f.cnt = min(f.cnt + 1, kFastListCap);
+						f.slot = reset ? list_base : f.slot;
+						*(lds_int_t*)(uintptr_t)f.slot = first + g + side;
+						f.slot = min(f.slot + 256u, list_limit);
 						f.Lmin = fmin_sel(reset ? __builtin_inff() : f.Lmin, lo_s);
 					}
 					f.U = fmin_sel(f.U, up_s);
@@ -553,10 +556,11 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	f.U = (sample && !exact) ? __builtin_inff() : -__builtin_inff();
 	f.Uprune = f.U;
 	f.Lmin = __builtin_inff();
-	f.cnt = 0;
+	const uint32_t list_base = (uint32_t)(uintptr_t)(lds_int_t*)(lds_list + lane); // LDS byte address of the lane's entry 0
+	f.slot = list_base;
 	if (__ballot(sample && !exact) != 0ull)
 	{
-		const int slot = traverse_fast(P.mesh, f, lds_lb16, lds_list, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
+		const int slot = traverse_fast(P.mesh, f, lds_lb16, list_base, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);
 		if (slot >= 0) // heavy brick: park the lanes' upper bounds as seeds, k_heavy_subtrees / k_heavy_finish take over
 		{
 			if (lane == 0)
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 			return;
 		}
 		// a degenerate triangle was met: nobody's list is complete
-		exact = exact || (sample && (slot == -2 || f.cnt >= kFastListCap));
+		exact = exact || (sample && (slot == -2 || f.slot >= list_base + 256u * (uint32_t)kFastListCap));
 	}
 	const LaneTask t = lane_task<POINTS>(P, brick, lane);
 	LaneQuery q;
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	const int ex_tri = q.best_tri;
 	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
-	const int n_cand = (sample && !exact) ? f.cnt : 0;
+	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
 	for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
 	{
 		if (k < n_cand)
