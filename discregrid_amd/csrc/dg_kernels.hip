@@ -597,6 +597,10 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
 	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
+#ifdef DG_EXPERIMENT_SKIP_EPILOGUE // timing experiment only (wrong results): how much of the kernel is the candidate loop?
+	if (n_cand > 0)
+		offer(q, 1.0, lds_list[lane]);
+#else
 	for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
 	{
 		if (k < n_cand)
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 			offer(q, h.d2, tri);
 		}
 	}
+#endif
 	if (exact)
 	{
 		q.best_d2 = ex_d2;
