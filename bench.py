@@ -223,7 +223,9 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
     for g in (False, True):
         fn = (lambda g=g: fld.interpolate_device(Ps.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
         fn()
-        fn()   # (the second call sees the probe's "ordered" verdict of the first and launches no sort)
+        torch.cuda.synchronize()   # the probe's verdict ("ordered") reaches the host through pinned memory ...
+        fn()                       # ... so that this and the timed calls launch no sort
+        torch.cuda.synchronize()
         ms = timed(torch, stream, fn, 5)
         bytes_q = 312 if g else 288
         k2["uniform_sorted_%s" % ("grad" if g else "value")] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms,

@@ -9,7 +9,7 @@
 # profiles/<tag>_kernel_stats.txt and the machine-readable profiles/counters.json that bench.py reads
 # (keyed by a hash of discregrid_amd/csrc, so that stale counters are never reported).
 set -u
-TAG=${1:-r02}; WHAT=${2:-all}
+TAG=${1:-r02b}; WHAT=${2:-all}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 OUT=/tmp/prof_$TAG; mkdir -p $OUT gpurun_out/prof_$TAG   # raw databases (100+ MB) stay on the box; summaries travel
 GROUPS_BASE=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
