@@ -369,6 +369,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
 	L.mask = d_pred_mask;
 	L.out = d_out;
+	L.brick_blocking = env_int("DG_K3_BLOCKED", 1, 0, 1);
 	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
 	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
 	int flag_idx = -1; // the flag k_field_check writes belongs to this launch (stream-ordered scratch)

@@ -127,6 +127,15 @@ struct ClassDesc
 	uint64_t brick_prefix;    // first brick id of this class in the launch
 };
 
+// K3's brick order (SampleParams::brick_blocking): the 128 waves an XCD has in flight integrate over a region of
+// +-h around their bricks in lockstep; as a compact block of bricks they sweep (nearly) the same tiles of the field
+// at the same time, as 128 bricks of two lattice rows they sweep 64 different tile planes.
+#ifndef DG_BLK0
+#define DG_BLK0 4
+#define DG_BLK1 4
+#define DG_BLKQ 8
+#endif
+static const uint32_t kBlk0 = DG_BLK0, kBlk1 = DG_BLK1, kBlkQ = DG_BLKQ;
 struct SampleParams
 {
 	MeshDev mesh;
@@ -143,6 +152,7 @@ struct SampleParams
 	double* out;
 	OverflowBuf ovf;
 	int32_t filtered;        // K1 / K1p: 1 = the filtered kernel (k_sample_fast), 0 = the exact kernel only
+	int32_t brick_blocking;  // 0: bricks of a class in row-major order; 1: in blocks of kBlk0 x kBlk1 x kBlkQ bricks (K3)
 	PointsDesc pts;          // K1p: "brick" b = the 64 points (in processing order) b*64 .. b*64+63
 };
 
@@ -164,9 +174,30 @@ DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
 	if (brick >= P.cls[3].brick_prefix) c = 3;
 	const ClassDesc& C = P.cls[c];
 	const uint32_t local = (uint32_t)(brick - C.brick_prefix);
-	const uint32_t b0 = local % C.nb0;
-	const uint32_t b1 = (local / C.nb0) % C.nb1;
-	const uint32_t bq = local / (C.nb0 * C.nb1);
+	uint32_t b0, b1, bq;
+	if (P.brick_blocking == 0)
+	{
+		b0 = local % C.nb0;
+		b1 = (local / C.nb0) % C.nb1;
+		bq = local / (C.nb0 * C.nb1);
+	}
+	else
+	{
+		// blocked order (K3): consecutive brick ids fill blocks of kBlk0 x kBlk1 x kBlkQ bricks (truncated at the
+		// upper faces), blocks in row-major order -- a bijection on [0, nb0 nb1 nbq), all in wave-uniform integers
+		const uint32_t slab = C.nb0 * C.nb1 * kBlkQ;
+		const uint32_t iq = local / slab, r = local - iq * slab;
+		const uint32_t sq = (C.nbq - iq * kBlkQ) < kBlkQ ? (C.nbq - iq * kBlkQ) : kBlkQ;
+		const uint32_t row = C.nb0 * kBlk1 * sq;
+		const uint32_t i1 = r / row, r2 = r - i1 * row;
+		const uint32_t s1 = (C.nb1 - i1 * kBlk1) < kBlk1 ? (C.nb1 - i1 * kBlk1) : kBlk1;
+		const uint32_t blk = kBlk0 * s1 * sq;
+		const uint32_t i0 = r2 / blk, r3 = r2 - i0 * blk;
+		const uint32_t s0 = (C.nb0 - i0 * kBlk0) < kBlk0 ? (C.nb0 - i0 * kBlk0) : kBlk0;
+		b0 = i0 * kBlk0 + r3 % s0;
+		b1 = i1 * kBlk1 + (r3 / s0) % s1;
+		bq = iq * kBlkQ + r3 / (s0 * s1);
+	}
 	const uint32_t a = b0 * 4u + (uint32_t)(lane & 3);
 	const uint32_t b = b1 * 4u + (uint32_t)((lane >> 2) & 3);
 	const uint32_t qp = C.q_begin + bq * 4u + (uint32_t)(lane >> 4);

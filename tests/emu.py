@@ -247,6 +247,11 @@ def filter_interval_check(rng, n_tri=2000, n_pts=64):
     return tot
 
 
+def set_brick_blocking(on=1):
+    """Emulated K1 launches enumerate the bricks in K3's blocked order (SampleParams::brick_blocking)."""
+    lib().emu_set_brick_blocking(int(on))
+
+
 def set_tile_major(on=1):
     """K2 / K3 bodies read unreduced fields through a tile-major copy (dg_lattice.h) built as k_expand_tiles does."""
     lib().emu_set_tile_major(int(on))

@@ -208,6 +208,7 @@ struct FastStats
 	}
 };
 int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_K1_FAST=0)
+int g_brick_blocking = 0; // 1: the blocked brick order K3 launches use (dg_kernels.h: map_lane)
 FastStats g_fs;
 
 struct FastLane
@@ -470,6 +471,7 @@ void emu_fast_stats(uint64_t* out /*28*/)
 	out[8] = g_fs.sum_list; out[9] = g_fs.lanes; out[10] = g_fs.parked;
 	for (int k = 0; k < 17; ++k) out[11 + k] = g_fs.hist[k];
 }
+void emu_set_brick_blocking(int on) { g_brick_blocking = on; }
 int emu_n_subtrees(void* h) { return static_cast<HostMesh*>(h)->dev.n_sub; }
 // number of triangles reachable from the subtree roots; -1 if a triangle is reachable twice
 long long emu_subtree_triangles(void* h)
@@ -644,6 +646,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		layout_shard(P, res, (int)a0, (int)a1);
 	P.mask = mask;
 	P.out = out;
+	P.brick_blocking = g_brick_blocking;
 	Stats st;
 	int err = 0;
 	// heavy-brick scratch exactly as dg_capi.cpp attaches it

@@ -366,3 +366,31 @@ def test_tile_major_copy_is_the_same_field(golden):
         np.testing.assert_array_equal(d0, d1)
     finally:
         emu.set_tile_major(0)
+
+
+def test_blocked_brick_order_is_a_bijection():
+    """K3 enumerates the bricks of a class in blocks of 4 x 4 x 8 (dg_kernels.h: map_lane with brick_blocking):
+    every lattice node still exactly once, same values -- on lattices whose brick counts are no multiples of
+    the block, on sub-ranges and on shards."""
+    V, F = T.icosphere(3)
+    dom = T.oracle_default_domain(V)
+    em = emu.EmuMesh(V, F)
+    try:
+        for res in ([5, 5, 5], [18, 7, 35], [33, 20, 3], [1, 1, 40]):
+            n = T.n_nodes(res)
+            emu.set_brick_blocking(0)
+            ref = em.sample_range(dom, res)
+            emu.set_brick_blocking(1)
+            got = em.sample_range(dom, res)
+            assert (em.written == 1).all()
+            np.testing.assert_array_equal(got, ref)
+            b, e = n // 5, (3 * n) // 4 + 3
+            part = em.sample_range(dom, res, b, e)
+            assert (em.written == 1).all()
+            np.testing.assert_array_equal(part, ref[b:e])
+            sh = em.sample_shard(dom, res, 1, 3)
+            assert (em.written == 1).all()
+            emu.set_brick_blocking(0)
+            np.testing.assert_array_equal(sh, em.sample_shard(dom, res, 1, 3))
+    finally:
+        emu.set_brick_blocking(0)

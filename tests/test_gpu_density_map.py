@@ -52,6 +52,10 @@ def test_density_map_vs_reference_golden(dg, golden, monkeypatch, name, res, h, 
     monkeypatch.setenv("DG_K3_TILES", "0")   # and without any copy
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
     monkeypatch.delenv("DG_K3_TILES")
+    monkeypatch.setenv("DG_K3_BLOCKED", "0")   # bricks in row-major instead of blocked order
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
+    np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 777, 2500), want[777:2500])
+    monkeypatch.delenv("DG_K3_BLOCKED")
     if key == "torus_density_h015":
         np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False), golden["torus_density_h015_nopred"])
 
