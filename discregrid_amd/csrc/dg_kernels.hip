@@ -490,7 +490,8 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 		else
 		{
 			const SPair pr = load_pair(M.pairs, cur);
-			const f2 lb = pair_lb2_fast(pr.r, f.a.x);
+			f2 cd;
+			const f2 lb = pair_lb2_fast(pr.r, f.a.x, &cd);
 			const bool hl = lb.x <= f.Uprune, hr = lb.y <= f.Uprune;
 			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
 			if ((bl | br) != 0ull)
@@ -498,7 +499,9 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 				bool left = bl != 0ull;
 				if (bl != 0ull && br != 0ull)
 				{
-					const unsigned long long pref = __ballot(lb.x <= lb.y) & (bl | br);
+					// both children are needed: the one most lanes are closer to -- by the distance to the box
+					// CENTRE -- first, the other is postponed
+					const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br);
 					left = 2 * __popcll(pref) >= __popcll(bl | br);
 					if (sp < M.stack_levels)
 					{

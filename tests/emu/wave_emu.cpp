@@ -218,8 +218,10 @@ struct FastLane
 	int cnt;
 	int list[kFastListCap + 1];
 };
+thread_local std::vector<std::pair<int,int>> g_leaf_log; // (first, cnt) of the leaves a traversal visited (design studies)
 int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowBuf* ovf)
 {
+	g_leaf_log.clear();
 	int stack_info[kStackDepth];
 	static thread_local float stack_lb[kStackDepth][64];
 	int sp = 0;
@@ -246,6 +248,19 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 			st.leaf_visits++;
 			const unsigned code = ~(unsigned)cur;
 			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
+			g_leaf_log.push_back(std::make_pair(first, cnt));
+			if (getenv("EMU_LEAF_TRACE"))
+			{
+				int acc = 0; float best_margin = 1e30f, umin = 1e30f, umax = -1e30f;
+				for (int l = 0; l < 64; ++l)
+				{
+					if (!(fl[l].U > -1e30f)) continue;
+					if (lbcur[l] <= fl[l].Uprune) acc++;
+					best_margin = std::min(best_margin, (lbcur[l] - fl[l].Uprune) / std::max(fl[l].Uprune, 1e-30f));
+					umin = std::min(umin, fl[l].U); umax = std::max(umax, fl[l].U);
+				}
+				fprintf(stderr, "  visit leaf first=%d cnt=%d lanes_accepting=%d min_rel_margin=%.3g U range [%.5g, %.5g]\n", first, cnt, acc, best_margin, umin, umax);
+			}
 			float theta[64], kappa[64];
 			for (int l = 0; l < 64; ++l)
 			{
@@ -297,7 +312,8 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 			int pref = 0, act = 0;
 			for (int k = 0; k < 64; ++k)
 			{
-				const f2 lb = pair_lb2_fast(&pr.f[0][0], fl[k].a.x);
+				f2 cd;
+				const f2 lb = pair_lb2_fast(&pr.f[0][0], fl[k].a.x, &cd);
 				lbl[k] = lb.x;
 				lbr[k] = lb.y;
 				const bool hl = lb.x <= fl[k].Uprune, hr = lb.y <= fl[k].Uprune;
@@ -306,7 +322,7 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 				if (hl || hr)
 				{
 					act++;
-					pref += (lb.x <= lb.y);
+					pref += (cd.x <= cd.y);
 				}
 			}
 			if (anyl || anyr)
@@ -816,6 +832,28 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 						fs.sum_max_list += mx;
 						write_nodes(ln, sample, w);
 					}
+				}
+				if (getenv("EMU_LEAF_DEBUG") && slot < 0)
+				{
+					int needed = 0, winners = 0;
+					for (auto const& lf : g_leaf_log)
+					{
+						bool cand = false, win = false;
+						for (int l = 0; l < 64 && !win; ++l)
+						{
+							if (!sample[l]) continue;
+							for (int k = 0; k < fl[l].cnt; ++k)
+								if (fl[l].list[k] >= lf.first && fl[l].list[k] < lf.first + lf.second)
+									cand = true;
+							if (w.q[l].best_tri >= lf.first && w.q[l].best_tri < lf.first + lf.second)
+								win = true;
+						}
+						needed += cand || win;
+						winners += win;
+					}
+					const double rx = w.q[21].px - P.mesh.origin[0], ry = w.q[21].py - P.mesh.origin[1], rz = w.q[21].pz - P.mesh.origin[2];
+#pragma omp critical
+					fprintf(stderr, "leaf %.3f %d %d %d\n", sqrt(rx*rx+ry*ry+rz*rz), (int)g_leaf_log.size(), needed, winners);
 				}
 				if (getenv("EMU_COST_DEBUG"))
 				{
