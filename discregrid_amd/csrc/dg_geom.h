@@ -374,11 +374,14 @@ DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_
 // r = the record's 30 interleaved floats (PairRec::f).  d = p - centre, then per axis
 // excess = |u.d| - (half + es), clamped at 0 and squared: 30 VALU instructions for the two items
 // (everything but the abs/clamp is packed two-wide; every instruction reads one SGPR pair).
-DG_HD f2 pair_lb2(const float* r, const FPoint& p)
+// *centre2 (optional): squared distances to the two box centres, what the traversals order children by.
+DG_HD f2 pair_lb2(const float* r, const FPoint& p, f2* centre2 = nullptr)
 {
 	const f2 dx = f2_splat(p.x[0]) - f2_make(r[0], r[1]);
 	const f2 dy = f2_splat(p.x[1]) - f2_make(r[2], r[3]);
 	const f2 dz = f2_splat(p.x[2]) - f2_make(r[4], r[5]);
+	if (centre2)
+		*centre2 = f2_fma(dx, dx, f2_fma(dy, dy, dz * dz));
 	const f2 es = f2_splat(p.es);
 	f2 acc = f2_splat(0.0f);
 	for (int a = 0; a < 3; ++a)
@@ -396,8 +399,18 @@ DG_HD f2 pair_lb2(const float* r, const FPoint& p)
 #else
 // Squared lower bounds (box and slab combined) of BOTH items of a pair record for one query.
 // r = the record's 22 interleaved floats (PairRec::f).
-DG_HD f2 pair_lb2(const float* r, const FPoint& p)
+DG_HD f2 pair_lb2(const float* r, const FPoint& p, f2* centre2 = nullptr)
 {
+	if (centre2) // box centres: (lo + hi) / 2
+	{
+		f2 c2 = f2_splat(0.0f);
+		for (int d = 0; d < 3; ++d)
+		{
+			const f2 m = f2_splat(p.x[d]) - (f2_make(r[2 * d], r[2 * d + 1]) + f2_make(r[6 + 2 * d], r[6 + 2 * d + 1])) * f2_splat(0.5f);
+			c2 = f2_fma(m, m, c2);
+		}
+		*centre2 = c2;
+	}
 	f2 acc = f2_splat(0.0f);
 	for (int d = 0; d < 3; ++d)
 	{

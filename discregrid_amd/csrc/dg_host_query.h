@@ -54,14 +54,15 @@ inline bool signed_distance_point(const MeshBuild& B, double px, double py, doub
 		else
 		{
 			const PairRec& r = B.pairs[(size_t)cur];
-			const f2 lb = pair_lb2(&r.f[0][0], q.fp);
+			f2 cd;
+			const f2 lb = pair_lb2(&r.f[0][0], q.fp, &cd);
 			const bool hl = lb.x < q.bestf, hr = lb.y < q.bestf;
 			if (hl || hr)
 			{
 				bool left = hl;
 				if (hl && hr)
 				{
-					left = lb.x <= lb.y;
+					left = cd.x <= cd.y; // nearer box centre first (as the kernels)
 					if (sp < 2 * kStackDepth)
 					{
 						stack[sp].info = left ? r.info[1] : r.info[0];

@@ -205,7 +205,8 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* 
 		else
 		{
 			const SPair pr = load_pair(M.pairs, cur);
-			const f2 lb = pair_lb2(pr.r, q.fp);
+			f2 cd;
+			const f2 lb = pair_lb2(pr.r, q.fp, &cd);
 			const bool hl = lb.x < q.bestf, hr = lb.y < q.bestf;
 			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
 			if ((bl | br) != 0ull)
@@ -215,7 +216,7 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* 
 				{
 					// both children are needed: the one most lanes are closer to first, the other is
 					// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
-					const unsigned long long pref = __ballot(lb.x <= lb.y) & (bl | br);
+					const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br); // (by the distance to the box centres)
 					left = 2 * __popcll(pref) >= __popcll(bl | br);
 					if (sp < M.stack_levels) // always true: one push per tree level at most
 					{

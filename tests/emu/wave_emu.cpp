@@ -134,7 +134,8 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 			int pref = 0, act = 0;
 			for (int k = 0; k < 64; ++k)
 			{
-				const f2 lb = pair_lb2(&pr.f[0][0], w.q[k].fp);
+				f2 cd;
+				const f2 lb = pair_lb2(&pr.f[0][0], w.q[k].fp, &cd);
 				lbl[k] = lb.x;
 				lbr[k] = lb.y;
 				const bool hl = lb.x < w.q[k].bestf, hr = lb.y < w.q[k].bestf;
@@ -143,7 +144,7 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 				if (hl || hr)
 				{
 					act++;
-					pref += (lb.x <= lb.y);
+					pref += (cd.x <= cd.y);
 				}
 			}
 			if (anyl || anyr)
