@@ -25,6 +25,7 @@ namespace
 #endif
 #if DG_OBB
 const double kFlatPatch = DG_FLAT_PATCH; // |mean normal| / area above which a patch gets an oriented box
+const int kMinRectPrims = 24;            // patches of at most this many triangles: minimum-area rectangle instead of principal axes
 #endif
 
 struct D3
@@ -174,7 +175,36 @@ Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
 				s12 += a * b;
 				s22 += b * b;
 			}
-		const double phi = 0.5 * std::atan2(2.0 * s12, s11 - s22);
+		double phi = 0.5 * std::atan2(2.0 * s12, s11 - s22);
+		// small patches: the in-plane rotation whose bounding rectangle has the smallest area (the principal axes
+		// leave empty corners around an irregular patch; the box only prunes, any rotation is valid)
+		if (n <= (size_t)kMinRectPrims && std::getenv("DG_NO_MINRECT") == nullptr)
+		{
+			double best_area = std::numeric_limits<double>::max();
+			for (int step = 0; step < 30; ++step)
+			{
+				const double a = (double)step * (3.14159265358979323846 / 60.0); // 0 .. 87 degrees in steps of 3
+				const double ca = std::cos(a), sa = std::sin(a);
+				double lo1 = std::numeric_limits<double>::max(), hi1 = -lo1, lo2 = lo1, hi2 = -lo1;
+				for (size_t i = 0; i < n; ++i)
+					for (int k = 0; k < 3; ++k)
+					{
+						const D3 v = {p[i].v[k][0], p[i].v[k][1], p[i].v[k][2]};
+						const double x1 = dot3(t1, v), x2 = dot3(t2, v);
+						const double q1 = ca * x1 + sa * x2, q2 = -sa * x1 + ca * x2;
+						lo1 = std::min(lo1, q1);
+						hi1 = std::max(hi1, q1);
+						lo2 = std::min(lo2, q2);
+						hi2 = std::max(hi2, q2);
+					}
+				const double area = (hi1 - lo1) * (hi2 - lo2);
+				if (area < best_area)
+				{
+					best_area = area;
+					phi = a;
+				}
+			}
+		}
 		const double cs = std::cos(phi), sn = std::sin(phi);
 		const D3 u1 = add(times(cs, t1), times(sn, t2));
 		const D3 u2 = cross3(nrm, u1);
