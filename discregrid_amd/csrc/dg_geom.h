@@ -483,8 +483,9 @@ DG_HD float best_as_float(double d2)
 // random and adversarial (triangle, point) pairs: no violation, largest |q - d2| / err = 0.14.
 struct alignas(64) TriApproxPair
 {
-	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 1/l0; 14,15 direction of side B->C;
-	// 16 l1; 17 1/l1; 18,19 direction of side A->C; 20 l2; 21 1/l2; 22 unused
+	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 xlo; 14,15 direction of side B->C;
+	// 16 l1; 17 xhi; 18,19 direction of side A->C; 20 l2; 21 cy; 22 unused.  In the frame (u, w, n) the triangle is
+	// A = (0,0), B = (l0,0), C = (cx,cy): [xlo, xhi] x [0, cy] is its bounding rectangle (xlo = min(0,cx), xhi = max(l0,cx))
 	float f[23][2];
 	int32_t valid[2]; // 1: triangle; 0: padding slot of an odd leaf (never tested); 2: degenerate triangle (floats all 0):
 	                  // a wave that meets one hands its brick to the exact kernel
@@ -492,6 +493,20 @@ struct alignas(64) TriApproxPair
 static_assert(sizeof(TriApproxPair) == 192, "TriApproxPair must be 192 bytes");
 static const int kApproxFloats = 46;
 
+inline float round_down_f(double v)
+{
+	float f = (float)v;
+	if ((double)f > v)
+		f = __builtin_nextafterf(f, -__builtin_inff());
+	return f;
+}
+inline float round_up_f(double v)
+{
+	float f = (float)v;
+	if ((double)f < v)
+		f = __builtin_nextafterf(f, __builtin_inff());
+	return f;
+}
 // host: fill one side of a record from the triangle's vertices (double, absolute coordinates)
 inline void make_tri_approx(const double v0[3], const double v1[3], const double v2[3], const double origin[3],
 							TriApproxPair& rec, int side)
@@ -542,15 +557,15 @@ inline void make_tri_approx(const double v0[3], const double v1[3], const double
 		put(9 + d, nn[d]);
 	}
 	put(12, l0);
-	put(13, 1.0 / l0);
+	f[2 * 13 + side] = round_down_f(cx < 0.0 ? cx : 0.0); // rectangle rounded outward
 	put(14, (cx - l0) / l1);
 	put(15, cy / l1);
 	put(16, l1);
-	put(17, 1.0 / l1);
+	f[2 * 17 + side] = round_up_f(cx > l0 ? cx : l0);
 	put(18, cx / l2);
 	put(19, cy / l2);
 	put(20, l2);
-	put(21, 1.0 / l2);
+	f[2 * 21 + side] = round_up_f(cy);
 }
 
 // per-lane constants of the filter
@@ -617,11 +632,20 @@ DG_HD float fmed3(float a, float lo, float hi) { return __builtin_fmaxf(__builti
 #endif
 DG_HD f2 f2_sat01(f2 a) { return f2_make(sat01(a.x), sat01(a.y)); }
 DG_HD f2 f2_neg(f2 a) { return f2_make(-a.x, -a.y); }
-// Both triangles of a record for one lane: the float value q of dist^2 (BEFORE the error terms; the
-// caller forms q -+ err(q)).  A point counts as inside (r = 0) only if it is inside by the margin
-// p.E >= 23 eps R; a point that is inside by less gets the distance to the nearest side, which is then
-// below 2 E: an upper value all the same, and as a lower value too high by at most 4 E^2 (in kappa).
-DG_HD f2 tri_approx_pair(const float* r, const ApproxLane& p)
+// The float filter of both triangles of a record for one lane, in two steps.
+// Step 1 (tri_approx_frame): the point in the triangles' frames and a cheap LOWER value qlb of dist^2 -- plane distance
+// plus the excess over the triangle's bounding rectangle in its own frame.  If qlb - err(qlb) is above every lane's
+// upper bound for both triangles, the wave skips step 2 (45 % of the pairs of visited leaves on the judged workload).
+// Step 2 (tri_approx_rest): the value q of dist^2 (BEFORE the error terms; the caller forms q -+ err(q)).  A point
+// counts as inside (r = 0) only if it is inside by the margin p.E >= 23 eps R; a point that is inside by less gets the
+// distance to the nearest side, which is then below 2 E: an upper value all the same, and as a lower value too high
+// by at most 4 E^2 (in kappa).  The same error bound covers qlb: the rectangle contains the triangle, its float
+// corners are rounded outward, and x, y, h carry the errors analysed above.
+struct TriFrame
+{
+	f2 x, y, h;
+};
+DG_HD f2 tri_approx_frame(const float* r, const ApproxLane& p, TriFrame* fr)
 {
 #define DG_R(k) f2_make(r[2 * (k)], r[2 * (k) + 1])
 	const f2 dx = f2_splat(p.x[0]) - DG_R(0);
@@ -630,30 +654,43 @@ DG_HD f2 tri_approx_pair(const float* r, const ApproxLane& p)
 	const f2 x = f2_fma(DG_R(3), dx, f2_fma(DG_R(4), dy, DG_R(5) * dz));
 	const f2 y = f2_fma(DG_R(6), dx, f2_fma(DG_R(7), dy, DG_R(8) * dz));
 	const f2 h = f2_fma(DG_R(9), dx, f2_fma(DG_R(10), dy, DG_R(11) * dz));
+	fr->x = x;
+	fr->y = y;
+	fr->h = h;
+	const f2 bx = x - f2_make(fmed3(x.x, r[26], r[34]), fmed3(x.y, r[27], r[35]));
+	const f2 by = y - f2_make(fmed3(y.x, 0.0f, r[42]), fmed3(y.y, 0.0f, r[43]));
+	return f2_fma(h, h, f2_fma(bx, bx, by * by));
+}
+DG_HD f2 tri_approx_rest(const float* r, const ApproxLane& p, const TriFrame& fr)
+{
+	const f2 x = fr.x, y = fr.y, h = fr.h;
 	// side A->B: along = x, perp = y
 	const f2 l0 = DG_R(12);
-	const f2 uc0 = f2_make(sat01(x.x * r[26]), sat01(x.y * r[27]));
-	const f2 ex0 = f2_fma(uc0, f2_neg(l0), x);
+	const f2 ex0 = x - f2_make(fmed3(x.x, 0.0f, l0.x), fmed3(x.y, 0.0f, l0.y));
 	const f2 t0 = f2_fma(ex0, ex0, y * y);
 	// side B->C: relative to B; interior on the left
 	const f2 xm = x - l0;
 	const f2 t1x = DG_R(14), t1y = DG_R(15), l1 = DG_R(16);
 	const f2 al1 = f2_fma(t1x, xm, t1y * y);
 	const f2 pp1 = f2_fma(t1x, y, f2_neg(t1y * xm));
-	const f2 uc1 = f2_make(sat01(al1.x * r[34]), sat01(al1.y * r[35]));
-	const f2 ex1 = f2_fma(uc1, f2_neg(l1), al1);
+	const f2 ex1 = al1 - f2_make(fmed3(al1.x, 0.0f, l1.x), fmed3(al1.y, 0.0f, l1.y));
 	const f2 t1 = f2_fma(ex1, ex1, pp1 * pp1);
 	// side A->C: relative to A; interior on the right
 	const f2 t2x = DG_R(18), t2y = DG_R(19), l2 = DG_R(20);
 	const f2 al2 = f2_fma(t2x, x, t2y * y);
 	const f2 pp2 = f2_fma(t2y, x, f2_neg(t2x * y));
-	const f2 uc2 = f2_make(sat01(al2.x * r[42]), sat01(al2.y * r[43]));
-	const f2 ex2 = f2_fma(uc2, f2_neg(l2), al2);
+	const f2 ex2 = al2 - f2_make(fmed3(al2.x, 0.0f, l2.x), fmed3(al2.y, 0.0f, l2.y));
 	const f2 t2 = f2_fma(ex2, ex2, pp2 * pp2);
 #undef DG_R
 	const float m0 = fmin3(y.x, pp1.x, pp2.x), m1 = fmin3(y.y, pp1.y, pp2.y);
 	const float tm0 = fmin3(t0.x, t1.x, t2.x), tm1 = fmin3(t0.y, t1.y, t2.y);
 	return f2_fma(h, h, f2_make(m0 >= p.E ? 0.0f : tm0, m1 >= p.E ? 0.0f : tm1));
+}
+DG_HD f2 tri_approx_pair(const float* r, const ApproxLane& p) // both steps (interval checks, emulator)
+{
+	TriFrame fr;
+	(void)tri_approx_frame(r, p, &fr);
+	return tri_approx_rest(r, p, fr);
 }
 
 #if DG_OBB

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 
 // ------------------------------------------------------------------------------------------------
 // K1 / K1p, filtered: the same packet traversal, but a visited leaf's triangles go through the FLOAT
-// filter (dg_geom.h: tri_approx_pair, two triangles per record with packed math) instead of a bound
+// filter (dg_geom.h: tri_approx_frame / tri_approx_rest, two triangles per record with packed math) instead of a bound
 // test plus the double test.  Every lane keeps an upper bound U of its minimum d^2 (what the traversal
 // prunes with) and, in LDS, the list of triangles whose interval [q - err, q + err] reaches below U:
 // the only ones that can attain the lane's minimum.  After the traversal each lane runs the double
@@ -459,19 +459,28 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 				for (int i = 0; i < kApproxFloats - 32; ++i)
 					r[32 + i] = __int_as_float(c[i]);
 				const int valid0 = c[14], valid1 = c[15]; // 1: triangle, 0: padding slot of an odd leaf, 2: degenerate triangle
-				const f2 q = tri_approx_pair(r, f.a);
+				degenerate = degenerate || valid0 == 2 || valid1 == 2;
+				// step 1: frame coordinates + rectangle bound; most pairs of a visited leaf end here
+				TriFrame fr;
+				const f2 qlb = tri_approx_frame(r, f.a, &fr);
+				const f2 lo_lb = qlb - f2_fma(qlb, f2_splat(theta), f2_splat(kappa));
+#ifndef DG_TRI_PREFILTER
+#define DG_TRI_PREFILTER 1 // 0: A/B variant without the early-out
+#endif
+				if (DG_TRI_PREFILTER && __ballot((valid0 == 1 && lo_lb.x <= f.U) || (valid1 == 1 && lo_lb.y <= f.U)) == 0ull)
+				{
+					++work;
+					continue;
+				}
+				const f2 q = tri_approx_rest(r, f.a, fr);
 				const f2 err = f2_fma(q, f2_splat(theta), f2_splat(kappa));
 				const f2 up = q + err, lo = q - err;
 				++work;
 #pragma unroll
 				for (int side = 0; side < 2; ++side)
 				{
-					const int valid = side == 0 ? valid0 : valid1; // wave-uniform
-					if (valid != 1)
-					{
-						degenerate = degenerate || valid == 2;
+					if ((side == 0 ? valid0 : valid1) != 1) // wave-uniform
 						continue;
-					}
 					const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
 					if (lo_s <= f.U)
 					{

@@ -271,21 +271,31 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 			{
 				const TriApproxPair& rec = M.tri_approx[(first + g) >> 1];
 				const float* r = &rec.f[0][0];
-				st.tri_pairs++;
+				degenerate = degenerate || rec.valid[0] == 2 || rec.valid[1] == 2;
 				++work;
+				// step 1 for the whole wave: does any lane's rectangle bound reach below its upper bound?
+				TriFrame frs[64];
+				bool any = false;
+				for (int l = 0; l < 64; ++l)
+				{
+					const f2 qlb = tri_approx_frame(r, fl[l].a, &frs[l]);
+					const f2 lo_lb = qlb - f2_fma(qlb, f2_splat(theta[l]), f2_splat(kappa[l]));
+					any = any || (rec.valid[0] == 1 && lo_lb.x <= fl[l].U) || (rec.valid[1] == 1 && lo_lb.y <= fl[l].U);
+				}
+				st.hist[16] += 1; // (pairs that reached step 1)
+				if (!any)
+					continue;
+				st.tri_pairs++;
 				for (int l = 0; l < 64; ++l)
 				{
 					FastLane& f = fl[l];
-					const f2 q = tri_approx_pair(r, f.a);
+					const f2 q = tri_approx_rest(r, f.a, frs[l]);
 					const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l]));
 					const f2 up = q + err, lo = q - err;
 					for (int side = 0; side < 2; ++side)
 					{
 						if (rec.valid[side] != 1)
-						{
-							degenerate = degenerate || rec.valid[side] == 2;
 							continue;
-						}
 						const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
 						if (lo_s <= f.U)
 						{
@@ -1090,7 +1100,9 @@ uint64_t emu_filter_check(const double* tri /* n_tri x 9 */, size_t n_tri, const
 			const ApproxLane a = make_approx_lane(p[0] - origin[0], p[1] - origin[1], p[2] - origin[2], l1);
 			if (!(a.E < __builtin_inff()))
 				continue;
-			const f2 q = tri_approx_pair(&rec.f[0][0], a);
+			TriFrame fr;
+			const f2 qlb = tri_approx_frame(&rec.f[0][0], a, &fr);
+			const f2 q = tri_approx_rest(&rec.f[0][0], a, fr);
 			for (int side = 0; side < 2; ++side)
 			{
 				if (rec.valid[side] != 1)
@@ -1104,7 +1116,9 @@ uint64_t emu_filter_check(const double* tri /* n_tri x 9 */, size_t n_tri, const
 					const float err = __builtin_fmaf(qs, theta, kappa);
 					const float lo = qs - err, up = qs + err;
 					++n;
-					if (!((double)lo <= d2 && d2 <= (double)up))
+					const float qb = side ? qlb.y : qlb.x; // the rectangle bound must stay below the double value too
+					const float lo_b = qb - __builtin_fmaf(qb, theta, kappa);
+					if (!((double)lo <= d2 && d2 <= (double)up && (double)lo_b <= d2))
 					{
 						++bad;
 						if (getenv("EMU_FILTER_DEBUG") && scale == 1.0)
