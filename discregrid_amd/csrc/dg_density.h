@@ -181,10 +181,12 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 						const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
 						// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
 						// consumed (same products as shape_functions(), no 32-entry array kept live)
-						bool ok = true;
+						// "no value" coefficients: one flag bit per cell in the tile-major copy, else 32 compares
+						bool ok = (MODE == kFieldTileMajor) ? !tile_cell_has_novalue(F.tile_major, F.ntile, ax.mi, ay.mi, az.mi) : true;
 						double phi = 0.0;
-#define DG_ACC(q, n)                  \
-	ok = ok && (cf[q] != NOVAL); \
+#define DG_ACC(q, n)                                   \
+	if (MODE != kFieldTileMajor)                       \
+		ok = ok && (cf[q] != NOVAL);                   \
 	phi += cf[q] * (n);
 						DG_ACC(0, fac * mxmy * mz)
 						DG_ACC(1, fac * pxmy * mz)

@@ -924,6 +924,24 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const FieldDev F, uint64_t
 		out[e] = node == 0xffffffffu ? 0.0 : F.coeffs[node];
 	}
 }
+// second pass: the "no value" flags of the 64 cells of every tile (dg_lattice.h: kTmFlags); one wave per tile
+__global__ __launch_bounds__(256) void k_tile_flags(uint64_t n_tiles, double* __restrict__ tiles)
+{
+	const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (tile >= n_tiles)
+		return;
+	const uint32_t c = threadIdx.x & 63u;
+	uint32_t slots[32];
+	tile_node_slots(c & 3u, (c >> 2) & 3u, c >> 4, slots);
+	const double* t = tiles + tile * kTmNodes;
+	bool nov = false;
+#pragma unroll
+	for (int q = 0; q < 32; ++q)
+		nov = nov || (t[slots[q]] == 1.7976931348623157e308);
+	const unsigned long long flags = __ballot(nov);
+	if (c == 0)
+		*(unsigned long long*)(tiles + tile * kTmNodes + kTmFlags) = flags;
+}
 
 // ------------------------------------------------------------------------------------------------
 // K3: SPH boundary density map (GenerateDensityMap).  One wave = one 4x4x4 brick of lattice nodes
@@ -1233,6 +1251,7 @@ hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_ou
 	const uint64_t total = n_tiles * kTmNodes;
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 64ull);
 	hipLaunchKernelGGL(k_expand_tiles, dim3(blocks), dim3(256), 0, stream, f, n_tiles, d_out);
+	hipLaunchKernelGGL(k_tile_flags, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, stream, n_tiles, d_out);
 	return hipGetLastError();
 }
 

@@ -214,6 +214,10 @@ DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t 
 static const uint32_t kTmCells = 4;     // tile edge in cells
 static const uint32_t kTmNodes = 736;   // doubles per tile (725 used)
 static const uint32_t kTmX = 125, kTmY = 325, kTmZ = 525; // first slot of the X / Y / Z edge nodes of a tile
+// Slot kTmFlags of a tile holds 64 bits (stored in the double's place): bit (lk 4 + lj) 4 + li is set iff one of the
+// 32 coefficients of the tile's cell (li, lj, lk) is DBL_MAX ("no value").  K3 tests that bit instead of comparing
+// all 32 coefficients at each of its thousand quadrature points per node.
+static const uint32_t kTmFlags = 725;
 // slots (tile-local) of the 32 nodes of the cell with tile-local coordinates (li, lj, lk), in the order of
 // cell_node_indices(); pairs (2m, 2m+1) are adjacent as there
 DG_HD void tile_node_slots(uint32_t li, uint32_t lj, uint32_t lk, uint32_t out[32])
@@ -242,6 +246,14 @@ DG_HD void tile_node_slots(uint32_t li, uint32_t lj, uint32_t lk, uint32_t out[3
 	out[30] = kTmZ + 2 * (((lj + 1) * 5 + li + 1) * 4 + lk);
 	for (int m = 8; m < 32; m += 2)
 		out[m + 1] = out[m] + 1;
+}
+// does cell (i, j, k) of an unreduced field with a tile-major copy hold a "no value" coefficient?
+struct FieldDev;
+DG_HD bool tile_cell_has_novalue(const double* tile_major, const uint32_t ntile[3], uint32_t i, uint32_t j, uint32_t k)
+{
+	const double* tile = tile_major + (size_t)kTmNodes * ((size_t)((k >> 2) * ntile[1] + (j >> 2)) * ntile[0] + (i >> 2));
+	const uint64_t flags = *(const uint64_t*)(tile + kTmFlags);
+	return ((flags >> (((k & 3u) * 4u + (j & 3u)) * 4u + (i & 3u))) & 1ull) != 0ull;
 }
 // global node index (reference order) stored in slot `slot` of tile (ti, tj, tk); 0xffffffff for padding slots
 // and for nodes beyond the lattice (tiles that stick out of a resolution that is no multiple of 4)

@@ -1185,6 +1185,20 @@ static std::vector<double> build_tiles(FieldDev& F)
 											 (uint32_t)(tile / ((uint64_t)F.ntile[0] * F.ntile[1])), F.res);
 		t[e] = node == 0xffffffffu ? 0.0 : F.coeffs[node];
 	}
+	for (uint64_t tile = 0; tile < n_tiles; ++tile) // k_tile_flags
+	{
+		uint64_t flags = 0;
+		for (uint32_t c = 0; c < 64; ++c)
+		{
+			uint32_t slots[32];
+			tile_node_slots(c & 3u, (c >> 2) & 3u, c >> 4, slots);
+			bool nov = false;
+			for (int q = 0; q < 32; ++q)
+				nov = nov || (t[tile * kTmNodes + slots[q]] == 1.7976931348623157e308);
+			flags |= (uint64_t)nov << c;
+		}
+		std::memcpy(&t[tile * kTmNodes + kTmFlags], &flags, 8);
+	}
 	return t;
 }
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],

@@ -364,6 +364,15 @@ def test_tile_major_copy_is_the_same_field(golden):
         emu.set_tile_major(1)
         d1 = emu.density_map(dom, res, coeffs, 0.1, 1000.0, begin=0, end=600)
         np.testing.assert_array_equal(d0, d1)
+        # "no value" coefficients: the tile copy answers with one flag bit per cell (kTmFlags) instead of 32 compares
+        c2 = coeffs.copy()
+        c2[::41] = DBL_MAX
+        emu.set_tile_major(0)
+        e0 = emu.density_map(dom, res, c2, 0.1, 1000.0, begin=0, end=600)
+        emu.set_tile_major(1)
+        e1 = emu.density_map(dom, res, c2, 0.1, 1000.0, begin=0, end=600)
+        np.testing.assert_array_equal(e0, e1)
+        assert (e0 != d0).any()
     finally:
         emu.set_tile_major(0)
 
