@@ -184,51 +184,48 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* 
 	float lbcur = 0.0f; // this lane's lower bound for `cur`
 	int work = 0;       // wave-uniform
 	int budget = ovf_count ? heavy_work : 0x7fffffff;
+	int parked = -1;
+	// (Shape of the loop: an inner loop for the way down and the budget test after a pop keep every wave-uniform
+	// variable defined on every path -- with one loop and a `continue` the compiler carries undefined values
+	// for cur/sp/work across the leaf branch and materialises them with VALU moves on every step.)
 	while (true)
 	{
-		if (work > budget)
+		// down the tree while some lane needs a child; `dead`: the node's children are out of every lane's reach
+		bool dead = false;
+		while (cur >= 0)
 		{
-			int slot = 0;
-			if (lane_id == 0)
-				slot = (int)atomicAdd(ovf_count, 1u);
-			slot = uniform(slot);
-			if ((unsigned)slot < ovf_slots)
-				return slot;
-			budget = 0x7fffffff;
-		}
-		++work;
-		if (cur < 0)
-		{
-			const unsigned code = ~(unsigned)cur;
-			work += test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
-		}
-		else
-		{
+			++work;
 			const SPair pr = load_pair(M.pairs, cur);
 			f2 cd;
 			const f2 lb = pair_lb2(pr.r, q.fp, &cd);
 			const bool hl = lb.x < q.bestf, hr = lb.y < q.bestf;
 			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
-			if ((bl | br) != 0ull)
+			if ((bl | br) == 0ull)
 			{
-				bool left = bl != 0ull;
-				if (bl != 0ull && br != 0ull)
-				{
-					// both children are needed: the one most lanes are closer to first, the other is
-					// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
-					const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br); // (by the distance to the box centres)
-					left = 2 * __popcll(pref) >= __popcll(bl | br);
-					if (sp < M.stack_levels) // always true: one push per tree level at most
-					{
-						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-						park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
-						++sp;
-					}
-				}
-				cur = left ? pr.info0 : pr.info1;
-				lbcur = left ? lb.x : lb.y;
-				continue;
+				dead = true;
+				break;
 			}
+			bool left = bl != 0ull;
+			if (bl != 0ull && br != 0ull)
+			{
+				// both children are needed: the one most lanes are closer to first, the other is
+				// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
+				const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br); // (by the distance to the box centres)
+				left = 2 * __popcll(pref) >= __popcll(bl | br);
+				if (sp < M.stack_levels) // always true: one push per tree level at most
+				{
+					stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
+					park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
+					++sp;
+				}
+			}
+			cur = left ? pr.info0 : pr.info1;
+			lbcur = left ? lb.x : lb.y;
+		}
+		if (!dead)
+		{
+			const unsigned code = ~(unsigned)cur;
+			work += 1 + test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
 		}
 		// pop the next postponed subtree that some lane still needs
 		bool found = false;
@@ -245,8 +242,22 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* 
 		}
 		if (!found)
 			break;
+		// the work budget is looked at when a subtree is finished, not on every step
+		if (work > budget)
+		{
+			int slot = 0;
+			if (lane_id == 0)
+				slot = (int)atomicAdd(ovf_count, 1u);
+			slot = uniform(slot);
+			if ((unsigned)slot < ovf_slots)
+			{
+				parked = slot;
+				break;
+			}
+			budget = 0x7fffffff;
+		}
 	}
-	return -1;
+	return parked;
 }
 
 struct DeviceSqrt
@@ -421,21 +432,44 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 	int work = 0;
 	int budget = ovf_count ? kFastWorkFactor * heavy_work : 0x7fffffff;
 	bool degenerate = false; // wave-uniform: a degenerate triangle was met
+	int parked = -1;
 	while (true)
 	{
-		if (work > budget)
+		// down the tree while some lane needs a child; `dead`: the node's children are out of every lane's reach
+		bool dead = false;
+		while (cur >= 0)
 		{
-			int slot = 0;
-			if (lane_id == 0)
-				slot = (int)atomicAdd(ovf_count, 1u);
-			slot = uniform(slot);
-			if ((unsigned)slot < ovf_slots)
-				return slot;
-			budget = 0x7fffffff;
+			++work;
+			const SPair pr = load_pair(M.pairs, cur);
+			f2 cd;
+			const f2 lb = pair_lb2_fast(pr.r, f.a.x, &cd);
+			const bool hl = lb.x <= f.Uprune, hr = lb.y <= f.Uprune;
+			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
+			if ((bl | br) == 0ull)
+			{
+				dead = true;
+				break;
+			}
+			bool left = bl != 0ull;
+			if (bl != 0ull && br != 0ull)
+			{
+				// both children are needed: the one most lanes are closer to -- by the distance to the box
+				// CENTRE -- first, the other is postponed
+				const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br);
+				left = 2 * __popcll(pref) >= __popcll(bl | br);
+				if (sp < M.stack_levels)
+				{
+					stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
+					park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
+					++sp;
+				}
+			}
+			cur = left ? pr.info0 : pr.info1;
+			lbcur = left ? lb.x : lb.y;
 		}
-		++work;
-		if (cur < 0)
+		if (!dead)
 		{
+			++work;
 			const unsigned code = ~(unsigned)cur;
 			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
 			// error terms for this leaf's triangles around the lane's current distance estimate (its upper
@@ -497,34 +531,6 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 			// the threshold the bound tests compare with (dg_geom.h: approx_err_terms)
 			f.Uprune = __builtin_fmaf(f.U, 1.0f + theta, kappa);
 		}
-		else
-		{
-			const SPair pr = load_pair(M.pairs, cur);
-			f2 cd;
-			const f2 lb = pair_lb2_fast(pr.r, f.a.x, &cd);
-			const bool hl = lb.x <= f.Uprune, hr = lb.y <= f.Uprune;
-			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
-			if ((bl | br) != 0ull)
-			{
-				bool left = bl != 0ull;
-				if (bl != 0ull && br != 0ull)
-				{
-					// both children are needed: the one most lanes are closer to -- by the distance to the box
-					// CENTRE -- first, the other is postponed
-					const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br);
-					left = 2 * __popcll(pref) >= __popcll(bl | br);
-					if (sp < M.stack_levels)
-					{
-						stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-						park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
-						++sp;
-					}
-				}
-				cur = left ? pr.info0 : pr.info1;
-				lbcur = left ? lb.x : lb.y;
-				continue;
-			}
-		}
 		bool found = false;
 		while (sp > 0)
 		{
@@ -539,7 +545,24 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 		}
 		if (!found)
 			break;
+		// the work budget is looked at when a subtree is finished (not on every step: the traversal is
+		// the same either way, only the moment a brick is declared heavy moves by a few steps)
+		if (work > budget)
+		{
+			int slot = 0;
+			if (lane_id == 0)
+				slot = (int)atomicAdd(ovf_count, 1u);
+			slot = uniform(slot);
+			if ((unsigned)slot < ovf_slots)
+			{
+				parked = slot;
+				break;
+			}
+			budget = 0x7fffffff;
+		}
 	}
+	if (parked >= 0)
+		return parked;
 	return degenerate ? -2 : -1;
 }
 

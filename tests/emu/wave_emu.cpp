@@ -110,13 +110,6 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 	int budget = ovf ? ovf->heavy_work : 0x7fffffff;
 	while (true)
 	{
-		if (work > budget)
-		{
-			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
-			if (slot < ovf->slots)
-				return (int)slot;
-			budget = 0x7fffffff;
-		}
 		++work;
 		bool descended = false;
 		if (cur < 0)
@@ -190,12 +183,22 @@ int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf*
 		}
 		if (!found)
 			break;
+		// the work budget is looked at when a subtree is finished (as the kernels do)
+		if (work > budget)
+		{
+			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
+			if (slot < ovf->slots)
+				return (int)slot;
+			budget = 0x7fffffff;
+		}
 	}
 	return -1;
 }
 
 
 // ---- filtered traversal: mirrors traverse_fast() / k_sample_fast of dg_kernels.hip ----------------------
+static unsigned long long g_need_sum = 0, g_need_max = 0;
+extern "C" void emu_need(unsigned long long* o) { o[0] = g_need_sum; o[1] = g_need_max; }
 struct FastStats
 {
 	uint64_t bricks = 0, pair_steps = 0, leaf_visits = 0, tri_pairs = 0, appends = 0, resets = 0, redo_bricks = 0,
@@ -235,13 +238,6 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 	bool degenerate = false;
 	while (true)
 	{
-		if (work > budget)
-		{
-			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
-			if (slot < ovf->slots)
-				return (int)slot;
-			budget = 0x7fffffff;
-		}
 		++work;
 		bool descended = false;
 		if (cur < 0)
@@ -377,6 +373,14 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 		}
 		if (!found)
 			break;
+		// the work budget is looked at when a subtree is finished (as the kernels do)
+		if (work > budget)
+		{
+			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
+			if (slot < ovf->slots)
+				return (int)slot;
+			budget = 0x7fffffff;
+		}
 	}
 	return degenerate ? -2 : -1;
 }
@@ -818,7 +822,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 					}
 					else
 					{
-						int mx = 0;
+						int mx = 0, mx2 = 0;
 						for (int l = 0; l < 64; ++l)
 						{
 							if (!sample[l])
@@ -833,13 +837,18 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 							fs.sum_list += fl[l].cnt;
 							fs.hist[fl[l].cnt]++;
 							mx = fl[l].cnt > mx ? fl[l].cnt : mx;
+							int need = 0;
 							for (int k = 0; k < fl[l].cnt; ++k)
 							{
 								const int t = fl[l].list[k];
 								const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
 								offer(w.q[l], h.d2, t);
+								need += h.d2 <= (double)fl[l].U * 1.00001;
 							}
+							g_need_sum += need;
+							mx2 = need > mx2 ? need : mx2;
 						}
+						g_need_max += mx2;
 						fs.sum_max_list += mx;
 						write_nodes(ln, sample, w);
 					}

@@ -56,3 +56,9 @@ print("        list length histogram:", (tot["hist"] / max(1, tot["hist"].sum())
 cur = 40 * tot["x_node_visits"] / 2 / tot["x_bricks"] + 34 * tot["x_leaf_groups"] / tot["x_bricks"] + 71 * tot["x_tri_tests"] / tot["x_bricks"]
 new = 30 * tot["pair_steps"] / B + 64 * tot["tri_pairs"] / B + 90 * tot["sum_max_list"] / max(1, B) + 15 * tot["leaf_visits"] / B
 print("VALU model per brick: exact %.0f  fast %.0f  (ratio %.2f)" % (cur, new, new / cur))
+try:
+    o = np.zeros(2, dtype=np.uint64)
+    emu.lib().emu_need(o.ctypes.data_as(T.c_u64p))
+    print("needed (d2 <= U_final): mean/lane %.2f  max/brick %.2f" % (o[0] / max(1, tot["lanes"]), o[1] / max(1, B)))
+except AttributeError:
+    pass
