@@ -113,6 +113,32 @@ struct PointsDesc
 	double* nearest;
 };
 
+// Division of wave-uniform 32-bit integers by a launch constant.  The GPU has no scalar divide: `n / d` with a
+// run-time d becomes a float reciprocal on the VECTOR unit (5 VALU + fix-ups per division, ~60 VALU per brick for
+// the brick map of a VALU-bound kernel).  With m = udiv_magic(d) from the host, floor(n m / 2^32) is floor(n / d)
+// or one less (n (2^32/d - m) / 2^32 < 1), so one multiply-high and one fix-up -- all scalar -- give the exact
+// quotient and remainder for every n < 2^32, d >= 1.
+DG_HD uint32_t udiv_magic(uint32_t d)
+{
+	return d <= 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / d);
+}
+DG_HD uint32_t udiv_by(uint32_t n, uint32_t d, uint32_t m, uint32_t* rem)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t q = __umulhi(n, m);
+#else
+	uint32_t q = (uint32_t)(((uint64_t)n * m) >> 32);
+#endif
+	uint32_t r = n - q * d;
+	if (r >= d)
+	{
+		++q;
+		r -= d;
+	}
+	*rem = r;
+	return q;
+}
+
 // One of the four node classes of the lattice as the K1 kernel sees it (see dg_geom.h
 // node_position() for the (a, b, s) coordinates).  The kernel walks "packed planes"
 // q in [q_begin, q_end); plane q is lattice plane s = q (whole-grid / range mode) or the
@@ -121,6 +147,7 @@ struct ClassDesc
 {
 	uint32_t D0, D1, D2;      // lattice extents (fastest, middle, slowest)
 	uint32_t nb0, nb1, nbq;   // bricks of 4x4x4 nodes along a, b, q
+	uint32_t rcp_nb0, rcp_nb01; // udiv_magic(nb0), udiv_magic(nb0 * nb1)
 	uint32_t q_begin, q_end;
 	uint64_t l_begin, l_end;  // valid class-local flat node range (range mode; full range otherwise)
 	int64_t out_base;         // out index = out_base + (q*D1 + b)*D0 + a
@@ -146,6 +173,7 @@ struct SampleParams
 	uint32_t n_blocks;       // ceil(total_bricks / kWavesPerBlock)
 	uint32_t blocks_per_xcd; // blocks launched per XCD (multiple of xcd_chunk); grid = 8 * blocks_per_xcd
 	uint32_t xcd_chunk;      // consecutive logical blocks that stay on one XCD
+	uint32_t rcp_xcd_chunk;  // udiv_magic(xcd_chunk)
 	int32_t shard_rank, shard_n; // shard_n == 1: identity plane map
 	int32_t invert;
 	const uint8_t* mask;     // indexed like out; nullable
@@ -165,9 +193,16 @@ struct LaneNode
 	bool valid;        // lane owns a node of the requested range
 	int64_t out_idx;
 };
-DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
+// The wave-uniform half of the map: class and brick coordinates of a brick id.  Kernels that need the lane map
+// twice (before and after a long traversal) keep this in scalar registers instead of repeating its divisions.
+struct BrickMap
 {
-	LaneNode n;
+	int cls;
+	uint32_t b0, b1, bq;
+};
+template <bool BLOCKED>
+DG_HD BrickMap map_brick_order(const SampleParams& P, uint64_t brick)
+{
 	int c = 0;
 	if (brick >= P.cls[1].brick_prefix) c = 1;
 	if (brick >= P.cls[2].brick_prefix) c = 2;
@@ -175,11 +210,11 @@ DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
 	const ClassDesc& C = P.cls[c];
 	const uint32_t local = (uint32_t)(brick - C.brick_prefix);
 	uint32_t b0, b1, bq;
-	if (P.brick_blocking == 0)
+	if (!BLOCKED)
 	{
-		b0 = local % C.nb0;
-		b1 = (local / C.nb0) % C.nb1;
-		bq = local / (C.nb0 * C.nb1);
+		uint32_t r;
+		bq = udiv_by(local, C.nb0 * C.nb1, C.rcp_nb01, &r);
+		b1 = udiv_by(r, C.nb0, C.rcp_nb0, &b0);
 	}
 	else
 	{
@@ -198,9 +233,27 @@ DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
 		b1 = i1 * kBlk1 + (r3 / s0) % s1;
 		bq = iq * kBlkQ + r3 / (s0 * s1);
 	}
-	const uint32_t a = b0 * 4u + (uint32_t)(lane & 3);
-	const uint32_t b = b1 * 4u + (uint32_t)((lane >> 2) & 3);
-	const uint32_t qp = C.q_begin + bq * 4u + (uint32_t)(lane >> 4);
+	BrickMap m;
+	m.cls = c;
+	m.b0 = b0;
+	m.b1 = b1;
+	m.bq = bq;
+	return m;
+}
+// (K1 launches never use the blocked order and instantiate map_brick_order<false> directly: with a run-time
+// choice the compiler hoists the blocked order's reciprocals in front of the branch)
+DG_HD BrickMap map_brick(const SampleParams& P, uint64_t brick)
+{
+	return P.brick_blocking == 0 ? map_brick_order<false>(P, brick) : map_brick_order<true>(P, brick);
+}
+DG_HD LaneNode map_lane(const SampleParams& P, const BrickMap& m, int lane)
+{
+	LaneNode n;
+	const int c = m.cls;
+	const ClassDesc& C = P.cls[c];
+	const uint32_t a = m.b0 * 4u + (uint32_t)(lane & 3);
+	const uint32_t b = m.b1 * 4u + (uint32_t)((lane >> 2) & 3);
+	const uint32_t qp = C.q_begin + m.bq * 4u + (uint32_t)(lane >> 4);
 	// plane map: identity, or the qp-th plane owned by this rank (slabs of 4 dealt round-robin)
 	uint32_t s = qp;
 	if (P.shard_n > 1)
@@ -217,6 +270,10 @@ DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
 	n.out_idx = C.out_base + (int64_t)(((uint64_t)qp * C.D1 + b) * C.D0 + a);
 	return n;
 }
+DG_HD LaneNode map_lane(const SampleParams& P, uint64_t brick, int lane)
+{
+	return map_lane(P, map_brick(P, brick), lane);
+}
 
 // XCD-aware remap: hardware deals blockIdx round-robin over the 8 XCDs (each with its own L2).
 // Logical blocks are cut into chunks of xcd_chunk consecutive blocks and the chunks are dealt
@@ -227,10 +284,11 @@ DG_HD bool logical_block(const SampleParams& P, uint32_t block_idx, uint32_t* bl
 {
 	const uint32_t xcd = block_idx & 7u;
 	const uint32_t within = block_idx >> 3;
-	const uint32_t group = within / P.xcd_chunk;
+	uint32_t in_chunk;
+	const uint32_t group = udiv_by(within, P.xcd_chunk, P.rcp_xcd_chunk, &in_chunk);
 	// the chunk an XCD takes rotates from group to group, so that a group period close to a
 	// row/plane period of the lattice cannot pin one XCD to one region
-	const uint32_t b = (group * 8u + ((xcd + group) & 7u)) * P.xcd_chunk + within % P.xcd_chunk;
+	const uint32_t b = (group * 8u + ((xcd + group) & 7u)) * P.xcd_chunk + in_chunk;
 	*blk = b;
 	return within < P.blocks_per_xcd && b < P.n_blocks;
 }

@@ -279,8 +279,9 @@ struct LaneTask
 	int64_t out_idx;
 	double x0, x1, x2;
 };
+// (`bm`: the brick's wave-uniform map for lattice launches -- map_brick(P, brick); unused for points)
 template <bool POINTS>
-__device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t brick, int lane)
+__device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t brick, const BrickMap& bm, int lane)
 {
 	LaneTask t;
 	if (POINTS)
@@ -298,7 +299,7 @@ __device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t br
 	}
 	else
 	{
-		const LaneNode ln = map_lane(P, brick, lane);
+		const LaneNode ln = map_lane(P, bm, lane);
 		t.valid = ln.valid;
 		t.out_idx = ln.out_idx;
 		t.sample = ln.valid;
@@ -312,6 +313,14 @@ __device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t br
 		t.x2 = x[2];
 	}
 	return t;
+}
+template <bool POINTS>
+__device__ __forceinline__ LaneTask lane_task(const SampleParams& P, uint64_t brick, int lane)
+{
+	BrickMap bm = {};
+	if (!POINTS)
+		bm = map_brick_order<false>(P, brick); // (K1 launches: row-major brick order, launch_k1 rejects the blocked one)
+	return lane_task<POINTS>(P, brick, bm, lane);
 }
 // epilogue: the lane's result(s)
 template <bool POINTS>
@@ -581,8 +590,11 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	int* lds_list = (int*)(lds_lb16 + P.mesh.stack_levels * 64);
 	FastLane f;
 	bool sample;
+	BrickMap bm = {}; // wave-uniform, kept in scalar registers across the traversal for the second lane_task below
+	if (!POINTS)
+		bm = map_brick_order<false>(P, brick);
 	{
-		const LaneTask t = lane_task<POINTS>(P, brick, lane);
+		const LaneTask t = lane_task<POINTS>(P, brick, bm, lane);
 		sample = t.sample;
 		f.a = make_approx_lane(t.x0 - P.mesh.origin[0], t.x1 - P.mesh.origin[1], t.x2 - P.mesh.origin[2], P.mesh.mesh_l1);
 	}
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 		// a degenerate triangle was met: nobody's list is complete
 		exact = exact || (sample && (slot == -2 || f.slot >= list_base + 256u * (uint32_t)kFastListCap));
 	}
-	const LaneTask t = lane_task<POINTS>(P, brick, lane);
+	const LaneTask t = lane_task<POINTS>(P, brick, bm, lane);
 	LaneQuery q;
 	if (__ballot(exact) != 0ull)
 	{
@@ -1291,6 +1303,8 @@ static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 {
 	if (p.total_bricks == 0)
 		return hipSuccess;
+	if (p.brick_blocking != 0) // the K1 kernels only know the row-major brick order (map_brick_order<false>)
+		return hipErrorInvalidValue;
 	const uint32_t grid = p.blocks_per_xcd * 8u;
 	const size_t lds = (size_t)kWavesPerBlock * p.mesh.stack_levels * 64 * sizeof(float);
 	if (p.filtered != 0)

@@ -40,8 +40,15 @@ DG_HD void node_position(int c, uint32_t a, uint32_t b, uint32_t s, const double
 	x[0] = dmin[0] + cell[0] * (double)i;
 	x[1] = dmin[1] + cell[1] * (double)j;
 	x[2] = dmin[2] + cell[2] * (double)k;
-	if (c > 0)
-		x[c - 1] += (1.0 + (double)h) / 3.0 * cell[c - 1];
+	// the reference's (1.0 + h) / 3.0 is one of two correctly rounded constants; the axis is picked with
+	// (wave-uniform) branches rather than a dynamic index, which costs a chain of selects per coordinate
+	const double third = h == 0u ? 1.0 / 3.0 : 2.0 / 3.0;
+	if (c == 1)
+		x[0] += third * cell[0];
+	else if (c == 2)
+		x[1] += third * cell[1];
+	else if (c == 3)
+		x[2] += third * cell[2];
 }
 
 // ---- 32 serendipity-cubic shape functions (+ derivatives) -------------------------------------------------

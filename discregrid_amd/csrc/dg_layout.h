@@ -64,6 +64,7 @@ inline void finish_blocks(SampleParams& P)
 		P.xcd_chunk = std::max(16u, std::min(kXcdChunk, P.n_blocks / 64u));
 	if (P.xcd_chunk == 0xffffffffu) // one chunk per XCD
 		P.xcd_chunk = std::max(1u, (P.n_blocks + 7) / 8);
+	P.rcp_xcd_chunk = udiv_magic(P.xcd_chunk);
 	const uint32_t per_group = 8u * P.xcd_chunk;
 	P.blocks_per_xcd = ((P.n_blocks + per_group - 1) / per_group) * P.xcd_chunk;
 }
@@ -78,6 +79,8 @@ inline void finish_bricks(SampleParams& P)
 		C.nb0 = (C.D0 + 3) / 4;
 		C.nb1 = (C.D1 + 3) / 4;
 		C.nbq = (nq + 3) / 4;
+		C.rcp_nb0 = udiv_magic(C.nb0);
+		C.rcp_nb01 = udiv_magic(C.nb0 * C.nb1);
 		C.brick_prefix = prefix; // an empty class shares its prefix with the next one; the
 		                         // kernel picks the LAST class whose prefix <= brick
 		prefix += (uint64_t)C.nb0 * C.nb1 * C.nbq;

@@ -252,6 +252,15 @@ def set_brick_blocking(on=1):
     lib().emu_set_brick_blocking(int(on))
 
 
+def udiv_mismatches(n, d):
+    """udiv_by(n, d, udiv_magic(d)) of dg_kernels.h (the brick map's scalar division) against n // d, n % d."""
+    n = np.ascontiguousarray(n, dtype=np.uint32)
+    d = np.ascontiguousarray(d, dtype=np.uint32)
+    L = lib()
+    L.emu_udiv_check.restype = C.c_uint64
+    return int(L.emu_udiv_check(n.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_uint64(len(n))))
+
+
 def set_tile_major(on=1):
     """K2 / K3 bodies read unreduced fields through a tile-major copy (dg_lattice.h) built as k_expand_tiles does."""
     lib().emu_set_tile_major(int(on))

@@ -503,6 +503,18 @@ void emu_fast_stats(uint64_t* out /*28*/)
 	for (int k = 0; k < 17; ++k) out[11 + k] = g_fs.hist[k];
 }
 void emu_set_brick_blocking(int on) { g_brick_blocking = on; }
+// udiv_by / udiv_magic of dg_kernels.h against the host's division; returns the number of mismatches
+uint64_t emu_udiv_check(const uint32_t* n, const uint32_t* d, uint64_t count)
+{
+	uint64_t bad = 0;
+	for (uint64_t i = 0; i < count; ++i)
+	{
+		uint32_t r;
+		const uint32_t q = udiv_by(n[i], d[i], udiv_magic(d[i]), &r);
+		bad += (q != n[i] / d[i]) || (r != n[i] % d[i]);
+	}
+	return bad;
+}
 int emu_n_subtrees(void* h) { return static_cast<HostMesh*>(h)->dev.n_sub; }
 // number of triangles reachable from the subtree roots; -1 if a triangle is reachable twice
 long long emu_subtree_triangles(void* h)

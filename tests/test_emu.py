@@ -377,6 +377,22 @@ def test_tile_major_copy_is_the_same_field(golden):
         emu.set_tile_major(0)
 
 
+def test_scalar_division_by_launch_constants_is_exact():
+    """The brick map divides by launch constants with a host-made reciprocal (dg_kernels.h: udiv_by): exact
+    quotient and remainder for every 32-bit dividend and every divisor >= 1, including the corners."""
+    rng = np.random.default_rng(5)
+    edge = np.array([0, 1, 2, 3, 5, 7, 63, 64, 65, 255, 256, 257, 641, 65535, 65536, 65537, 2**24 - 1, 2**24, 2**31 - 1,
+                     2**31, 2**31 + 1, 2**32 - 2, 2**32 - 1], dtype=np.uint64)
+    dd = np.concatenate([edge[1:], rng.integers(1, 5000, 200, dtype=np.uint64), rng.integers(1, 2**32, 200, dtype=np.uint64)])
+    for d in dd:
+        # dividends: the corners, random ones, and the neighbourhoods of multiples of d (where a quotient off by one shows)
+        k = rng.integers(0, max(1, (2**32 - 1) // int(d)) + 1, 64).astype(np.int64)
+        near = np.concatenate([k * int(d) + o for o in (-1, 0, 1)])
+        near = near[(near >= 0) & (near < 2**32)]
+        n = np.concatenate([edge.astype(np.int64), rng.integers(0, 2**32, 256), near]).astype(np.uint32)
+        assert emu.udiv_mismatches(n, np.full(len(n), d, dtype=np.uint32)) == 0, int(d)
+
+
 def test_blocked_brick_order_is_a_bijection():
     """K3 enumerates the bricks of a class in blocks of 4 x 4 x 8 (dg_kernels.h: map_lane with brick_blocking):
     every lattice node still exactly once, same values -- on lattices whose brick counts are no multiples of
