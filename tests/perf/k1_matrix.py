@@ -23,7 +23,10 @@ def main():
     for name, (V, F) in meshes.items():
         m = dg.Mesh(V, F)
         dom = dg.default_domain(V)
-        for res in ([64] * 3, [256] * 3, [512, 64, 32]):
+        sizes = [[64] * 3, [256] * 3, [512, 64, 32]]
+        if len(F) >= 8192: # the meshes the kernel-choice rule (dg_capi.cpp) is about: more cell sizes around its threshold
+            sizes += [[128] * 3, [384] * 3, [512] * 3]
+        for res in sizes:
             g = dg.grid_desc(dom[:3], dom[3:], res)
             n = dg.n_nodes(g)
             out = torch.empty(n, dtype=torch.float64, device="cuda")
