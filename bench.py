@@ -318,22 +318,44 @@ def main():
             c, stride = dg.shard_layout(grid, p * world + rank, vworld)
             counts.append(c)
         launch_nodes = sum(counts)
-        if args.python_gather:
+        comm_note = None
+        if not args.python_gather:
+            # the library's own RCCL communicator: rank 0's unique id travels through torch.distributed.  Should the
+            # library's communicator not come up on some rank (it never ran with more than one rank on the boxes this
+            # was developed on), EVERY rank takes the torch.distributed form below -- same kernels, same bytes on the
+            # links -- and the line says so; a scaling run is not lost to the plumbing.
+            failed = torch.zeros(1, dtype=torch.int32, device="cuda")
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(dg.Comm.unique_id()), dtype=torch.uint8))
+            except Exception as exc:  # noqa: BLE001 (reported on the line)
+                comm_note = "%s: %s" % (type(exc).__name__, exc)
+                failed += 1
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if int(failed.item()) == 0:
+                dist.broadcast(uid, 0)
+                try:
+                    if os.environ.get("DG_BENCH_BREAK_LIBRARY_COMM") == "1":   # (tests: exercise the way out)
+                        raise RuntimeError("simulated failure of dg_comm_create")
+                    comm = dg.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                except Exception as exc:  # noqa: BLE001
+                    comm_note = "%s: %s" % (type(exc).__name__, exc)
+                    failed += 1
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            if int(failed.item()) != 0:
+                comm = None
+                comm_note = "library communicator unavailable (%s)" % (comm_note or "on another rank")
+        if comm is None:
             # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
             # 4-plane slabs; `gathered` is exactly the buffer a single all-gather among pieces*world ranks
             # would produce and the unpack kernel is unchanged
             gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
             mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
             unpack_stream = torch.cuda.Stream()
-        else:
-            # the library's own RCCL communicator: rank 0's unique id travels through torch.distributed
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(dg.Comm.unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            comm = dg.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
     else:
         launch_nodes = n_nodes
+        comm_note = None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -410,7 +432,8 @@ def main():
                 "nodes_per_gpu_launch": launch_nodes,
                 "sharding": "none" if not sharded else
                             "4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
-                            % (pieces, "torch.distributed (python)" if comm is None else "dg_sdf_sample_allgather_device (RCCL inside the library)"),
+                            % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
+                               else "dg_sdf_sample_allgather_device (RCCL inside the library)"),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {

@@ -35,6 +35,20 @@ def test_library_allgather_one_rank():
     assert "dg_sdf_sample_allgather_device" in rec["config"]["sharding"] and rec["value"] > 0
 
 
+def test_bench_falls_back_to_torch_distributed_when_the_library_communicator_fails():
+    """A scaling run must not be lost to plumbing: if dg_comm_create fails on any rank, every rank of bench.py gathers
+    through torch.distributed instead (same kernels, same unpack), says so on its line, and the field still equals
+    the direct launch bit for bit (bench.py asserts that with --force-shard-path)."""
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--force-shard-path", "--steps", "2", "--warmup", "1",
+           "--no-extras", "--pieces", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_PORT=str(_free_port()), DG_BENCH_BREAK_LIBRARY_COMM="1"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    sharding = rec["config"]["sharding"]
+    assert "torch.distributed (python)" in sharding and "library communicator unavailable" in sharding and rec["value"] > 0
+
+
 def test_cpp_multi_gpu_tool_one_rank(tmp_path):
     """GenerateSDFMultiGPU (C++, one process per GPU, ncclCommInitRank through dg_comm_create, device-resident
     field on every rank) with one rank writes the file GenerateSDF writes, byte for byte; with --steps it
