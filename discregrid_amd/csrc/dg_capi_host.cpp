@@ -214,70 +214,101 @@ double resident_fraction(const void* p, size_t bytes)
 	return seen ? (double)resident / (double)seen : 1.0;
 }
 
-struct HostTarget // RAII: the registration ends with the call
+struct HostTarget // RAII: the registrations end with the call
 {
-	void* base = nullptr;
-	bool registered = false;
+	char* out = nullptr;
+	size_t bytes = 0;
+	bool caller_pinned = false; // the caller's array already is a DMA target
+	bool fresh = false;         // untouched so far: this code faults it in (2 MiB pages, several threads)
+	size_t prepared = 0;        // bytes made a DMA target so far
+	std::vector<void*> registered;
 	~HostTarget()
 	{
-		if (registered)
-			(void)hipHostUnregister(base);
+		for (void* p : registered)
+			(void)hipHostUnregister(p);
 	}
 };
-// Makes [out, out + bytes) -- an array this call overwrites completely -- a DMA target.  Returns false if
-// the staged form should run instead (array already resident in pages of unknown size, registration
-// refused, or switched off with DG_HOST_DIRECT=0; =2 takes the direct form whatever the state of the pages).
-bool prepare_host_target(void* out, size_t bytes, HostTarget& T)
+// May [out, out + bytes) -- an array this call overwrites completely -- become a DMA target?  Returns false if
+// the staged form should run instead (array already resident in pages of unknown size, or switched off with
+// DG_HOST_DIRECT=0; =2 takes the direct form whatever the state of the pages).  Nothing is touched or pinned yet:
+// prepare_host_piece() does that range by range, so that the first copies run while the rest is prepared.
+bool begin_host_target(void* out, size_t bytes, HostTarget& T)
 {
 	const int mode = env_int("DG_HOST_DIRECT", 1, 0, 2);
 	if (mode == 0 || (mode != 2 && bytes < (1u << 22)))
 		return false;
+	T.out = static_cast<char*>(out);
+	T.bytes = bytes;
 	hipPointerAttribute_t attr;
 	if (hipPointerGetAttributes(&attr, out) == hipSuccess)
 	{
 		if (attr.type == hipMemoryTypeHost)
-			return true; // pinned or registered by the caller
+		{
+			T.caller_pinned = true; // pinned or registered by the caller
+			return true;
+		}
 		if (attr.type != hipMemoryTypeUnregistered)
 			return false;
 	}
 	else
 		(void)hipGetLastError(); // ordinary memory the runtime has never seen
-	const bool fresh = resident_fraction(out, bytes) < 0.1;
-	if (mode != 2 && !fresh && !g_prepared.contains(out, bytes))
+	T.fresh = resident_fraction(out, bytes) < 0.1;
+	if (mode != 2 && !T.fresh && !g_prepared.contains(out, bytes))
 		return false;
-	if (fresh)
+	if (T.fresh)
 	{
-		// huge pages for the 2 MiB-aligned interior, then first touch from several threads (every byte of
-		// the range is overwritten by this call, so writing to it is safe)
+		// huge pages for the 2 MiB-aligned interior (every byte of the range is overwritten by this call)
 		const uintptr_t a = ((uintptr_t)out + (1u << 21) - 1) & ~(uintptr_t)((1u << 21) - 1);
 		const uintptr_t b = ((uintptr_t)out + bytes) & ~(uintptr_t)((1u << 21) - 1);
 		if (b > a)
 			(void)madvise(reinterpret_cast<void*>(a), b - a, MADV_HUGEPAGE);
+	}
+	return true;
+}
+// Bytes [lo, hi) of the array become a DMA target: first touch from several threads if the array is fresh, then
+// hipHostRegister.  Interior boundaries must be multiples of the page size (the callers use 2 MiB) so that no page
+// belongs to two registrations.
+bool prepare_host_piece(HostTarget& T, size_t lo, size_t hi)
+{
+	if (T.caller_pinned || hi <= lo)
+		return true;
+	char* base = T.out + lo;
+	const size_t bytes = hi - lo;
+	if (T.fresh)
+	{
 		const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
 		const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, bytes >> 24));
 		const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+		volatile char* c = base;
+		auto touch = [=](unsigned t) {
+			const size_t b = std::min(bytes, per * t), e = std::min(bytes, per * (t + 1));
+			for (size_t o = b; o < e; o += 4096)
+				c[o] = 0;
+			if (e > b)
+				c[e - 1] = 0;
+		};
 		std::vector<std::thread> th;
-		volatile char* c = static_cast<volatile char*>(out);
-		for (unsigned t = 0; t < nt; ++t)
-			th.emplace_back([=]() {
-				const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
-				for (size_t o = lo; o < hi; o += 4096)
-					c[o] = 0;
-				if (hi > lo)
-					c[hi - 1] = 0;
-			});
+		for (unsigned t = 1; t < nt; ++t)
+			th.emplace_back(touch, t);
+		touch(0);
 		for (auto& t : th)
 			t.join();
-		g_prepared.add(out, bytes);
 	}
-	if (hipHostRegister(out, bytes, hipHostRegisterPortable) != hipSuccess)
+	if (hipHostRegister(base, bytes, hipHostRegisterPortable) != hipSuccess)
 	{
 		(void)hipGetLastError();
 		return false;
 	}
-	T.base = out;
-	T.registered = true;
+	T.registered.push_back(base);
+	T.prepared += bytes;
+	if (T.fresh && T.prepared >= T.bytes)
+		g_prepared.add(T.out, T.bytes);
 	return true;
+}
+// the whole array at once (calls that deal one array to several devices)
+bool prepare_host_target(void* out, size_t bytes, HostTarget& T)
+{
+	return begin_host_target(out, bytes, T) && prepare_host_piece(T, 0, bytes);
 }
 
 // dst <- src with a few threads (one thread tops out near 10 GB/s, the PCIe link delivers 50+)
@@ -350,6 +381,36 @@ void schedule_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end
 			cuts.push_back(*it);
 	}
 	cuts.push_back(node_end);
+}
+// chunk sizes of the direct form as fractions of the range (DG_HOST_DIRECT_FRACTIONS="0.1,0.2,...": experiments)
+std::vector<double> direct_fractions()
+{
+	std::vector<double> f = {0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03};
+	if (const char* e = std::getenv("DG_HOST_DIRECT_FRACTIONS"))
+	{
+		std::vector<double> g;
+		double sum = 0;
+		for (const char* p = e; *p;)
+		{
+			char* end = nullptr;
+			const double v = std::strtod(p, &end);
+			if (end == p)
+				break;
+			if (v > 0)
+			{
+				g.push_back(v);
+				sum += v;
+			}
+			p = (*end == ',') ? end + 1 : end;
+		}
+		if (g.size() >= 1 && sum > 0)
+		{
+			for (double& v : g)
+				v /= sum;
+			f = g;
+		}
+	}
+	return f;
 }
 } // namespace
 
@@ -471,14 +532,26 @@ static dg_status run_k1_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 	return run_pipeline(pipe, cuts, first, stride, arrays, launch, "dg_sdf_sample_nodes", kernel_ms, t_wait, t_copy);
 }
 
-// K1, direct form: `out` is a DMA target (prepare_host_target()).  Everything is enqueued up front -- the
-// compute stream samples chunk i into device buffer i & 1 as soon as the copy of chunk i - 2 has left
-// it, the copy stream writes chunk i into the caller's array as soon as it is sampled -- and the host
-// only waits for the last copy.  `host_ready` runs on the host after the first two chunks are enqueued
-// (the GPU is busy by then) and before the first copy is: it makes `out` a DMA target, or says no.
+// K1, direct form: the copy engine writes every chunk straight into the caller's array.  Everything is enqueued up
+// front: the compute stream samples chunk i into device buffer i & 1 as soon as the copy of chunk i - 2 has left it, the
+// copy stream writes chunk i into the caller's array as soon as it is sampled, and the host only waits for the last
+// copy.  Meanwhile the host makes the array a DMA target PIECE BY PIECE (DirectHost::piece: first touch + registration
+// of the bytes chunk i ends in), one piece ahead of the copy that needs it: preparing the whole array first took 6 ms
+// of a 23 ms call at 256^3 during which no copy ran; piece by piece the preparation costs more in total (~1.4 ms per
+// registration) but hides behind the sampling, and the call ends one kernel tail after the last chunk: 23.0 -> 21.9 ms
+// on the same box (DG_HOST_PIECES=0: the whole array at once, as before).  Measured and not kept: the chunks alternating
+// between two compute streams so that a chunk's tail runs under the next chunk's bulk (25.0 ms: the two launches slow
+// each other down by more than the tails they hide), other chunk size profiles (DG_HOST_DIRECT_FRACTIONS).
+// `begin` runs on the host after the first two chunks are enqueued (the GPU is busy by then): may the direct form
+// run at all?  If it says no, or a piece cannot be prepared, the caller runs the staged form over the whole range.
+struct DirectHost
+{
+	std::function<bool()> begin;
+	std::function<bool(size_t, size_t)> piece; // bytes [lo, hi) of `out`; empty: the whole array already is a DMA target
+};
 static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_grid_desc* grid, int invert,
 							   const std::vector<uint64_t>& cuts, size_t first, size_t stride, const uint8_t* pred_mask, double* out,
-							   const std::function<bool()>& host_ready, bool* went_direct, double* kernel_ms, Progress* progress = nullptr)
+							   const DirectHost& host, bool* went_direct, double* kernel_ms, Progress* progress = nullptr)
 {
 	*went_direct = true;
 	const size_t n_chunks = cuts.size() - 1;
@@ -496,43 +569,74 @@ static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 	hipError_t e = pipe.prepare(out_bytes + mask_bytes, false);
 	if (e == hipSuccess) e = pipe.events(3 * mine.size());
 	dg_status st = DG_OK;
+	// piece i = bytes [bound[i], bound[i + 1]) of the array: chunk i's bytes end in it.  Interior bounds are the chunk
+	// starts rounded up to 2 MiB (of the address), so a chunk may begin in the last 2 MiB of the piece before.
+	const bool by_piece = env_int("DG_HOST_PIECES", 1, 0, 1) != 0;
+	const bool pieces = (bool)host.piece && stride == 1 && first == 0 && by_piece;
+	const size_t total_bytes = (size_t)(cuts[n_chunks] - cuts[0]) * sizeof(double);
+	std::vector<size_t> bound(mine.size() + 1, 0);
+	bound[mine.size()] = total_bytes;
+	for (size_t i = 1; i < mine.size(); ++i)
+	{
+		const uintptr_t at = (uintptr_t)out + (size_t)(cuts[mine[i]] - cuts[0]) * sizeof(double);
+		const uintptr_t up = (at + ((uintptr_t)1 << 21) - 1) & ~(((uintptr_t)1 << 21) - 1);
+		bound[i] = std::max(bound[i - 1], std::min<size_t>(total_bytes, (size_t)(up - (uintptr_t)out)));
+	}
+
 	auto enqueue_kernel = [&](size_t i) {
 		const size_t k = mine[i];
 		const int b = (int)(i & 1);
+		const hipStream_t cs = pipe.compute;
 		const uint64_t cn = cuts[k + 1] - cuts[k];
 		double* d_out = static_cast<double*>(pipe.d_buf[b]);
 		uint8_t* d_mask = pred_mask ? reinterpret_cast<uint8_t*>(static_cast<char*>(pipe.d_buf[b]) + out_bytes) : nullptr;
 		if (i >= 2)
-			e = hipStreamWaitEvent(pipe.compute, pipe.ev[3 * (i - 2) + 2], 0);
-		if (e == hipSuccess) e = hipEventRecord(pipe.ev[3 * i], pipe.compute);
+			e = hipStreamWaitEvent(cs, pipe.ev[3 * (i - 2) + 2], 0);
+		if (e == hipSuccess) e = hipEventRecord(pipe.ev[3 * i], cs);
 		if (e == hipSuccess && pred_mask)
-			e = hipMemcpyAsync(d_mask, pred_mask + (cuts[k] - cuts[0]), cn, hipMemcpyHostToDevice, pipe.compute);
+			e = hipMemcpyAsync(d_mask, pred_mask + (cuts[k] - cuts[0]), cn, hipMemcpyHostToDevice, cs);
 		if (e == hipSuccess)
-			st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask, d_out, pipe.compute);
-		if (e == hipSuccess && st == DG_OK) e = hipEventRecord(pipe.ev[3 * i + 1], pipe.compute);
+			st = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask, d_out, cs);
+		if (e == hipSuccess && st == DG_OK) e = hipEventRecord(pipe.ev[3 * i + 1], cs);
 	};
 	auto enqueue_copy = [&](size_t i) {
 		const size_t k = mine[i];
-		const uint64_t cn = cuts[k + 1] - cuts[k];
+		const size_t lo = (size_t)(cuts[k] - cuts[0]) * sizeof(double), hi = (size_t)(cuts[k + 1] - cuts[0]) * sizeof(double);
 		e = hipStreamWaitEvent(pipe.copy, pipe.ev[3 * i + 1], 0);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(out + (cuts[k] - cuts[0]), pipe.d_buf[i & 1], cn * sizeof(double), hipMemcpyDeviceToHost, pipe.copy);
+		// one copy per registration the chunk's bytes lie in (a copy must not straddle two registrations)
+		size_t at = lo;
+		while (e == hipSuccess && at < hi)
+		{
+			size_t end = hi;
+			if (pieces)
+				for (size_t j = 1; j < mine.size(); ++j)
+					if (bound[j] > at && bound[j] < end)
+						end = bound[j];
+			e = hipMemcpyAsync(reinterpret_cast<char*>(out) + at, static_cast<const char*>(pipe.d_buf[i & 1]) + (at - lo), end - at,
+							   hipMemcpyDeviceToHost, pipe.copy);
+			at = end;
+		}
 		if (e == hipSuccess) e = hipEventRecord(pipe.ev[3 * i + 2], pipe.copy);
+	};
+	auto give_up = [&]() { // the chunks already in flight are simply sampled again by the staged form
+		(void)hipStreamSynchronize(pipe.compute);
+		(void)hipStreamSynchronize(pipe.copy);
+		*went_direct = false;
+		return DG_OK;
 	};
 	const size_t head = std::min<size_t>(2, mine.size());
 	for (size_t i = 0; i < head && e == hipSuccess && st == DG_OK; ++i)
 		enqueue_kernel(i);
-	if (e == hipSuccess && st == DG_OK && !host_ready())
+	if (e == hipSuccess && st == DG_OK && !host.begin())
+		return give_up();
+	if (e == hipSuccess && st == DG_OK && !pieces && (bool)host.piece && !host.piece(0, total_bytes)) // the whole array at once
+		return give_up();
+	for (size_t i = 0; i < mine.size() && e == hipSuccess && st == DG_OK; ++i)
 	{
-		(void)hipStreamSynchronize(pipe.compute); // the two chunks already in flight are simply sampled again
-		*went_direct = false;
-		return DG_OK;
-	}
-	for (size_t i = 0; i < head && e == hipSuccess && st == DG_OK; ++i)
-		enqueue_copy(i);
-	for (size_t i = head; i < mine.size() && e == hipSuccess && st == DG_OK; ++i)
-	{
-		enqueue_kernel(i);
+		if (i >= head)
+			enqueue_kernel(i);
+		if (e == hipSuccess && st == DG_OK && pieces && !host.piece(bound[i], bound[i + 1]))
+			return give_up();
 		if (e == hipSuccess && st == DG_OK)
 			enqueue_copy(i);
 	}
@@ -607,12 +711,12 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
 	std::vector<uint64_t> cuts, direct_cuts;
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
-	// direct form: seven chunks, the first two big enough to cover the preparation of the caller's array,
-	// the last one small (DG_HOST_CHUNK_NODES set: the uniform chunks above, as in the staged form)
+	// direct form: seven chunks, the last one small -- its copy is the only one nothing overlaps
+	// (DG_HOST_CHUNK_NODES set: the uniform chunks above, as in the staged form)
 	if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
 		direct_cuts = cuts;
 	else
-		schedule_cuts(grid->resolution, node_begin, node_end, {0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, direct_cuts);
+		schedule_cuts(grid->resolution, node_begin, node_end, direct_fractions(), direct_cuts);
 	double kernel_ms = 0, t_wait = 0, t_copy = 0;
 	DG_ON_DEVICE_OF(mesh);
 	PipeLease lease = lease_pipe(mesh->device);
@@ -620,14 +724,18 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	bool direct = false;
 	double t_prepare = 0;
 	Progress progress{t_progress, t_progress_user, n};
-	s = run_k1_direct(*lease.pipe, mesh, grid, invert, direct_cuts, 0, 1, pred_mask, out,
-					  [&]() {
-						  const auto t0 = std::chrono::steady_clock::now();
-						  const bool ok = prepare_host_target(out, n * sizeof(double), host_target);
-						  t_prepare = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-						  return ok;
-					  },
-					  &direct, &kernel_ms, &progress);
+	DirectHost host;
+	host.begin = [&]() { return begin_host_target(out, n * sizeof(double), host_target); };
+	host.piece = [&](size_t lo, size_t hi) {
+		const auto t0 = std::chrono::steady_clock::now();
+		const bool ok = prepare_host_piece(host_target, lo, hi);
+		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if (std::getenv("DG_HOST_DEBUG"))
+			std::fprintf(stderr, "  piece [%zu, %zu) MiB prepared in %.2f ms\n", lo >> 20, hi >> 20, dt * 1e3);
+		t_prepare += dt;
+		return ok;
+	};
+	s = run_k1_direct(*lease.pipe, mesh, grid, invert, direct_cuts, 0, 1, pred_mask, out, host, &direct, &kernel_ms, &progress);
 	if (s == DG_OK && !direct)
 	{
 		kernel_ms = 0;
@@ -692,8 +800,12 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 			PipeLease lease = lease_pipe(meshes[i]->device);
 			bool went = false;
 			if (direct)
+			{
+				DirectHost whole; // the array was prepared above, for all devices
+				whole.begin = []() { return true; };
 				status[(size_t)i] = run_k1_direct(*lease.pipe, meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
-												  []() { return true; }, &went, &kernel_ms[(size_t)i]);
+												  whole, &went, &kernel_ms[(size_t)i]);
+			}
 			else
 				status[(size_t)i] = run_k1_chunks(*lease.pipe, meshes[i], grid, invert, cuts, (size_t)i, (size_t)n_meshes, pred_mask, out,
 												  &kernel_ms[(size_t)i], &t_wait, &t_copy);
