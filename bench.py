@@ -215,8 +215,27 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         fn()
         ms = timed(torch, stream, fn, 5)
         k2["%s_value_tile_major" % name] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "hbm_frac_algorithmic": nq * 288 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    # queries that arrive sorted by cell (what a caller with spatially sorted particles hands over), plain layout
     fld.drop_tile_major()
+    # ... and with the optional CELL-major copy (dg_field_build_cell_major: 256 B per cell, 4.3 GB at 256^3, built once per
+    # field): one contiguous row per query, fetched cooperatively by the wave -- no binning, the order does not matter
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fld.build_cell_major(s)
+    torch.cuda.synchronize()
+    k2["cell_major_build_ms"] = (time.perf_counter() - t0) * 1e3
+    k2["cell_major_bytes"] = 256 * int(np.prod(res))
+    for name, Q in (("uniform", P), ("shell", S)):
+        if len(Q) < nq:
+            continue
+        for g in (False, True):
+            fn = (lambda Q=Q, g=g: fld.interpolate_device(Q.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
+            fn()
+            ms = timed(torch, stream, fn, 5)
+            bytes_q = 312 if g else 288
+            k2["%s_%s_cell_major" % (name, "grad" if g else "value")] = {
+                "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    fld.drop_cell_major()
+    # queries that arrive sorted by cell (what a caller with spatially sorted particles hands over), plain layout
     h3 = torch.tensor((dom[3:] - dom[:3]) / np.array(res, dtype=np.float64), device="cuda")
     cell = ((P - torch.tensor(dom[:3], device="cuda")) / h3).floor().clamp(0, res[0] - 1).long()
     Ps = P[torch.argsort((cell[:, 2] * res[1] + cell[:, 1]) * res[0] + cell[:, 0])].contiguous()

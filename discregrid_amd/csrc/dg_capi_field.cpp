@@ -138,10 +138,16 @@ void dg_field_destroy(dg_field* f)
 	delete f;
 }
 
+static dg_status build_cell_major_locked(dg_field* field, void* stream);
 dg_status dg_field_build_cell_major(dg_field* field, void* stream)
 {
 	if (!field)
 		return fail(DG_ERR_INVALID, "null argument");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
+	return build_cell_major_locked(field, stream);
+}
+static dg_status build_cell_major_locked(dg_field* field, void* stream) // field->copy_mutex held
+{
 	if (field->d_cell_major)
 		return DG_OK;
 	if (field->n_rows == 0)
@@ -172,6 +178,7 @@ dg_status dg_field_build_tile_major(dg_field* field, void* stream)
 {
 	if (!field)
 		return fail(DG_ERR_INVALID, "null argument");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
 	if (field->d_tile_major)
 		return DG_OK;
 	if (field->dev.cells != nullptr || field->dev.cell_map != nullptr)
@@ -203,6 +210,7 @@ dg_status dg_field_drop_tile_major(dg_field* field)
 {
 	if (!field)
 		return fail(DG_ERR_INVALID, "null argument");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
 	if (field->d_tile_major)
 	{
 		DG_ON_DEVICE_OF(field);
@@ -218,6 +226,8 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 {
 	if (!field)
 		return fail(DG_ERR_INVALID, "null argument");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
+	field->auto_copy_tried = true; // the caller decided against the copy: K2 does not bring it back by itself
 	if (field->d_cell_major)
 	{
 		DG_ON_DEVICE_OF(field);
@@ -419,26 +429,60 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 		return DG_OK;
 	DG_ON_DEVICE_OF(field);
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	if ((field->d_cell_major || field->d_tile_major) && field->cell_major_ready) // the copy may still be being built on another stream
-		DG_HIP(hipStreamWaitEvent(st, field->cell_major_ready, 0));
+	const bool big = n >= (1u << 18) && field->n_coeffs * sizeof(double) >= (32u << 20);
+	dg::FieldDev dev;
+	hipEvent_t copy_ready = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(field->copy_mutex);
+		// A field whose coefficients this library owns (dg_field_create: they cannot change) that gets a large batch and
+		// has no copy yet: build the cell-major copy now, on this stream, once (5 ms and 4.3 GB at 256^3 against 0.7 ms
+		// saved on every 10 M queries from then on).  Not for attached device arrays (they may change between calls: their
+		// owner calls dg_field_build_cell_major), not beyond DG_K2_AUTO_CELL_MAJOR_MB (default 16384; 0: never) or a
+		// quarter of the free device memory, not after dg_field_drop_cell_major.
+		if (big && field->owned[0] != nullptr && !field->d_cell_major && !field->d_tile_major && !field->auto_copy_tried)
+		{
+			field->auto_copy_tried = true;
+			const uint64_t need = field->n_rows * 256ull;
+			const uint64_t cap = (uint64_t)env_int("DG_K2_AUTO_CELL_MAJOR_MB", 16384, 0, 1 << 20) << 20;
+			size_t free_b = 0, total_b = 0;
+			if (need <= cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4)
+			{
+				if (build_cell_major_locked(const_cast<dg_field*>(field), stream) != DG_OK)
+					(void)hipGetLastError(); // without the copy then
+			}
+			else
+				(void)hipGetLastError();
+		}
+		dev = field->dev;
+		if (field->d_cell_major || field->d_tile_major)
+			copy_ready = field->cell_major_ready;
+	}
+	if (copy_ready) // the copy may still be being built on another stream
+		DG_HIP(hipStreamWaitEvent(st, copy_ready, 0));
+	// A field with a cell-major copy: one contiguous row per query, fetched cooperatively -- the order of the queries
+	// does not matter, nothing is sorted (DG_K2_ROWS=0: the binned / per-lane kernels on the copy, as in round 1).
+	if (dev.cell_major != nullptr && dev.tile_major == nullptr && env_int("DG_K2_ROWS", 1, 0, 1) != 0)
+	{
+		DG_HIP(dg::launch_interpolate_rows(dev, d_xyz, n, d_phi, d_grad, st));
+		return DG_OK;
+	}
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and
 	// run as they are).  DG_K2_BINNING=0 switches it off, =2 forces it for any size.
 	const int binning = env_int("DG_K2_BINNING", 1, 0, 2);
-	const bool big = n >= (1u << 18) && field->n_coeffs * sizeof(double) >= (32u << 20);
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
 		dg::BinScratch S;
-		const int idx = acquire_bin_scratch(field->scratch, &field->bin_flag_host, dg::field_tiles(field->dev, dg::kSortCells), n, st, S);
+		const int idx = acquire_bin_scratch(field->scratch, &field->bin_flag_host, dg::field_tiles(dev, dg::kSortCells), n, st, S);
 		if (idx >= 0)
 		{
-			const hipError_t e = dg::launch_interpolate_binned(field->dev, d_xyz, n, d_phi, d_grad, S, st);
+			const hipError_t e = dg::launch_interpolate_binned(dev, d_xyz, n, d_phi, d_grad, S, st);
 			field->scratch.release(idx, st);
 			DG_HIP(e);
 			return DG_OK;
 		}
 	}
-	DG_HIP(dg::launch_interpolate(field->dev, d_xyz, n, d_phi, d_grad, st));
+	DG_HIP(dg::launch_interpolate(dev, d_xyz, n, d_phi, d_grad, st));
 	return DG_OK;
 }
 

@@ -133,6 +133,8 @@ struct dg_field
 	mutable ScratchPool flag_scratch;     // K3: the flag word k_field_check writes, one per launch in flight
 	std::mutex wtab_mutex;
 	std::map<double, void*> wtabs;        // K3: support radius -> immutable device table of 4096 kernel values
+	mutable std::mutex copy_mutex;        // guards d_cell_major / d_tile_major / dev.{cell,tile}_major (built on demand by K2)
+	mutable bool auto_copy_tried = false; // K2 built (or could not build) the cell-major copy of an owned field by itself
 	dg_grid_desc grid;
 	uint64_t n_coeffs = 0;
 	uint64_t n_rows = 0; // rows of the cell table (= grid cells for an unreduced field)

@@ -333,6 +333,8 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
 // f.ntile must be set; d_out: n_tiles * kTmNodes doubles
 hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_out, hipStream_t stream);
+// K2 over the cell-major copy of a field (f.cell_major set), queries in any order, no binning
+hipError_t launch_interpolate_rows(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream);
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 							  hipStream_t stream);
 

@@ -918,6 +918,67 @@ __global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate_binned(const F
 	}
 }
 
+// K2 over a field with a CELL-MAJOR copy, queries in ANY order, no binning: one wave = 64 queries.  A query's 32
+// coefficients are one contiguous 256-byte row of the copy; left to itself every lane would read its own row with
+// sixteen 16-byte loads, 64 different lines per instruction.  Here the wave fetches the 64 rows TOGETHER -- sixteen
+// loads, each covering four whole rows (lane = (row in the group, 16-byte piece)), i.e. four fully used 256-byte
+// segments per instruction --, hands them to their owners through LDS (rows padded to 33 doubles: the owners' reads are
+// conflict-free) and every lane then evaluates its own query exactly as interpolate_point_mode does (locate_query /
+// evaluate_cell: the same statements).  HBM moves 256 B + 24 B + 8 B per query whatever the order of the queries.
+static const int kRowStride = 33; // doubles per staged row
+template <bool GRAD>
+__global__ __launch_bounds__(64) void k_interpolate_rows(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+														   double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	__shared__ double rows[64 * kRowStride];
+	const int lane = (int)threadIdx.x;
+	const int sub = lane & 15, grp = lane >> 4;
+	for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n; base += (uint64_t)gridDim.x * 64u)
+	{
+		const uint64_t gid = base + (uint64_t)lane;
+		const bool have = gid < n;
+		double x[3] = {0.0, 0.0, 0.0};
+		if (have)
+		{
+			x[0] = xyz[3 * gid];
+			x[1] = xyz[3 * gid + 1];
+			x[2] = xyz[3 * gid + 2];
+		}
+		CellQuery q = locate_query(F, x);
+		q.valid = q.valid && have;
+		const uint32_t my_row = q.valid ? q.row : 0u; // (row 0 exists: a field has at least one cell row)
+		__syncthreads(); // the previous round's rows have been read
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const int owner = 4 * k + grp;
+			const uint32_t r = (uint32_t)__shfl((int)my_row, owner);
+			const double2 v = *reinterpret_cast<const double2*>(F.cell_major + 32 * (size_t)r + 2 * sub);
+			rows[owner * kRowStride + 2 * sub] = v.x;
+			rows[owner * kRowStride + 2 * sub + 1] = v.y;
+		}
+		__syncthreads();
+		double cf[32];
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			cf[j] = rows[lane * kRowStride + j];
+		double g[3] = {0.0, 0.0, 0.0};
+		double phi = 1.7976931348623157e308;
+		if (q.valid)
+			phi = evaluate_cell<GRAD>(cf, q.xi, q.c0, g);
+		if (have)
+		{
+			phi_out[gid] = phi;
+			if (GRAD)
+			{
+				grad_out[3 * gid] = g[0];
+				grad_out[3 * gid + 1] = g[1];
+				grad_out[3 * gid + 2] = g[2];
+			}
+		}
+	}
+}
+
 // Builds the cell-major copy of a field (FieldDev::cell_major): one thread per cell row.
 __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t n_rows, double* __restrict__ out)
 {
@@ -1414,6 +1475,21 @@ hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n
 	default: DG_K2_LAUNCH(kFieldClosed)
 	}
 #undef DG_K2_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_rows(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	if (f.cell_major == nullptr)
+		return hipErrorInvalidValue;
+	const uint64_t waves = (n + 63) / 64;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(waves, 256ull * 64ull); // grid-stride beyond 64 waves per CU
+	if (d_grad)
+		hipLaunchKernelGGL((k_interpolate_rows<true>), dim3(grid), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	else
+		hipLaunchKernelGGL((k_interpolate_rows<false>), dim3(grid), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad);
 	return hipGetLastError();
 }
 

@@ -447,6 +447,85 @@ DG_HD double interpolate_point_mode(const FieldDev& F, const double x[3], double
 	}
 	return phi;
 }
+// interpolate_point_mode() in two halves, for kernels that fetch the coefficients themselves (k_interpolate_rows): the
+// same statements in the same order (the K2 kernels keep the one-piece form above -- split, the compiler allocates 18
+// more registers for them).  locate_query: the query's cell and its local coordinates, everything up to the fetch.
+struct CellQuery
+{
+	bool valid;       // false: outside the domain or in a removed cell -> DBL_MAX, zero gradient
+	uint32_t mi[3];   // cell multi-index
+	uint32_t row;     // cell row (through cell_map for reduced fields)
+	double c0[3], xi[3];
+};
+DG_HD CellQuery locate_query(const FieldDev& F, const double x[3])
+{
+	CellQuery q;
+	q.valid = false;
+	q.row = 0;
+	for (int d = 0; d < 3; ++d)
+	{
+		q.mi[d] = 0;
+		q.c0[d] = q.xi[d] = 0.0;
+	}
+	for (int d = 0; d < 3; ++d)
+		if (!((F.dmin[d] <= x[d]) && (x[d] <= F.dmax[d]))) // AlignedBox::contains, inclusive (:981)
+			return q;
+	for (int d = 0; d < 3; ++d)
+	{
+		q.mi[d] = (uint32_t)((x[d] - F.dmin[d]) * F.inv_cell[d]); // :984
+		if (q.mi[d] >= F.res[d])
+			q.mi[d] = F.res[d] - 1;
+	}
+	const uint32_t ci = F.res[1] * F.res[0] * q.mi[2] + F.res[0] * q.mi[1] + q.mi[0];
+	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
+	if (cm == 0xffffffffu)
+		return q;
+	q.row = cm;
+	for (int d = 0; d < 3; ++d)
+	{
+		const double lo = F.dmin[d] + (double)q.mi[d] * F.cell[d]; // subdomain(), discrete_grid.cpp:26-32
+		const double hi = lo + F.cell[d];
+		const double den = hi - lo; // :1000
+		q.c0[d] = 2.0 / den;
+		const double c1 = (hi + lo) / den;
+		q.xi[d] = q.c0[d] * x[d] - c1;
+	}
+	q.valid = true;
+	return q;
+}
+// The 32-term sum in j order over the cell's coefficients cf (parity); DBL_MAX if one of them is DBL_MAX.
+template <bool GRAD>
+DG_HD double evaluate_cell(const double cf[32], const double xi[3], const double c0[3], double g[3])
+{
+	const double NOVAL = 1.7976931348623157e308;
+	double N[32], dNx[32], dNy[32], dNz[32];
+	shape_functions<GRAD>(xi[0], xi[1], xi[2], N, dNx, dNy, dNz);
+	bool ok = true;
+	double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#if defined(__HIP__)
+#pragma unroll
+#endif
+	for (int j = 0; j < 32; ++j)
+	{
+		ok = ok && (cf[j] != NOVAL);
+		phi += cf[j] * N[j];
+		if (GRAD)
+		{
+			gx += cf[j] * dNx[j];
+			gy += cf[j] * dNy[j];
+			gz += cf[j] * dNz[j];
+		}
+	}
+	if (!ok)
+		return NOVAL;
+	if (GRAD)
+	{
+		g[0] = gx * c0[0];
+		g[1] = gy * c0[1];
+		g[2] = gz * c0[2];
+	}
+	return phi;
+}
 // runtime dispatch (host scalar API, emulator)
 template <bool GRAD>
 DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3])

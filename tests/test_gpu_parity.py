@@ -193,7 +193,7 @@ def test_far_and_on_surface_queries(dg):
 
 
 @pytest.mark.parametrize("name", list(MESHES))
-def test_interpolate_vs_golden(dg, golden, name):
+def test_interpolate_vs_golden(dg, golden, name, monkeypatch):
     dom, res = golden[name + "_domain"], golden[name + "_res"]
     coeffs, P = golden[name + "_coeffs"], golden[name + "_P"]
     g = grid_of(dg, dom, res)
@@ -205,12 +205,18 @@ def test_interpolate_vs_golden(dg, golden, name):
     np.testing.assert_array_equal(grad[inside], golden[name + "_grad"][inside])
     assert (grad[~inside] == 0).all()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
-    # cell-major device copy: bit-identical results
+    # cell-major device copy: bit-identical results -- through the cooperative row kernel (default: no binning, any
+    # query order, batch sizes that are no multiples of a wave) and through the per-lane kernels (DG_K2_ROWS=0)
     f.build_cell_major()
-    phi2, grad2 = f.interpolate(P, grad=True)
-    np.testing.assert_array_equal(phi2, phi)
-    np.testing.assert_array_equal(grad2, grad)
-    np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    for rows in ("1", "0"):
+        monkeypatch.setenv("DG_K2_ROWS", rows)
+        phi2, grad2 = f.interpolate(P, grad=True)
+        np.testing.assert_array_equal(phi2, phi)
+        np.testing.assert_array_equal(grad2, grad)
+        np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+        for m in (1, 63, 65, 1000):
+            np.testing.assert_array_equal(f.interpolate(P[:m]), golden[name + "_phi"][:m])
+    monkeypatch.delenv("DG_K2_ROWS")
     f.drop_cell_major()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     # tile-major device copy (4^3-cell tiles of 736 doubles): bit-identical results, takes precedence over cell-major
@@ -411,3 +417,43 @@ def test_config3_icosphere_256(dg, torch, golden):
     want = T.OracleMesh(V, F).signed_distance(pos)
     assert_parity(got[sel], want, "ico71 256^3 random nodes")
     np.testing.assert_array_equal(got[sel], want)
+
+
+def test_k2_builds_the_cell_major_copy_of_an_owned_field_by_itself(dg, monkeypatch):
+    """A field created from host coefficients (the library owns its device copy: it cannot change) that receives a
+    large batch gets its cell-major copy built by dg_interpolate_batch itself, once, and from then on every batch --
+    whatever the order of its queries -- runs through the cooperative row kernel: same bits as the plain layout and
+    as the oracle; the memory shows up and, after dg_field_drop_cell_major, stays away."""
+    import torch
+    V, F = T.torus(40, 20)
+    dom = T.oracle_default_domain(V)
+    res = [96, 96, 96]
+    g = grid_of(dg, dom, res)
+    coeffs = dg.Mesh(V, F).sample_nodes(g)
+    assert coeffs.nbytes >= (32 << 20)
+    P = T.uniform_points(99, 300_000, dom[:3] - 0.05, dom[3:] + 0.05)   # unordered, a few outside the domain
+    monkeypatch.setenv("DG_K2_AUTO_CELL_MAJOR_MB", "0")
+    f0 = dg.Field(g, coeffs)
+    phi0, grad0 = f0.interpolate(P, grad=True)
+    monkeypatch.delenv("DG_K2_AUTO_CELL_MAJOR_MB")
+    f1 = dg.Field(g, coeffs)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    phi1, grad1 = f1.interpolate(P, grad=True)
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    np.testing.assert_array_equal(phi1, phi0)
+    np.testing.assert_array_equal(grad1, grad0)
+    copy_bytes = 256 * int(np.prod(res))
+    assert free_before - free_after >= 0.9 * copy_bytes          # the copy was built ...
+    np.testing.assert_array_equal(f1.interpolate(P[::-1].copy()), phi0[::-1])
+    assert free_after - torch.cuda.mem_get_info()[0] < 0.5 * copy_bytes   # ... once
+    want = T.oracle_interpolate(dom, res, coeffs, P[:5000])
+    np.testing.assert_array_equal(phi1[:5000], want)
+    f1.drop_cell_major()
+    torch.cuda.synchronize()
+    free_dropped = torch.cuda.mem_get_info()[0]
+    assert free_dropped - free_after >= 0.9 * copy_bytes
+    np.testing.assert_array_equal(f1.interpolate(P), phi0)
+    torch.cuda.synchronize()
+    assert free_dropped - torch.cuda.mem_get_info()[0] < 0.5 * copy_bytes  # the caller dropped it: it stays away
