@@ -194,6 +194,28 @@ def interpolate(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
     return (phi, g) if grad else phi
 
 
+def interpolate_rows(domain, res, coeffs, P, grad=False, cells=None, cell_map=None):
+    """K2 through the cooperative row kernel's data path (k_interpolate_rows): cell-major copy, staged rows, split
+    evaluation.  Same arguments and results as interpolate()."""
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    cell = np.empty(3)
+    inv = np.empty(3)
+    T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+    phi = np.empty(len(P))
+    g = np.empty((len(P), 3)) if grad else None
+    n_rows = int(np.prod(res.astype(np.uint64)))
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell_map = np.ascontiguousarray(cell_map, dtype=np.uint32)
+        n_rows = len(cells)
+    lib().emu_interpolate_rows(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), T.up(cells), C.c_uint64(n_rows),
+                               T.up(cell_map), T.dp(P), C.c_uint64(len(P)), T.dp(phi), T.dp(g))
+    return (phi, g) if grad else phi
+
+
 def set_fast(on=1):
     """Filtered K1 kernel (float filter + per-lane candidate lists) in the emulated launches; 0 = exact kernel
     only (DG_K1_FAST=0).  Resets the counters of fast_stats()."""

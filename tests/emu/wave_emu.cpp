@@ -1258,6 +1258,90 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	}
 }
 
+// k_interpolate_rows on the host: the cell-major copy as k_expand_cells builds it (n_rows rows of 32 doubles), waves
+// of 64 queries whose rows are staged with the kernel's lane -> (row, piece) map into padded rows, then locate_query /
+// evaluate_cell per lane -- the two halves of interpolate_point_mode the kernel uses.
+void emu_interpolate_rows(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
+						  const double* coeffs, const uint32_t* cells, uint64_t n_rows, const uint32_t* cell_map, const double* xyz,
+						  uint64_t n, double* phi, double* grad)
+{
+	FieldDev F;
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = domain[d];
+		F.dmax[d] = domain[3 + d];
+		F.cell[d] = cell[d];
+		F.inv_cell[d] = inv_cell[d];
+		F.res[d] = res[d];
+	}
+	F.coeffs = coeffs;
+	F.cells = cells;
+	F.cell_map = cell_map;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
+	std::vector<double> cm((size_t)n_rows * 32);
+	for (uint64_t row = 0; row < n_rows; ++row) // k_expand_cells
+	{
+		uint32_t idx[32];
+		if (cells)
+			for (int j = 0; j < 32; ++j)
+				idx[j] = cells[32 * row + j];
+		else
+		{
+			const uint32_t n01 = res[0] * res[1];
+			const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+			cell_node_indices(r % res[0], r / res[0], k, res, idx);
+		}
+		for (int j = 0; j < 32; ++j)
+			cm[32 * row + j] = coeffs[idx[j]];
+	}
+	F.cell_major = cm.data();
+	const int stride = 33;
+#pragma omp parallel for schedule(static)
+	for (long long base = 0; base < (long long)n; base += 64)
+	{
+		std::vector<double> rows(64 * stride, 0.0);
+		CellQuery q[64];
+		uint32_t my_row[64];
+		for (int lane = 0; lane < 64; ++lane)
+		{
+			const uint64_t gid = (uint64_t)base + (uint64_t)lane;
+			const bool have = gid < n;
+			double x[3] = {0.0, 0.0, 0.0};
+			if (have)
+				for (int d = 0; d < 3; ++d)
+					x[d] = xyz[3 * gid + d];
+			q[lane] = locate_query(F, x);
+			q[lane].valid = q[lane].valid && have;
+			my_row[lane] = q[lane].valid ? q[lane].row : 0u;
+		}
+		for (int k = 0; k < 16; ++k)
+			for (int lane = 0; lane < 64; ++lane)
+			{
+				const int sub = lane & 15, grp = lane >> 4, owner = 4 * k + grp;
+				const double* v = F.cell_major + 32 * (size_t)my_row[owner] + 2 * sub;
+				rows[owner * stride + 2 * sub] = v[0];
+				rows[owner * stride + 2 * sub + 1] = v[1];
+			}
+		for (int lane = 0; lane < 64; ++lane)
+		{
+			const uint64_t gid = (uint64_t)base + (uint64_t)lane;
+			if (gid >= n)
+				continue;
+			double cf[32], g[3] = {0.0, 0.0, 0.0};
+			for (int j = 0; j < 32; ++j)
+				cf[j] = rows[lane * stride + j];
+			double v = 1.7976931348623157e308;
+			if (q[lane].valid)
+				v = grad ? evaluate_cell<true>(cf, q[lane].xi, q[lane].c0, g) : evaluate_cell<false>(cf, q[lane].xi, q[lane].c0, g);
+			phi[gid] = v;
+			if (grad)
+				for (int d = 0; d < 3; ++d)
+					grad[3 * gid + d] = g[d];
+		}
+	}
+}
+
 int g_density_skip = 1;
 void emu_set_density_skip(int on) { g_density_skip = on; }
 // K3 on the host: the product's density_prefilter / density_integral and launch constants

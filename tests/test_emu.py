@@ -212,6 +212,43 @@ def test_interpolate_body_bit_exact(golden):
         np.testing.assert_array_equal(ga[ok], gb[ok])
 
 
+def test_interpolate_row_kernel_data_path_bit_exact(golden):
+    """k_interpolate_rows on the host (emu_interpolate_rows): the cell-major copy as k_expand_cells builds it, waves of
+    64 queries whose rows are staged with the kernel's lane map, and the two halves of interpolate_point_mode the
+    kernel evaluates with (locate_query / evaluate_cell).  Same bits as the one-piece body and as the reference's
+    golden values: unreduced, table mode, removed cells, DBL_MAX coefficients, batches that are no multiple of 64,
+    queries outside the domain."""
+    for name in MESHES:
+        dom, res = golden[name + "_domain"], golden[name + "_res"]
+        coeffs, P = golden[name + "_coeffs"], golden[name + "_P"]
+        phi, grad = emu.interpolate_rows(dom, res, coeffs, P, grad=True)
+        np.testing.assert_array_equal(phi, golden[name + "_phi"])
+        inside = golden[name + "_phi"] != DBL_MAX
+        assert (~inside).any() or name != "box"
+        np.testing.assert_array_equal(grad[inside], golden[name + "_grad"][inside])
+        assert (grad[~inside] == 0).all()
+        for m in (1, 63, 64, 65, 1001):
+            np.testing.assert_array_equal(emu.interpolate_rows(dom, res, coeffs, P[:m]), golden[name + "_phi"][:m])
+        cells = T.oracle_cell_table(res)
+        cmap = np.arange(len(cells), dtype=np.uint32)
+        cmap2 = cmap.copy()
+        cmap2[::3] = 0xFFFFFFFF
+        c2 = coeffs.copy()
+        c2[::7] = DBL_MAX
+        keep = cmap2 != 0xFFFFFFFF
+        cells2 = cells[keep]                                   # a reduced table: rows renumbered through the map
+        cmap3 = cmap2.copy()
+        cmap3[keep] = np.arange(keep.sum(), dtype=np.uint32)
+        a, ga = emu.interpolate_rows(dom, res, c2, P, grad=True, cells=cells2, cell_map=cmap3)
+        b, gb = emu.interpolate(dom, res, c2, P, grad=True, cells=cells2, cell_map=cmap3)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ga, gb)
+        w, gw = T.oracle_interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap2)
+        np.testing.assert_array_equal(a, w)
+        ok = w != DBL_MAX
+        np.testing.assert_array_equal(ga[ok], gw[ok])
+
+
 def test_config3_planes_bit_exact():
     """Icosphere nu=71 (100 820 triangles) at 256^3: four V planes through the costly centre
     and two X planes, against the oracle (bit-exact)."""
