@@ -76,10 +76,14 @@ inline uint64_t z_value(const double x[3], double inv_cell) { return dg::referen
 // device-side mirrors of the fields, created lazily by the batched interpolate
 struct CubicLagrangeDiscreteGrid::DeviceCache
 {
-	std::vector<dg_field*> fields;
+	std::vector<dg_field*> fields;         // batched interpolate (K2): may grow a cell-major copy on their first large batch
+	std::vector<dg_field*> density_fields; // addDensityMap (K3) keeps handles of its own: K3 is fastest on its per-launch
+	                                       // tile copy and would read through a cell-major copy if the handle had one
 	~DeviceCache()
 	{
 		for (auto f : fields)
+			dg_field_destroy(f);
+		for (auto f : density_fields)
 			dg_field_destroy(f);
 	}
 };
@@ -156,6 +160,11 @@ void CubicLagrangeDiscreteGrid::invalidateDevice(unsigned int f) const
 	{
 		dg_field_destroy(m_dev->fields[f]);
 		m_dev->fields[f] = nullptr;
+	}
+	if (m_dev && f < m_dev->density_fields.size() && m_dev->density_fields[f])
+	{
+		dg_field_destroy(m_dev->density_fields[f]);
+		m_dev->density_fields[f] = nullptr;
 	}
 }
 
@@ -290,9 +299,9 @@ unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, do
 	if (sdf_field >= m_nodes.size())
 		throw std::out_of_range("CubicLagrangeDiscreteGrid::addDensityMap: no such field");
 	const unsigned int n_nodes = nNodesFull();
-	if (m_dev->fields.size() < m_nodes.size())
-		m_dev->fields.resize(m_nodes.size(), nullptr);
-	dg_field*& f = m_dev->fields[sdf_field];
+	if (m_dev->density_fields.size() < m_nodes.size())
+		m_dev->density_fields.resize(m_nodes.size(), nullptr);
+	dg_field*& f = m_dev->density_fields[sdf_field];
 	if (f == nullptr)
 	{
 		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);

