@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence on the GPU box (run through gpurun) and turns it into the committed
 # summaries:
-#   profiles/collect.sh <tag> [k1|k2|k3|u|all]
+#   profiles/collect.sh <tag> [k1|k2|k2r|k3|u|all]   (k2r: K2's row kernel on the cell-major copy)
 # Per workload: one --kernel-trace --stats run (kernel durations) and the PMC passes (own runs, counters
 # only -- never combined with a trace).  K1 = the default bench (python bench.py, 256^3 icosphere);
 # K2 / K3 / U = profiles/pmc_workloads.py at BASELINE configs[4] sizes.  Raw databases stay under
@@ -29,7 +29,7 @@ if [ $WHAT = k1 ] || [ $WHAT = all ]; then
   GRP=("${GROUPS_BASE[@]}" "${GROUPS_K1[@]}")
   run_set k1 python bench.py --steps 10 --warmup 2 --no-extras
 fi
-for w in k2 k3 u; do
+for w in k2 k2r k3 u; do
   if [ $WHAT = $w ] || [ $WHAT = all ]; then
     GRP=("${GROUPS_BASE[@]}")
     run_set $w python profiles/pmc_workloads.py $w

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workloads profiles/collect.sh profiles besides the default bench: K2 (batched interpolate), K3 (density
 map) and U (unpack) at BASELINE configs[4] / configs[2] sizes on the 256^3 icosphere field.
-    python profiles/pmc_workloads.py k2|k3|u
+    python profiles/pmc_workloads.py k2|k2r|k3|u
 Measurement tooling (uses the test helpers for the mesh and the config-5 query generator)."""
 import os
 import sys
@@ -47,6 +47,19 @@ def main():
         for rep in range(4):
             fld.interpolate_device(Ps.data_ptr(), nq, phi.data_ptr(), stream=s)
         torch.cuda.synchronize()
+    elif what == "k2r":
+        # K2 through the cooperative row kernel on the cell-major copy: unordered queries, no binning
+        fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
+        fld.build_cell_major(s)
+        nq = 10_000_000
+        P = torch.from_numpy(T.uniform_points(1234, nq, dom[:3], dom[3:])).cuda()
+        phi = torch.empty(nq, dtype=torch.float64, device="cuda")
+        grad = torch.empty(3 * nq, dtype=torch.float64, device="cuda")
+        for rep in range(3):
+            fld.interpolate_device(P.data_ptr(), nq, phi.data_ptr(), stream=s)
+        for rep in range(3):
+            fld.interpolate_device(P.data_ptr(), nq, phi.data_ptr(), grad.data_ptr(), stream=s)
+        torch.cuda.synchronize()
     elif what == "k3":
         fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
         dens = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -69,7 +82,7 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(out, field)
     else:
-        raise SystemExit("k2 | k3 | u")
+        raise SystemExit("k2 | k2r | k3 | u")
 
 
 if __name__ == "__main__":
