@@ -36,6 +36,13 @@ class MeshInfo(C.Structure):
                 ("build_seconds", C.c_double)]
 
 
+class FieldInfo(C.Structure):
+    _fields_ = [("n_coeffs", C.c_uint64), ("n_cell_rows", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("d_coeffs", C.c_void_p), ("device", C.c_int32), ("owns_coefficients", C.c_int32),
+                ("has_cell_major", C.c_int32), ("has_tile_major", C.c_int32), ("immutable", C.c_int32),
+                ("host_copy_pending", C.c_int32)]
+
+
 class ShardInfo(C.Structure):
     _fields_ = [("count", C.c_uint64), ("stride", C.c_uint64)]
 
@@ -87,6 +94,13 @@ SYMBOLS = {
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_field_destroy": (None, [C.c_void_p]),
+    "dg_field_get_info": (C.c_int, [C.c_void_p, C.POINTER(FieldInfo)]),
+    "dg_field_set_immutable": (C.c_int, [C.c_void_p, C.c_int]),
+    "dg_sdf_sample_field": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, _u8p, _dp, C.POINTER(C.c_void_p)]),
+    "dg_density_map_field": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, _u8p, _dp, C.POINTER(C.c_void_p)]),
+    "dg_field_host_wait": (C.c_int, [C.c_void_p]),
+    "dg_reduce_field_device": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "dg_reduction_to_field": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_field_build_cell_major": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_field_drop_cell_major": (C.c_int, [C.c_void_p]),
     "dg_field_build_tile_major": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -250,6 +264,22 @@ class Mesh:
                                                   C.byref(ent), near.ctypes.data_as(_dp)))
         return (d.value, tri.value, ent.value, near) if full else d.value
 
+    def sample_field(self, grid, invert=False, mask=None, host_out=None):
+        """dg_sdf_sample_field: K1 into a new device-resident Field; host_out (a float64 array of n_nodes, or True to
+        have one allocated) is filled asynchronously -- Field.host_wait() returns it complete."""
+        n = n_nodes(grid)
+        if host_out is True:
+            host_out = np.empty(n, dtype=np.float64)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert len(m) == n
+        h = C.c_void_p()
+        _check(self._lib.dg_sdf_sample_field(self.handle, C.byref(grid), int(invert),
+                                             None if m is None else m.ctypes.data_as(_u8p),
+                                             None if host_out is None else host_out.ctypes.data_as(_dp), C.byref(h)))
+        return Field._adopt(h, host_out)
+
     # ---- device-pointer entry points (ints = device addresses, stream = hipStream_t address) ---
     def sample_nodes_device(self, grid, begin, end, d_out, invert=False, d_mask=None, stream=0):
         _check(self._lib.dg_sdf_sample_nodes_device(self.handle, C.byref(grid), int(invert), begin, end,
@@ -295,17 +325,21 @@ def reduce_field(grid, coeffs, lo, hi, offset=0.0, closed=False):
     h = C.c_void_p()
     _check(lib.dg_reduce_field(C.byref(grid), c.ctypes.data_as(_dp), len(c), int(closed), lo, hi, offset, C.byref(h)))
     try:
-        m, rows, tied = C.c_uint64(), C.c_uint64(), C.c_int()
-        _check(lib.dg_reduction_info(h, C.byref(m), C.byref(rows), C.byref(tied)))
-        if tied.value:
-            return None, None, None, True
-        out = np.empty(m.value)
-        cells = np.empty((rows.value, 32), dtype=np.uint32)
-        cmap = np.empty(n_cells(grid), dtype=np.uint32)
-        _check(lib.dg_reduction_fetch(h, out.ctypes.data_as(_dp), cells.ctypes.data_as(_u32p), cmap.ctypes.data_as(_u32p)))
-        return out, cells, cmap, False
+        return _fetch_reduction(lib, h, n_cells(grid))
     finally:
         lib.dg_reduction_destroy(h)
+
+
+def _fetch_reduction(lib, h, ncells):
+    m, rows, tied = C.c_uint64(), C.c_uint64(), C.c_int()
+    _check(lib.dg_reduction_info(h, C.byref(m), C.byref(rows), C.byref(tied)))
+    if tied.value:
+        return None, None, None, True
+    out = np.empty(m.value)
+    cells = np.empty((rows.value, 32), dtype=np.uint32)
+    cmap = np.empty(ncells, dtype=np.uint32)
+    _check(lib.dg_reduction_fetch(h, out.ctypes.data_as(_dp), cells.ctypes.data_as(_u32p), cmap.ctypes.data_as(_u32p)))
+    return out, cells, cmap, False
 
 
 class Comm:
@@ -358,12 +392,64 @@ class Field:
                                              None if cm is None else cm.ctypes.data_as(_u32p), C.byref(h)))
         self.handle = h
 
+    @classmethod
+    def _adopt(cls, handle, host_out=None):
+        f = cls.__new__(cls)
+        f._lib = load_library()
+        f.handle = handle
+        f._host_out = host_out  # keeps the array alive while the copy runs
+        return f
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.dg_field_destroy(self.handle)
             self.handle = None
 
     __del__ = close
+
+    def info(self):
+        i = FieldInfo()
+        _check(self._lib.dg_field_get_info(self.handle, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in FieldInfo._fields_}
+
+    def has_cell_major(self):
+        return bool(self.info()["has_cell_major"])
+
+    def set_immutable(self, immutable=True):
+        _check(self._lib.dg_field_set_immutable(self.handle, int(immutable)))
+
+    def host_wait(self):
+        """dg_field_host_wait: blocks until the host array of the producing call is complete and returns it."""
+        _check(self._lib.dg_field_host_wait(self.handle))
+        return getattr(self, "_host_out", None)
+
+    def density_map_field(self, support_radius, rho0, band_predicate=True, mask=None, host_out=None):
+        """dg_density_map_field: K3 over this SDF's whole lattice into a new device-resident Field."""
+        n = int(self.info()["n_coeffs"])
+        if host_out is True:
+            host_out = np.empty(n, dtype=np.float64)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(self._lib.dg_density_map_field(self.handle, support_radius, rho0, int(band_predicate),
+                                              None if m is None else m.ctypes.data_as(_u8p),
+                                              None if host_out is None else host_out.ctypes.data_as(_dp), C.byref(h)))
+        return Field._adopt(h, host_out)
+
+    def reduce(self, lo, hi, offset=0.0, closed=False, as_field=False):
+        """dg_reduce_field_device on this handle's coefficients: (coeffs, cells, cell_map, tied) like reduce_field();
+        with as_field a fifth element, the reduced field as a device handle (dg_reduction_to_field)."""
+        h = C.c_void_p()
+        _check(self._lib.dg_reduce_field_device(self.handle, int(closed), lo, hi, offset, C.byref(h)))
+        try:
+            i = self.info()
+            out = _fetch_reduction(self._lib, h, int(i["n_cell_rows"]))
+            if as_field and not out[3]:
+                fh = C.c_void_p()
+                _check(self._lib.dg_reduction_to_field(h, C.byref(fh)))
+                return out + (Field._adopt(fh),)
+            return out + ((None,) if as_field else ())
+        finally:
+            self._lib.dg_reduction_destroy(h)
 
     def build_cell_major(self, stream=0):
         _check(self._lib.dg_field_build_cell_major(self.handle, C.c_void_p(stream)))

@@ -36,29 +36,51 @@ def build(force=False, verbose=False, defines=(), out=None):
     if out is None and not force and not _stale():
         return OUT
     if out is not None:
-        return _build(verbose, tuple(defines), os.path.join(HERE, "build", os.path.basename(out) + ".d"), out)
-    return _build(verbose, tuple(defines), os.path.join(HERE, "build"), OUT)
+        return _build(verbose, tuple(defines), os.path.join(HERE, "build", os.path.basename(out) + ".d"), out, force)
+    return _build(verbose, tuple(defines), os.path.join(HERE, "build"), OUT, force)
 
 
-def _build(verbose, defines, objdir, target):
+# headers each source includes (directly or not): an object is rebuilt only when one of these is newer
+DEPS = {
+    "dg_kernels.hip": ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h"],
+    "dg_build.cpp": ["dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h"],
+    "dg_host_query.cpp": ["dg_host_query.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_capi_internal.h", "dg_layout.h",
+                          os.path.join("..", "..", "include", "discregrid_hip.h")],
+}
+
+
+def _object_stale(obj, src, defines, force):
+    if force or not os.path.exists(obj):
+        return True
+    stamp = obj + ".flags"
+    flags = " ".join(COMMON + list(defines))
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src), os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in DEPS.get(src, HEADERS)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _build(verbose, defines, objdir, target, force=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    for src in SOURCES_HIP:
+    for src in SOURCES_HIP + SOURCES_CXX:
         obj = os.path.join(objdir, src + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        if not _object_stale(obj, src, defines, force):
+            continue
+        if src in SOURCES_HIP:
+            cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        else:
+            cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", *COMMON, *defines, "-I" + os.path.join(ROCM, "include"), "-c",
+                   os.path.join(CSRC, src), "-o", obj]
         if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
-    for src in SOURCES_CXX:
-        obj = os.path.join(objdir, src + ".o")
-        cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", *COMMON, *defines, "-I" + os.path.join(ROCM, "include"), "-c",
-               os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        with open(obj + ".flags", "w") as fh:
+            fh.write(" ".join(COMMON + list(defines)))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", target]
     if verbose:
         print(" ".join(cmd))

@@ -14,6 +14,13 @@
 //   * interpolate(field, points, n, phi, grad): batched evaluation on the GPU.
 //   * The 32-index cell table (2.1 GB at 256^3 in the reference) is implicit until something
 //     needs it materialised (reduceField, or a file that was saved after a reduction).
+//   * ONE device-resident copy per field.  The reference has one m_nodes vector per field (:69); here a field the
+//     GPU produced (addFunction(MeshSDF), addDensityMap) stays in the device array its kernel wrote, and batched
+//     interpolate, addDensityMap and reduceField(ValuePredicate) read that array -- nothing is uploaded again.
+//     The host vector is filled by an asynchronous copy that addFunction starts and does NOT wait for: the call
+//     returns once the work is enqueued, and the first HOST reader of the field (interpolate(x), save,
+//     reduceField with an opaque predicate, nodeData, a copy of the grid) waits for the copy.  DG_LAZY_HOST=0
+//     makes addFunction / addDensityMap wait before they return.
 #pragma once
 
 #include "discrete_grid.hpp"
@@ -48,8 +55,12 @@ public:
 	CubicLagrangeDiscreteGrid(std::string const& filename);
 	CubicLagrangeDiscreteGrid(Eigen::AlignedBox3d const& domain, std::array<unsigned int, 3> const& resolution);
 	~CubicLagrangeDiscreteGrid() override;
-	CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid const&) = delete;
-	CubicLagrangeDiscreteGrid& operator=(CubicLagrangeDiscreteGrid const&) = delete;
+	// copyable and movable like the reference class (implicit members there, :9-73): a copy gets the host state
+	// (waiting for copies still in flight) and fresh, empty device handles of its own
+	CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid const& other);
+	CubicLagrangeDiscreteGrid& operator=(CubicLagrangeDiscreteGrid const& other);
+	CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid&& other) noexcept;
+	CubicLagrangeDiscreteGrid& operator=(CubicLagrangeDiscreteGrid&& other) noexcept;
 
 	void save(std::string const& filename) const override;
 	void load(std::string const& filename) override;
@@ -100,7 +111,17 @@ public:
 	unsigned int nNodes() const { return nNodesFull(); }
 
 	std::size_t nFields() const { return m_n_fields; }
-	FieldVector const& nodeData(unsigned int field_id) const { return m_nodes[field_id]; }
+	FieldVector const& nodeData(unsigned int field_id) const
+	{
+		hostReady(field_id);
+		return m_nodes[field_id];
+	}
+	// Blocks until the host vector of the field (of every field) is complete; returns at once if it already is.
+	void waitForHostData(unsigned int field_id) const { hostReady(field_id); }
+	void waitForHostData() const;
+	// The field's device handle (dg_field* of include/discregrid_hip.h, created on first use), for callers that
+	// chain further device work; nullptr never (throws if the GPU call fails).
+	void* deviceField(unsigned int field_id) const;
 	// Seconds spent in the last addFunction call (whole call) and in its node-sampling stage.
 	double lastAddFunctionSeconds() const { return m_last_total_s; }
 	double lastSamplingSeconds() const { return m_last_sampling_s; }
@@ -113,6 +134,8 @@ private:
 	void cellRow(unsigned int field_id, unsigned int cell_row, unsigned int out[32]) const;
 	void materializeCells(unsigned int field_id);
 	void invalidateDevice(unsigned int field_id) const;
+	void hostReady(unsigned int field_id) const; // waits for the field's host copy if one is in flight
+	void adoptDeviceField(unsigned int field_id, void* handle, bool host_pending);
 
 private:
 	// one FieldVector per field: a std::vector<double> whose allocator skips the zero fill and

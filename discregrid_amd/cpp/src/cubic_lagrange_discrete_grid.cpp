@@ -17,6 +17,7 @@
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
@@ -71,20 +72,27 @@ dg_grid_desc make_desc(Eigen::AlignedBox3d const& dom, std::array<unsigned int, 
 // Morton key of the reference's zValue()/morton_lut(): dg::reference_z_value (dg_lattice.h), shared with
 // the device version of reduceField.
 inline uint64_t z_value(const double x[3], double inv_cell) { return dg::reference_z_value(x, inv_cell); }
+int env_flag(const char* name, int fallback)
+{
+	const char* e = std::getenv(name);
+	return e ? std::atoi(e) : fallback;
+}
 } // namespace
 
-// device-side mirrors of the fields, created lazily by the batched interpolate
+// ONE device handle per field: the array K1 / K3 wrote for a field the GPU produced (dg_sdf_sample_field,
+// dg_density_map_field), or an upload made once, on first use, for fields that came from a file or a host callback.
+// K2 batches, K3 (which ignores a cell-major copy K2 may have built on the handle) and the device reduceField all
+// read it.  `pending[f]`: the asynchronous copy into m_nodes[f] has not been collected yet.
 struct CubicLagrangeDiscreteGrid::DeviceCache
 {
-	std::vector<dg_field*> fields;         // batched interpolate (K2): may grow a cell-major copy on their first large batch
-	std::vector<dg_field*> density_fields; // addDensityMap (K3) keeps handles of its own: K3 is fastest on its per-launch
-	                                       // tile copy and would read through a cell-major copy if the handle had one
+	std::vector<dg_field*> fields;
+	std::vector<char> pending;
+	std::atomic<unsigned int> n_pending{0u};
+	std::mutex mutex; // guards `pending` and the creation of handles (const methods may run concurrently)
 	~DeviceCache()
 	{
 		for (auto f : fields)
-			dg_field_destroy(f);
-		for (auto f : density_fields)
-			dg_field_destroy(f);
+			dg_field_destroy(f); // waits for a copy that is still running
 	}
 };
 
@@ -99,7 +107,124 @@ CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(Eigen::AlignedBox3d const& 
 {
 }
 
-CubicLagrangeDiscreteGrid::~CubicLagrangeDiscreteGrid() = default;
+CubicLagrangeDiscreteGrid::~CubicLagrangeDiscreteGrid() = default; // m_dev goes first (declared last): copies end before m_nodes is freed
+
+CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid const& other)
+	: DiscreteGrid((other.waitForHostData(), static_cast<DiscreteGrid const&>(other))), m_nodes(other.m_nodes), m_cells(other.m_cells),
+	  m_cell_map(other.m_cell_map), m_dev(new DeviceCache), m_last_total_s(other.m_last_total_s),
+	  m_last_sampling_s(other.m_last_sampling_s), m_last_used_gpu(other.m_last_used_gpu),
+	  m_last_reduce_used_gpu(other.m_last_reduce_used_gpu)
+{
+	m_dev->fields.resize(m_nodes.size(), nullptr);
+	m_dev->pending.resize(m_nodes.size(), 0);
+}
+
+CubicLagrangeDiscreteGrid& CubicLagrangeDiscreteGrid::operator=(CubicLagrangeDiscreteGrid const& other)
+{
+	if (this != &other)
+	{
+		CubicLagrangeDiscreteGrid tmp(other);
+		*this = std::move(tmp);
+	}
+	return *this;
+}
+
+CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid&& other) noexcept
+	: DiscreteGrid(static_cast<DiscreteGrid const&>(other)), m_nodes(std::move(other.m_nodes)), m_cells(std::move(other.m_cells)),
+	  m_cell_map(std::move(other.m_cell_map)), m_dev(std::move(other.m_dev)), m_last_total_s(other.m_last_total_s),
+	  m_last_sampling_s(other.m_last_sampling_s), m_last_used_gpu(other.m_last_used_gpu),
+	  m_last_reduce_used_gpu(other.m_last_reduce_used_gpu)
+{
+	// the heap buffers of the field vectors moved with them, so copies in flight keep writing to the right place
+	other.m_dev.reset(new (std::nothrow) DeviceCache);
+	other.m_nodes.clear();
+	other.m_cells.clear();
+	other.m_cell_map.clear();
+	other.m_n_fields = 0;
+}
+
+CubicLagrangeDiscreteGrid& CubicLagrangeDiscreteGrid::operator=(CubicLagrangeDiscreteGrid&& other) noexcept
+{
+	if (this != &other)
+	{
+		m_dev.reset(); // ends this grid's copies before its vectors are replaced
+		DiscreteGrid::operator=(static_cast<DiscreteGrid const&>(other));
+		m_nodes = std::move(other.m_nodes);
+		m_cells = std::move(other.m_cells);
+		m_cell_map = std::move(other.m_cell_map);
+		m_dev = std::move(other.m_dev);
+		m_last_total_s = other.m_last_total_s;
+		m_last_sampling_s = other.m_last_sampling_s;
+		m_last_used_gpu = other.m_last_used_gpu;
+		m_last_reduce_used_gpu = other.m_last_reduce_used_gpu;
+		other.m_dev.reset(new (std::nothrow) DeviceCache);
+		other.m_nodes.clear();
+		other.m_cells.clear();
+		other.m_cell_map.clear();
+		other.m_n_fields = 0;
+	}
+	return *this;
+}
+
+void CubicLagrangeDiscreteGrid::hostReady(unsigned int f) const
+{
+	if (m_dev->n_pending.load(std::memory_order_acquire) == 0u)
+		return;
+	std::lock_guard<std::mutex> lock(m_dev->mutex);
+	if (f >= m_dev->pending.size() || !m_dev->pending[f])
+		return;
+	const dg_status st = dg_field_host_wait(m_dev->fields[f]);
+	m_dev->pending[f] = 0;
+	m_dev->n_pending.fetch_sub(1u, std::memory_order_release);
+	if (st != DG_OK)
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid: copy of a field to the host failed: ") + dg_last_error());
+}
+
+void CubicLagrangeDiscreteGrid::waitForHostData() const
+{
+	for (unsigned int f = 0; f < m_nodes.size(); ++f)
+		hostReady(f);
+}
+
+void CubicLagrangeDiscreteGrid::adoptDeviceField(unsigned int f, void* handle, bool host_pending)
+{
+	std::lock_guard<std::mutex> lock(m_dev->mutex);
+	if (m_dev->fields.size() <= f)
+		m_dev->fields.resize(f + 1, nullptr);
+	if (m_dev->pending.size() <= f)
+		m_dev->pending.resize(f + 1, 0);
+	m_dev->fields[f] = static_cast<dg_field*>(handle);
+	if (host_pending)
+	{
+		m_dev->pending[f] = 1;
+		m_dev->n_pending.fetch_add(1u, std::memory_order_release);
+	}
+}
+
+void* CubicLagrangeDiscreteGrid::deviceField(unsigned int field_id) const
+{
+	if (field_id >= m_nodes.size())
+		throw std::out_of_range("CubicLagrangeDiscreteGrid: no such field");
+	std::lock_guard<std::mutex> lock(m_dev->mutex);
+	if (m_dev->fields.size() < m_nodes.size())
+		m_dev->fields.resize(m_nodes.size(), nullptr);
+	if (m_dev->pending.size() < m_nodes.size())
+		m_dev->pending.resize(m_nodes.size(), 0);
+	dg_field*& f = m_dev->fields[field_id];
+	if (f == nullptr)
+	{
+		// a field that came from a file, a host callback or addNodeData: uploaded once
+		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+		auto const& cells = m_cells[field_id];
+		auto const& map = m_cell_map[field_id];
+		static_assert(sizeof(unsigned int) == sizeof(uint32_t), "unsigned int must be 32 bits");
+		if (dg_field_create(&g, m_nodes[field_id].data(), m_nodes[field_id].size(),
+							cells.empty() ? nullptr : reinterpret_cast<const uint32_t*>(cells[0].data()), cells.size(),
+							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
+			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid (GPU): ") + dg_last_error());
+	}
+	return f;
+}
 
 unsigned int CubicLagrangeDiscreteGrid::nNodesFull() const
 {
@@ -156,15 +281,12 @@ void CubicLagrangeDiscreteGrid::materializeCells(unsigned int f)
 
 void CubicLagrangeDiscreteGrid::invalidateDevice(unsigned int f) const
 {
-	if (m_dev && f < m_dev->fields.size() && m_dev->fields[f])
+	hostReady(f); // a copy in flight reads the handle's array
+	std::lock_guard<std::mutex> lock(m_dev->mutex);
+	if (f < m_dev->fields.size() && m_dev->fields[f])
 	{
 		dg_field_destroy(m_dev->fields[f]);
 		m_dev->fields[f] = nullptr;
-	}
-	if (m_dev && f < m_dev->density_fields.size() && m_dev->density_fields[f])
-	{
-		dg_field_destroy(m_dev->density_fields[f]);
-		m_dev->density_fields[f] = nullptr;
 	}
 }
 
@@ -225,11 +347,28 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 			~ProgressScope() { dg_set_progress_callback(nullptr, nullptr); }
 		} progress_scope(verbose);
 		dg_status st;
+		const unsigned int id = static_cast<unsigned int>(m_nodes.size() - 1);
 		if (all.size() > 1)
 			st = dg_sdf_sample_nodes_multi(reinterpret_cast<const dg_mesh* const*>(all.data()), (int)all.size(), &g,
 										   sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr, coeffs.data());
 		else
-			st = dg_sdf_sample_nodes(mesh, &g, sdf->invert ? 1 : 0, 0, n_nodes, pred ? mask.data() : nullptr, coeffs.data());
+		{
+			// One GPU: the field stays in the device array K1 writes (the handle K2 / K3 / reduceField will read) and the
+			// host vector is filled by an asynchronous copy -- this call does not wait for it (see the header).
+			dg_field* produced = nullptr;
+			st = dg_sdf_sample_field(mesh, &g, sdf->invert ? 1 : 0, pred ? mask.data() : nullptr, coeffs.data(), &produced);
+			if (st == DG_OK)
+			{
+				adoptDeviceField(id, produced, true);
+				if (verbose || env_flag("DG_LAZY_HOST", 1) == 0)
+				{
+					hostReady(id);
+					if (verbose)
+						std::cout << "\r"
+								  << "Construction " << std::setw(20) << 100.0 << "%" << std::flush;
+				}
+			}
+		}
 		if (st != DG_OK)
 			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addFunction (GPU): ") + dg_last_error());
 		m_last_used_gpu = true;
@@ -274,8 +413,13 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 				  << static_cast<double>(std::chrono::duration_cast<std::chrono::milliseconds>(t_end - t_begin).count()) /
 						 1000.0
 				  << "s" << std::endl;
-	if (m_dev->fields.size() < m_nodes.size())
-		m_dev->fields.resize(m_nodes.size(), nullptr);
+	{
+		std::lock_guard<std::mutex> lock(m_dev->mutex);
+		if (m_dev->fields.size() < m_nodes.size())
+			m_dev->fields.resize(m_nodes.size(), nullptr);
+		if (m_dev->pending.size() < m_nodes.size())
+			m_dev->pending.resize(m_nodes.size(), 0);
+	}
 	return static_cast<unsigned int>(m_n_fields++);
 }
 
@@ -287,7 +431,11 @@ unsigned int CubicLagrangeDiscreteGrid::addNodeData(FieldVector coeffs)
 	m_nodes.push_back(std::move(coeffs));
 	m_cells.push_back({});
 	m_cell_map.push_back({});
-	m_dev->fields.resize(m_nodes.size(), nullptr);
+	{
+		std::lock_guard<std::mutex> lock(m_dev->mutex);
+		m_dev->fields.resize(m_nodes.size(), nullptr);
+		m_dev->pending.resize(m_nodes.size(), 0);
+	}
 	return static_cast<unsigned int>(m_n_fields++);
 }
 
@@ -299,26 +447,24 @@ unsigned int CubicLagrangeDiscreteGrid::addDensityMap(unsigned int sdf_field, do
 	if (sdf_field >= m_nodes.size())
 		throw std::out_of_range("CubicLagrangeDiscreteGrid::addDensityMap: no such field");
 	const unsigned int n_nodes = nNodesFull();
-	if (m_dev->density_fields.size() < m_nodes.size())
-		m_dev->density_fields.resize(m_nodes.size(), nullptr);
-	dg_field*& f = m_dev->density_fields[sdf_field];
-	if (f == nullptr)
-	{
-		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
-		auto const& cells = m_cells[sdf_field];
-		auto const& map = m_cell_map[sdf_field];
-		if (dg_field_create(&g, m_nodes[sdf_field].data(), m_nodes[sdf_field].size(),
-							cells.empty() ? nullptr : reinterpret_cast<const uint32_t*>(cells[0].data()), cells.size(),
-							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
-			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
-	}
-	FieldVector coeffs(n_nodes);
-	if (dg_density_map_nodes(f, support_radius, rho0, band_predicate ? 1 : 0, 0, n_nodes, nullptr, coeffs.data()) != DG_OK)
-		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
-	m_nodes.push_back(std::move(coeffs));
+	// the SDF's ONE device handle: the array K1 wrote if addFunction(MeshSDF) produced the field in this process, an
+	// upload made once otherwise.  K3 writes the new field's device array; its host vector is filled asynchronously.
+	dg_field* sdf = static_cast<dg_field*>(deviceField(sdf_field));
+	m_nodes.push_back(FieldVector(n_nodes));
 	m_cells.push_back({});
 	m_cell_map.push_back({});
-	m_dev->fields.resize(m_nodes.size(), nullptr);
+	const unsigned int id = static_cast<unsigned int>(m_nodes.size() - 1);
+	dg_field* produced = nullptr;
+	if (dg_density_map_field(sdf, support_radius, rho0, band_predicate ? 1 : 0, nullptr, m_nodes[id].data(), &produced) != DG_OK)
+	{
+		m_nodes.pop_back();
+		m_cells.pop_back();
+		m_cell_map.pop_back();
+		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::addDensityMap (GPU): ") + dg_last_error());
+	}
+	adoptDeviceField(id, produced, true);
+	if (verbose || env_flag("DG_LAZY_HOST", 1) == 0)
+		hostReady(id);
 	m_last_used_gpu = true;
 	const auto t1 = clock::now();
 	m_last_total_s = m_last_sampling_s = std::chrono::duration<double>(t1 - t0).count();
@@ -362,6 +508,7 @@ dg::FieldDev host_field(Eigen::AlignedBox3d const& dom, std::array<unsigned int,
 double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vector3d const& x,
 											  Eigen::Vector3d* gradient) const
 {
+	hostReady(field_id); // one relaxed load unless a copy is in flight
 	const dg::FieldDev F = host_field(m_domain, m_resolution, m_cell_size, m_inv_cell_size, m_nodes[field_id],
 									  m_cells[field_id], m_cell_map[field_id]);
 	const double p[3] = {x[0], x[1], x[2]};
@@ -383,20 +530,7 @@ void CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, double const*
 {
 	if (field_id >= m_nodes.size())
 		throw std::out_of_range("CubicLagrangeDiscreteGrid::interpolate: no such field");
-	if (m_dev->fields.size() < m_nodes.size())
-		m_dev->fields.resize(m_nodes.size(), nullptr);
-	dg_field*& f = m_dev->fields[field_id];
-	if (f == nullptr)
-	{
-		const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
-		auto const& cells = m_cells[field_id];
-		auto const& map = m_cell_map[field_id];
-		static_assert(sizeof(unsigned int) == sizeof(uint32_t), "unsigned int must be 32 bits");
-		if (dg_field_create(&g, m_nodes[field_id].data(), m_nodes[field_id].size(),
-							cells.empty() ? nullptr : reinterpret_cast<const uint32_t*>(cells[0].data()), cells.size(),
-							map.empty() ? nullptr : reinterpret_cast<const uint32_t*>(map.data()), &f) != DG_OK)
-			throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::interpolate (GPU): ") + dg_last_error());
-	}
+	dg_field* f = static_cast<dg_field*>(deviceField(field_id));
 	if (dg_interpolate_batch(f, xyz, n, phi, grad) != DG_OK)
 		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::interpolate (GPU): ") + dg_last_error());
 }
@@ -454,6 +588,7 @@ double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vect
 											  const Eigen::Matrix<double, 32, 1>& N, Eigen::Vector3d* gradient,
 											  Eigen::Matrix<double, 32, 3>* dN) const
 {
+	hostReady(field_id);
 	auto const& coeffs = m_nodes[field_id];
 	double phi = 0.0;
 	if (!gradient)
@@ -494,10 +629,10 @@ double CubicLagrangeDiscreteGrid::interpolate(unsigned int field_id, Eigen::Vect
 // then whatever libstdc++'s unstable sort makes of the tie, which only the host algorithm below reproduces.
 bool CubicLagrangeDiscreteGrid::reduceFieldOnDevice(unsigned int field_id, ValuePredicate const& pred)
 {
-	const dg_grid_desc g = make_desc(m_domain, m_resolution, m_cell_size, m_inv_cell_size);
+	// on the field's device handle: no upload if the GPU produced the field or a batch / density map used it before
 	dg_reduction* red = nullptr;
-	if (dg_reduce_field(&g, m_nodes[field_id].data(), m_nodes[field_id].size(), pred.closed ? 1 : 0, pred.lo, pred.hi, pred.offset,
-						&red) != DG_OK)
+	if (dg_reduce_field_device(static_cast<dg_field*>(deviceField(field_id)), pred.closed ? 1 : 0, pred.lo, pred.hi, pred.offset,
+							   &red) != DG_OK)
 		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::reduceField (GPU): ") + dg_last_error());
 	struct Guard
 	{
@@ -516,10 +651,14 @@ bool CubicLagrangeDiscreteGrid::reduceFieldOnDevice(unsigned int field_id, Value
 	if (dg_reduction_fetch(red, out.data(), rows ? reinterpret_cast<uint32_t*>(cells[0].data()) : nullptr,
 						   reinterpret_cast<uint32_t*>(map.data())) != DG_OK)
 		throw std::runtime_error(std::string("CubicLagrangeDiscreteGrid::reduceField (GPU): ") + dg_last_error());
-	invalidateDevice(field_id);
+	invalidateDevice(field_id); // (waits for a host copy of the unreduced field that is still in flight)
 	m_nodes[field_id].swap(out);
 	m_cells[field_id].swap(cells);
 	m_cell_map[field_id].swap(map);
+	// the reduced field's device arrays become its handle: a batched interpolate that follows uploads nothing
+	dg_field* reduced = nullptr;
+	if (dg_reduction_to_field(red, &reduced) == DG_OK)
+		adoptDeviceField(field_id, reduced, false);
 	return true;
 }
 
@@ -543,6 +682,7 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 		last = now;
 	};
 	tick("start");
+	hostReady(field_id);
 	materializeCells(field_id);
 	invalidateDevice(field_id);
 	tick("materialize cells");
@@ -641,6 +781,7 @@ void CubicLagrangeDiscreteGrid::forEachCell(
 // ---------------------------------------------------------------------------------------------
 void CubicLagrangeDiscreteGrid::save(std::string const& filename) const
 {
+	waitForHostData();
 	std::ofstream out(filename, std::ios::binary);
 	std::streambuf& b = *out.rdbuf();
 	for (int d = 0; d < 3; ++d)
@@ -716,6 +857,7 @@ void CubicLagrangeDiscreteGrid::load(std::string const& filename)
 		std::cerr << "ERROR: Discrete grid can not be loaded. Input file does not exist!" << std::endl;
 		return;
 	}
+	m_dev.reset(new DeviceCache); // ends copies into the vectors that are about to be replaced
 	std::streambuf& b = *in.rdbuf();
 	Eigen::Vector3d lo, hi;
 	for (int d = 0; d < 3; ++d)
@@ -786,8 +928,8 @@ void CubicLagrangeDiscreteGrid::load(std::string const& filename)
 			std::vector<unsigned int>().swap(m_cell_map[f]);
 		}
 	}
-	m_dev.reset(new DeviceCache);
 	m_dev->fields.resize(m_nodes.size(), nullptr);
+	m_dev->pending.resize(m_nodes.size(), 0);
 }
 
 } // namespace Discregrid

@@ -120,6 +120,16 @@ void dg_field_destroy(dg_field* f)
 	if (!f)
 		return;
 	DeviceGuard guard(f->device);
+	(void)finish_host_job(f); // a copy into the caller's array that is still running
+	if (f->producer_stream)
+	{
+		(void)hipStreamSynchronize(f->producer_stream);
+		(void)hipStreamDestroy(f->producer_stream);
+	}
+	if (f->produced)
+		(void)hipEventDestroy(f->produced);
+	if (f->d_producer_mask)
+		(void)hipFree(f->d_producer_mask);
 	for (void* p : f->owned)
 		if (p)
 			(void)hipFree(p);
@@ -129,6 +139,8 @@ void dg_field_destroy(dg_field* f)
 		(void)hipFree(f->d_tile_major);
 	if (f->cell_major_ready)
 		(void)hipEventDestroy(f->cell_major_ready);
+	if (f->tile_major_ready)
+		(void)hipEventDestroy(f->tile_major_ready);
 	for (auto& kv : f->wtabs)
 		(void)hipFree(kv.second);
 	f->scratch.destroy();
@@ -161,6 +173,8 @@ static dg_status build_cell_major_locked(dg_field* field, void* stream) // field
 	if (!field->cell_major_ready)
 		e = hipEventCreateWithFlags(&field->cell_major_ready, hipEventDisableTiming);
 	if (e == hipSuccess)
+		e = wait_produced(field, static_cast<hipStream_t>(stream));
+	if (e == hipSuccess)
 		e = dg::launch_expand_cells(field->dev, field->n_rows, static_cast<double*>(p), static_cast<hipStream_t>(stream));
 	if (e == hipSuccess)
 		e = hipEventRecord(field->cell_major_ready, static_cast<hipStream_t>(stream));
@@ -190,12 +204,14 @@ dg_status dg_field_build_tile_major(dg_field* field, void* stream)
 	if (e != hipSuccess)
 		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "tile-major allocation of %llu bytes: %s",
 					(unsigned long long)(n_tiles * dg::kTmNodes * sizeof(double)), hipGetErrorString(e));
-	if (!field->cell_major_ready)
-		e = hipEventCreateWithFlags(&field->cell_major_ready, hipEventDisableTiming);
+	if (!field->tile_major_ready)
+		e = hipEventCreateWithFlags(&field->tile_major_ready, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = wait_produced(field, static_cast<hipStream_t>(stream));
 	if (e == hipSuccess)
 		e = dg::launch_expand_tiles(field->dev, n_tiles, static_cast<double*>(p), static_cast<hipStream_t>(stream));
 	if (e == hipSuccess)
-		e = hipEventRecord(field->cell_major_ready, static_cast<hipStream_t>(stream)); // (one event serves both copies: launches wait for the later build)
+		e = hipEventRecord(field->tile_major_ready, static_cast<hipStream_t>(stream));
 	if (e != hipSuccess)
 	{
 		(void)hipFree(p);
@@ -239,6 +255,45 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 	return DG_OK;
 }
 
+dg_status dg_field_set_immutable(dg_field* field, int immutable)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
+	field->immutable = immutable != 0;
+	return DG_OK;
+}
+
+dg_status dg_field_get_info(const dg_field* field, dg_field_info* info)
+{
+	if (!field || !info)
+		return fail(DG_ERR_INVALID, "null argument");
+	std::memset(info, 0, sizeof(*info));
+	info->n_coeffs = field->n_coeffs;
+	info->n_cell_rows = field->n_rows;
+	info->device = field->device;
+	info->owns_coefficients = field->owned[0] != nullptr;
+	info->d_coeffs = field->dev.coeffs;
+	{
+		std::lock_guard<std::mutex> lock(field->copy_mutex);
+		info->has_cell_major = field->d_cell_major != nullptr;
+		info->has_tile_major = field->d_tile_major != nullptr;
+		info->immutable = field->immutable;
+	}
+	{
+		std::lock_guard<std::mutex> lock(field->host_mutex);
+		info->host_copy_pending = field->host_job != nullptr;
+	}
+	uint64_t bytes = field->owned[0] ? field->n_coeffs * sizeof(double) : 0;
+	if (field->owned[1]) bytes += field->n_rows * 32 * sizeof(uint32_t);
+	if (field->owned[2]) bytes += dg_grid_n_cells(&field->grid) * sizeof(uint32_t);
+	if (info->has_cell_major) bytes += field->n_rows * 256ull;
+	if (info->has_tile_major)
+		bytes += (uint64_t)field->dev.ntile[0] * field->dev.ntile[1] * field->dev.ntile[2] * dg::kTmNodes * sizeof(double);
+	info->device_bytes = bytes;
+	return DG_OK;
+}
+
 // ---- reduceField -------------------------------------------------------------------------------------------
 } // extern "C"
 struct dg_reduction
@@ -246,6 +301,7 @@ struct dg_reduction
 	dg::ReduceResult r;
 	uint64_t n_cells = 0;
 	int device = -1;
+	dg_grid_desc grid;
 };
 extern "C"
 {
@@ -270,6 +326,7 @@ dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64
 	if (!red)
 		return fail(DG_ERR_ALLOC, "host allocation failed");
 	red->n_cells = dg_grid_n_cells(grid);
+	red->grid = *grid;
 	(void)hipGetDevice(&red->device);
 	void* d_c = nullptr;
 	hipError_t e = hipMalloc(&d_c, n_coeffs * sizeof(double));
@@ -294,6 +351,71 @@ dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64
 	return DG_OK;
 }
 
+// The same on the coefficients a field handle already holds on the device: no upload.
+dg_status dg_reduce_field_device(const dg_field* field, int closed, double lo, double hi, double offset, dg_reduction** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (field->dev.cells || field->dev.cell_map || field->n_coeffs != dg_grid_n_nodes(&field->grid))
+		return fail(DG_ERR_INVALID, "dg_reduce_field_device needs an unreduced field");
+	DG_ON_DEVICE_OF(field);
+	dg_reduction* red = new (std::nothrow) dg_reduction;
+	if (!red)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	red->n_cells = dg_grid_n_cells(&field->grid);
+	red->device = field->device;
+	red->grid = field->grid;
+	hipError_t e = wait_produced(field, nullptr);
+	if (e == hipSuccess)
+	{
+		dg::ReducePredicate P;
+		P.lo = lo;
+		P.hi = hi;
+		P.offset = offset;
+		P.closed = closed ? 1 : 0;
+		e = dg::reduce_field_device(field->grid.resolution, field->grid.domain_min, field->grid.cell_size, field->grid.inv_cell_size,
+									field->dev.coeffs, field->n_coeffs, P, red->r, nullptr);
+	}
+	if (e != hipSuccess)
+	{
+		dg_reduction_destroy(red);
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_reduce_field_device: %s", hipGetErrorString(e));
+	}
+	*out = red;
+	return DG_OK;
+}
+
+// The reduced field as a handle of its own: the reduction's device arrays (coefficients, cell rows, cell map) change
+// owner, nothing is copied; the reduction can still be destroyed (and no longer fetched) afterwards.
+dg_status dg_reduction_to_field(dg_reduction* r, dg_field** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!r)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (r->r.tied_keys)
+		return fail(DG_ERR_INVALID, "tied Morton keys: the node order is not unique, run the host algorithm");
+	if (!r->r.d_cell_map)
+		return fail(DG_ERR_INVALID, "the reduction's arrays were already moved into a field");
+	DG_ON_DEVICE_OF(r);
+	const dg_status st = dg_field_attach_device(&r->grid, static_cast<const double*>(r->r.d_coeffs), r->r.n_nodes_out,
+												 r->r.n_rows ? static_cast<const uint32_t*>(r->r.d_cells) : nullptr, r->r.n_rows,
+												 static_cast<const uint32_t*>(r->r.d_cell_map), out);
+	if (st != DG_OK)
+		return st;
+	(*out)->owned[0] = r->r.d_coeffs;
+	(*out)->owned[1] = r->r.d_cells;
+	(*out)->owned[2] = r->r.d_cell_map;
+	r->r.d_coeffs = nullptr;
+	r->r.d_cells = nullptr;
+	r->r.d_cell_map = nullptr;
+	return DG_OK;
+}
+
 dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys)
 {
 	if (!r)
@@ -310,6 +432,8 @@ dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* ce
 		return fail(DG_ERR_INVALID, "null argument");
 	if (r->r.tied_keys)
 		return fail(DG_ERR_INVALID, "tied Morton keys: the node order is not unique, run the host algorithm");
+	if (!r->r.d_cell_map)
+		return fail(DG_ERR_INVALID, "the reduction's arrays were moved into a field (dg_reduction_to_field): fetch first");
 	DG_ON_DEVICE_OF(r);
 	if (r->r.n_nodes_out)
 		DG_HIP(hipMemcpy(coeffs, r->r.d_coeffs, r->r.n_nodes_out * sizeof(double), hipMemcpyDeviceToHost));
@@ -346,8 +470,22 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		return DG_OK;
 	DG_ON_DEVICE_OF(sdf);
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	if ((sdf->d_cell_major || sdf->d_tile_major) && sdf->cell_major_ready)
-		DG_HIP(hipStreamWaitEvent(st, sdf->cell_major_ready, 0));
+	// One handle serves K2 and K3: K2 may build a cell-major copy on this handle at any moment (from another thread,
+	// on its first large batch), so the device view is snapshotted under the lock -- and the cell-major copy is NOT
+	// taken along: in brick order neighbouring cells share most of their nodes, cell-major rows share none (K3 is
+	// 1.8 x slower through it than through its tile copy).
+	dg::FieldDev dev;
+	hipEvent_t tiles_ready = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(sdf->copy_mutex);
+		dev = sdf->dev;
+		dev.cell_major = nullptr;
+		if (dev.tile_major)
+			tiles_ready = sdf->tile_major_ready;
+	}
+	if (tiles_ready)
+		DG_HIP(hipStreamWaitEvent(st, tiles_ready, 0));
+	DG_HIP(wait_produced(sdf, st));
 	dg::DensityParams P;
 	std::vector<double> w;
 	dg::init_density_params(P, support_radius, rho0, sdf->grid.cell_size, band_predicate, w);
@@ -396,7 +534,6 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// the coefficients as they are NOW -- an attached device array may have changed since the last call).  One
 	// pass over the field against 1 + 4096 interpolations per integrated node: 128^3 161 -> 135 ms
 	// (DG_K3_TILES=0: off).  Launches over a small part of the lattice are not worth the pass.
-	dg::FieldDev dev = sdf->dev;
 	int tile_idx = -1;
 	if (dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
 		env_int("DG_K3_TILES", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
@@ -439,7 +576,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 		// saved on every 10 M queries from then on).  Not for attached device arrays (they may change between calls: their
 		// owner calls dg_field_build_cell_major), not beyond DG_K2_AUTO_CELL_MAJOR_MB (default 16384; 0: never) or a
 		// quarter of the free device memory, not after dg_field_drop_cell_major.
-		if (big && field->owned[0] != nullptr && !field->d_cell_major && !field->d_tile_major && !field->auto_copy_tried)
+		if (big && (field->owned[0] != nullptr || field->immutable) && !field->d_cell_major && !field->d_tile_major && !field->auto_copy_tried)
 		{
 			field->auto_copy_tried = true;
 			const uint64_t need = field->n_rows * 256ull;
@@ -454,9 +591,13 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 				(void)hipGetLastError();
 		}
 		dev = field->dev;
-		if (field->d_cell_major || field->d_tile_major)
+		// the event of the copy the kernels below will actually read (field_mode(): tiles before cells)
+		if (field->d_tile_major)
+			copy_ready = field->tile_major_ready;
+		else if (field->d_cell_major)
 			copy_ready = field->cell_major_ready;
 	}
+	DG_HIP(wait_produced(field, st));
 	if (copy_ready) // the copy may still be being built on another stream
 		DG_HIP(hipStreamWaitEvent(st, copy_ready, 0));
 	// A field with a cell-major copy: one contiguous row per query, fetched cooperatively -- the order of the queries

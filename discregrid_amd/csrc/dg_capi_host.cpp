@@ -222,11 +222,13 @@ struct HostTarget // RAII: the registrations end with the call
 	bool fresh = false;         // untouched so far: this code faults it in (2 MiB pages, several threads)
 	size_t prepared = 0;        // bytes made a DMA target so far
 	std::vector<void*> registered;
-	~HostTarget()
+	void release()
 	{
 		for (void* p : registered)
 			(void)hipHostUnregister(p);
+		registered.clear();
 	}
+	~HostTarget() { release(); }
 };
 // May [out, out + bytes) -- an array this call overwrites completely -- become a DMA target?  Returns false if
 // the staged form should run instead (array already resident in pages of unknown size, or switched off with
@@ -542,8 +544,9 @@ static dg_status run_k1_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 // on the same box (DG_HOST_PIECES=0: the whole array at once, as before).  Measured and not kept: the chunks alternating
 // between two compute streams so that a chunk's tail runs under the next chunk's bulk (25.0 ms: the two launches slow
 // each other down by more than the tails they hide), other chunk size profiles (DG_HOST_DIRECT_FRACTIONS).
-// `begin` runs on the host after the first two chunks are enqueued (the GPU is busy by then): may the direct form
-// run at all?  If it says no, or a piece cannot be prepared, the caller runs the staged form over the whole range.
+// `begin` (cheap: mode, size, page state) runs before anything is enqueued: may the direct form run at all?  If it
+// says no the caller runs the staged form and nothing was sampled twice; only if a PIECE cannot be prepared later
+// (registration fails) are the chunks in flight given up and the staged form run over the whole range.
 struct DirectHost
 {
 	std::function<bool()> begin;
@@ -624,11 +627,17 @@ static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 		*went_direct = false;
 		return DG_OK;
 	};
+	// The cheap tests (mode, size, who owns the pages, are they resident) run BEFORE anything is enqueued: a caller
+	// whose array cannot take the direct form goes straight to the staged form and samples nothing twice.  Only
+	// the expensive part -- first touch and registration, piece by piece -- runs under the first chunks.
+	if (e == hipSuccess && !host.begin())
+	{
+		*went_direct = false;
+		return DG_OK;
+	}
 	const size_t head = std::min<size_t>(2, mine.size());
 	for (size_t i = 0; i < head && e == hipSuccess && st == DG_OK; ++i)
 		enqueue_kernel(i);
-	if (e == hipSuccess && st == DG_OK && !host.begin())
-		return give_up();
 	if (e == hipSuccess && st == DG_OK && !pieces && (bool)host.piece && !host.piece(0, total_bytes)) // the whole array at once
 		return give_up();
 	for (size_t i = 0; i < mine.size() && e == hipSuccess && st == DG_OK; ++i)
@@ -664,6 +673,158 @@ static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 		if (hipEventElapsedTime(&ms, pipe.ev[3 * i], pipe.ev[3 * i + 1]) == hipSuccess)
 			*kernel_ms += ms;
 	}
+	return DG_OK;
+}
+
+// ---- fields produced on the device: the asynchronous copy into the caller's host array ---------------------------
+// dg_sdf_sample_field / dg_density_map_field leave the coefficients in a device array the new field handle owns and
+// return once the kernels are enqueued.  If the caller wants the coefficients on the host as well, a worker thread
+// does what run_k1_direct does inline: it makes the caller's array a DMA target piece by piece (first touch +
+// hipHostRegister, ~1.4 ms per piece) and enqueues, on a copy stream of its own, the copy of every segment behind
+// the event that says the segment is final on the device; then it waits for the copies and unregisters.  An array
+// that cannot take the direct form (resident 4 KiB pages: pinning would cost more than it saves) is filled by
+// blocking copies, segment by segment, still from the worker.  dg_field_host_wait() joins the worker.
+struct HostCopyJob
+{
+	std::thread worker;
+	int device = -1;
+	const char* d_src = nullptr;
+	char* h_dst = nullptr;
+	std::vector<hipEvent_t> ev; // owned; ev[i]: bytes [seg[i], seg[i + 1]) are final on the device
+	std::vector<size_t> seg;
+	dg_status status = DG_OK;
+	std::string message;
+	bool direct = false;
+	double seconds = 0.0;
+
+	void run()
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		DeviceGuard guard(device);
+		hipError_t e = guard.err;
+		hipStream_t copy = nullptr;
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+		const size_t total = seg.back();
+		HostTarget T;
+		direct = e == hipSuccess && begin_host_target(h_dst, total, T);
+		const size_t n = ev.size();
+		// piece i = bytes [bound[i], bound[i + 1]): interior bounds are the segment starts rounded up to 2 MiB of the address
+		std::vector<size_t> bound(n + 1, 0);
+		bound[n] = total;
+		for (size_t i = 1; i < n; ++i)
+		{
+			const uintptr_t at = (uintptr_t)h_dst + seg[i];
+			const uintptr_t up = (at + ((uintptr_t)1 << 21) - 1) & ~(((uintptr_t)1 << 21) - 1);
+			bound[i] = std::max(bound[i - 1], std::min<size_t>(total, (size_t)(up - (uintptr_t)h_dst)));
+		}
+		size_t next = 0; // first segment that has not been enqueued / copied
+		for (; direct && next < n && e == hipSuccess; ++next)
+		{
+			if (!prepare_host_piece(T, bound[next], bound[next + 1]))
+			{
+				direct = false;
+				break;
+			}
+			e = hipStreamWaitEvent(copy, ev[next], 0);
+			size_t at = seg[next];
+			while (e == hipSuccess && at < seg[next + 1]) // a copy must not straddle two registrations
+			{
+				size_t end = seg[next + 1];
+				for (size_t j = 1; j < n; ++j)
+					if (bound[j] > at && bound[j] < end)
+						end = bound[j];
+				e = hipMemcpyAsync(h_dst + at, d_src + at, end - at, hipMemcpyDeviceToHost, copy);
+				at = end;
+			}
+		}
+		if (copy && e == hipSuccess) e = hipStreamSynchronize(copy);
+		if (next < n && e == hipSuccess)
+		{
+			// the rest (or everything) by blocking copies into ordinary memory
+			T.release();
+			for (; next < n && e == hipSuccess; ++next)
+			{
+				e = hipEventSynchronize(ev[next]);
+				if (e == hipSuccess)
+					e = hipMemcpy(h_dst + seg[next], d_src + seg[next], seg[next + 1] - seg[next], hipMemcpyDeviceToHost);
+			}
+		}
+		if (copy) (void)hipStreamDestroy(copy);
+		if (e != hipSuccess)
+		{
+			status = e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP;
+			message = std::string("copy of a device-resident field into the host array: ") + hipGetErrorString(e);
+			(void)hipGetLastError();
+		}
+		seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
+	~HostCopyJob()
+	{
+		if (worker.joinable())
+			worker.join();
+		for (hipEvent_t x : ev)
+			(void)hipEventDestroy(x);
+	}
+};
+
+dg_status finish_host_job(dg_field* field)
+{
+	HostCopyJob* job = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(field->host_mutex);
+		job = field->host_job;
+		if (job && job->worker.joinable())
+			job->worker.join(); // under the lock: concurrent waiters all return only when the array is complete
+		field->host_job = nullptr;
+	}
+	if (!job)
+		return DG_OK;
+	const dg_status st = job->status;
+	const std::string msg = job->message;
+	if (std::getenv("DG_HOST_DEBUG"))
+		std::fprintf(stderr, "host copy job: %s, %zu segments, %.1f ms\n", job->direct ? "direct" : "blocking copies", job->ev.size(),
+					 job->seconds * 1e3);
+	{
+		DeviceGuard guard(field->device);
+		delete job;
+	}
+	return st == DG_OK ? DG_OK : fail(st, "%s", msg.c_str());
+}
+
+// a new field on `grid` whose coefficient array (n doubles, uninitialised) it owns, with a producer stream and event
+static dg_status new_produced_field(const dg_grid_desc* grid, uint64_t n, dg_field** out)
+{
+	void* d_c = nullptr;
+	hipError_t e = hipMalloc(&d_c, std::max<uint64_t>(n, 1) * sizeof(double));
+	if (e != hipSuccess)
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "device allocation of %llu bytes: %s",
+					(unsigned long long)(n * sizeof(double)), hipGetErrorString(e));
+	dg_status st = dg_field_attach_device(grid, static_cast<const double*>(d_c), n, nullptr, 0, nullptr, out);
+	if (st != DG_OK)
+	{
+		(void)hipFree(d_c);
+		return st;
+	}
+	dg_field* f = *out;
+	f->owned[0] = d_c;
+	e = hipStreamCreateWithFlags(&f->producer_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&f->produced, hipEventDisableTiming);
+	if (e != hipSuccess)
+	{
+		dg_field_destroy(f);
+		*out = nullptr;
+		return fail(DG_ERR_HIP, "stream / event creation: %s", hipGetErrorString(e));
+	}
+	return DG_OK;
+}
+
+// uploads the predicate mask of a producing call (kept with the field until it is destroyed)
+static dg_status upload_producer_mask(dg_field* f, const uint8_t* pred_mask, uint64_t n)
+{
+	if (!pred_mask)
+		return DG_OK;
+	DG_HIP(hipMalloc(&f->d_producer_mask, n));
+	DG_HIP(hipMemcpy(f->d_producer_mask, pred_mask, n, hipMemcpyHostToDevice));
 	return DG_OK;
 }
 
@@ -749,6 +910,166 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		std::fprintf(stderr, "dg_sdf_sample_nodes: %s, %zu chunks, kernels %.1f ms, host prepared the array in %.1f ms, waited %.1f ms, copied %.1f ms\n",
 					 direct ? "direct" : "staged", (direct ? direct_cuts : cuts).size() - 1, kernel_ms, t_prepare * 1e3, t_wait * 1e3, t_copy * 1e3);
 	return DG_OK;
+}
+
+dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
+							  double* host_out, dg_field** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!mesh || !grid)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	const uint64_t n = dg_grid_n_nodes(grid);
+	DG_ON_DEVICE_OF(mesh);
+	dg_field* f = nullptr;
+	s = new_produced_field(grid, n, &f);
+	if (s == DG_OK) s = upload_producer_mask(f, pred_mask, n);
+	if (s != DG_OK)
+	{
+		dg_field_destroy(f);
+		return s;
+	}
+	double* d_c = static_cast<double*>(f->owned[0]);
+	const uint8_t* d_mask = static_cast<const uint8_t*>(f->d_producer_mask);
+	// Without a host array: one launch over the whole lattice.  With one: the chunk profile of the direct form, so
+	// that the copy of chunk i runs under the sampling of chunk i + 1 (every chunk costs a kernel tail of ~0.4 ms).
+	std::vector<uint64_t> cuts;
+	if (host_out == nullptr || n < (1u << 22))
+		cuts = {0, n};
+	else if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
+	{
+		const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
+		chunk_cuts(grid->resolution, 0, n, (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28), cuts);
+	}
+	else
+		schedule_cuts(grid->resolution, 0, n, direct_fractions(), cuts);
+	HostCopyJob* job = nullptr;
+	if (host_out)
+	{
+		job = new (std::nothrow) HostCopyJob;
+		if (!job)
+		{
+			dg_field_destroy(f);
+			return fail(DG_ERR_ALLOC, "host allocation failed");
+		}
+		job->device = mesh->device;
+		job->d_src = reinterpret_cast<const char*>(d_c);
+		job->h_dst = reinterpret_cast<char*>(host_out);
+	}
+	hipError_t e = hipSuccess;
+	for (size_t k = 0; k + 1 < cuts.size() && e == hipSuccess && s == DG_OK; ++k)
+	{
+		if (cuts[k + 1] == cuts[k])
+			continue;
+		s = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask ? d_mask + cuts[k] : nullptr, d_c + cuts[k],
+									   f->producer_stream);
+		if (s == DG_OK && job)
+		{
+			hipEvent_t ev = nullptr;
+			e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+			if (e == hipSuccess)
+			{
+				job->ev.push_back(ev);
+				if (job->seg.empty())
+					job->seg.push_back(cuts[k] * sizeof(double));
+				job->seg.push_back(cuts[k + 1] * sizeof(double));
+				e = hipEventRecord(ev, f->producer_stream);
+			}
+		}
+	}
+	if (e == hipSuccess && s == DG_OK) e = hipEventRecord(f->produced, f->producer_stream);
+	if (e != hipSuccess || s != DG_OK)
+	{
+		(void)hipStreamSynchronize(f->producer_stream);
+		delete job;
+		dg_field_destroy(f);
+		return s != DG_OK ? s : fail(DG_ERR_HIP, "dg_sdf_sample_field: %s", hipGetErrorString(e));
+	}
+	if (job)
+	{
+		f->host_job = job;
+		job->worker = std::thread([job]() { job->run(); });
+	}
+	*out = f;
+	return DG_OK;
+}
+
+dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+							   const uint8_t* pred_mask, double* host_out, dg_field** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!sdf)
+		return fail(DG_ERR_INVALID, "null argument");
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	const uint64_t n = dg_grid_n_nodes(&sdf->grid);
+	DG_ON_DEVICE_OF(sdf);
+	dg_field* f = nullptr;
+	s = new_produced_field(&sdf->grid, n, &f);
+	if (s == DG_OK) s = upload_producer_mask(f, pred_mask, n);
+	if (s == DG_OK)
+		s = dg_density_map_nodes_device(sdf, support_radius, rho0, band_predicate, 0, n, static_cast<const uint8_t*>(f->d_producer_mask),
+										static_cast<double*>(f->owned[0]), f->producer_stream);
+	hipError_t e = hipSuccess;
+	if (s == DG_OK) e = hipEventRecord(f->produced, f->producer_stream);
+	HostCopyJob* job = nullptr;
+	if (s == DG_OK && e == hipSuccess && host_out)
+	{
+		// one kernel, one event: the copy starts when K3 ends; eight pieces so that the registration of piece i + 1
+		// runs under the copy of piece i
+		job = new (std::nothrow) HostCopyJob;
+		if (!job)
+			s = fail(DG_ERR_ALLOC, "host allocation failed");
+		else
+		{
+			job->device = sdf->device;
+			job->d_src = static_cast<const char*>(f->owned[0]);
+			job->h_dst = reinterpret_cast<char*>(host_out);
+			const size_t total = n * sizeof(double);
+			const size_t pieces = std::max<size_t>(1, std::min<size_t>(8, total >> 24));
+			job->seg.push_back(0);
+			for (size_t i = 1; i <= pieces && e == hipSuccess; ++i)
+			{
+				hipEvent_t ev = nullptr;
+				e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+				if (e != hipSuccess)
+					break;
+				job->ev.push_back(ev);
+				job->seg.push_back(i == pieces ? total : ((total / pieces * i) & ~(size_t)4095));
+				e = hipEventRecord(ev, f->producer_stream);
+			}
+		}
+	}
+	if (s != DG_OK || e != hipSuccess)
+	{
+		if (f && f->producer_stream) (void)hipStreamSynchronize(f->producer_stream);
+		delete job;
+		dg_field_destroy(f);
+		return s != DG_OK ? s : fail(DG_ERR_HIP, "dg_density_map_field: %s", hipGetErrorString(e));
+	}
+	if (job)
+	{
+		f->host_job = job;
+		job->worker = std::thread([job]() { job->run(); });
+	}
+	*out = f;
+	return DG_OK;
+}
+
+dg_status dg_field_host_wait(dg_field* field)
+{
+	if (!field)
+		return fail(DG_ERR_INVALID, "null argument");
+	return finish_host_job(field);
 }
 
 void dg_set_progress_callback(dg_progress_fn cb, void* user)

@@ -120,6 +120,8 @@ struct dg_mesh
 	dg::MeshBuild host;                  // the arrays that were uploaded, kept for dg_signed_distance_point (immutable)
 };
 
+struct HostCopyJob; // dg_capi_host.cpp: the asynchronous copy of a device-resident field into the caller's host array
+
 struct dg_field
 {
 	dg::FieldDev dev;
@@ -130,6 +132,17 @@ struct dg_field
 	void* d_tile_major = nullptr;
 	void* d_cell_major = nullptr;
 	hipEvent_t cell_major_ready = nullptr; // recorded behind k_expand_cells: launches on other streams wait for it
+	hipEvent_t tile_major_ready = nullptr; // the same for k_expand_tiles (one event per copy: they may be built on different streams)
+	// A field whose coefficients a kernel of this library produces (dg_sdf_sample_field, dg_density_map_field): the
+	// device array is owned, `produced` is recorded behind the last producing kernel on `producer_stream`, and every
+	// consumer on another stream waits for it.  The copy into the caller's host array, if one was asked for, runs
+	// from a worker thread (host_job) until dg_field_host_wait() / dg_field_destroy() collects it.
+	hipEvent_t produced = nullptr;
+	hipStream_t producer_stream = nullptr;
+	void* d_producer_mask = nullptr; // the predicate mask of the producing launch (freed with the job / the field)
+	mutable std::mutex host_mutex;   // guards host_job
+	HostCopyJob* host_job = nullptr;
+	bool immutable = false;          // dg_field_set_immutable: an attached array that will not change (K2 may build its copy)
 	mutable ScratchPool flag_scratch;     // K3: the flag word k_field_check writes, one per launch in flight
 	std::mutex wtab_mutex;
 	std::map<double, void*> wtabs;        // K3: support radius -> immutable device table of 4096 kernel values
@@ -172,6 +185,16 @@ struct DeviceGuard
 	DeviceGuard device_guard_((handle)->device);                                                      \
 	if (device_guard_.err != hipSuccess)                                                              \
 		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))
+
+// collects the field's host copy job, if any (dg_capi_host.cpp); returns its status
+dg_status finish_host_job(dg_field* field);
+// makes `stream` wait for the kernels that produce the field's coefficients (no-op for ordinary fields)
+inline hipError_t wait_produced(const dg_field* field, hipStream_t stream)
+{
+	if (field->produced && stream != field->producer_stream)
+		return hipStreamWaitEvent(stream, field->produced, 0);
+	return hipSuccess;
+}
 
 // ---- shared internals (defined in dg_capi.cpp) ---------------------------------------------------------------
 extern thread_local std::string g_error;  // dg_last_error()

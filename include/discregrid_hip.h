@@ -18,6 +18,9 @@
  *   dg_field_create / dg_field_attach_device
  *                             the per-field storage m_nodes / m_cells / m_cell_map
  *                             discregrid/include/Discregrid/cubic_lagrange_discrete_grid.hpp:69-71
+ *   dg_sdf_sample_field / dg_density_map_field / dg_field_host_wait
+ *                             addFunction as a whole (:780-899): the new field's storage is created by the call,
+ *                             device-resident, with the host vector filled asynchronously
  *   dg_interpolate_batch[_device]
  *                             CubicLagrangeDiscreteGrid::interpolate(field_id, x, gradient*)
  *                             discregrid/src/cubic_lagrange_discrete_grid.cpp:977-1063 (shape functions :339-580)
@@ -207,6 +210,46 @@ dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeff
 								 dg_field** out);
 void dg_field_destroy(dg_field* field);
 
+typedef struct dg_field_info {
+	uint64_t n_coeffs;
+	uint64_t n_cell_rows;      /* rows of the cell table (= grid cells for an unreduced field) */
+	uint64_t device_bytes;     /* device memory the handle owns (coefficients it owns, tables, cell-/tile-major copies) */
+	const double* d_coeffs;    /* the coefficient vector on the device (m_nodes[field], cubic_lagrange_discrete_grid.hpp:69) */
+	int32_t device;
+	int32_t owns_coefficients; /* dg_field_create / dg_sdf_sample_field / dg_density_map_field / dg_reduction_to_field */
+	int32_t has_cell_major, has_tile_major;
+	int32_t immutable;         /* dg_field_set_immutable */
+	int32_t host_copy_pending; /* the asynchronous copy into the caller's host array has not been collected yet */
+} dg_field_info;
+dg_status dg_field_get_info(const dg_field* field, dg_field_info* info);
+/* An ATTACHED device array (dg_field_attach_device) may change between calls, so batched queries never build the
+ * cell-major copy for it by themselves.  immutable != 0 promises that it will not change while the handle lives:
+ * the handle then behaves like one made by dg_field_create (copy built on the first batch of >= 2^18 queries). */
+dg_status dg_field_set_immutable(dg_field* field, int immutable);
+
+/* ---- fields produced ON the device (one resident copy per field) ------------------------------------------
+ * The reference keeps ONE coefficient vector per field (m_nodes, cubic_lagrange_discrete_grid.hpp:69) that
+ * addFunction fills (:806-831) and interpolate reads (:977-1063).  Here that vector lives on the device: the
+ * producing call returns a field handle that OWNS the device array its kernel wrote, and K2 (dg_interpolate_batch*),
+ * K3 (dg_density_map_field / dg_density_map_nodes*), dg_reduce_field_device and the cell-/tile-major builders read
+ * that very array -- nothing is uploaded again.  If host_out is not NULL the coefficients are ALSO copied into the
+ * caller's host array (n doubles), asynchronously: the call returns as soon as everything is enqueued (node
+ * sampling is cut into chunks whose copies overlap the sampling of the next chunk; the array is made a DMA target
+ * piece by piece from a worker thread), consumers on the device start when the last kernel ends, and
+ * dg_field_host_wait() blocks until host_out is complete (dg_field_destroy waits too).  host_out must stay
+ * allocated until then and is scratch from the moment of the call.  pred_mask (host, nullable, one byte per node)
+ * works as in dg_sdf_sample_nodes.  */
+dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
+							  double* host_out, dg_field** out);
+/* K3 over the whole lattice of `sdf` into a NEW device-resident field on the same grid (the density map the
+ * reference's GenerateDensityMap adds as field 1, cmd/generate_density_map/main.cpp:83-133); arguments as
+ * dg_density_map_nodes, host_out / asynchrony as dg_sdf_sample_field. */
+dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+							   const uint8_t* pred_mask, double* host_out, dg_field** out);
+/* Blocks until the host copy a producing call started is complete (DG_OK at once if there is none or it was
+ * collected before); returns the status of that copy. */
+dg_status dg_field_host_wait(dg_field* field);
+
 /* Optional: builds (once, asynchronously on `stream`) a cell-major device copy of the field --
  * 32 doubles = 256 contiguous bytes per cell row -- that dg_interpolate_batch* then reads
  * instead of gathering 16 scattered 16-byte segments per query.  Costs 256 bytes per cell of
@@ -252,6 +295,12 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 typedef struct dg_reduction dg_reduction;
 dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, int closed, double lo,
 						  double hi, double offset, dg_reduction** out);
+/* The same on the coefficients a field handle already holds on the device (no upload). */
+dg_status dg_reduce_field_device(const dg_field* field, int closed, double lo, double hi, double offset,
+								 dg_reduction** out);
+/* The reduced field as a handle of its own (table mode): the reduction's device arrays change owner, nothing is
+ * copied or uploaded; call dg_reduction_fetch BEFORE this if the host needs the arrays too. */
+dg_status dg_reduction_to_field(dg_reduction* r, dg_field** out);
 dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys);
 dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* cells, uint32_t* cell_map);
 void dg_reduction_destroy(dg_reduction* r);

@@ -59,6 +59,47 @@ struct RefGrid
 };
 } // namespace
 
+// GenerateDensityMap's lambdas (cmd/generate_density_map/main.cpp:83-133) around the grid's field 0, re-typed
+// around the reference's CubicKernel, GaussQuadrature and DiscreteGrid::interpolate; `use(density_func, predicate)`
+// runs with them in scope.
+template <class Use>
+static void with_density_lambdas(CubicLagrangeDiscreteGrid* sdf, double h, double rho0, int no_reduction, Use use)
+{
+	auto sph_kernel = CubicKernel{};
+	sph_kernel.setRadius(h);
+	auto gamma = [&](Eigen::Vector3d const& x) {
+		auto ar = sph_kernel.getRadius();
+		auto dist = sdf->interpolate(0u, x);
+		if (dist > ar)
+			return 0.0;
+		return 1.0 - dist / ar;
+	};
+	auto int_domain = Eigen::AlignedBox3d(Eigen::Vector3d::Constant(-h), Eigen::Vector3d::Constant(h));
+	auto density_func = [&](Eigen::Vector3d const& x) {
+		auto dist = sdf->interpolate(0u, x);
+		if (dist > 2.0 * sph_kernel.getRadius())
+			return 0.0;
+		auto integrand = [&sph_kernel, &gamma, &x](Eigen::Vector3d const& xi) {
+			auto res = gamma(x + xi) * sph_kernel.W(xi);
+			return res;
+		};
+		auto res = GaussQuadrature::integrate(integrand, int_domain, 30);
+		return rho0 * res;
+	};
+	auto cell_diag = sdf->cellSize().norm();
+	auto predicate = [&](Eigen::Vector3d const& x_) {
+		if (no_reduction)
+			return true;
+		auto x = x_.cwiseMax(sdf->domain().min()).cwiseMin(sdf->domain().max());
+		auto dist = sdf->interpolate(0u, x);
+		if (dist == std::numeric_limits<double>::max())
+			return false;
+		return -6.0 * h < dist + cell_diag && dist - cell_diag < 2.0 * h;
+	};
+	use(density_func, predicate);
+}
+
+
 extern "C"
 {
 
@@ -239,46 +280,39 @@ void ref_grid_reduce_abs_lt(void* h, unsigned field, double bound)
 		field, [bound](Eigen::Vector3d const&, double v) { return std::abs(v) < bound; });
 }
 
-// GenerateDensityMap's addFunction call (cmd/generate_density_map/main.cpp:83-133) on the grid's
-// field 0: the lambdas below are the tool's own, re-typed around the reference's CubicKernel,
-// GaussQuadrature and DiscreteGrid::interpolate.  Returns the wall time of addFunction.
+// GenerateDensityMap's addFunction call on the grid's field 0.  Returns the wall time of addFunction.
 double ref_grid_add_density_map(void* hh, double h, double rho0, int no_reduction)
 {
 	auto* sdf = static_cast<RefGrid*>(hh)->grid.get();
-	auto sph_kernel = CubicKernel{};
-	sph_kernel.setRadius(h);
-	auto gamma = [&](Eigen::Vector3d const& x) {
-		auto ar = sph_kernel.getRadius();
-		auto dist = sdf->interpolate(0u, x);
-		if (dist > ar)
-			return 0.0;
-		return 1.0 - dist / ar;
-	};
-	auto int_domain = Eigen::AlignedBox3d(Eigen::Vector3d::Constant(-h), Eigen::Vector3d::Constant(h));
-	auto density_func = [&](Eigen::Vector3d const& x) {
-		auto dist = sdf->interpolate(0u, x);
-		if (dist > 2.0 * sph_kernel.getRadius())
-			return 0.0;
-		auto integrand = [&sph_kernel, &gamma, &x](Eigen::Vector3d const& xi) {
-			auto res = gamma(x + xi) * sph_kernel.W(xi);
-			return res;
-		};
-		auto res = GaussQuadrature::integrate(integrand, int_domain, 30);
-		return rho0 * res;
-	};
-	auto cell_diag = sdf->cellSize().norm();
-	auto t0 = std::chrono::high_resolution_clock::now();
-	sdf->addFunction(density_func, false, [&](Eigen::Vector3d const& x_) {
-		if (no_reduction)
-			return true;
-		auto x = x_.cwiseMax(sdf->domain().min()).cwiseMin(sdf->domain().max());
-		auto dist = sdf->interpolate(0u, x);
-		if (dist == std::numeric_limits<double>::max())
-			return false;
-		return -6.0 * h < dist + cell_diag && dist - cell_diag < 2.0 * h;
+	double secs = 0.0;
+	with_density_lambdas(sdf, h, rho0, no_reduction, [&](auto& density_func, auto& predicate) {
+		auto t0 = std::chrono::high_resolution_clock::now();
+		sdf->addFunction(density_func, false, predicate);
+		auto t1 = std::chrono::high_resolution_clock::now();
+		secs = std::chrono::duration<double>(t1 - t0).count();
 	});
-	auto t1 = std::chrono::high_resolution_clock::now();
-	return std::chrono::duration<double>(t1 - t0).count();
+	return secs;
+}
+// The same lambdas over a node RANGE, the way addFunction's node loop applies them
+// (cubic_lagrange_discrete_grid.cpp:806-831: `pred && !pred(x) ? DBL_MAX : func(x)`), without the cell table:
+// full-lattice digests in resumable chunks (tests/golden/make_digests.py) and the bounded-sample CPU baseline of K3.
+// Nodes are independent, so the dynamic schedule changes no bit.
+double ref_density_nodes(void* hh, double h, double rho0, int no_reduction, unsigned begin, unsigned end, double* out)
+{
+	auto* sdf = static_cast<RefGrid*>(hh)->grid.get();
+	double secs = 0.0;
+	with_density_lambdas(sdf, h, rho0, no_reduction, [&](auto& density_func, auto& predicate) {
+		auto t0 = std::chrono::high_resolution_clock::now();
+#pragma omp parallel for schedule(dynamic, 64)
+		for (long long l = begin; l < (long long)end; ++l)
+		{
+			auto x = sdf->indexToNodePosition((unsigned)l);
+			out[l - begin] = !predicate(x) ? std::numeric_limits<double>::max() : density_func(x);
+		}
+		auto t1 = std::chrono::high_resolution_clock::now();
+		secs = std::chrono::duration<double>(t1 - t0).count();
+	});
+	return secs;
 }
 // the two reduceField calls of main.cpp:135-147
 void ref_grid_reduce_density(void* hh, double h, double rho0)

@@ -8,11 +8,14 @@
 //   host_api_driver reduceband in.cdf lo hi out.cdf gpu|host  the same through the typed ValuePredicate (GPU path)
 //   host_api_driver eval       in.cdf pts.bin out.bin     scalar interpolate (value + gradient)
 //   host_api_driver evalsplit  in.cdf pts.bin out.bin     determineShapeFunctions + split interpolate
+//   host_api_driver flow       mesh.obj "rx ry rz" h pts.bin prefix   GPU: addFunction -> addDensityMap -> batches ->
+//                                                         host reads -> copies / moves -> reduceField x 2 -> .cdf / .cdm
 //   host_api_driver gpu        mesh.obj pts.bin out.bin   GPU: MeshSDF addFunction (with a predicate
 //                                                         on field 1), batched vs scalar interpolate,
 //                                                         batched vs single signed_distance
 #include <Discregrid/All>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -166,6 +169,83 @@ int main(int argc, char** argv)
 		write_doubles(argv[4], out);
 		std::printf("gpu driver: %zu mismatches, addFunction %.4f s (sampling %.4f s)\n", bad, g.lastAddFunctionSeconds(),
 					g.lastSamplingSeconds());
+		return bad ? 4 : 0;
+	}
+	if (cmd == "flow" && argc == 7)
+	{
+		// GenerateSDF -> GenerateDensityMap -> batched queries in ONE process, the way a simulation sets up a boundary:
+		// every field is produced on the device and stays there; the host vectors fill in the background.
+		//   host_api_driver flow mesh.obj "rx ry rz" h pts.bin out_prefix
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		Eigen::AlignedBox3d dom;
+		dom.setEmpty();
+		for (auto const& x : mesh.vertices())
+			dom.extend(x);
+		dom.max() += 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		dom.min() -= 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		unsigned rx = 0, ry = 0, rz = 0;
+		if (std::sscanf(argv[3], "%u %u %u", &rx, &ry, &rz) != 3)
+			return 2;
+		const double h = std::stod(argv[4]);
+		const std::vector<double> pts = read_doubles(argv[5]);
+		const size_t n = pts.size() / 3;
+		const std::string prefix = argv[6];
+		auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = now();
+		CubicLagrangeDiscreteGrid g(dom, {{rx, ry, rz}});
+		const unsigned f_sdf = g.addFunction(MeshSDF{&md, false});
+		const double t1 = now();
+		const unsigned f_rho = g.addDensityMap(f_sdf, h, 1000.0, true);
+		const double t2 = now();
+		std::vector<double> phi(n), grad(3 * n), rho(n);
+		g.interpolate(f_sdf, pts.data(), n, phi.data(), grad.data());
+		g.interpolate(f_rho, pts.data(), n, rho.data());
+		const double t3 = now();
+		// the first host readers: scalar interpolate (waits for the SDF's copy), then copies of the grid
+		size_t bad = 0;
+		for (size_t q = 0; q < n && q < 2000; ++q)
+		{
+			Eigen::Vector3d x(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]), gr;
+			bad += !(g.interpolate(f_sdf, x, &gr) == phi[q] && gr[0] == grad[3 * q] && gr[1] == grad[3 * q + 1] && gr[2] == grad[3 * q + 2]);
+			bad += !(g.interpolate(f_rho, x) == rho[q]);
+		}
+		const double t4 = now();
+		// value semantics like the reference class: by-value containers, copies, moves
+		std::vector<CubicLagrangeDiscreteGrid> grids;
+		grids.push_back(g);                 // copy
+		grids.emplace_back(dom, std::array<unsigned int, 3>{{2, 2, 2}});
+		grids[1] = grids[0];                // copy assignment
+		CubicLagrangeDiscreteGrid moved(std::move(grids[0]));
+		grids.erase(grids.begin());
+		for (size_t q = 0; q < n && q < 500; ++q)
+		{
+			Eigen::Vector3d x(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]);
+			bad += !(moved.interpolate(f_sdf, x) == phi[q] && grids[0].interpolate(f_rho, x) == rho[q]);
+		}
+		std::vector<double> rho2(n);
+		moved.interpolate(f_rho, pts.data(), n, rho2.data()); // a copy uploads its own device handle on first use
+		for (size_t q = 0; q < n; ++q)
+			bad += !(rho2[q] == rho[q]);
+		g.save(prefix + ".cdf");
+		moved.save(prefix + "_copy.cdf");
+		// the tool's two reductions on the device handles, then the .cdm the reference tool would write
+		const double cell_diag = g.cellSize().norm();
+		g.reduceField(f_sdf, ValuePredicate::band(-6.0 * h, 2.0 * h, cell_diag));
+		g.reduceField(f_rho, ValuePredicate::range(0.0, 3.0 * 1000.0));
+		std::vector<double> rho3(n);
+		g.interpolate(f_rho, pts.data(), n, rho3.data()); // reduced field: its device handle came out of the reduction
+		for (size_t q = 0; q < n && q < 2000; ++q)
+			bad += !(g.interpolate(f_rho, Eigen::Vector3d(pts[3 * q], pts[3 * q + 1], pts[3 * q + 2])) == rho3[q]);
+		g.save(prefix + ".cdm");
+		std::vector<double> out;
+		out.push_back((double)bad);
+		out.insert(out.end(), phi.begin(), phi.end());
+		out.insert(out.end(), rho.begin(), rho.end());
+		out.insert(out.end(), rho3.begin(), rho3.end());
+		write_doubles(prefix + ".bin", out);
+		std::printf("{\"mismatches\": %zu, \"add_function_s\": %.6f, \"add_density_map_s\": %.6f, \"batches_s\": %.6f, \"first_host_reads_s\": %.6f}\n",
+					bad, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
 		return bad ? 4 : 0;
 	}
 	std::fprintf(stderr, "bad arguments\n");

@@ -137,10 +137,19 @@ int main(int argc, char** argv)
 			CubicLagrangeDiscreteGrid sdf(domain, resolution); // a fresh grid per call, like the tool
 			const double t0 = now();
 			sdf.addFunction(MeshSDF{&md, false}, false);
+			const double t_return = now() - t0; // the work is enqueued; the field is being produced on the device
+			// a GPU-side consumer: one batched query needs the WHOLE field on the device, nothing on the host
+			const double q[3] = {domain.min()[0] + 0.25 * domain.diagonal()[0], domain.min()[1] + 0.5 * domain.diagonal()[1],
+								 domain.min()[2] + 0.5 * domain.diagonal()[2]};
+			double phi = 0.0;
+			sdf.interpolate(0u, q, 1, &phi);
+			const double t_device = now() - t0;
+			sdf.waitForHostData(); // the first host reader would wait here
 			const double dt = now() - t0;
-			if (!sdf.lastAddFunctionUsedGpu())
+			if (!sdf.lastAddFunctionUsedGpu() || !(phi == sdf.interpolate(0u, Eigen::Vector3d(q[0], q[1], q[2]))))
 				return 4;
-			std::printf("%s{\"total_s\": %.6f, \"sampling_s\": %.6f}", r ? ", " : "", dt, sdf.lastSamplingSeconds());
+			std::printf("%s{\"total_s\": %.6f, \"return_s\": %.6f, \"device_ready_s\": %.6f, \"sampling_s\": %.6f}", r ? ", " : "", dt,
+						t_return, t_device, sdf.lastSamplingSeconds());
 		}
 		std::printf("], \"cells\": %zu}\n", CubicLagrangeDiscreteGrid(domain, resolution).nCells());
 		return 0;

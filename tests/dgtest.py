@@ -478,6 +478,8 @@ def ref_lib():
         L.ref_grid_add_density_map.restype = C.c_double
         L.ref_grid_add_density_map.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
         L.ref_grid_reduce_density.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ref_density_nodes.restype = C.c_double
+        L.ref_density_nodes.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint, C.c_uint, c_dp]
         L.ref_md_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 3
         L.ref_md_get.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_ip]
         _ref = L
@@ -567,6 +569,12 @@ class RefGrid:
 
     def add_density_map(self, h, rho0, no_reduction=False):
         return self.L.ref_grid_add_density_map(self.h, h, rho0, int(no_reduction))
+
+    def density_nodes(self, h, rho0, begin, end, no_reduction=False):
+        """The density-map tool's predicate + density_func over nodes [begin, end) of field 0 (no cell table)."""
+        out = np.empty(end - begin)
+        self.last_seconds = self.L.ref_density_nodes(self.h, h, rho0, int(no_reduction), begin, end, dp(out))
+        return out
 
     def reduce_density(self, h, rho0):
         self.L.ref_grid_reduce_density(self.h, h, rho0)

@@ -17,9 +17,19 @@ nodes: the first 16 bytes of SHA-256 over the raw little-endian doubles.  The GP
               seed 4321, whose reference value passes the test); CubicLagrangeDiscreteGrid::
               interpolate value-only and value+gradient (:977-1063); digests per 2^20 queries.
 
+  density128  K3 at full lattice: the icosphere SDF at 128^3 (14 926 977 nodes, sampled by the reference; its
+              digests are stored as ico71_128_*) goes through the UNMODIFIED reference's GenerateDensityMap
+              lambdas -- node predicate + density_func = 1 + 4096 interpolate calls per integrated node,
+              cmd/generate_density_map/main.cpp:86-133, h = 0.1, rho0 = 1000, band predicate on -- over ALL
+              nodes (46 G interpolations, ~1 h on 8 cores; resumable: partial results are kept in
+              /tmp/dg_density128_partial.npz).  Digests per 2^20 nodes + a strided sample of the values.
+  density256  the same on the 256^3 field of ico71_256 (BASELINE configs[4]'s SDF): all 118 425 857 nodes, 89.7 M
+              integrated = 367 G interpolate calls of the UNMODIFIED reference (~2 h on 8 cores; resumable).
+
 Output: tests/golden/lattice_digests.npz (a few tens of KB).
 
-Run:  python tests/golden/make_digests.py [bunny128] [ico71_256] [ico71_512]     (default: all)
+Run:  python tests/golden/make_digests.py [bunny128] [ico71_256] [ico71_512] [density128] [density256]
+      (default: the three lattices)
 """
 import os
 import sys
@@ -99,11 +109,79 @@ def config5(dom, res, field):
     return out
 
 
+DENSITY_H = 0.1
+DENSITY_RHO0 = 1000.0
+DENSITY_SAMPLE_STRIDE = 4099
+
+
+def density_full(tag, n_res):
+    """K3's reference at full lattice, resumable: the icosphere SDF at n_res^3 sampled by the reference, then the
+    reference's GenerateDensityMap lambdas over every node."""
+    V, F = T.icosphere(71)
+    res = [n_res] * 3
+    dom = T.ref_default_domain(V)
+    n = T.n_nodes(res)
+    part_path = "/tmp/dg_%s_partial.npz" % tag
+    part = dict(np.load(part_path)) if os.path.exists(part_path) else {}
+    if "sdf" in part:
+        sdf = part["sdf"]
+    else:
+        g = T.RefGrid(V, F, dom, res)
+        sdf = np.empty(n)
+        for b in range(0, n, CHUNK):
+            e = min(n, b + CHUNK)
+            sdf[b:e] = g.sample_nodes(b, e)
+        del g
+        part = {"sdf": sdf, "done": np.uint64(0), "dens": np.empty(n)}
+        np.savez(part_path, **part)
+    g = T.RefGrid(None, None, dom, res)
+    assert g.add_coeffs(sdf) == 0
+    dens = part["dens"]
+    done = int(part["done"])
+    step = 1 << 18
+    t0 = time.time()
+    secs = float(part.get("seconds", 0.0))
+    for b in range(done, n, step):
+        e = min(n, b + step)
+        dens[b:e] = g.density_nodes(DENSITY_H, DENSITY_RHO0, b, e)
+        secs += g.last_seconds
+        part.update(done=np.uint64(e), dens=dens, seconds=np.float64(secs))
+        if (b // step) % 16 == 15 or e == n:
+            np.savez(part_path, **part)
+        print("%s: %d / %d nodes, %.0f s (this run), %.0f s total" % (tag, e, n, time.time() - t0, secs), flush=True)
+    integrated = int(np.count_nonzero((dens != DBL_MAX) & (sdf <= 2 * DENSITY_H)))
+    sdf_tag = "ico71_%d" % n_res
+    out = {tag + "_h": np.float64(DENSITY_H), tag + "_rho0": np.float64(DENSITY_RHO0),
+           tag + "_digest": T.block_digests(dens, BLOCK),
+           tag + "_sample_stride": np.uint64(DENSITY_SAMPLE_STRIDE),
+           tag + "_sample": dens[::DENSITY_SAMPLE_STRIDE].copy(),
+           tag + "_integrated_nodes": np.uint64(integrated),
+           tag + "_seconds": np.float64(secs)}
+    if n_res != 256:       # (ico71_256_* is written by the lattice run)
+        out.update({sdf_tag + "_domain": dom, sdf_tag + "_res": np.array(res, dtype=np.uint32), sdf_tag + "_nodes": np.uint64(n),
+                    sdf_tag + "_digest": T.block_digests(sdf, BLOCK)})
+    return out
+
+
+def density128():
+    return density_full("density128", 128)
+
+
+def density256():
+    return density_full("density256", 256)
+
+
 def main():
     assert T.ref_available(), "build oracle/_ref first: make -C oracle ref"
     want = sys.argv[1:] or list(meshes())
     res = dict(np.load(OUT)) if os.path.exists(OUT) else {}
     res["block"] = np.uint64(BLOCK)
+    for name, fn in (("density128", density128), ("density256", density256)):
+        if name in want:
+            want.remove(name)
+            res.update(fn())
+            np.savez_compressed(OUT, **res)
+            print("%s done" % name, flush=True)
     for name in want:
         out, (V, F, dom, r, field) = lattice(name, keep_field=(name == "ico71_256"))
         res.update(out)

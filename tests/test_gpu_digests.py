@@ -81,66 +81,177 @@ def test_config3_icosphere_256_every_node(dg, gold, ico256):
     assert len(bad) == 0, "blocks of 2^20 nodes that differ from the reference: %s" % bad[:10]
 
 
-def test_config5_interpolate_10m_queries(dg, gold, ico256):
-    """BASELINE configs[4], part 1: 10 M uniform queries (std::mt19937_64 seed 1234) and 10 M queries of the
-    SPH-like shell |phi| < 2h on the 256^3 field, value-only and value + gradient: every block of 2^20
-    results == the reference's CubicLagrangeDiscreteGrid::interpolate (:977-1063)."""
-    import torch
-    V, F, dom, mesh, grid, field = ico256
-    s = torch.cuda.current_stream().cuda_stream
-    n = len(field)
+def _config5_points(gold, dom, evaluate_stream):
+    """The two query sets of config 5.  The shell is selected with the values `evaluate_stream` returns for the
+    26 M-point stream, so the selection itself is part of the check."""
     nq = int(gold["c5_n_queries"])
-    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
-
-    def evaluate(P):
-        d_P = torch.from_numpy(P).cuda()
-        phi = torch.empty(len(P), dtype=torch.float64, device="cuda")
-        fld.interpolate_device(d_P.data_ptr(), len(P), phi.data_ptr(), stream=s)
-        phi_g = torch.empty(len(P), dtype=torch.float64, device="cuda")
-        grad = torch.empty(3 * len(P), dtype=torch.float64, device="cuda")
-        fld.interpolate_device(d_P.data_ptr(), len(P), phi_g.data_ptr(), grad.data_ptr(), stream=s)
-        torch.cuda.synchronize()
-        return phi.cpu().numpy(), phi_g.cpu().numpy(), grad.cpu().numpy().reshape(-1, 3)
-
     P = T.uniform_points(1234, nq, dom[:3], dom[3:])
-    phi, phi_g, grad = evaluate(P)
-    np.testing.assert_array_equal(phi[:64], gold["c5_uniform_phi_head"])
-    for name, got in (("phi", phi), ("phi_g", phi_g), ("grad", grad)):
-        bad = mismatching_blocks(T.block_digests(got), gold["c5_uniform_" + name])
-        assert len(bad) == 0, ("uniform", name, bad[:10])
-    # the shell: the first 10 M points of a 26 M uniform stream whose value passes |phi| < 0.2 -- selected with
-    # the GPU's own values, so the selection itself is part of the check
     C = T.uniform_points(4321, int(gold["c5_shell_stream"]), dom[:3], dom[3:])
-    d_C = torch.from_numpy(C).cuda()
-    phic = torch.empty(len(C), dtype=torch.float64, device="cuda")
-    fld.interpolate_device(d_C.data_ptr(), len(C), phic.data_ptr(), stream=s)
-    torch.cuda.synchronize()
-    pc = phic.cpu().numpy()
-    del d_C, phic
+    pc = evaluate_stream(C)
     keep = np.flatnonzero((pc != DBL_MAX) & (np.abs(pc) < 0.2))
     assert len(keep) >= nq and keep[nq - 1] == int(gold["c5_shell_last_candidate"])
     S = np.ascontiguousarray(C[keep[:nq]])
     assert len(mismatching_blocks(T.block_digests(S), gold["c5_shell_points"])) == 0
+    return P, S
+
+
+def _check_config5(gold, evaluate, P, S, what):
+    phi, phi_g, grad = evaluate(P)
+    np.testing.assert_array_equal(phi[:64], gold["c5_uniform_phi_head"])
+    for name, got in (("phi", phi), ("phi_g", phi_g), ("grad", grad)):
+        bad = mismatching_blocks(T.block_digests(got), gold["c5_uniform_" + name])
+        assert len(bad) == 0, (what, "uniform", name, bad[:10])
     phi, phi_g, grad = evaluate(S)
     for name, got in (("phi", phi), ("phi_g", phi_g), ("grad", grad)):
         bad = mismatching_blocks(T.block_digests(got), gold["c5_shell_" + name])
-        assert len(bad) == 0, ("shell", name, bad[:10])
+        assert len(bad) == 0, (what, "shell", name, bad[:10])
+
+
+def _device_evaluator(torch, fld, order=None):
+    """P -> (phi, phi with gradient, gradient) through dg_interpolate_batch_device; with `order` (a callable
+    P -> permutation) the queries are handed over in that order and the results put back before digesting."""
+    s = torch.cuda.current_stream().cuda_stream
+
+    def evaluate(P):
+        perm = None if order is None else order(P)
+        Q = P if perm is None else np.ascontiguousarray(P[perm])
+        d_P = torch.from_numpy(Q).cuda()
+        phi = torch.empty(len(Q), dtype=torch.float64, device="cuda")
+        fld.interpolate_device(d_P.data_ptr(), len(Q), phi.data_ptr(), stream=s)
+        phi_g = torch.empty(len(Q), dtype=torch.float64, device="cuda")
+        grad = torch.empty(3 * len(Q), dtype=torch.float64, device="cuda")
+        fld.interpolate_device(d_P.data_ptr(), len(Q), phi_g.data_ptr(), grad.data_ptr(), stream=s)
+        torch.cuda.synchronize()
+        out = [phi.cpu().numpy(), phi_g.cpu().numpy(), grad.cpu().numpy().reshape(-1, 3)]
+        if perm is not None:
+            for i, a in enumerate(out):
+                b = np.empty_like(a)
+                b[perm] = a
+                out[i] = b
+        return out
+    return evaluate
+
+
+@pytest.fixture(scope="module")
+def config5_points(dg, gold, ico256):
+    import torch
+    V, F, dom, mesh, grid, field = ico256
+    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=len(field))
+    P, S = _config5_points(gold, dom, lambda C: _stream_values(torch, fld, C))
+    fld.close()
+    return P, S
+
+
+def _stream_values(torch, fld, C):
+    d_C = torch.from_numpy(C).cuda()
+    phic = torch.empty(len(C), dtype=torch.float64, device="cuda")
+    fld.interpolate_device(d_C.data_ptr(), len(C), phic.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return phic.cpu().numpy()
+
+
+def test_config5_interpolate_10m_queries(dg, gold, ico256, config5_points):
+    """BASELINE configs[4], part 1: 10 M uniform queries (std::mt19937_64 seed 1234) and 10 M queries of the
+    SPH-like shell |phi| < 2h on the 256^3 field, value-only and value + gradient: every block of 2^20
+    results == the reference's CubicLagrangeDiscreteGrid::interpolate (:977-1063).  Attached device array,
+    plain layout: the binned gather kernels."""
+    import torch
+    V, F, dom, mesh, grid, field = ico256
+    P, S = config5_points
+    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=len(field))
+    _check_config5(gold, _device_evaluator(torch, fld), P, S, "attached, plain layout, binned")
     fld.close()
 
 
-def test_config5_density_map_256(dg, ico256):
-    """BASELINE configs[4], part 2: GenerateDensityMap's node function (K3) on the whole 256^3 SDF;
-    a strided sample of integrated, zero and rejected nodes == the oracle's restatement of
-    cmd/generate_density_map/main.cpp:86-133 (one node = 1 + 4096 interpolations), bit for bit."""
+def cell_order(dom, res):
+    """P -> the permutation that sorts the queries by the cell they fall into (the order an SPH code's
+    spatially sorted particles arrive in): K2's "already ordered" branch."""
+    lo, hi, res = np.asarray(dom[:3]), np.asarray(dom[3:]), np.asarray(res)
+
+    def order(P):
+        c = np.clip(((P - lo) / (hi - lo) * res).astype(np.int64), 0, res - 1)
+        return np.argsort(c[:, 0] + res[0] * (c[:, 1] + res[1] * c[:, 2]), kind="stable")
+    return order
+
+
+@pytest.mark.parametrize("path", ["cell_major_rows", "cell_major_per_lane", "owned_auto_copy", "tile_major",
+                                  "cell_sorted_input", "cell_sorted_input_cell_major", "no_binning"])
+def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, path, monkeypatch):
+    """The same 2 x 3 x 10 digest blocks through EVERY other K2 path that carries a quoted number
+    (secondary.k2_interpolate on the bench line): the cooperative row kernel on the cell-major copy
+    (k_interpolate_rows: the 18 Gq/s figure), the per-lane kernels on that copy, an OWNED field that builds the
+    copy by itself on its first large batch, the tile-major copy, cell-sorted input (the device-side "already
+    ordered" decision; results un-permuted before digesting) on both layouts, and the unbinned gather."""
     import torch
     V, F, dom, mesh, grid, field = ico256
+    P, S = config5_points
+    order = None
+    if path == "owned_auto_copy":
+        fld = dg.Field(grid, field.cpu().numpy())          # dg_field_create: the library owns the coefficients
+    else:
+        fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=len(field))
+    if path in ("cell_major_rows", "cell_major_per_lane", "cell_sorted_input_cell_major"):
+        fld.build_cell_major(stream=torch.cuda.current_stream().cuda_stream)
+    if path == "cell_major_per_lane":
+        monkeypatch.setenv("DG_K2_ROWS", "0")
+    if path == "tile_major":
+        fld.build_tile_major(stream=torch.cuda.current_stream().cuda_stream)
+    if path.startswith("cell_sorted_input"):
+        order = cell_order(dom, [256] * 3)
+    if path == "no_binning":
+        monkeypatch.setenv("DG_K2_BINNING", "0")
+    _check_config5(gold, _device_evaluator(torch, fld, order), P, S, path)
+    if path == "owned_auto_copy":
+        assert fld.has_cell_major(), "the owned field did not build its cell-major copy on a 10 M batch"
+    fld.close()
+
+
+def _density_on_device(dg, torch, grid, field, h, rho0):
     s = torch.cuda.current_stream().cuda_stream
-    n = len(field)
-    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
-    dens = torch.empty(n, dtype=torch.float64, device="cuda")
-    fld.density_map_nodes_device(0.1, 1000.0, True, 0, n, dens.data_ptr(), stream=s)
+    fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=len(field))
+    dens = torch.empty(len(field), dtype=torch.float64, device="cuda")
+    fld.density_map_nodes_device(h, rho0, True, 0, len(field), dens.data_ptr(), stream=s)
     torch.cuda.synchronize()
     got = dens.cpu().numpy()
+    fld.close()
+    return got
+
+
+def test_density_map_128_every_node(dg, gold):
+    """K3 at FULL lattice against the UNMODIFIED reference: the 128^3 icosphere SDF (its own digests checked
+    first) through GenerateDensityMap's node predicate + density_func (cmd/generate_density_map/main.cpp:86-133;
+    11.3 M integrated nodes = 46 G reference interpolate calls): every block of 2^20 of the 14 926 977 results."""
+    import torch
+    if "density128_digest" not in gold:
+        pytest.skip("density128 digests not generated (python tests/golden/make_digests.py density128)")
+    V, F = T.icosphere(71)
+    dom = gold["ico71_128_domain"]
+    mesh, grid, field = sample_on_device(dg, torch, V, F, dom, [128] * 3)
+    assert len(field) == int(gold["ico71_128_nodes"])
+    assert len(mismatching_blocks(T.block_digests(field.cpu().numpy()), gold["ico71_128_digest"])) == 0
+    got = _density_on_device(dg, torch, grid, field, float(gold["density128_h"]), float(gold["density128_rho0"]))
+    stride = int(gold["density128_sample_stride"])
+    np.testing.assert_array_equal(got[::stride], gold["density128_sample"])     # readable failure first
+    bad = mismatching_blocks(T.block_digests(got), gold["density128_digest"])
+    assert len(bad) == 0, "blocks of 2^20 nodes that differ from the reference: %s" % bad[:10]
+    integrated = int(np.count_nonzero((got != DBL_MAX) & (field.cpu().numpy() <= 0.2)))
+    assert integrated == int(gold["density128_integrated_nodes"])
+
+
+def test_config5_density_map_256(dg, gold, ico256):
+    """BASELINE configs[4], part 2: GenerateDensityMap's node function (K3) on the whole 256^3 SDF.  With the
+    reference digests (tests/golden/make_digests.py density256: the unmodified reference over all 118 425 857
+    nodes, 367 G interpolate calls) every block of 2^20 results is compared; without them a strided sample of
+    integrated, zero and rejected nodes == the oracle's restatement of cmd/generate_density_map/main.cpp:86-133."""
+    import torch
+    V, F, dom, mesh, grid, field = ico256
+    got = _density_on_device(dg, torch, grid, field, 0.1, 1000.0)
+    if "density256_digest" in gold:
+        stride = int(gold["density256_sample_stride"])
+        np.testing.assert_array_equal(got[::stride], gold["density256_sample"])
+        bad = mismatching_blocks(T.block_digests(got), gold["density256_digest"])
+        assert len(bad) == 0, "blocks of 2^20 nodes that differ from the reference: %s" % bad[:10]
+        return
     coeffs = field.cpu().numpy()
     integrated = np.flatnonzero((got != DBL_MAX) & (got != 0.0))
     zero = np.flatnonzero(got == 0.0)
@@ -151,7 +262,6 @@ def test_config5_density_map_256(dg, ico256):
     for l in pick:
         want = T.oracle_density_map(dom, [256] * 3, coeffs, 0.1, 1000.0, band=True, begin=int(l), end=int(l) + 1)
         assert want[0] == got[l] or (np.isnan(want[0]) and np.isnan(got[l])), (int(l), want[0], got[l])
-    fld.close()
 
 
 def test_config4_lattice_512_every_node(dg, gold):

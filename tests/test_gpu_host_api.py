@@ -277,3 +277,113 @@ def test_discrete_field_to_bitmap_cli_default_output_and_errors(tmp_path):
     assert subprocess.call([exe], stdout=subprocess.DEVNULL) == 1
     assert subprocess.call([exe, "-p", "xyz", src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
     assert subprocess.call([exe, "-f", "3", src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
+
+
+# ---- one device-resident copy per field (dg_sdf_sample_field / dg_density_map_field / dg_reduce_field_device) ----
+@pytest.mark.parametrize("lazy", ["1", "0"])
+def test_flow_device_resident_fields_reproduce_the_reference_files(tmp_path, golden, lazy):
+    """addFunction(MeshSDF) -> addDensityMap -> batched interpolate -> first host reads -> copies / moves of the
+    grid -> reduceField x 2 -> save, in ONE process: every field is produced into a device array its handle owns
+    and never uploaded; the host vectors fill asynchronously (DG_LAZY_HOST=1, default) or before the call returns
+    (=0).  The .cdm written at the end == the file the REFERENCE's GenerateSDF + GenerateDensityMap flow wrote
+    (tests/golden/torus_16_16_6_density_reduced.cdm), byte for byte, in both modes."""
+    exe = _need(os.path.join(TEST_BUILD, "host_api_driver"))
+    obj = str(tmp_path / "torus.obj")
+    V, F = T.torus()
+    T.write_obj(obj, V, F)
+    dom = T.oracle_default_domain(V)
+    ext = dom[3:] - dom[:3]
+    P = np.random.default_rng(5).uniform(dom[:3] - 0.02 * ext, dom[3:] + 0.02 * ext, size=(6000, 3))
+    pts = str(tmp_path / "pts.bin")
+    P.tofile(pts)
+    prefix = str(tmp_path / "flow")
+    log = subprocess.check_output([exe, "flow", obj, "16 16 6", "0.1", pts, prefix], env=dict(os.environ, DG_LAZY_HOST=lazy)).decode()
+    print(log)
+    got = np.fromfile(prefix + ".bin")
+    assert got[0] == 0.0            # batched == scalar, copies == original, reduced batched == reduced scalar
+    ref_sdf = T.read_cdf(os.path.join(T.GOLDEN, "torus_16_16_6.cdf"))
+    g = T.read_cdf(prefix + ".cdf")
+    np.testing.assert_array_equal(g["domain"], ref_sdf["domain"])
+    np.testing.assert_array_equal(g["nodes"][0], ref_sdf["nodes"][0])
+    np.testing.assert_array_equal(g["nodes"][1], golden["torus16_density_h01"])
+    assert open(prefix + ".cdf", "rb").read() == open(prefix + "_copy.cdf", "rb").read()
+    assert open(prefix + ".cdm", "rb").read() == open(os.path.join(T.GOLDEN, "torus_16_16_6_density_reduced.cdm"), "rb").read()
+    n = len(P)
+    np.testing.assert_array_equal(got[1:1 + n], T.oracle_interpolate(dom, [16, 16, 6], ref_sdf["nodes"][0], P))
+    np.testing.assert_array_equal(got[1 + n:1 + 2 * n], T.oracle_interpolate(dom, [16, 16, 6], golden["torus16_density_h01"], P))
+
+
+@pytest.mark.parametrize("res,host_memory", [([9, 7, 8], "fresh"), ([160, 150, 140], "fresh"), ([160, 150, 140], "resident"),
+                                             ([112, 96, 120], "pinned"), ([112, 96, 120], "none")])
+def test_sample_field_is_device_resident_and_fills_the_host_array(res, host_memory):
+    """dg_sdf_sample_field: K1 into a device array the new field handle owns; the host array is filled by a
+    worker (direct DMA into fresh / pinned memory, blocking copies into resident 4 KiB pages) while consumers on
+    the device already run.  Chunked (>= 2^22 nodes), scheduled (>= 2^24) and single-launch forms; mask; K2 / K3 /
+    reduceField straight off the handle == the host-pointer entry points, bit for bit."""
+    import torch
+    import discregrid_amd as dg
+    V, F = T.icosphere(10)
+    dom = T.oracle_default_domain(V)
+    grid = dg.grid_desc(dom[:3], dom[3:], res)
+    n = dg.n_nodes(grid)
+    mesh = dg.Mesh(V, F)
+    want = mesh.sample_nodes(grid)
+    if host_memory == "fresh":
+        host = np.empty(n)
+    elif host_memory == "resident":
+        host = np.zeros(n) + 1.0
+    elif host_memory == "pinned":
+        pin = torch.empty(n, dtype=torch.float64).pin_memory()
+        host = pin.numpy()
+    else:
+        host = None
+    fld = mesh.sample_field(grid, host_out=host)
+    info = fld.info()
+    assert info["owns_coefficients"] == 1 and info["n_coeffs"] == n and info["device_bytes"] >= 8 * n
+    # device consumers need no host data
+    P = np.random.default_rng(1).uniform(dom[:3], dom[3:], size=(30000, 3))
+    phi, grad = fld.interpolate(P, grad=True)
+    wphi, wgrad = dg.Field(grid, want).interpolate(P, grad=True)
+    np.testing.assert_array_equal(phi, wphi)
+    np.testing.assert_array_equal(grad, wgrad)
+    if host is not None:
+        got = fld.host_wait()
+        assert fld.info()["host_copy_pending"] == 0
+        np.testing.assert_array_equal(got, want)
+        assert fld.host_wait() is got            # idempotent
+    dev = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    import ctypes
+    assert ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(info["d_coeffs"]),
+                                                                ctypes.c_size_t(8 * n), 3) == 0
+    np.testing.assert_array_equal(dev.cpu().numpy(), want)
+    if n < 1 << 20:
+        mask = (np.arange(n) % 3 != 1).astype(np.uint8)
+        mf = mesh.sample_field(grid, invert=True, mask=mask, host_out=True)
+        np.testing.assert_array_equal(mf.host_wait(), mesh.sample_nodes(grid, invert=True, mask=mask))
+        # K3 and the device reduction straight off the handle
+        h = 0.2
+        rho = fld.density_map_field(h, 1000.0, True, host_out=True)
+        wrho = dg.Field(grid, want).density_map_nodes(n, h, 1000.0, True)
+        np.testing.assert_array_equal(rho.host_wait(), wrho)
+        np.testing.assert_array_equal(rho.interpolate(P), dg.Field(grid, wrho).interpolate(P))
+        a = fld.reduce(-0.15, 0.15, as_field=True)
+        b = dg.reduce_field(grid, want, -0.15, 0.15)
+        assert a[3] == b[3]
+        if not a[3]:
+            for x, y in zip(a[:3], b[:3]):
+                np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(a[4].interpolate(P), dg.Field(grid, b[0], b[1], b[2]).interpolate(P))
+
+
+def test_sample_field_destroyed_while_the_copy_runs():
+    """dg_field_destroy on a handle whose host copy is still in flight waits for it (no write after free)."""
+    import discregrid_amd as dg
+    V, F = T.icosphere(10)
+    dom = T.oracle_default_domain(V)
+    grid = dg.grid_desc(dom[:3], dom[3:], [150, 150, 150])
+    mesh = dg.Mesh(V, F)
+    host = np.empty(dg.n_nodes(grid))
+    fld = mesh.sample_field(grid, host_out=host)
+    fld.close()
+    np.testing.assert_array_equal(host, mesh.sample_nodes(grid))
