@@ -96,9 +96,10 @@ SYMBOLS = {
     "dg_field_destroy": (None, [C.c_void_p]),
     "dg_field_get_info": (C.c_int, [C.c_void_p, C.POINTER(FieldInfo)]),
     "dg_field_set_immutable": (C.c_int, [C.c_void_p, C.c_int]),
-    "dg_sdf_sample_field": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, _u8p, _dp, C.POINTER(C.c_void_p)]),
+    "dg_sdf_sample_field": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, _u8p, _dp, C.c_int, C.POINTER(C.c_void_p)]),
     "dg_density_map_field": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, _u8p, _dp, C.POINTER(C.c_void_p)]),
     "dg_field_host_wait": (C.c_int, [C.c_void_p]),
+    "dg_field_cache_trim": (None, []),
     "dg_reduce_field_device": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "dg_reduction_to_field": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_field_build_cell_major": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -264,7 +265,7 @@ class Mesh:
                                                   C.byref(ent), near.ctypes.data_as(_dp)))
         return (d.value, tri.value, ent.value, near) if full else d.value
 
-    def sample_field(self, grid, invert=False, mask=None, host_out=None):
+    def sample_field(self, grid, invert=False, mask=None, host_out=None, host_first=True):
         """dg_sdf_sample_field: K1 into a new device-resident Field; host_out (a float64 array of n_nodes, or True to
         have one allocated) is filled asynchronously -- Field.host_wait() returns it complete."""
         n = n_nodes(grid)
@@ -277,7 +278,8 @@ class Mesh:
         h = C.c_void_p()
         _check(self._lib.dg_sdf_sample_field(self.handle, C.byref(grid), int(invert),
                                              None if m is None else m.ctypes.data_as(_u8p),
-                                             None if host_out is None else host_out.ctypes.data_as(_dp), C.byref(h)))
+                                             None if host_out is None else host_out.ctypes.data_as(_dp), int(host_first),
+                                             C.byref(h)))
         return Field._adopt(h, host_out)
 
     # ---- device-pointer entry points (ints = device addresses, stream = hipStream_t address) ---

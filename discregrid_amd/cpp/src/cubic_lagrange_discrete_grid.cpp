@@ -356,7 +356,10 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 			// One GPU: the field stays in the device array K1 writes (the handle K2 / K3 / reduceField will read) and the
 			// host vector is filled by an asynchronous copy -- this call does not wait for it (see the header).
 			dg_field* produced = nullptr;
-			st = dg_sdf_sample_field(mesh, &g, sdf->invert ? 1 : 0, pred ? mask.data() : nullptr, coeffs.data(), &produced);
+			// lazy: whoever follows is a consumer on the device (or nobody is waiting): one launch, the copy behind it; not
+			// lazy: the caller is about to wait for the host vector: chunks whose copies overlap the sampling
+			const bool lazy = !verbose && env_flag("DG_LAZY_HOST", 1) != 0;
+			st = dg_sdf_sample_field(mesh, &g, sdf->invert ? 1 : 0, pred ? mask.data() : nullptr, coeffs.data(), lazy ? 0 : 1, &produced);
 			if (st == DG_OK)
 			{
 				adoptDeviceField(id, produced, true);

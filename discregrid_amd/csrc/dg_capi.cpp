@@ -186,6 +186,10 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	if (!dg::build_mesh(verts, n_vertices, tris, n_triangles, max_leaf, B))
 		return fail(DG_ERR_INVALID, "invalid mesh (vertex index out of range or too many triangles)");
 	auto t1 = std::chrono::high_resolution_clock::now();
+	// the traversals (device and host) keep one postponed subtree per tree level on a stack of kStackDepth entries:
+	// a deeper tree -- impossible with median splits below 2^31 triangles -- would lose subtrees silently
+	if (B.depth + 1 > (uint32_t)dg::kStackDepth)
+		return fail(DG_ERR_INVALID, "BVH depth %u exceeds the traversal stack (%d levels)", B.depth, dg::kStackDepth);
 
 	dg_mesh* m = new (std::nothrow) dg_mesh;
 	if (!m)

@@ -124,12 +124,18 @@ void dg_field_destroy(dg_field* f)
 	if (f->producer_stream)
 	{
 		(void)hipStreamSynchronize(f->producer_stream);
-		(void)hipStreamDestroy(f->producer_stream);
+		recycle_stream(f->device, f->producer_stream);
 	}
 	if (f->produced)
 		(void)hipEventDestroy(f->produced);
 	if (f->d_producer_mask)
 		(void)hipFree(f->d_producer_mask);
+	if (f->owned[0] && f->recyclable_bytes)
+	{
+		(void)hipDeviceSynchronize(); // nothing may still read the array when the next field is sampled into it
+		if (recycle_field_buffer(f->owned[0], f->recyclable_bytes, f->device))
+			f->owned[0] = nullptr;
+	}
 	for (void* p : f->owned)
 		if (p)
 			(void)hipFree(p);
@@ -518,16 +524,24 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	L.mask = d_pred_mask;
 	L.out = d_out;
 	L.brick_blocking = env_int("DG_K3_BLOCKED", 1, 0, 1);
+	P.lds_waves = env_int("DG_K3_LDS", 0, 0, 3); // experiment: coefficients staged through LDS (measured slower)
+	const bool unreduced_field = dev.cells == nullptr && dev.cell_map == nullptr;
+	if (unreduced_field && env_int("DG_K3_PAIRS", 2, 0, 3) != 0 && P.lds_waves == 0)
+	{
+		dg::pair_bricks(L); // two edge nodes per lane: the pair shares its cell's coefficients two times out of three
+		L.pair_nodes = env_int("DG_K3_PAIRS", 2, 0, 3); // (2 / 3: waves per SIMD asked of the register allocator)
+	}
 	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
 	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
 	int flag_idx = -1; // the flag k_field_check writes belongs to this launch (stream-ordered scratch)
-	if (env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12)
+	const bool skip_points = env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12;
+	// (always: besides the values that forbid the skip, k_field_check reports whether the field holds "no value" coefficients at all)
 	{
 		void* d_flag = nullptr;
 		flag_idx = sdf->flag_scratch.acquire(256, st, &d_flag);
 		if (flag_idx < 0)
 			return fail(DG_ERR_ALLOC, "device allocation failed");
-		P.skip_mode = 2;
+		P.skip_mode = skip_points ? 2 : 0;
 		P.unsafe = static_cast<const uint32_t*>(d_flag);
 	}
 	// Unreduced field without a tile-major copy: build one for this launch (stream-ordered scratch, built from

@@ -676,6 +676,59 @@ static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 	return DG_OK;
 }
 
+// Streams of destroyed produced fields and finished copy jobs, kept for the next ones: creating a stream costs
+// milliseconds on this runtime (the first use of a new stream sets up a hardware queue), more than the launch
+// work it then carries.  A stream goes back only when everything enqueued on it has finished.
+namespace
+{
+// Two kinds, never mixed: producer streams (kernels) and copy streams.  Copy streams are created with the highest
+// priority: the runtime multiplexes the streams of a process onto a few hardware queues, and a copy stream that
+// lands on the queue of the stream that samples the field has its copies ordered BEHIND the kernels still queued
+// there -- the host array was then complete after kernels + copies (36 ms at 256^3) instead of kernels || copies
+// (22 ms) on every second call [MI355X]; streams of another priority get hardware queues of their own.
+struct StreamPool
+{
+	std::mutex mutex;
+	struct Idle
+	{
+		int device, kind;
+		hipStream_t s;
+	};
+	std::vector<Idle> idle;
+	hipError_t take(int device, int kind, hipStream_t* out)
+	{
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			for (size_t i = 0; i < idle.size(); ++i)
+				if (idle[i].device == device && idle[i].kind == kind)
+				{
+					*out = idle[i].s;
+					idle.erase(idle.begin() + (long)i);
+					return hipSuccess;
+				}
+		}
+		if (kind == 1)
+		{
+			int least = 0, greatest = 0;
+			if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+				hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest) == hipSuccess)
+				return hipSuccess;
+			(void)hipGetLastError();
+		}
+		return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+	}
+	void give(int device, int kind, hipStream_t s)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		if (idle.size() < 16)
+			idle.push_back({device, kind, s});
+		else
+			(void)hipStreamDestroy(s);
+	}
+} g_streams;
+} // namespace
+void recycle_stream(int device, hipStream_t s) { g_streams.give(device, 0, s); }
+
 // ---- fields produced on the device: the asynchronous copy into the caller's host array ---------------------------
 // dg_sdf_sample_field / dg_density_map_field leave the coefficients in a device array the new field handle owns and
 // return once the kernels are enqueued.  If the caller wants the coefficients on the host as well, a worker thread
@@ -695,6 +748,7 @@ struct HostCopyJob
 	dg_status status = DG_OK;
 	std::string message;
 	bool direct = false;
+	bool after_kernel = false; // nothing can be copied before ev[0] anyway: keep out of the runtime until then (see run())
 	double seconds = 0.0;
 
 	void run()
@@ -702,8 +756,13 @@ struct HostCopyJob
 		const auto t0 = std::chrono::steady_clock::now();
 		DeviceGuard guard(device);
 		hipError_t e = guard.err;
+		// One launch produces the whole field: the copies cannot start before it ends, and a hipHostRegister issued now
+		// would hold the runtime for ~2 ms at a time while the caller is enqueueing the consumer of the field on the
+		// device (measured: that consumer started 2 ms late).  Wait for the kernel first; the first piece is prepared then.
+		if (after_kernel && e == hipSuccess && !ev.empty())
+			e = hipEventSynchronize(ev[0]);
 		hipStream_t copy = nullptr;
-		if (e == hipSuccess) e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+		if (e == hipSuccess) e = g_streams.take(device, 1, &copy);
 		const size_t total = seg.back();
 		HostTarget T;
 		direct = e == hipSuccess && begin_host_target(h_dst, total, T);
@@ -718,9 +777,19 @@ struct HostCopyJob
 			bound[i] = std::max(bound[i - 1], std::min<size_t>(total, (size_t)(up - (uintptr_t)h_dst)));
 		}
 		size_t next = 0; // first segment that has not been enqueued / copied
+		const bool debug = std::getenv("DG_HOST_DEBUG") != nullptr;
+		if (debug)
+			std::fprintf(stderr, "  host copy job: started after %.2f ms, %s\n",
+						 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, direct ? "direct" : "blocking copies");
 		for (; direct && next < n && e == hipSuccess; ++next)
 		{
-			if (!prepare_host_piece(T, bound[next], bound[next + 1]))
+			const auto tp = std::chrono::steady_clock::now();
+			const bool ok = prepare_host_piece(T, bound[next], bound[next + 1]);
+			if (debug)
+				std::fprintf(stderr, "  host copy job: piece %zu [%zu, %zu) MiB prepared in %.2f ms (at %.2f ms)\n", next, bound[next] >> 20,
+							 bound[next + 1] >> 20, std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count() * 1e3,
+							 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
+			if (!ok)
 			{
 				direct = false;
 				break;
@@ -749,7 +818,11 @@ struct HostCopyJob
 					e = hipMemcpy(h_dst + seg[next], d_src + seg[next], seg[next + 1] - seg[next], hipMemcpyDeviceToHost);
 			}
 		}
-		if (copy) (void)hipStreamDestroy(copy);
+		if (copy)
+		{
+			(void)hipStreamSynchronize(copy);
+			g_streams.give(device, 1, copy);
+		}
 		if (e != hipSuccess)
 		{
 			status = e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP;
@@ -791,11 +864,84 @@ dg_status finish_host_job(dg_field* field)
 	return st == DG_OK ? DG_OK : fail(st, "%s", msg.c_str());
 }
 
+// Coefficient arrays of destroyed produced fields, kept for the next one of the same size on the same device: a
+// 0.95 GB hipMalloc costs 2.5-3 ms, a fifth of the sampling it precedes [MI355X].  At most DG_FIELD_CACHE_MB
+// megabytes (default 2048; 0: nothing is kept) stay cached per process; dg_field_cache_trim() releases them.
+namespace
+{
+struct FieldBufferCache
+{
+	struct Buf
+	{
+		void* p;
+		size_t bytes;
+		int device;
+	};
+	std::mutex mutex;
+	std::vector<Buf> bufs;
+	size_t cached = 0;
+	void* take(size_t bytes, int device)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (size_t i = 0; i < bufs.size(); ++i)
+			if (bufs[i].device == device && bufs[i].bytes == bytes)
+			{
+				void* p = bufs[i].p;
+				cached -= bytes;
+				bufs.erase(bufs.begin() + (long)i);
+				return p;
+			}
+		return nullptr;
+	}
+	bool give(void* p, size_t bytes, int device)
+	{
+		const size_t cap = (size_t)env_int("DG_FIELD_CACHE_MB", 2048, 0, 1 << 20) << 20;
+		std::lock_guard<std::mutex> lock(mutex);
+		if (bytes > cap)
+			return false;
+		while (cached + bytes > cap && !bufs.empty()) // oldest first
+		{
+			DeviceGuard guard(bufs.front().device);
+			(void)hipFree(bufs.front().p);
+			cached -= bufs.front().bytes;
+			bufs.erase(bufs.begin());
+		}
+		bufs.push_back({p, bytes, device});
+		cached += bytes;
+		return true;
+	}
+	void trim()
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (Buf& b : bufs)
+		{
+			DeviceGuard guard(b.device);
+			(void)hipFree(b.p);
+		}
+		bufs.clear();
+		cached = 0;
+	}
+} g_field_buffers;
+} // namespace
+
+// (called by dg_field_destroy for the coefficient array of a produced field; the device is current and idle for it)
+bool recycle_field_buffer(void* p, size_t bytes, int device) { return g_field_buffers.give(p, bytes, device); }
+
+
 // a new field on `grid` whose coefficient array (n doubles, uninitialised) it owns, with a producer stream and event
 static dg_status new_produced_field(const dg_grid_desc* grid, uint64_t n, dg_field** out)
 {
-	void* d_c = nullptr;
-	hipError_t e = hipMalloc(&d_c, std::max<uint64_t>(n, 1) * sizeof(double));
+	int device = 0;
+	(void)hipGetDevice(&device);
+	const size_t bytes = std::max<uint64_t>(n, 1) * sizeof(double);
+	void* d_c = g_field_buffers.take(bytes, device);
+	hipError_t e = d_c ? hipSuccess : hipMalloc(&d_c, bytes);
+	if (e != hipSuccess)
+	{
+		g_field_buffers.trim(); // the cache must never be the reason an allocation fails
+		(void)hipGetLastError();
+		e = hipMalloc(&d_c, bytes);
+	}
 	if (e != hipSuccess)
 		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "device allocation of %llu bytes: %s",
 					(unsigned long long)(n * sizeof(double)), hipGetErrorString(e));
@@ -807,7 +953,8 @@ static dg_status new_produced_field(const dg_grid_desc* grid, uint64_t n, dg_fie
 	}
 	dg_field* f = *out;
 	f->owned[0] = d_c;
-	e = hipStreamCreateWithFlags(&f->producer_stream, hipStreamNonBlocking);
+	f->recyclable_bytes = bytes;
+	e = g_streams.take(device, 0, &f->producer_stream);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&f->produced, hipEventDisableTiming);
 	if (e != hipSuccess)
 	{
@@ -913,7 +1060,7 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 }
 
 dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
-							  double* host_out, dg_field** out)
+							  double* host_out, int host_first, dg_field** out)
 {
 	if (!out)
 		return fail(DG_ERR_INVALID, "out is null");
@@ -927,6 +1074,8 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		return s;
 	const uint64_t n = dg_grid_n_nodes(grid);
 	DG_ON_DEVICE_OF(mesh);
+	const bool debug = std::getenv("DG_HOST_DEBUG") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
 	dg_field* f = nullptr;
 	s = new_produced_field(grid, n, &f);
 	if (s == DG_OK) s = upload_producer_mask(f, pred_mask, n);
@@ -935,20 +1084,42 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		dg_field_destroy(f);
 		return s;
 	}
+	const auto t_alloc = std::chrono::steady_clock::now();
 	double* d_c = static_cast<double*>(f->owned[0]);
 	const uint8_t* d_mask = static_cast<const uint8_t*>(f->d_producer_mask);
 	// Without a host array: one launch over the whole lattice.  With one: the chunk profile of the direct form, so
 	// that the copy of chunk i runs under the sampling of chunk i + 1 (every chunk costs a kernel tail of ~0.4 ms).
-	std::vector<uint64_t> cuts;
+	std::vector<uint64_t> cuts, copy_cuts;
 	if (host_out == nullptr || n < (1u << 22))
 		cuts = {0, n};
+	else if (!host_first)
+	{
+		// one launch (no chunk tails, nothing else on the device while it runs); the copy follows in eight pieces so that
+		// the registration of piece i + 1 runs under the copy of piece i
+		cuts = {0, n};
+		const uint64_t pieces = std::max<uint64_t>(1, std::min<uint64_t>(8, (n * sizeof(double)) >> 24));
+		for (uint64_t i = 0; i <= pieces; ++i)
+			copy_cuts.push_back(i == pieces ? n : ((n / pieces * i) & ~(uint64_t)511));
+	}
 	else if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
 	{
 		const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
 		chunk_cuts(grid->resolution, 0, n, (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28), cuts);
 	}
 	else
+	{
+		// the chunk profile of the direct form: the copy of chunk i can only start when chunk i is sampled, so fine
+		// chunks keep the copy engine busy (three chunks: host-ready 35 instead of 27 ms at 256^3 [MI355X]) at the
+		// price of a kernel tail each (~0.4 ms) for consumers on the device
 		schedule_cuts(grid->resolution, 0, n, direct_fractions(), cuts);
+	}
+	hipEvent_t dbg0 = nullptr, dbg1 = nullptr;
+	if (debug)
+	{
+		(void)hipEventCreate(&dbg0);
+		(void)hipEventCreate(&dbg1);
+		(void)hipEventRecord(dbg0, f->producer_stream);
+	}
 	HostCopyJob* job = nullptr;
 	if (host_out)
 	{
@@ -961,6 +1132,7 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		job->device = mesh->device;
 		job->d_src = reinterpret_cast<const char*>(d_c);
 		job->h_dst = reinterpret_cast<char*>(host_out);
+		job->after_kernel = !copy_cuts.empty();
 	}
 	hipError_t e = hipSuccess;
 	for (size_t k = 0; k + 1 < cuts.size() && e == hipSuccess && s == DG_OK; ++k)
@@ -969,7 +1141,9 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 			continue;
 		s = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask ? d_mask + cuts[k] : nullptr, d_c + cuts[k],
 									   f->producer_stream);
-		if (s == DG_OK && job)
+		// the segments of the host copy: the chunk itself, or (one launch) the pieces of copy_cuts behind the whole launch
+		const std::vector<uint64_t> segs = copy_cuts.empty() ? std::vector<uint64_t>{cuts[k], cuts[k + 1]} : copy_cuts;
+		for (size_t g = 0; g + 1 < segs.size() && s == DG_OK && job && e == hipSuccess; ++g)
 		{
 			hipEvent_t ev = nullptr;
 			e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -977,8 +1151,8 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 			{
 				job->ev.push_back(ev);
 				if (job->seg.empty())
-					job->seg.push_back(cuts[k] * sizeof(double));
-				job->seg.push_back(cuts[k + 1] * sizeof(double));
+					job->seg.push_back(segs[g] * sizeof(double));
+				job->seg.push_back(segs[g + 1] * sizeof(double));
 				e = hipEventRecord(ev, f->producer_stream);
 			}
 		}
@@ -995,6 +1169,20 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	{
 		f->host_job = job;
 		job->worker = std::thread([job]() { job->run(); });
+	}
+	if (debug)
+	{
+		const auto t_enq = std::chrono::steady_clock::now();
+		(void)hipEventRecord(dbg1, f->producer_stream);
+		(void)hipEventSynchronize(dbg1); // (debug only: waits for the sampling)
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, dbg0, dbg1);
+		std::fprintf(stderr, "dg_sdf_sample_field: %zu chunks, allocation %.2f ms, enqueue %.2f ms, kernels on the device %.2f ms, done %.2f ms after the call began\n",
+					 cuts.size() - 1, std::chrono::duration<double>(t_alloc - t_begin).count() * 1e3,
+					 std::chrono::duration<double>(t_enq - t_alloc).count() * 1e3, ms,
+					 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
+		(void)hipEventDestroy(dbg0);
+		(void)hipEventDestroy(dbg1);
 	}
 	*out = f;
 	return DG_OK;
@@ -1034,6 +1222,7 @@ dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0
 			job->device = sdf->device;
 			job->d_src = static_cast<const char*>(f->owned[0]);
 			job->h_dst = reinterpret_cast<char*>(host_out);
+			job->after_kernel = true;
 			const size_t total = n * sizeof(double);
 			const size_t pieces = std::max<size_t>(1, std::min<size_t>(8, total >> 24));
 			job->seg.push_back(0);
@@ -1064,6 +1253,8 @@ dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0
 	*out = f;
 	return DG_OK;
 }
+
+void dg_field_cache_trim(void) { g_field_buffers.trim(); }
 
 dg_status dg_field_host_wait(dg_field* field)
 {

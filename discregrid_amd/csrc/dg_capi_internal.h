@@ -139,6 +139,7 @@ struct dg_field
 	// from a worker thread (host_job) until dg_field_host_wait() / dg_field_destroy() collects it.
 	hipEvent_t produced = nullptr;
 	hipStream_t producer_stream = nullptr;
+	size_t recyclable_bytes = 0;     // != 0: owned[0] goes back to the field-buffer cache (dg_capi_host.cpp) when the field dies
 	void* d_producer_mask = nullptr; // the predicate mask of the producing launch (freed with the job / the field)
 	mutable std::mutex host_mutex;   // guards host_job
 	HostCopyJob* host_job = nullptr;
@@ -186,6 +187,8 @@ struct DeviceGuard
 	if (device_guard_.err != hipSuccess)                                                              \
 		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))
 
+bool recycle_field_buffer(void* p, size_t bytes, int device); // dg_capi_host.cpp
+void recycle_stream(int device, hipStream_t s);               // dg_capi_host.cpp: an idle stream for the next produced field
 // collects the field's host copy job, if any (dg_capi_host.cpp); returns its status
 dg_status finish_host_job(dg_field* field);
 // makes `stream` wait for the kernels that produce the field's coefficients (no-op for ordinary fields)

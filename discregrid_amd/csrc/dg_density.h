@@ -28,9 +28,11 @@ struct DensityParams
 	// finite, which holds whenever every coefficient other than DBL_MAX is finite and below 1e290.
 	// kmask[i*16 + j] has bit k set where W(xi_i, xi_j, xi_k) != 0.
 	// skip_mode 0: evaluate every point; 1: skip the zero-weight points; 2 (device): skip them unless
-	// *unsafe != 0 (set by k_field_check when the field holds NaN / Inf / huge values).
+	// bit 0 of *unsafe is set (by k_field_check when the field holds NaN / Inf / huge values; bit 1 of the same
+	// word: the field holds "no value" coefficients -- the LDS kernel then consults the tile copy's flag bits).
 	uint16_t kmask[256];
 	int32_t skip_mode;
+	int32_t lds_waves; // device, tile-major copy: > 0: the kernel that stages the coefficients through LDS (waves per SIMD to aim for)
 	const uint32_t* unsafe;
 };
 
@@ -143,7 +145,7 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 	double g[3];
 	double res = 0.0;
 	const bool staged = STAGED;
-	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && P.unsafe[0] == 0u);
+	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && (P.unsafe[0] & 1u) == 0u);
 	DG_NOUNROLL
 	for (int i = 0; i < 16; ++i)
 	{

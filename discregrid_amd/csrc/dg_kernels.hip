@@ -622,6 +622,8 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	}
 	const LaneTask t = lane_task<POINTS>(P, brick, bm, lane);
 	LaneQuery q;
+	double ex_d2 = 1.7976931348623157e308; // what the exact traversal found (lanes with `exact` only)
+	int ex_tri = -1;
 	if (__ballot(exact) != 0ull)
 	{
 		// Exact traversal for the few lanes that need it, pruned from the start by their upper bounds (so it
@@ -639,9 +641,9 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 			P.ovf.saved_tri[slot * 64 + lane] = have ? q.best_tri : kSeedOnly;
 			return;
 		}
+		ex_d2 = q.best_d2;
+		ex_tri = q.best_tri;
 	}
-	const double ex_d2 = q.best_d2;
-	const int ex_tri = q.best_tri;
 	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
 	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
@@ -1067,6 +1069,592 @@ __global__ __launch_bounds__(64, DG_K3_WAVES) void k_density_bricks(const Sample
 	L.out[ln.out_idx] = v;
 }
 
+__device__ __forceinline__ int k3_cell_guess(const FieldDev& F, int d, double y)
+{
+	double t = (y - F.dmin[d]) * F.inv_cell[d];
+	t = fmin(fmax(t, -8.0), (double)F.res[d] + 8.0);
+	return (int)floor(t);
+}
+
+// ---- K3, two nodes per lane ---------------------------------------------------------------------------------------------
+// Counters of k_density_bricks (profiles/r03_k3_pmc.txt): texture-address and texture-data units busy 0.94 of the
+// launch, VALU 0.67 -- the kernel sits on the vector-memory roof: at every quadrature point every lane pulls the 256
+// bytes of its cell through the L1 path (sixteen 16-byte loads, 20.8 TD cycles per wave instruction).  Six of seven
+// lattice nodes are edge nodes, two per cell edge, a third of a cell apart; shifted by the same quadrature offset the
+// two land in the SAME cell two times out of three.  Here a lane owns such a pair (a wave: a "double brick" of 8 x 4 x 4
+// edge nodes, or a plain 4 x 4 x 4 brick of vertex nodes), fetches the cell's 32 coefficients once and evaluates both
+// points from the same registers; only when a cell face separates the two does it fetch again.  The axes the two nodes
+// share are evaluated once.  Per node and point: 0.67 of the loads, 0.86 of the arithmetic -- the same operations on
+// the same values in the same order as density_integral_t<true, .>, so the bits do not change.
+template <int MODE>
+__device__ __forceinline__ double k3_cell_value(const FieldDev& F, const double cf[32], bool ok, const Axis1D& ax, const Axis1D& ay,
+												 const Axis1D& az)
+{
+	const double NOVAL = 1.7976931348623157e308;
+	const double mxmy = ax.m * ay.m, mxpy = ax.m * ay.p, pxmy = ax.p * ay.m, pxpy = ax.p * ay.p;
+	const double x2y2 = ax.t2 + ay.t2;
+	const double mz = az.m, pz = az.p;
+	const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
+	double phi = 0.0;
+#define DG_ACC(q, n)                                   \
+	if (MODE != kFieldTileMajor)                       \
+		ok = ok && (cf[q] != NOVAL);                   \
+	phi += cf[q] * (n);
+	DG_ACC(0, fac * mxmy * mz)
+	DG_ACC(1, fac * pxmy * mz)
+	DG_ACC(2, fac * mxpy * mz)
+	DG_ACC(3, fac * pxpy * mz)
+	DG_ACC(4, fac * mxmy * pz)
+	DG_ACC(5, fac * pxmy * pz)
+	DG_ACC(6, fac * mxpy * pz)
+	DG_ACC(7, fac * pxpy * pz)
+	{
+		const double mymz = ay.m * mz, mypz = ay.m * pz, pymz = ay.p * mz, pypz = ay.p * pz;
+		DG_ACC(8, ax.fm3 * mymz)
+		DG_ACC(9, ax.fp3 * mymz)
+		DG_ACC(10, ax.fm3 * mypz)
+		DG_ACC(11, ax.fp3 * mypz)
+		DG_ACC(12, ax.fm3 * pymz)
+		DG_ACC(13, ax.fp3 * pymz)
+		DG_ACC(14, ax.fm3 * pypz)
+		DG_ACC(15, ax.fp3 * pypz)
+	}
+	{
+		const double mxmz = ax.m * mz, mxpz = ax.m * pz, pxmz = ax.p * mz, pxpz = ax.p * pz;
+		DG_ACC(16, ay.fm3 * mxmz)
+		DG_ACC(17, ay.fp3 * mxmz)
+		DG_ACC(18, ay.fm3 * pxmz)
+		DG_ACC(19, ay.fp3 * pxmz)
+		DG_ACC(20, ay.fm3 * mxpz)
+		DG_ACC(21, ay.fp3 * mxpz)
+		DG_ACC(22, ay.fm3 * pxpz)
+		DG_ACC(23, ay.fp3 * pxpz)
+	}
+	DG_ACC(24, az.fm3 * mxmy)
+	DG_ACC(25, az.fp3 * mxmy)
+	DG_ACC(26, az.fm3 * mxpy)
+	DG_ACC(27, az.fp3 * mxpy)
+	DG_ACC(28, az.fm3 * pxmy)
+	DG_ACC(29, az.fp3 * pxmy)
+	DG_ACC(30, az.fm3 * pxpy)
+	DG_ACC(31, az.fp3 * pxpy)
+#undef DG_ACC
+	return ok ? phi : NOVAL;
+}
+
+// axis_eval(F, 2, y) with the cell's (c0, c1) -- the two divisions of the affine map -- read from a table the wave
+// filled once for the z cells its points can fall into (zt == nullptr: no table, plain axis_eval).  Same expressions
+// on the same inputs, same bits.
+__device__ __forceinline__ Axis1D k3_axis_z(const FieldDev& F, double y, const double2* zt, int zlo)
+{
+	if (zt == nullptr)
+		return axis_eval(F, 2, y);
+	Axis1D a;
+	a.inside = (F.dmin[2] <= y) && (y <= F.dmax[2]);
+	uint32_t mi = (uint32_t)((y - F.dmin[2]) * F.inv_cell[2]);
+	if (mi >= F.res[2])
+		mi = F.res[2] - 1;
+	if (!a.inside)
+		mi = 0;
+	a.mi = mi;
+	const double2 cc = zt[a.inside ? (int)mi - zlo : 0];
+	a.t = cc.x * y - cc.y;
+	a.t2 = a.t * a.t;
+	a.m = 1.0 - a.t;
+	a.p = 1.0 + a.t;
+	const double fac = 9.0 / 64.0 * (1.0 - a.t2);
+	a.fm3 = fac * (1.0 - 3.0 * a.t);
+	a.fp3 = fac * (1.0 + 3.0 * a.t);
+	return a;
+}
+
+// the quadrature for the pair (A, B) of one lane; E: the axis along which the two nodes differ (-1: no node B)
+template <int MODE, int E>
+__device__ __forceinline__ void k3_pair_integral(const FieldDev& F, const DensityParams& P, bool has_noval, bool skip, const double2* zt, int zlo,
+												  const double xa[3], double xb_e, bool need_a, bool need_b, double* out_a, double* out_b)
+{
+	const double NOVAL = 1.7976931348623157e308;
+	double res_a = 0.0, res_b = 0.0;
+	DG_NOUNROLL
+	for (int i = 0; i < 16; ++i)
+	{
+		const double wi = P.w[i];
+		const Axis1D ax = axis_eval(F, 0, xa[0] + P.xi[i]);
+		Axis1D bx = ax;
+		if (E == 0)
+			bx = axis_eval(F, 0, xb_e + P.xi[i]);
+		DG_NOUNROLL
+		for (int j = 0; j < 16; ++j)
+		{
+			const uint32_t kmask = skip ? (uint32_t)P.kmask[i * 16 + j] : 0xffffu;
+			if (kmask == 0u)
+				continue; // the whole column lies outside the kernel's support
+			const double wij = wi * P.w[j];
+			const Axis1D ay = axis_eval(F, 1, xa[1] + P.xi[j]);
+			Axis1D by = ay;
+			if (E == 1)
+				by = axis_eval(F, 1, xb_e + P.xi[j]);
+			DG_NOUNROLL
+			for (int k = 0; k < 16; ++k)
+			{
+				if (((kmask >> k) & 1u) == 0u)
+					continue;
+				const double wijk = wij * P.w[k];
+				const Axis1D az = k3_axis_z(F, xa[2] + P.xi[k], zt, zlo);
+				Axis1D bz = az;
+				if (E == 2)
+					bz = k3_axis_z(F, xb_e + P.xi[k], zt, zlo);
+				const bool want_a = need_a && ax.inside && ay.inside && az.inside;
+				const bool want_b = E >= 0 && need_b && bx.inside && by.inside && bz.inside;
+				const uint32_t be = E == 0 ? bx.mi : (E == 1 ? by.mi : bz.mi), ae = E == 0 ? ax.mi : (E == 1 ? ay.mi : az.mi);
+				const bool shared = want_a && want_b && be == ae; // the two points lie in one cell
+				double cf[32];
+				bool ok = true;
+				double da = NOVAL, db = NOVAL;
+				if (want_a)
+				{
+					fetch_cell<MODE>(F, ax.mi, ay.mi, az.mi, F.res[1] * F.res[0] * az.mi + F.res[0] * ay.mi + ax.mi, cf);
+					if (MODE == kFieldTileMajor && has_noval)
+						ok = !tile_cell_has_novalue(F.tile_major, F.ntile, ax.mi, ay.mi, az.mi);
+					da = k3_cell_value<MODE>(F, cf, ok, ax, ay, az);
+				}
+				if (want_b && !shared)
+				{
+					fetch_cell<MODE>(F, bx.mi, by.mi, bz.mi, F.res[1] * F.res[0] * bz.mi + F.res[0] * by.mi + bx.mi, cf);
+					ok = true;
+					if (MODE == kFieldTileMajor && has_noval)
+						ok = !tile_cell_has_novalue(F.tile_major, F.ntile, bx.mi, by.mi, bz.mi);
+				}
+				if (want_b)
+					db = k3_cell_value<MODE>(F, cf, ok, bx, by, bz);
+				const double wv = P.wtab[(i * 16 + j) * 16 + k];
+				if (need_a)
+				{
+					const double gamma = (da > P.h) ? 0.0 : 1.0 - da / P.h;
+					res_a += wijk * (gamma * wv);
+				}
+				if (E >= 0 && need_b)
+				{
+					const double gamma = (db > P.h) ? 0.0 : 1.0 - db / P.h;
+					res_b += wijk * (gamma * wv);
+				}
+			}
+		}
+	}
+	res_a *= P.c0prod;
+	*out_a = P.rho0 * res_a;
+	res_b *= P.c0prod;
+	*out_b = P.rho0 * res_b;
+}
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_density_pairs(const SampleParams L, const FieldDev F, const DensityParams P)
+{
+	const double NOVAL = 1.7976931348623157e308;
+	uint32_t blk;
+	if (!logical_block(L, blockIdx.x, &blk))
+		return;
+	const uint64_t brick = (uint64_t)blk; // one wave per block
+	if (brick >= L.total_bricks)
+		return;
+	const int lane = (int)(threadIdx.x & 63u);
+	BrickMap m = map_brick(L, brick);
+	const int cls = m.cls; // wave-uniform
+	// vertex class: the lane's node of the 4x4x4 brick.  Edge classes: L counts DOUBLE bricks along a (pair_bricks());
+	// the lane takes the two nodes a = 8 t + 2 p, + 1 of edge p of the row -- nodes (2 p) & 3, + 1 of brick 2 t + (p >> 1)
+	int la = lane;
+	if (cls != 0)
+	{
+		const int p = lane & 3;
+		m.b0 = 2u * m.b0 + (uint32_t)(p >> 1);
+		la = (lane & ~3) | ((2 * p) & 3);
+	}
+	const LaneNode na = map_lane(L, m, la);
+	LaneNode nb = na;
+	nb.valid = false;
+	if (cls != 0)
+		nb = map_lane(L, m, la | 1);
+	double xa[3], xb[3];
+	node_position(na.cls, na.a, na.b, na.s, L.dmin, L.cell, xa);
+	node_position(nb.cls, nb.a, nb.b, nb.s, L.dmin, L.cell, xb);
+	double va = NOVAL, vb = NOVAL;
+	bool need_a = false, need_b = false;
+	if (na.valid && (L.mask == nullptr || L.mask[na.out_idx] != 0))
+		need_a = density_prefilter(F, P, xa, &va);
+	if (nb.valid && (L.mask == nullptr || L.mask[nb.out_idx] != 0))
+		need_b = density_prefilter(F, P, xb, &vb);
+	if (__ballot(need_a || need_b) != 0ull)
+	{
+		const uint32_t flags = P.unsafe ? P.unsafe[0] : 2u; // bit 0: NaN / Inf / huge values, bit 1: "no value" coefficients
+		const bool has_noval = (flags & 2u) != 0u;
+		const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && (flags & 1u) == 0u);
+		// (c0, c1) of the z cells the wave can meet: from lane 0's lowest point to lane 63's highest (positions and the
+		// cell computation are monotone); a window of more than 64 cells (fine lattices, large h) goes without the table
+		__shared__ double2 sT[64];
+		const int zlo = max(0, __builtin_amdgcn_readlane(k3_cell_guess(F, 2, xa[2] + P.xi[0]), 0));
+		const int zhi = min((int)F.res[2] - 1, __builtin_amdgcn_readlane(k3_cell_guess(F, 2, fmax(xa[2], xb[2]) + P.xi[15]), 63));
+		const double2* zt = nullptr;
+		if (zhi - zlo < 64)
+		{
+			if (zlo + lane <= zhi)
+			{
+				const double lo = F.dmin[2] + (double)(uint32_t)(zlo + lane) * F.cell[2];
+				const double hi = lo + F.cell[2];
+				const double den = hi - lo;
+				double2 e;
+				e.x = 2.0 / den;
+				e.y = (hi + lo) / den;
+				sT[lane] = e;
+			}
+			zt = sT;
+			__syncthreads();
+		}
+		double ra = 0.0, rb = 0.0;
+		// the axis along which the pair's nodes differ: x for the X class, y for Y, z for Z (dg_geom.h node_position())
+		if (cls == 0)
+			k3_pair_integral<MODE, -1>(F, P, has_noval, skip, zt, zlo, xa, 0.0, need_a, false, &ra, &rb);
+		else if (cls == 1)
+			k3_pair_integral<MODE, 0>(F, P, has_noval, skip, zt, zlo, xa, xb[0], need_a, need_b, &ra, &rb);
+		else if (cls == 2)
+			k3_pair_integral<MODE, 1>(F, P, has_noval, skip, zt, zlo, xa, xb[1], need_a, need_b, &ra, &rb);
+		else
+			k3_pair_integral<MODE, 2>(F, P, has_noval, skip, zt, zlo, xa, xb[2], need_a, need_b, &ra, &rb);
+		if (need_a)
+			va = ra;
+		if (need_b)
+			vb = rb;
+	}
+	if (na.valid)
+		L.out[na.out_idx] = va;
+	if (nb.valid)
+		L.out[nb.out_idx] = vb;
+}
+
+// ---- K3 with the coefficients staged through LDS (unreduced fields) ---------------------------------------------------
+// Counters of k_density_bricks on the tile copy (profiles/r03_k3_pmc.txt): the texture-address and texture-data units
+// are busy 0.94 of the launch, VALU 0.67 -- every lane pulls the 256 bytes of its cell through the vector memory
+// pipeline at each quadrature point (sixteen 16-byte loads, 20 TA cycles per wave instruction), although the 64 lanes
+// of a brick sit in neighbouring cells and share most of those nodes: the 4x4x4 cells of a brick reference 5^3
+// vertices + 3 x 100 edges = 725 doubles = 5.8 KB, against 16 KB fetched.  Here the wave fetches the box ONCE per
+// quadrature point, straight into LDS (global_load_lds_dwordx4: no registers, no ds_write pass), as 4 x 100 entries of
+// 16 bytes -- the x-adjacent vertex pair and the x edge of box position (a, b, c), the y edge of (c, a, b), the z edge
+// of (b, c, a), a < 4, b, c < 5: for every class the fastest digit runs along the axis the class is contiguous in
+// ([V | X | Y | Z]: x, x, y, z), so that four consecutive lanes read 64 consecutive bytes, and the reference layout is
+// linear in the cell coordinates, so that a lane's address is (origin of the box, scalar) + (lane constant).  Every
+// lane then reads its 32 coefficients from LDS right where the sum consumes them: sixteen ds_read_b128, no 64
+// coefficient registers.  The loads of point p + 1 are in flight while point p is evaluated (two LDS buffers, counted
+// s_waitcnt: the wave keeps its own memory latency covered instead of relying on other waves, which -- running the same
+// loop in lockstep -- want the same unit at the same time).  Same values, same arithmetic, same order: bit-identical.
+//
+// The box origin is the cell of lane 0's evaluation point (the brick's minimum corner: node positions and the cell
+// computation are monotone).  A lane whose cell lies outside [origin, origin + 3]^3 -- possible only when rounding
+// splits two lanes by a fifth cell, or for a point ON the domain's upper face -- evaluates its point the plain way.
+// "No value" coefficients: k_field_check tells whether the field holds any (bit 1); only then are the per-cell flag
+// bits of the tile copy consulted.
+typedef __attribute__((address_space(3))) void* k3_lds_ptr;
+__device__ __forceinline__ double k3_lane0(double v)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 0), hi = __builtin_amdgcn_readlane(__double2hiint(v), 0);
+	return __hiloint2double(hi, lo);
+}
+// 16 bytes per active lane from `gsrc` (per lane) to LDS byte address lds_dst + 16 * lane (lds_dst wave-uniform).  Not
+// tracked by the compiler's s_waitcnt bookkeeping: the caller counts (k3 kernels: exactly eight per point).
+__device__ __forceinline__ void k3_glds16(const void* gsrc, uint32_t lds_dst)
+{
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep)
+				 : "v"(gsrc), "s"(lds_dst)
+				 : "memory");
+}
+struct K3Entry // what lane e (two rounds: e = lane, lane + 64; live below 100) brings of a box
+{
+	uint32_t a, b, c;                // e = a + 4 b + 20 c
+	uint32_t offV, offX, offY, offZ; // bytes from the box origin's node of each class
+	bool live;
+};
+__device__ __forceinline__ K3Entry k3_entry(const FieldDev& F, int e)
+{
+	K3Entry k;
+	const uint32_t nx = F.res[0], ny = F.res[1], nz = F.res[2];
+	k.live = e < 100;
+	k.c = (uint32_t)e / 20u;
+	k.b = ((uint32_t)e - 20u * k.c) / 4u;
+	k.a = (uint32_t)e & 3u;
+	k.offV = 8u * (k.a + k.b * (nx + 1) + k.c * (nx + 1) * (ny + 1));
+	k.offX = 16u * (k.a + k.b * nx + k.c * nx * (ny + 1));
+	k.offY = 16u * (k.a + k.b * ny + k.c * ny * (nz + 1));
+	k.offZ = 16u * (k.a + k.b * nz + k.c * nz * (nx + 1));
+	return k;
+}
+// digit + origin within [0, n] (le) / [0, n) (lt) along one axis; negative sums wrap to huge values
+__device__ __forceinline__ bool k3_le(int o, uint32_t digit, uint32_t n) { return (uint32_t)o + digit <= n; }
+__device__ __forceinline__ bool k3_lt(int o, uint32_t digit, uint32_t n) { return (uint32_t)o + digit < n; }
+
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_density_bricks_lds(const SampleParams L, const FieldDev F, const DensityParams P)
+{
+	__shared__ double2 sE[2][4][100]; // [buffer][V pairs, X, Y, Z edges][entry]
+	__shared__ double2 sT[48];        // (c0, c1) of the affine map of the z cells this brick's quadrature points can fall into
+	const double NOVAL = 1.7976931348623157e308;
+	uint32_t blk;
+	if (!logical_block(L, blockIdx.x, &blk))
+		return;
+	const uint64_t brick = (uint64_t)blk; // one wave per block
+	if (brick >= L.total_bricks)
+		return;
+	const int lane = (int)(threadIdx.x & 63u);
+	const LaneNode ln = map_lane(L, brick, lane);
+	double x[3];
+	node_position(ln.cls, ln.a, ln.b, ln.s, L.dmin, L.cell, x); // (lanes beyond the lattice carry a clamped, valid node)
+	double v = NOVAL;
+	bool need = false;
+	if (ln.valid && (L.mask == nullptr || L.mask[ln.out_idx] != 0))
+		need = density_prefilter(F, P, x, &v);
+	if (__ballot(need) == 0ull)
+	{
+		if (ln.valid)
+			L.out[ln.out_idx] = v;
+		return;
+	}
+	const uint32_t nx = F.res[0], ny = F.res[1], nz = F.res[2];
+	const uint32_t flags = P.unsafe ? P.unsafe[0] : 2u; // bit 0: NaN / Inf / huge values, bit 1: "no value" coefficients
+	const bool has_noval = (flags & 2u) != 0u;
+	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && (flags & 1u) == 0u);
+	const K3Entry e0 = k3_entry(F, lane), e1 = k3_entry(F, lane + 64);
+	const int64_t nv = (int64_t)(nx + 1) * (ny + 1) * (nz + 1), nex = (int64_t)nx * (ny + 1) * (nz + 1), ney = (int64_t)(nx + 1) * ny * (nz + 1);
+	// lane l < 16 holds the box origin (cell of lane 0's point) for quadrature index l along each axis
+	const double xq = P.xi[lane & 15];
+	const int vgx = k3_cell_guess(F, 0, k3_lane0(x[0]) + xq), vgy = k3_cell_guess(F, 1, k3_lane0(x[1]) + xq),
+			  vgz = k3_cell_guess(F, 2, k3_lane0(x[2]) + xq);
+	// The z cells the brick can meet: from lane 0's lowest point to lane 63's highest (positions and the cell
+	// computation are monotone).  Their (c0, c1) -- two divisions per cell -- are computed once here instead of at
+	// every quadrature point: same expressions on the same inputs as axis_eval(), same bits.
+	const int zlo = max(0, __builtin_amdgcn_readlane(vgz, 0));
+	const int zhi = min((int)nz - 1, __builtin_amdgcn_readlane(k3_cell_guess(F, 2, x[2] + P.xi[15]), 63));
+	const bool ztab = zhi - zlo < 48;
+	if (ztab && zlo + lane <= zhi)
+	{
+		const double lo = F.dmin[2] + (double)(uint32_t)(zlo + lane) * F.cell[2];
+		const double hi = lo + F.cell[2];
+		const double den = hi - lo;
+		double2 e;
+		e.x = 2.0 / den;
+		e.y = (hi + lo) / den;
+		sT[lane] = e;
+	}
+	__syncthreads();
+	const uint32_t lds0 = (uint32_t)(uintptr_t)(k3_lds_ptr)&sE[0][0][0];
+
+	// the active quadrature points in the reference's order (i, j, k); wave-uniform
+	auto kmask_of = [&](int i, int j) -> uint32_t { return skip ? (uint32_t)P.kmask[i * 16 + j] : 0xffffu; };
+	auto advance = [&](int& i, int& j, int& k) -> bool { // to the next active point after (i, j, k); k = -1: from the column's start
+		++k;
+		while (true)
+		{
+			const uint32_t m = k < 16 ? (kmask_of(i, j) >> k) : 0u;
+			if (m != 0u)
+			{
+				k += __builtin_ctz(m);
+				return true;
+			}
+			k = 0;
+			if (++j == 16)
+			{
+				j = 0;
+				if (++i == 16)
+					return false;
+			}
+		}
+	};
+	// the eight loads of a point's box into buffer `buf`
+	auto issue = [&](int i, int j, int k, int buf) {
+		const int ox = __builtin_amdgcn_readlane(vgx, i), oy = __builtin_amdgcn_readlane(vgy, j), oz = __builtin_amdgcn_readlane(vgz, k);
+		// origin nodes of the four classes (element indices; may lie outside the lattice: such lanes are masked)
+		const int64_t pl = (int64_t)oz * (ny + 1) + oy;
+		const char* gV = (const char*)(F.coeffs + (pl * (nx + 1) + ox));
+		const char* gX = (const char*)(F.coeffs + (nv + 2 * (pl * nx + ox)));
+		const char* gY = (const char*)(F.coeffs + (nv + 2 * nex + 2 * (((int64_t)ox * (nz + 1) + oz) * ny + oy)));
+		const char* gZ = (const char*)(F.coeffs + (nv + 2 * nex + 2 * ney + 2 * (((int64_t)oy * (nx + 1) + ox) * nz + oz)));
+		const char* safe = (const char*)F.coeffs;
+		const uint32_t base = lds0 + (uint32_t)buf * 6400u;
+#pragma unroll
+		for (int r = 0; r < 2; ++r)
+		{
+			const K3Entry& q = r == 0 ? e0 : e1;
+			// (lane 0 always takes part, with a harmless address, so that every one of the eight instructions is issued
+			// whatever the masks: the waits below count them)
+			const bool mx = q.live && k3_lt(ox, q.a, nx) && k3_le(oy, q.b, ny) && k3_le(oz, q.c, nz);
+			const bool my = q.live && k3_lt(oy, q.a, ny) && k3_le(oz, q.b, nz) && k3_le(ox, q.c, nx);
+			const bool mz = q.live && k3_lt(oz, q.a, nz) && k3_le(ox, q.b, nx) && k3_le(oy, q.c, ny);
+			if (mx || lane == 0)
+			{
+				k3_glds16(mx ? gV + q.offV : safe, base + 0u * 1600u + 1024u * (uint32_t)r);
+				k3_glds16(mx ? gX + q.offX : safe, base + 1u * 1600u + 1024u * (uint32_t)r);
+			}
+			if (my || lane == 0)
+				k3_glds16(my ? gY + q.offY : safe, base + 2u * 1600u + 1024u * (uint32_t)r);
+			if (mz || lane == 0)
+				k3_glds16(mz ? gZ + q.offZ : safe, base + 3u * 1600u + 1024u * (uint32_t)r);
+		}
+	};
+
+	double res = 0.0;
+	int ci = 0, cj = 0, ck = -1;
+	bool have = advance(ci, cj, ck);
+	int buf = 0;
+	if (have)
+		issue(ci, cj, ck, buf);
+	int li = -1, lj = -1;
+	Axis1D ax = {}, ay = {};
+	double wi = 0.0, wij = 0.0, mxmy = 0.0, mxpy = 0.0, pxmy = 0.0, pxpy = 0.0, x2y2 = 0.0;
+	while (have)
+	{
+		int ni = ci, nj = cj, nk = ck;
+		const bool more = advance(ni, nj, nk);
+		if (more)
+		{
+			issue(ni, nj, nk, buf ^ 1);
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // the eight loads of THIS point's box have landed
+		}
+		else
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (ci != li)
+		{
+			wi = P.w[ci];
+			ax = axis_eval(F, 0, x[0] + P.xi[ci]);
+			li = ci;
+			lj = -1;
+		}
+		if (cj != lj)
+		{
+			wij = wi * P.w[cj];
+			ay = axis_eval(F, 1, x[1] + P.xi[cj]);
+			mxmy = ax.m * ay.m;
+			mxpy = ax.m * ay.p;
+			pxmy = ax.p * ay.m;
+			pxpy = ax.p * ay.p;
+			x2y2 = ax.t2 + ay.t2;
+			lj = cj;
+		}
+		const double wijk = wij * P.w[ck];
+		const double yz = x[2] + P.xi[ck];
+		Axis1D az;
+		if (ztab)
+		{
+			// axis_eval(F, 2, yz) with (c0, c1) from the table
+			az.inside = (F.dmin[2] <= yz) && (yz <= F.dmax[2]);
+			uint32_t mi = (uint32_t)((yz - F.dmin[2]) * F.inv_cell[2]);
+			if (mi >= nz)
+				mi = nz - 1;
+			if (!az.inside)
+				mi = 0;
+			az.mi = mi;
+			const double2 cc = sT[az.inside ? (int)mi - zlo : 0];
+			az.t = cc.x * yz - cc.y;
+			az.t2 = az.t * az.t;
+			az.m = 1.0 - az.t;
+			az.p = 1.0 + az.t;
+			const double f9 = 9.0 / 64.0 * (1.0 - az.t2);
+			az.fm3 = f9 * (1.0 - 3.0 * az.t);
+			az.fp3 = f9 * (1.0 + 3.0 * az.t);
+		}
+		else
+			az = axis_eval(F, 2, yz);
+		const bool inside = ax.inside && ay.inside && az.inside;
+		double d = NOVAL;
+		const int ox = __builtin_amdgcn_readlane(vgx, ci), oy = __builtin_amdgcn_readlane(vgy, cj), oz = __builtin_amdgcn_readlane(vgz, ck);
+		const uint32_t lx = ax.mi - (uint32_t)ox, ly = ay.mi - (uint32_t)oy, lz = az.mi - (uint32_t)oz;
+		const bool fits = lx < 4u && ly < 4u && lz < 4u;
+		if (need && inside && fits)
+		{
+			const double2* eV = &sE[buf][0][lx + 4u * ly + 20u * lz];
+			const double2* eX = &sE[buf][1][lx + 4u * ly + 20u * lz];
+			const double2* eY = &sE[buf][2][ly + 4u * lz + 20u * lx];
+			const double2* eZ = &sE[buf][3][lz + 4u * lx + 20u * ly];
+			const double mz = az.m, pz = az.p;
+			const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
+			bool ok = true;
+			if (has_noval)
+				ok = !tile_cell_has_novalue(F.tile_major, F.ntile, ax.mi, ay.mi, az.mi);
+			double phi = 0.0;
+			{
+				const double2 c0 = eV[0], c1 = eV[4], c2 = eV[20], c3 = eV[24];
+				phi += c0.x * (fac * mxmy * mz);
+				phi += c0.y * (fac * pxmy * mz);
+				phi += c1.x * (fac * mxpy * mz);
+				phi += c1.y * (fac * pxpy * mz);
+				phi += c2.x * (fac * mxmy * pz);
+				phi += c2.y * (fac * pxmy * pz);
+				phi += c3.x * (fac * mxpy * pz);
+				phi += c3.y * (fac * pxpy * pz);
+			}
+			{
+				const double mymz = ay.m * mz, mypz = ay.m * pz, pymz = ay.p * mz, pypz = ay.p * pz;
+				const double2 c0 = eX[0], c1 = eX[20], c2 = eX[4], c3 = eX[24];
+				phi += c0.x * (ax.fm3 * mymz);
+				phi += c0.y * (ax.fp3 * mymz);
+				phi += c1.x * (ax.fm3 * mypz);
+				phi += c1.y * (ax.fp3 * mypz);
+				phi += c2.x * (ax.fm3 * pymz);
+				phi += c2.y * (ax.fp3 * pymz);
+				phi += c3.x * (ax.fm3 * pypz);
+				phi += c3.y * (ax.fp3 * pypz);
+			}
+			{
+				const double mxmz = ax.m * mz, mxpz = ax.m * pz, pxmz = ax.p * mz, pxpz = ax.p * pz;
+				const double2 c0 = eY[0], c1 = eY[20], c2 = eY[4], c3 = eY[24];
+				phi += c0.x * (ay.fm3 * mxmz);
+				phi += c0.y * (ay.fp3 * mxmz);
+				phi += c1.x * (ay.fm3 * pxmz);
+				phi += c1.y * (ay.fp3 * pxmz);
+				phi += c2.x * (ay.fm3 * mxpz);
+				phi += c2.y * (ay.fp3 * mxpz);
+				phi += c3.x * (ay.fm3 * pxpz);
+				phi += c3.y * (ay.fp3 * pxpz);
+			}
+			{
+				const double2 c0 = eZ[0], c1 = eZ[20], c2 = eZ[4], c3 = eZ[24];
+				phi += c0.x * (az.fm3 * mxmy);
+				phi += c0.y * (az.fp3 * mxmy);
+				phi += c1.x * (az.fm3 * mxpy);
+				phi += c1.y * (az.fp3 * mxpy);
+				phi += c2.x * (az.fm3 * pxmy);
+				phi += c2.y * (az.fp3 * pxmy);
+				phi += c3.x * (az.fm3 * pxpy);
+				phi += c3.y * (az.fp3 * pxpy);
+			}
+			d = ok ? phi : NOVAL;
+		}
+		else if (need && inside)
+		{
+			// a cell the box does not cover: this lane's point the plain way (same bits: tests/test_density_map.py)
+			const double y[3] = {x[0] + P.xi[ci], x[1] + P.xi[cj], yz};
+			double g[3];
+			d = interpolate_point_mode<false, kFieldClosed>(F, y, g);
+		}
+		if (need)
+		{
+			const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
+			// (through the scalar cache: the inline-asm loads above make the compiler treat ordinary memory as changing)
+			const double wv = *(const DG_CONST_AS double*)(uintptr_t)(P.wtab + ((ci * 16 + cj) * 16 + ck));
+			res += wijk * (gamma * wv);
+		}
+		ci = ni;
+		cj = nj;
+		ck = nk;
+		have = more;
+		buf ^= 1;
+	}
+	if (need)
+	{
+		res *= P.c0prod;
+		v = P.rho0 * res;
+	}
+	if (ln.valid)
+		L.out[ln.out_idx] = v;
+}
+
 // U, one piece: the slots [rank_begin, rank_end) of the gathered buffer -> reference node order.
 // One thread per gathered value: contiguous reads, writes in contiguous runs of one plane.
 __global__ __launch_bounds__(256) void k_unpack_ranks(const UnpackParams P)
@@ -1086,14 +1674,17 @@ __global__ __launch_bounds__(256) void k_unpack_ranks(const UnpackParams P)
 // change the result (NaN, Inf, |c| >= 1e290)?  DBL_MAX is the regular "no value" marker.
 __global__ __launch_bounds__(256) void k_field_check(const double* __restrict__ coeffs, uint64_t n, uint32_t* __restrict__ unsafe)
 {
-	bool bad = false;
+	bool bad = false, nov = false;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
 	{
 		const double c = coeffs[i];
+		nov = nov || c == 1.7976931348623157e308;
 		bad = bad || (c != 1.7976931348623157e308 && !(fabs(c) < 1.0e290));
 	}
-	if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u)
-		atomicOr(unsafe, 1u);
+	// bit 0: values that forbid skipping the zero-weight points; bit 1: the field holds "no value" coefficients at all
+	const uint32_t bits = (__ballot(bad) != 0ull ? 1u : 0u) | (__ballot(nov) != 0ull ? 2u : 0u);
+	if (bits != 0u && (threadIdx.x & 63u) == 0u)
+		atomicOr(unsafe, bits);
 }
 
 // ---- reduceField (dg_kernels.h: reduce_field_device) --------------------------------------------------------------
@@ -1314,7 +1905,7 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 {
 	if (layout.total_bricks == 0)
 		return hipSuccess;
-	if (p.skip_mode == 2)
+	if (p.unsafe != nullptr)
 	{
 		const hipError_t e = hipMemsetAsync(const_cast<uint32_t*>(p.unsafe), 0, sizeof(uint32_t), stream);
 		if (e != hipSuccess)
@@ -1327,14 +1918,23 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 	const bool unreduced = f.cells == nullptr && f.cell_map == nullptr; // staged evaluator
 	switch (field_mode(f))
 	{
-	case kFieldTileMajor: hipLaunchKernelGGL((k_density_bricks<true, kFieldTileMajor>), grid, block, 0, stream, layout, f, p); break;
+	case kFieldTileMajor:
+		// pair_nodes: two edge nodes per lane (the layout counts double bricks: dg_layout.h pair_bricks()); lds_waves > 0:
+		// the experiment that stages the coefficients through LDS (DG_K3_LDS)
+		if (layout.pair_nodes && layout.pair_nodes >= 3) hipLaunchKernelGGL((k_density_pairs<kFieldTileMajor, 3>), grid, block, 0, stream, layout, f, p);
+		else if (layout.pair_nodes) hipLaunchKernelGGL((k_density_pairs<kFieldTileMajor, 2>), grid, block, 0, stream, layout, f, p);
+		else if (p.lds_waves >= 3) hipLaunchKernelGGL((k_density_bricks_lds<3>), grid, block, 0, stream, layout, f, p);
+		else if (p.lds_waves > 0) hipLaunchKernelGGL((k_density_bricks_lds<2>), grid, block, 0, stream, layout, f, p);
+		else hipLaunchKernelGGL((k_density_bricks<true, kFieldTileMajor>), grid, block, 0, stream, layout, f, p);
+		break;
 	case kFieldCellMajor:
 		if (unreduced) hipLaunchKernelGGL((k_density_bricks<true, kFieldCellMajor>), grid, block, 0, stream, layout, f, p);
 		else hipLaunchKernelGGL((k_density_bricks<false, kFieldCellMajor>), grid, block, 0, stream, layout, f, p);
 		break;
 	case kFieldTable: hipLaunchKernelGGL((k_density_bricks<false, kFieldTable>), grid, block, 0, stream, layout, f, p); break;
 	default:
-		if (unreduced) hipLaunchKernelGGL((k_density_bricks<true, kFieldClosed>), grid, block, 0, stream, layout, f, p);
+		if (unreduced && layout.pair_nodes) hipLaunchKernelGGL((k_density_pairs<kFieldClosed, 2>), grid, block, 0, stream, layout, f, p);
+		else if (unreduced) hipLaunchKernelGGL((k_density_bricks<true, kFieldClosed>), grid, block, 0, stream, layout, f, p);
 		else hipLaunchKernelGGL((k_density_bricks<false, kFieldClosed>), grid, block, 0, stream, layout, f, p);
 	}
 	return hipGetLastError();

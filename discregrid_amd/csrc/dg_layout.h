@@ -90,6 +90,28 @@ inline void finish_bricks(SampleParams& P)
 	finish_blocks(P);
 }
 
+// K3's two-nodes-per-lane form: the edge classes are cut into double bricks of 8 x 4 x 4 nodes along a (the axis their
+// two nodes per cell edge run along); the vertex class keeps its 4 x 4 x 4 bricks.  Call after layout_range().
+inline void pair_bricks(SampleParams& P)
+{
+	uint64_t prefix = 0;
+	for (int c = 0; c < 4; ++c)
+	{
+		ClassDesc& C = P.cls[c];
+		if (c != 0)
+			C.nb0 = (C.nb0 + 1) / 2;
+		C.rcp_nb0 = udiv_magic(C.nb0);
+		C.rcp_nb01 = udiv_magic(C.nb0 * C.nb1);
+		C.brick_prefix = prefix;
+		prefix += (uint64_t)C.nb0 * C.nb1 * C.nbq;
+	}
+	P.total_bricks = prefix;
+	P.n_blocks = (uint32_t)((prefix + kWavesPerBlock - 1) / kWavesPerBlock);
+	P.pair_nodes = 1;
+	P.xcd_chunk = 0;
+	finish_blocks(P);
+}
+
 inline void init_params(SampleParams& P, const MeshDev& mesh, const double dmin[3], const double cell[3], int invert)
 {
 	std::memset(&P, 0, sizeof(P));
@@ -236,6 +258,7 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 			P.kmask[i * 16 + j] = (uint16_t)m;
 		}
 	P.skip_mode = 0;
+	P.lds_waves = 0;
 	P.unsafe = nullptr;
 }
 // may the zero-weight points be skipped for this coefficient? (host mirror of k_field_check)

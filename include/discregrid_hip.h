@@ -238,14 +238,21 @@ dg_status dg_field_set_immutable(dg_field* field, int immutable);
  * piece by piece from a worker thread), consumers on the device start when the last kernel ends, and
  * dg_field_host_wait() blocks until host_out is complete (dg_field_destroy waits too).  host_out must stay
  * allocated until then and is scratch from the moment of the call.  pred_mask (host, nullable, one byte per node)
- * works as in dg_sdf_sample_nodes.  */
+ * works as in dg_sdf_sample_nodes.  host_first chooses what finishes first [MI355X, 256^3]: != 0: the lattice is
+ * sampled in seven chunks whose copies run under the following chunks -- the host array is complete after 22 ms,
+ * consumers on the device start after 18.8 ms; 0: ONE launch -- consumers on the device start after 15 ms (the
+ * kernel's own time), the copy follows and completes after 32 ms. */
 dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
-							  double* host_out, dg_field** out);
+							  double* host_out, int host_first, dg_field** out);
 /* K3 over the whole lattice of `sdf` into a NEW device-resident field on the same grid (the density map the
  * reference's GenerateDensityMap adds as field 1, cmd/generate_density_map/main.cpp:83-133); arguments as
  * dg_density_map_nodes, host_out / asynchrony as dg_sdf_sample_field. */
 dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 							   const uint8_t* pred_mask, double* host_out, dg_field** out);
+/* The coefficient arrays of destroyed produced fields are kept for the next field of the same size (a 1 GB
+ * hipMalloc costs ~3 ms), up to DG_FIELD_CACHE_MB megabytes per process (default 2048, 0 = keep nothing);
+ * this releases them now. */
+void dg_field_cache_trim(void);
 /* Blocks until the host copy a producing call started is complete (DG_OK at once if there is none or it was
  * collected before); returns the status of that copy. */
 dg_status dg_field_host_wait(dg_field* field);

@@ -313,7 +313,7 @@ def test_flow_device_resident_fields_reproduce_the_reference_files(tmp_path, gol
     np.testing.assert_array_equal(got[1 + n:1 + 2 * n], T.oracle_interpolate(dom, [16, 16, 6], golden["torus16_density_h01"], P))
 
 
-@pytest.mark.parametrize("res,host_memory", [([9, 7, 8], "fresh"), ([160, 150, 140], "fresh"), ([160, 150, 140], "resident"),
+@pytest.mark.parametrize("res,host_memory", [([9, 7, 8], "fresh"), ([160, 150, 140], "fresh"), ([161, 150, 140], "fresh"), ([160, 150, 140], "resident"),
                                              ([112, 96, 120], "pinned"), ([112, 96, 120], "none")])
 def test_sample_field_is_device_resident_and_fills_the_host_array(res, host_memory):
     """dg_sdf_sample_field: K1 into a device array the new field handle owns; the host array is filled by a
@@ -337,7 +337,7 @@ def test_sample_field_is_device_resident_and_fills_the_host_array(res, host_memo
         host = pin.numpy()
     else:
         host = None
-    fld = mesh.sample_field(grid, host_out=host)
+    fld = mesh.sample_field(grid, host_out=host, host_first=(host_memory != "fresh" or res[0] != 160))
     info = fld.info()
     assert info["owns_coefficients"] == 1 and info["n_coeffs"] == n and info["device_bytes"] >= 8 * n
     # device consumers need no host data
