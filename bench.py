@@ -372,6 +372,10 @@ def main():
                     help="N > 1: issue the all-gather in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
                     help="run the N > 1 protocol (communicator, shards, all-gather, unpack) even at N = 1 (self-test)")
+    ap.add_argument("--exchange", choices=["slabs", "inplace", "inplace-p2p", "to-root"], default="slabs",
+                    help="N > 1: slabs = interleaved 4-plane slabs, packed buffers, all-gather, unpack (default); inplace = contiguous "
+                         "chunks cut by measured cost, sampled into place and exchanged with grouped broadcasts (no unpack pass, no "
+                         "scratch); inplace-p2p: the same with send / recv pairs; to-root: only rank 0 gets the whole field")
     ap.add_argument("--python-gather", action="store_true",
                     help="N > 1: drive the pieces from here with torch.distributed's all_gather instead of the library's "
                          "dg_sdf_sample_allgather_device (A/B, and the one-GPU self-test)")
@@ -418,6 +422,7 @@ def main():
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
     comm = None
     pieces = 1
+    inplace = sharded and args.exchange != "slabs"
     if sharded:
         pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
         vworld = pieces * world
@@ -455,7 +460,7 @@ def main():
             if int(failed.item()) != 0:
                 comm = None
                 comm_note = "library communicator unavailable (%s)" % (comm_note or "on another rank")
-        if comm is None:
+        if comm is None and not inplace:
             # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
             # 4-plane slabs; `gathered` is exactly the buffer a single all-gather among pieces*world ranks
             # would produce and the unpack kernel is unchanged
@@ -466,12 +471,67 @@ def main():
         launch_nodes = n_nodes
         comm_note = None
 
+    plane_cost = [None]            # inplace: relative cost per plane of every class (None: uniform), refined from measured times
+    ex_flags = 0
+    if inplace:
+        ex_flags = dg.EXCHANGE_INPLACE | (dg.EXCHANGE_P2P if args.exchange == "inplace-p2p" else 0) | \
+            (dg.EXCHANGE_TO_ROOT if args.exchange == "to-root" else 0)
+        cg_D = [(res[0] + 1, res[1] + 1, res[2] + 1), (2 * res[0], res[1] + 1, res[2] + 1), (2 * res[1], res[2] + 1, res[0] + 1),
+                (2 * res[2], res[0] + 1, res[1] + 1)]      # class dims (fastest, middle, slowest = k, k, i, j)
+        cg_off = np.concatenate([[0], np.cumsum([int(np.prod(d)) for d in cg_D])])
+
+    def rebalance(piece_ms):
+        """piece_ms[r][p]: sampling time of piece p on rank r -> plane costs: every plane of the chunks of virtual rank
+        v = p * world + r gets (time of that launch / its nodes) x (nodes of the plane)."""
+        cuts = dg.chunk_layout(grid, vworld, plane_cost[0])
+        cost = [np.zeros(d[2], dtype=np.float32) for d in cg_D]
+        for r in range(world):
+            for p in range(pieces):
+                v = p * world + r
+                nodes = sum(int(cuts[c][v + 1] - cuts[c][v]) * cg_D[c][0] * cg_D[c][1] for c in range(4))
+                if nodes == 0:
+                    continue
+                per_node = piece_ms[r][p] / nodes
+                for c in range(4):
+                    cost[c][cuts[c][v]:cuts[c][v + 1]] = per_node * cg_D[c][0] * cg_D[c][1]
+        plane_cost[0] = cost
+
+    def python_inplace_step():
+        """the in-place exchange driven from here (one-GPU self-test over gloo, A/B): same chunks, same kernels"""
+        cuts = dg.chunk_layout(grid, vworld, plane_cost[0])
+        times = []
+        for p in range(pieces):
+            v = p * world + rank
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dg.sample_planes_device(mesh, grid, cuts[:, v], cuts[:, v + 1], field.data_ptr(), stream=s)
+            e1.record(stream)
+            times.append((e0, e1))
+            for o in range(world):
+                vo = p * world + o
+                for c in range(4):
+                    a = int(cg_off[c]) + int(cuts[c][vo]) * cg_D[c][0] * cg_D[c][1]
+                    b = int(cg_off[c]) + int(cuts[c][vo + 1]) * cg_D[c][0] * cg_D[c][1]
+                    if b > a and (args.exchange != "to-root" or True):
+                        dist.broadcast(field[a:b], src=o)
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in times]
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record(stream)
-        if sharded and comm is not None:
+        if inplace and comm is not None:
+            comm.sample_exchange_device(mesh, grid, field.data_ptr(), pieces=pieces, flags=ex_flags, root=0, plane_cost=plane_cost[0],
+                                        stream=s)
+            if i is not None:
+                ev[i][1].record(stream)
+        elif inplace:
+            python_inplace_step()
+            if i is not None:
+                ev[i][1].record(stream)
+        elif sharded and comm is not None:
             comm.sample_allgather_device(mesh, grid, field.data_ptr(), pieces=pieces, stream=s)
             if i is not None:
                 ev[i][1].record(stream)    # the call makes `stream` wait for the last unpack
@@ -494,8 +554,16 @@ def main():
             if i is not None:
                 ev[i][1].record(stream)
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
         step()
+        if inplace and world > 1:
+            # cost-weighted cuts: every rank's sampling times of the step just run, shared, turned into plane costs
+            torch.cuda.synchronize()
+            ms = comm.last_chunk_ms(pieces) if comm is not None else python_inplace_step()
+            mine_ms = torch.tensor(ms, dtype=torch.float32, device="cuda")
+            all_ms = [torch.empty_like(mine_ms) for _ in range(world)]
+            dist.all_gather(all_ms, mine_ms)
+            rebalance([t.cpu().tolist() for t in all_ms])
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -521,7 +589,8 @@ def main():
         ref = torch.empty_like(field)
         mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
         torch.cuda.synchronize()
-        assert torch.equal(ref, field), "shard + all_gather + unpack differs from the direct launch"
+        if args.exchange != "to-root" or rank == 0 or comm is None:
+            assert torch.equal(ref, field), "the sharded protocol's field differs from the direct launch"
 
     if rank == 0:
         balg = load_balg()
@@ -540,9 +609,12 @@ def main():
                             % ("x".join(map(str, res)), n_nodes),
                 "nodes_per_gpu_launch": launch_nodes,
                 "sharding": "none" if not sharded else
-                            "4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
-                            % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
-                               else "dg_sdf_sample_allgather_device (RCCL inside the library)"),
+                            ("4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
+                             % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
+                                else "dg_sdf_sample_allgather_device (RCCL inside the library)")) if not inplace else
+                            ("contiguous chunks cut by measured cost, sampled in place, %s in %d piece(s) by %s"
+                             % (args.exchange, pieces, "torch.distributed broadcasts (python)" if comm is None
+                                else "dg_sdf_sample_exchange_device (RCCL inside the library)")),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {

@@ -89,6 +89,11 @@ SYMBOLS = {
     "dg_comm_destroy": (None, [C.c_void_p]),
     "dg_sdf_sample_allgather_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p]),
+    "dg_chunk_layout": (C.c_int, [C.POINTER(GridDesc), C.c_int, C.c_void_p, _u32p]),
+    "dg_sdf_sample_planes_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, _u32p, _u32p, C.c_void_p, C.c_void_p]),
+    "dg_sdf_sample_exchange_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dg_comm_last_chunk_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
                                   C.POINTER(C.c_void_p)]),
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -310,6 +315,33 @@ def sample_nodes_multi(meshes, grid, begin=0, end=None, invert=False, mask=None)
     return out
 
 
+EXCHANGE_INPLACE, EXCHANGE_P2P, EXCHANGE_TO_ROOT = 1, 2, 4
+
+
+def _plane_cost_arg(plane_cost):
+    """four float32 arrays (one per class, nullable entries) -> (const float* const[4], keep-alive list)"""
+    if plane_cost is None:
+        return None, []
+    keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in plane_cost]
+    arr = (C.c_void_p * 4)(*[None if a is None else a.ctypes.data for a in keep])
+    return arr, keep
+
+
+def chunk_layout(grid, nchunks, plane_cost=None):
+    """dg_chunk_layout: cuts[4][nchunks + 1], first plane of every contiguous chunk of every class."""
+    arr, keep = _plane_cost_arg(plane_cost)
+    cuts = np.empty((4, nchunks + 1), dtype=np.uint32)
+    _check(load_library().dg_chunk_layout(C.byref(grid), nchunks, arr, cuts.ctypes.data_as(_u32p)))
+    return cuts
+
+
+def sample_planes_device(mesh, grid, plane_begin, plane_end, d_field, invert=False, stream=0):
+    b = np.ascontiguousarray(plane_begin, dtype=np.uint32)
+    e = np.ascontiguousarray(plane_end, dtype=np.uint32)
+    _check(load_library().dg_sdf_sample_planes_device(mesh.handle, C.byref(grid), int(invert), b.ctypes.data_as(_u32p),
+                                                      e.ctypes.data_as(_u32p), C.c_void_p(d_field), C.c_void_p(stream)))
+
+
 def unpack_shards_device(grid, nranks, d_gathered, stride, d_field, stream=0):
     _check(load_library().dg_unpack_shards_device(C.byref(grid), nranks, C.c_void_p(d_gathered), stride,
                                                   C.c_void_p(d_field), C.c_void_p(stream)))
@@ -367,6 +399,18 @@ class Comm:
             self.handle = None
 
     __del__ = close
+
+    def sample_exchange_device(self, mesh, grid, d_field, pieces=4, flags=EXCHANGE_INPLACE, root=0, plane_cost=None, invert=False,
+                               stream=0):
+        arr, keep = _plane_cost_arg(plane_cost)
+        _check(self._lib.dg_sdf_sample_exchange_device(mesh.handle, C.byref(grid), int(invert), self.handle, pieces, flags, root,
+                                                       arr, C.c_void_p(d_field), C.c_void_p(stream)))
+
+    def last_chunk_ms(self, pieces=64):
+        ms = (C.c_float * pieces)()
+        n = C.c_int(pieces)
+        _check(self._lib.dg_comm_last_chunk_ms(self.handle, ms, C.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
 
     def sample_allgather_device(self, mesh, grid, d_field, pieces=4, invert=False, stream=0):
         _check(self._lib.dg_sdf_sample_allgather_device(mesh.handle, C.byref(grid), int(invert), self.handle, pieces,

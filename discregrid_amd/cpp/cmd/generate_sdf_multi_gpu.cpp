@@ -12,6 +12,12 @@
 // time of the K steps (the figure bench.py reports for N GPUs).
 #include <Discregrid/All>
 
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <hip/hip_runtime_api.h>
 
 #include <sys/wait.h>
@@ -41,6 +47,7 @@ struct Options
 	Eigen::AlignedBox3d domain;
 	bool invert = false;
 	int gpus = 1, pieces = 4, steps = 1;
+	int exchange = 0; // flags of dg_sdf_sample_exchange_device (--inplace, --p2p)
 	std::string output, input;
 };
 
@@ -99,8 +106,8 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 	{
 		check(rank, dg_comm_unique_id(id), "dg_comm_unique_id");
 		const std::string tmp = id_file + ".tmp";
-		std::ofstream(tmp, std::ios::binary).write(reinterpret_cast<const char*>(id), sizeof(id));
-		if (std::rename(tmp.c_str(), id_file.c_str()) != 0)
+		const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600); // (never through a file somebody else made)
+		if (fd < 0 || write(fd, id, sizeof(id)) != (ssize_t)sizeof(id) || close(fd) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
 			die(rank, "cannot publish the communicator id");
 	}
 	else
@@ -126,14 +133,14 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 	const dg_mesh* dmesh = static_cast<const dg_mesh*>(md.deviceMesh());
 
 	// one untimed step (first-use allocations, RCCL channel set-up), then the timed ones
-	check(rank, dg_sdf_sample_allgather_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, d_field, stream), "sample + all-gather");
+	check(rank, dg_sdf_sample_exchange_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, opt.exchange, 0, nullptr, d_field, stream), "sample + exchange");
 	check_hip(rank, hipStreamSynchronize(stream), "synchronize");
 	double seconds = 0.0;
 	if (opt.steps > 1 || !time_file.empty())
 	{
 		const double t0 = now();
 		for (int k = 0; k < opt.steps; ++k)
-			check(rank, dg_sdf_sample_allgather_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, d_field, stream), "sample + all-gather");
+			check(rank, dg_sdf_sample_exchange_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, opt.exchange, 0, nullptr, d_field, stream), "sample + exchange");
 		check_hip(rank, hipStreamSynchronize(stream), "synchronize");
 		seconds = now() - t0;
 	}
@@ -173,7 +180,7 @@ int main(int argc, char* argv[])
 		if (a == "-h" || a == "--help")
 		{
 			std::cout << "Usage: " << argv[0]
-					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--steps k] [-o out.cdf] mesh.obj"
+					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p] [--steps k] [-o out.cdf] mesh.obj"
 					  << std::endl;
 			return 0;
 		}
@@ -194,6 +201,10 @@ int main(int argc, char* argv[])
 			opt.gpus = std::atoi(value().c_str());
 		else if (a == "--pieces")
 			opt.pieces = std::atoi(value().c_str());
+		else if (a == "--inplace") // contiguous chunks sampled into place, grouped broadcasts, no unpack
+			opt.exchange |= DG_EXCHANGE_INPLACE;
+		else if (a == "--p2p") // ... exchanged with send / recv pairs instead
+			opt.exchange |= DG_EXCHANGE_INPLACE | DG_EXCHANGE_P2P;
 		else if (a == "--steps")
 		{
 			opt.steps = std::atoi(value().c_str());
@@ -219,7 +230,15 @@ int main(int argc, char* argv[])
 		std::cerr << "ERROR: --gpus must be 1..64, --steps >= 1" << std::endl;
 		return 1;
 	}
-	const std::string base = "/tmp/dg_multi_gpu_" + std::to_string((long)getpid());
+	// rendezvous files live in a directory of our own (mkdtemp: mode 0700, unpredictable name): nobody else can plant
+	// or read the communicator id
+	char dir_template[] = "/tmp/dg_multi_gpu_XXXXXX";
+	if (mkdtemp(dir_template) == nullptr)
+	{
+		std::perror("mkdtemp");
+		return 1;
+	}
+	const std::string base = std::string(dir_template) + "/r";
 	const std::string id_file = base + ".id";
 	std::vector<pid_t> kids;
 	for (int r = 0; r < opt.gpus; ++r)
@@ -234,12 +253,22 @@ int main(int argc, char* argv[])
 			_exit(run_rank(opt, r, id_file, timing ? base + ".t" + std::to_string(r) : std::string()));
 		kids.push_back(pid);
 	}
+	// Wait for the ranks in the order they finish.  A rank that fails leaves the others inside a collective (or the
+	// communicator set-up) that can never complete: they are terminated instead of being waited for.
 	int failed = 0;
-	for (pid_t pid : kids)
+	for (size_t left = kids.size(); left > 0; --left)
 	{
 		int st = 0;
-		waitpid(pid, &st, 0);
-		failed += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+		const pid_t pid = wait(&st);
+		if (pid < 0)
+			break;
+		if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0))
+		{
+			if (failed++ == 0)
+				for (pid_t k : kids)
+					if (k != pid)
+						kill(k, SIGTERM);
+		}
 	}
 	std::remove(id_file.c_str());
 	double slowest = 0.0;
@@ -251,9 +280,10 @@ int main(int argc, char* argv[])
 		slowest = std::max(slowest, s);
 		std::remove(f.c_str());
 	}
+	rmdir(dir_template);
 	if (failed)
 	{
-		std::cerr << "GenerateSDFMultiGPU: " << failed << " rank(s) failed" << std::endl;
+		std::cerr << "GenerateSDFMultiGPU: " << failed << " rank(s) failed or were stopped" << std::endl;
 		return 1;
 	}
 	if (timing)

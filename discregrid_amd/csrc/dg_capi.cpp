@@ -560,6 +560,42 @@ dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* gr
 	return DG_OK;
 }
 
+dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts)
+{
+	if (!grid || !cuts)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	if (nchunks < 1 || nchunks > dg::kMaxRanks)
+		return fail(DG_ERR_INVALID, "nchunks %d out of range (max %d)", nchunks, dg::kMaxRanks);
+	uint32_t c4[4][dg::kMaxRanks + 1];
+	dg::chunk_planes(grid->resolution, nchunks, plane_cost, c4);
+	for (int c = 0; c < 4; ++c)
+		for (int v = 0; v <= nchunks; ++v)
+			cuts[c * (nchunks + 1) + v] = c4[c][v];
+	return DG_OK;
+}
+
+dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint32_t plane_begin[4],
+									  const uint32_t plane_end[4], double* d_field, void* stream)
+{
+	if (!mesh || !grid || !plane_begin || !plane_end || !d_field)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!valid_grid(grid))
+		return fail(DG_ERR_INVALID, "invalid grid");
+	DG_ON_DEVICE_OF(mesh);
+	dg::SampleParams P;
+	dg::init_params(P, mesh->dev, grid->domain_min, grid->cell_size, invert);
+	P.xcd_chunk = env_xcd_chunk();
+	dg::layout_class_planes(P, grid->resolution, plane_begin, plane_end);
+	if (P.total_bricks == 0)
+		return DG_OK;
+	P.mask = nullptr;
+	P.out = d_field;
+	DG_HIP(launch_k1(mesh, P, static_cast<hipStream_t>(stream)));
+	return DG_OK;
+}
+
 dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 								  double* d_field, void* stream)
 {

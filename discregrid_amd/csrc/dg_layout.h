@@ -158,6 +158,63 @@ inline void layout_range(SampleParams& P, const uint32_t res[3], uint64_t node_b
 	finish_bricks(P);
 }
 
+// Contiguous chunks: every class's planes [0, D2) are cut into `nchunks` runs of whole planes, chunk v of class c =
+// planes [cuts[c][v], cuts[c][v + 1]) -- one contiguous run of the coefficient vector per class (the slowest index of
+// each class is k, k, i, j).  The cuts equalise the cumulated plane cost (cost[c][s]: relative cost of plane s of
+// class c; null: every plane costs the same) and fall on multiples of the brick depth where the class has at least
+// one brick layer per chunk.
+inline void chunk_planes(const uint32_t res[3], int nchunks, const float* const cost[4], uint32_t cuts[4][kMaxRanks + 1])
+{
+	ClassGeom cg[4];
+	class_geometry(res, cg);
+	for (int c = 0; c < 4; ++c)
+	{
+		const uint32_t D2 = cg[c].D[2];
+		const uint32_t step = D2 >= (uint32_t)nchunks * (uint32_t)kSlabPlanes ? (uint32_t)kSlabPlanes : 1u;
+		std::vector<double> cum(D2 + 1, 0.0);
+		for (uint32_t sl = 0; sl < D2; ++sl)
+		{
+			const double w = cost && cost[c] ? (double)cost[c][sl] : 1.0;
+			cum[sl + 1] = cum[sl] + (w > 0.0 ? w : 0.0);
+		}
+		if (!(cum[D2] > 0.0))
+			for (uint32_t sl = 0; sl <= D2; ++sl)
+				cum[sl] = (double)sl;
+		cuts[c][0] = 0;
+		for (int v = 1; v < nchunks; ++v)
+		{
+			const double want = cum[D2] * (double)v / (double)nchunks;
+			uint32_t at = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+			at = std::min(D2, (at + step / 2) / step * step);
+			cuts[c][v] = std::max(at, cuts[c][v - 1]);
+		}
+		cuts[c][nchunks] = D2;
+	}
+}
+
+// planes [q_begin[c], q_end[c]) of every class, written to their places in the whole coefficient vector
+inline void layout_class_planes(SampleParams& P, const uint32_t res[3], const uint32_t q_begin[4], const uint32_t q_end[4])
+{
+	ClassGeom cg[4];
+	class_geometry(res, cg);
+	for (int c = 0; c < 4; ++c)
+	{
+		ClassDesc& C = P.cls[c];
+		C.D0 = cg[c].D[0];
+		C.D1 = cg[c].D[1];
+		C.D2 = cg[c].D[2];
+		const uint64_t plane = (uint64_t)C.D0 * C.D1;
+		C.q_begin = std::min(q_begin[c], C.D2);
+		C.q_end = std::max(C.q_begin, std::min(q_end[c], C.D2));
+		C.l_begin = (uint64_t)C.q_begin * plane;
+		C.l_end = (uint64_t)C.q_end * plane;
+		C.out_base = (int64_t)cg[c].off;
+	}
+	P.shard_rank = 0;
+	P.shard_n = 1;
+	finish_bricks(P);
+}
+
 // packed buffer of rank `rank`: [V planes | X planes | Y planes | Z planes] it owns
 inline void layout_shard(SampleParams& P, const uint32_t res[3], int rank, int nranks)
 {

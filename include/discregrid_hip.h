@@ -198,6 +198,31 @@ void dg_comm_destroy(dg_comm* comm);
 dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm,
 										 int pieces, double* d_field, void* stream);
 
+/* The same step with the lattice cut into CONTIGUOUS chunks, exchanged in place (DG_EXCHANGE_INPLACE): every class's
+ * planes are cut into pieces * nranks runs of whole planes (dg_chunk_layout; chunk v belongs to rank v % nranks and to
+ * piece v / nranks), a rank samples its chunks straight into their places in d_field, and the chunks travel with one
+ * grouped set of ncclBroadcast per piece (DG_EXCHANGE_P2P: ncclSend / ncclRecv pairs, every pair of GPUs over its own
+ * xGMI link) -- no packed buffers, no unpack pass over the whole field, no scratch beyond d_field itself.  Interleaved
+ * thin slabs balance the uneven cost per node by construction; contiguous chunks need the cuts to follow the cost:
+ * plane_cost[c] (nullable) holds a relative cost for each plane of class c along its slowest index (k, k, i, j) --
+ * e.g. the times dg_comm_last_chunk_ms() reported for the previous call, spread over the planes of each chunk.
+ * DG_EXCHANGE_TO_ROOT: only rank `root` ends up with the whole field (the others keep their own chunks): every other
+ * GPU then SENDS its 1 / nranks of the field instead of receiving (nranks - 1) / nranks of it.  flags == 0 is
+ * dg_sdf_sample_allgather_device (interleaved slabs, packed buffers, all-gather, unpack).  No reference counterpart. */
+#define DG_EXCHANGE_INPLACE 1
+#define DG_EXCHANGE_P2P 2
+#define DG_EXCHANGE_TO_ROOT 4
+/* cuts[c * (nchunks + 1) + v], v = 0..nchunks: first plane of chunk v of class c (class order V, X, Y, Z); host only */
+dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts);
+/* planes [plane_begin[c], plane_end[c]) of every class, sampled into their places in d_field (the WHOLE vector) */
+dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint32_t plane_begin[4],
+									  const uint32_t plane_end[4], double* d_field, void* stream);
+dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
+										int flags, int root, const float* const plane_cost[4], double* d_field, void* stream);
+/* device time of this rank's sampling launches of the most recent dg_sdf_sample_exchange_device / _allgather_device
+ * call on `comm`, one value per piece (waits for that call); *n_pieces in: capacity of ms, out: pieces */
+dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces);
+
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both
  * be NULL for an unreduced field: the kernel then uses the closed-form node indices the

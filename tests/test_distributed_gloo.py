@@ -107,3 +107,52 @@ def test_shard_balance_at_scale():
         vcounts = [sum(dg.shard_layout(g, p * world + r, pieces * world)[0] for p in range(pieces))
                    for r in range(world)]
         assert vcounts == counts
+
+
+def _inplace_worker(rank, world, port, res, pieces, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import discregrid_amd as dg
+        dg.load_library()
+        V, F = T.torus()
+        dom = T.oracle_default_domain(V)
+        grid = dg.grid_desc(dom[:3], dom[3:], res)
+        om = T.OracleMesh(V, F)
+        D = [(res[0] + 1, res[1] + 1, res[2] + 1), (2 * res[0], res[1] + 1, res[2] + 1), (2 * res[1], res[2] + 1, res[0] + 1),
+             (2 * res[2], res[0] + 1, res[1] + 1)]
+        off = np.concatenate([[0], np.cumsum([int(np.prod(d)) for d in D])])
+        vworld = pieces * world
+        rng = np.random.default_rng(7)      # (the same skewed cost profile on every rank)
+        cost = [rng.uniform(0.5, 4.0, d[2]).astype(np.float32) for d in D]
+        cuts = dg.chunk_layout(grid, vworld, cost)
+        field = torch.full((int(off[4]),), float("nan"), dtype=torch.float64)
+        mine = 0
+        for p in range(pieces):
+            v = p * world + rank
+            for c in range(4):          # this rank's chunks, sampled straight into their places (CPU oracle here)
+                a, b = int(off[c]) + int(cuts[c][v]) * D[c][0] * D[c][1], int(off[c]) + int(cuts[c][v + 1]) * D[c][0] * D[c][1]
+                if b > a:
+                    field[a:b] = torch.from_numpy(om.sample_nodes(dom, res, a, b))
+                    mine += b - a
+            for o in range(world):      # dg_sdf_sample_exchange_device's grouped broadcasts, in place
+                vo = p * world + o
+                for c in range(4):
+                    a, b = int(off[c]) + int(cuts[c][vo]) * D[c][0] * D[c][1], int(off[c]) + int(cuts[c][vo + 1]) * D[c][0] * D[c][1]
+                    if b > a:
+                        dist.broadcast(field[a:b], src=o)
+        ret[rank] = (bool(np.array_equal(field.numpy(), om.sample_nodes(dom, res))), mine)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,res,pieces", [(2, [10, 7, 13], 2), (3, [6, 9, 5], 1)])
+def test_inplace_chunks_broadcast_gloo(world, res, pieces):
+    """The in-place exchange (contiguous cost-weighted chunks of dg_chunk_layout, broadcast into place, no unpack) with
+    world_size 2 and 3 over gloo: every rank ends with the whole field, every node is sampled exactly once."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_inplace_worker, args=(world, _free_port(), res, pieces, ret), nprocs=world, join=True)
+    assert len(ret) == world and all(v[0] for v in ret.values())
+    assert sum(v[1] for v in ret.values()) == T.n_nodes(res)

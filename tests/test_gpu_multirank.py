@@ -62,12 +62,13 @@ def test_cpp_multi_gpu_tool_one_rank(tmp_path):
     subprocess.check_call([os.path.join(build, "GenerateSDF"), "-r", "24 20 22", "-o", ref, obj], stdout=subprocess.DEVNULL)
     dg.load_library()
     for gpus in sorted({1, min(dg.device_count(), 8)}):
-        out = str(tmp_path / ("multi%d.cdf" % gpus))
-        txt = subprocess.check_output([os.path.join(build, "GenerateSDFMultiGPU"), "-g", str(gpus), "-r", "24 20 22", "--steps", "3",
-                                       "--pieces", "2", "-o", out, obj], timeout=600).decode()
-        rec = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
-        assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["nodes"] == T.n_nodes([24, 20, 22])
-        assert open(out, "rb").read() == open(ref, "rb").read()
+        for extra in ([], ["--inplace"], ["--p2p"]):      # interleaved slabs + unpack / contiguous chunks exchanged in place
+            out = str(tmp_path / ("multi%d%s.cdf" % (gpus, "".join(extra))))
+            txt = subprocess.check_output([os.path.join(build, "GenerateSDFMultiGPU"), "-g", str(gpus), "-r", "24 20 22", "--steps", "3",
+                                           "--pieces", "2", "-o", out, obj] + extra, timeout=600).decode()
+            rec = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+            assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["nodes"] == T.n_nodes([24, 20, 22])
+            assert open(out, "rb").read() == open(ref, "rb").read()
 
 
 @pytest.mark.parametrize("world,pieces", [(2, 4), (4, 2)])
@@ -82,3 +83,79 @@ def test_sharded_protocol_with_several_ranks_on_one_gpu(world, pieces):
     rec = json.loads(line)
     assert rec["n_gpus"] == world and rec["scaling"] == "weak" and rec["value"] > 0
     assert "pipelined in %d piece" % pieces in rec["config"]["sharding"]
+
+
+@pytest.mark.parametrize("exchange", ["inplace", "inplace-p2p", "to-root"])
+def test_library_inplace_exchange_one_rank(exchange):
+    """dg_sdf_sample_exchange_device (contiguous chunks cut by dg_chunk_layout, sampled straight into the field,
+    grouped ncclBroadcast / ncclSend + ncclRecv, no unpack) through the library's own RCCL communicator with a world
+    of one rank; bench.py asserts field == direct launch, bit for bit."""
+    cmd = [sys.executable, os.path.join(T.ROOT, "bench.py"), "--force-shard-path", "--steps", "2", "--warmup", "1",
+           "--no-extras", "--pieces", "4", "--exchange", exchange]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "dg_sdf_sample_exchange_device" in rec["config"]["sharding"] and exchange in rec["config"]["sharding"] and rec["value"] > 0
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 4), (4, 2)])
+def test_inplace_exchange_with_several_ranks_on_one_gpu(world, pieces):
+    """The in-place protocol with real kernels and several ranks sharing the one GPU (broadcasts through gloo):
+    chunks of dg_chunk_layout, re-cut after the warm-up step from the measured sampling times of every rank
+    (cost-weighted cuts), sampled into place by dg_sdf_sample_planes_device; every rank asserts field == direct launch."""
+    env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(T.ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "2",
+           "--pieces", str(pieces), "--exchange", "inplace"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == world and "contiguous chunks" in rec["config"]["sharding"]
+
+
+def test_sample_planes_and_chunk_layout():
+    """dg_chunk_layout + dg_sdf_sample_planes_device: the chunks of a 6-way cut (uniform and with a skewed cost
+    profile), sampled one by one into one array, give the direct launch's field; cuts are monotone, cover every plane,
+    sit on brick layers, and follow the cost."""
+    import numpy as np
+    import torch
+    import discregrid_amd as dg
+    dg.load_library()
+    V, F = T.torus()
+    dom = T.oracle_default_domain(V)
+    res = [30, 41, 52]
+    grid = dg.grid_desc(dom[:3], dom[3:], res)
+    n = dg.n_nodes(grid)
+    mesh = dg.Mesh(V, F)
+    want = mesh.sample_nodes(grid)
+    D2 = [res[2] + 1, res[2] + 1, res[0] + 1, res[1] + 1]
+    cost = [np.linspace(1.0, 9.0, d).astype(np.float32) for d in D2]
+    for pc in (None, cost):
+        cuts = dg.chunk_layout(grid, 6, pc)
+        assert (cuts[:, 0] == 0).all() and list(cuts[:, -1]) == D2 and (np.diff(cuts.astype(np.int64), axis=1) >= 0).all()
+        assert (cuts[:, 1:-1] % 4 == 0).all()
+        if pc is not None:      # the expensive end gets fewer planes
+            assert (np.diff(cuts.astype(np.int64), axis=1)[:, 0] > np.diff(cuts.astype(np.int64), axis=1)[:, -1]).all()
+        field = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        for v in range(6):
+            dg.sample_planes_device(mesh, grid, cuts[:, v], cuts[:, v + 1], field.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(field.cpu().numpy(), want)
+
+
+def test_comm_create_gives_up_when_a_rank_never_arrives():
+    """Communicator set-up is a collective; with a rank missing it can never complete.  dg_comm_create must fail
+    after DG_COMM_TIMEOUT_S seconds instead of blocking forever (run in a child process, which leaves at once: the
+    helper thread that sits in ncclCommInitRank cannot be recalled)."""
+    code = ("import os, sys, time; sys.path.insert(0, %r); import discregrid_amd as dg; dg.load_library(); dg.set_device(0)\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    dg.Comm(dg.Comm.unique_id(), 0, 2)\n"
+            "    print('NO ERROR')\n"
+            "except dg.DiscregridError as e:\n"
+            "    print('FAILED AFTER %%.1f s: %%s' %% (time.time() - t0, e))\n"
+            "sys.stdout.flush(); os._exit(0)\n") % T.ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, DG_COMM_TIMEOUT_S="4"))
+    assert "FAILED AFTER" in out.stdout and "did not complete within 4 s" in out.stdout, out.stdout + out.stderr[-2000:]
