@@ -471,16 +471,32 @@ DG_HD float best_as_float(double d2)
 // Hence |dist_float - dist| <= sqrt(29^2 + 11^2) eps R < E := 2^-19 R, and in squares
 //   dist^2 in [q - err(q), q + err(q)],  err(q) >= 2 sqrt(q) E + 5 E^2 + 2^-18 q   (approx_err_terms).
 //
-// What has to lie in that interval is the DOUBLE value the reference computes (the minimum is taken over
-// those), not the true distance.  For a well-shaped triangle the two differ by ~1e-15 |p - v0|^2 <= 4e-15 R^2,
-// far below the 1.8e-14 R^2 of slack in 5 E^2 x 1.001.  For a sliver they do not: the reference solves
-// the 2x2 system with det = a00 a11 - a01^2, whose cancellation leaves (s, t) with an error of
-// ~1e-16 (l^2 / area)^2 and the value with l^2 times its square -- 3e-9 instead of 5e-15 was seen for
-// area / l^2 = 5e-7.  Triangles with area below 1e-4 of the longest side squared (reference error
-// <= 1e-16 l^2), with a zero-length side or with non-finite data are therefore DEGENERATE for the filter
-// (valid = 2): a wave that meets one gives all its lanes the exact traversal.
-// tests/test_emu.py::test_float_filter_interval_contains_the_double_value checks the interval on 36 M
-// random and adversarial (triangle, point) pairs: no violation, largest |q - d2| / err = 0.14.
+// What has to lie in that interval is the DOUBLE value the reference computes (the minimum is taken over those), not
+// the true distance, so the reference's own rounding error must fit into the slack of err(q) (5 E^2 = 1.8e-11 R^2, of
+// which the float side uses a small part).  Bound, with u = 2^-53, D = |p - v0|, l the longest side, rho = area2 / l^2
+// the shape ratio (area2 = |e0 x e1|):
+//   * the reference evaluates Q(s, t) = |v0 - p + s e0 + t e1|^2 = a00 s^2 + 2 a01 s t + a11 t^2 + 2 b0 s + 2 b1 t + c
+//     at the (s, t) it computed; the dozen roundings of that evaluation (and of a00 .. c) each cost at most u times
+//     the sum of the absolute terms, (D + 2 l)^2: a first-order term c1 u (D + l)^2, c1 <= 16;
+//   * the computed (s, t) is not the minimiser.  On the sides and at the corners the parameter comes from a
+//     one-dimensional, well-conditioned quotient (-b / a); in the interior from the 2x2 system with det = a00 a11 -
+//     a01^2 = rho^2 l^4, whose cancellation leaves |ds|, |dt| <= 2 u D l^3 / det = 2 u D / (rho^2 l).  Q is a convex
+//     quadratic whose gradient vanishes at an interior minimiser, so the value rises by |ds e0 + dt e1|^2 <=
+//     (4 u D / rho^2)^2 only: a second-order term c2 u^2 (D + l)^2 / rho^4, c2 <= 16.  A point that changes region
+//     because of (ds, dt) is evaluated at a feasible point within (ds, dt) of the minimiser: the same bound.
+// |d2_reference - d2_true| <= (c1 u + c2 u^2 / rho^4) (D + l)^2, D + l <= 3 R.  Measured (tests/perf/filter_campaign.py
+// -> profiles/r03_filter_campaign.json, seeded, 80-bit reference values): c1 = 3.8, c2 = 0.54; the error is
+// 4.2e-16 (D + l)^2 for every rho >= 1e-4 and climbs as rho^-4 below (1.6e-13 at 1e-5, 1.7e-9 at 1e-6, 2.4e-6 at 1e-7).
+// With the proven constants the slack is used up at rho = 1.7e-5 (16 u^2 9 R^2 / rho^4 = 1.8e-11 R^2).  Triangles with
+// area2 below 1e-4 of the longest side squared -- a factor 6 in rho, 1300 in the error term, above that point --, with
+// a zero-length side or with non-finite data are therefore DEGENERATE for the filter (valid = 2): a wave that meets
+// one gives all its lanes the exact traversal.  At rho >= 1e-4 the bound is 16 u (1 + 1e-16) 9 R^2 = 1.6e-14 R^2,
+// 1100 times below the slack (measured: 4.0e-17 R^2).  The first version of the threshold, 1e-7, was caught by
+// tests/test_emu.py::test_float_filter_interval_contains_the_double_value with 36 violations.  The campaign checks
+// the interval on 33.5 M seeded pairs -- random and adversarial, half of them slivers within two decades of the
+// threshold with points 1e-6 .. 1 side lengths off the plane and beyond the sharp corners --: no violation, largest
+// |q - d2| / err = 0.14; tests/test_gpu_edge_cases.py::test_sliver_band_around_the_filter_threshold runs the band
+// through both kernels on the GPU.
 struct alignas(64) TriApproxPair
 {
 	// [k][side]: 0..2 v0 - origin; 3..5 u; 6..8 w; 9..11 n; 12 l0; 13 xlo; 14,15 direction of side B->C;

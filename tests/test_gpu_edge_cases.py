@@ -119,3 +119,36 @@ def test_maximum_lattice_512_cubed(dg):
     mine = field != 0.0          # nodes of the other ranks were gathered as 0
     assert abs(int(mine.sum().item()) - cnt) <= 64  # (a handful of rank-3 nodes may be exactly 0)
     assert torch.equal(field[mine], out[mine])
+
+
+def test_sliver_band_around_the_filter_threshold(dg, monkeypatch):
+    """A triangle soup of slivers whose shape ratio area2 / lmax^2 is swept over 1e-6 .. 1e-2 -- both sides of the
+    float filter's 1e-4 threshold (dg_geom.h: below it a triangle is degenerate for the filter and its wave runs the
+    exact traversal) --, acute and obtuse, with points 1e-6 .. 1 side lengths off the planes, over the sharp corners
+    and beyond them: the filtered kernel, the exact kernel and the oracle must agree bit for bit, through the point
+    entry (K1p, binned and not) and on a lattice (K1).  (The k1_variant fixture runs this with either kernel forced;
+    the test itself forces both once more so that one run compares them directly.)"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(T.ROOT, "tests", "perf"))
+    import filter_campaign as fc
+    rng = np.random.default_rng(99)
+    tri = np.concatenate([fc.sliver_band(rng, 3000, lo, hi, 1.0) for lo, hi in ((1e-6, 1e-4), (1e-4, 3e-4), (3e-4, 1e-2))])
+    rho, _ = fc.shape_ratio(tri)
+    assert (rho < 1e-4).sum() > 2000 and ((rho > 1e-4) & (rho < 1e-3)).sum() > 2000
+    V = tri.reshape(-1, 3)
+    F = np.arange(len(V), dtype=np.uint32).reshape(-1, 3)
+    P = np.concatenate([fc.adversarial_points(rng, tri, 60000), rng.uniform(-1.5, 1.5, size=(20000, 3))])
+    want = np.abs(T.OracleMesh(V, F).signed_distance(P))
+    got = {}
+    for fast in ("0", "1"):
+        monkeypatch.setenv("DG_K1_FAST", fast)
+        m = dg.Mesh(V, F)
+        for binning in ("1", "0"):
+            monkeypatch.setenv("DG_K1P_BINNING", binning)
+            d = np.abs(m.signed_distance(P))     # (a soup has no inside: only the magnitude is defined by the reference)
+            np.testing.assert_array_equal(d, want)
+        dom = np.array([-1.2, -1.2, -1.2, 1.2, 1.2, 1.2])
+        got[fast] = m.sample_nodes(dg.grid_desc(dom[:3], dom[3:], [24, 20, 28]))
+    np.testing.assert_array_equal(got["0"], got["1"])
+    np.testing.assert_array_equal(np.abs(got["1"]), np.abs(T.OracleMesh(V, F).sample_nodes(np.array([-1.2, -1.2, -1.2, 1.2, 1.2, 1.2]), [24, 20, 28])))
