@@ -293,9 +293,15 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "interpolations in the reference's count" % n_nodes}
     counters, _ = load_counters()
     k3c = ((counters or {}).get("workloads", {}).get("k3") or {})
-    k3k = next((v for k, v in k3c.items() if k.startswith("k_density_bricks")), None)
+    k3k = next((v for k, v in k3c.items() if k.startswith("k_density_pairs")), None) or \
+        next((v for k, v in k3c.items() if k.startswith("k_density_bricks")), None)
     out_secondary["k3_density_map"]["roofline"] = None if k3k is None else {
-        "bound": "vector memory pipeline (L1 / TA gathers: 256 B of coefficients per lane and quadrature point) + f64 VALU",
+        "bound": "vector memory pipeline (texture address / data units: every lane gathers the 256 B of its cell at each quadrature point) "
+                 "+ f64 VALU, latency-bound at 2-3 waves per SIMD",
+        "achieved": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]), "peak": 1.0,
+        "unit": "busy fraction of the busiest unit (TA / TD / VALU)",
+        "frac": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]),
+        "ta_busy": k3k.get("ta_busy"), "td_busy": k3k.get("td_busy"),
         "valu_busy": k3k["valu_busy"], "hbm_frac": k3k["hbm_frac"], "l2_hit_rate": k3k["l2_hit_rate"],
         "valu_per_wave": k3k["per_wave"]["valu"], "kernel_ms_when_profiled": k3k["kernel_ms"], "replayed": True,
         "vgprs": k3k.get("vgprs"), "waves_per_simd": k3k.get("waves_per_simd")}

@@ -20,7 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ["k_sample_fast", "k_sample_nodes", "k_heavy_subtrees", "k_expand_tiles", "k_heavy_finish", "k_interpolate_binned", "k_interpolate_rows", "k_interpolate", "k_bin_probe",
-           "k_bin_keys", "k_density_bricks", "k_field_check", "k_unpack_shards", "k_unpack_ranks", "k_expand_cells"]
+           "k_bin_keys", "k_density_pairs", "k_density_bricks_lds", "k_density_bricks", "k_tile_flags", "k_field_check", "k_unpack_shards", "k_unpack_ranks", "k_expand_cells"]
 
 
 def short(name):
@@ -88,10 +88,12 @@ def main():
             if s:
                 dur[s] = (avg, calls)
         seen = set()
+        regs = {}
         for r in disp:
             s = short(r[0])
             if s and s not in seen:
                 seen.add(s)
+                regs[s] = int(r[4])
                 stats_lines.append("#   %-40s grid=%d wg=%d vgpr=%d sgpr=%d lds=%d scratch=%d" % ((s,) + tuple(r[2:])))
         stats_lines.append("")
         allc = {}
@@ -133,6 +135,17 @@ def main():
                     e["per_wave"]["valu_f32"] = f32 / wv
                 if "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"] > 0:
                     e["wait_inst_any_frac"] = cs.get("SQ_WAIT_INST_ANY", 0.0) / cs["SQ_WAVE_CYCLES"]
+            if "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"] > 0:
+                cyc = cs["GRBM_GUI_ACTIVE"] / 8.0
+                if "TA_TA_BUSY_sum" in cs:   # 256 texture-address / texture-data units, one per CU
+                    e["ta_busy"] = cs["TA_TA_BUSY_sum"] / (256.0 * cyc)
+                if "TD_TD_BUSY_sum" in cs:
+                    e["td_busy"] = cs["TD_TD_BUSY_sum"] / (256.0 * cyc)
+                if "TA_FLAT_READ_WAVEFRONTS_sum" in cs and cs["TA_FLAT_READ_WAVEFRONTS_sum"] > 0 and "TD_TD_BUSY_sum" in cs:
+                    e["td_cycles_per_load_instruction"] = cs["TD_TD_BUSY_sum"] / cs["TA_FLAT_READ_WAVEFRONTS_sum"]
+            if k in regs and regs[k] > 0:
+                e["vgprs"] = regs[k]
+                e["waves_per_simd"] = min(8, 512 // ((regs[k] + 7) // 8 * 8))
             derived.setdefault(w, {})[k] = e
     k1 = None
     if "k1" in derived:
@@ -162,6 +175,8 @@ def main():
                 parts.append("L2 hit %.3f" % e["l2_hit_rate"])
             if "valu_busy" in e:
                 parts.append("VALU busy %.3f" % e["valu_busy"])
+            if "ta_busy" in e:
+                parts.append("TA busy %.3f, TD busy %.3f" % (e["ta_busy"], e.get("td_busy", float("nan"))))
             if "per_wave" in e and "valu" in e["per_wave"]:
                 parts.append("VALU/wave %.0f" % e["per_wave"]["valu"])
             tail.append("# %-3s %-28s %s" % (w, k, "; ".join(parts)))

@@ -171,6 +171,51 @@ int main(int argc, char** argv)
 					g.lastSamplingSeconds());
 		return bad ? 4 : 0;
 	}
+	if (cmd == "flowtrace" && argc == 6)
+	{
+		// addFunction(MeshSDF) -> addDensityMap -> 10 M-query batches -> host vectors complete, nothing else: the run the
+		// memory-copy trace of profiles/ is taken from (every field should cross PCIe exactly once, device to host)
+		//   host_api_driver flowtrace mesh.obj "rx ry rz" h n_queries
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		Eigen::AlignedBox3d dom;
+		dom.setEmpty();
+		for (auto const& x : mesh.vertices())
+			dom.extend(x);
+		dom.max() += 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		dom.min() -= 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		unsigned rx = 0, ry = 0, rz = 0;
+		if (std::sscanf(argv[3], "%u %u %u", &rx, &ry, &rz) != 3)
+			return 2;
+		const double h = std::stod(argv[4]);
+		const size_t n = (size_t)std::atoll(argv[5]);
+		std::vector<double> pts(3 * n), phi(n), grad(3 * n), rho(n);
+		uint64_t st = 88172645463325252ull;
+		for (size_t q = 0; q < 3 * n; ++q)
+		{
+			st ^= st << 13;
+			st ^= st >> 7;
+			st ^= st << 17;
+			const int d = (int)(q % 3);
+			pts[q] = dom.min()[d] + (double)(st >> 11) * (1.0 / 9007199254740992.0) * (dom.max()[d] - dom.min()[d]);
+		}
+		auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t0 = now();
+		CubicLagrangeDiscreteGrid g(dom, {{rx, ry, rz}});
+		const unsigned f_sdf = g.addFunction(MeshSDF{&md, false});
+		const double t1 = now();
+		const unsigned f_rho = g.addDensityMap(f_sdf, h, 1000.0, true);
+		const double t2 = now();
+		g.interpolate(f_sdf, pts.data(), n, phi.data(), grad.data());
+		g.interpolate(f_rho, pts.data(), n, rho.data());
+		const double t3 = now();
+		g.waitForHostData();
+		const double t4 = now();
+		std::printf("{\"nodes\": %u, \"queries\": %zu, \"add_function_returns_s\": %.6f, \"add_density_map_returns_s\": %.6f, "
+					"\"two_batches_s\": %.6f, \"host_vectors_complete_after_s\": %.6f, \"phi0\": %.17g, \"rho0\": %.17g}\n",
+					g.nNodes(), n, t1 - t0, t2 - t1, t3 - t2, t4 - t0, phi[0], rho[0]);
+		return 0;
+	}
 	if (cmd == "flow" && argc == 7)
 	{
 		// GenerateSDF -> GenerateDensityMap -> batched queries in ONE process, the way a simulation sets up a boundary:
