@@ -304,7 +304,7 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         "ta_busy": k3k.get("ta_busy"), "td_busy": k3k.get("td_busy"),
         "valu_busy": k3k["valu_busy"], "hbm_frac": k3k["hbm_frac"], "l2_hit_rate": k3k["l2_hit_rate"],
         "valu_per_wave": k3k["per_wave"]["valu"], "kernel_ms_when_profiled": k3k["kernel_ms"], "replayed": True,
-        "vgprs": k3k.get("vgprs"), "waves_per_simd": k3k.get("waves_per_simd")}
+        "td_cycles_per_load_instruction": k3k.get("td_cycles_per_load_instruction")}
     k2c = ((counters or {}).get("workloads", {}).get("k2r") or {})
     k2k = next((v for k, v in k2c.items() if k.startswith("k_interpolate_rows<false")), None)
     k2["roofline_rows_kernel"] = None if k2k is None else {

@@ -144,8 +144,7 @@ def main():
                 if "TA_FLAT_READ_WAVEFRONTS_sum" in cs and cs["TA_FLAT_READ_WAVEFRONTS_sum"] > 0 and "TD_TD_BUSY_sum" in cs:
                     e["td_cycles_per_load_instruction"] = cs["TD_TD_BUSY_sum"] / cs["TA_FLAT_READ_WAVEFRONTS_sum"]
             if k in regs and regs[k] > 0:
-                e["vgprs"] = regs[k]
-                e["waves_per_simd"] = min(8, 512 // ((regs[k] + 7) // 8 * 8))
+                e["arch_vgprs"] = regs[k]   # (what rocprofv3 reports; accumulation registers used as spill space come on top)
             derived.setdefault(w, {})[k] = e
     k1 = None
     if "k1" in derived:
