@@ -220,11 +220,14 @@ DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t 
 // arithmetic: bit-identical results.
 static const uint32_t kTmCells = 4;     // tile edge in cells
 static const uint32_t kTmNodes = 736;   // doubles per tile (725 used)
-static const uint32_t kTmX = 125, kTmY = 325, kTmZ = 525; // first slot of the X / Y / Z edge nodes of a tile
+// first slot of the X / Y / Z edge nodes of a tile.  EVEN slots (one pad slot after the 125 vertices): an edge's two nodes
+// are then 16-byte aligned and one 16-byte load never straddles a 64-byte sector (with the vertices packed to 125 a
+// quarter of the edge-pair loads did; round 3, K3's texture-data units are its roof)
+static const uint32_t kTmX = 126, kTmY = 326, kTmZ = 526;
 // Slot kTmFlags of a tile holds 64 bits (stored in the double's place): bit (lk 4 + lj) 4 + li is set iff one of the
 // 32 coefficients of the tile's cell (li, lj, lk) is DBL_MAX ("no value").  K3 tests that bit instead of comparing
 // all 32 coefficients at each of its thousand quadrature points per node.
-static const uint32_t kTmFlags = 725;
+static const uint32_t kTmFlags = 726;
 // slots (tile-local) of the 32 nodes of the cell with tile-local coordinates (li, lj, lk), in the order of
 // cell_node_indices(); pairs (2m, 2m+1) are adjacent as there
 DG_HD void tile_node_slots(uint32_t li, uint32_t lj, uint32_t lk, uint32_t out[32])
@@ -268,6 +271,8 @@ DG_HD uint32_t tile_slot_node(uint32_t slot, uint32_t ti, uint32_t tj, uint32_t 
 {
 	const uint32_t nx = res[0], ny = res[1], nz = res[2];
 	const uint32_t i0 = ti * kTmCells, j0 = tj * kTmCells, k0 = tk * kTmCells;
+	if (slot >= 125 && slot < kTmX)
+		return 0xffffffffu; // the pad slot behind the vertices
 	if (slot < kTmX)
 	{
 		const uint32_t a = slot % 5, b = (slot / 5) % 5, c = slot / 25;
@@ -276,7 +281,7 @@ DG_HD uint32_t tile_slot_node(uint32_t slot, uint32_t ti, uint32_t tj, uint32_t 
 			return 0xffffffffu;
 		return (nx + 1) * (ny + 1) * k + (nx + 1) * j + i;
 	}
-	if (slot >= 725)
+	if (slot >= kTmZ + 200)
 		return 0xffffffffu;
 	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
 	const uint32_t nex = nx * (ny + 1) * (nz + 1);
