@@ -220,14 +220,15 @@ DG_HD void cell_node_indices(uint32_t i, uint32_t j, uint32_t k, const uint32_t 
 // arithmetic: bit-identical results.
 static const uint32_t kTmCells = 4;     // tile edge in cells
 static const uint32_t kTmNodes = 736;   // doubles per tile (725 used)
-// first slot of the X / Y / Z edge nodes of a tile.  EVEN slots (one pad slot after the 125 vertices): an edge's two nodes
-// are then 16-byte aligned and one 16-byte load never straddles a 64-byte sector (with the vertices packed to 125 a
-// quarter of the edge-pair loads did; round 3, K3's texture-data units are its roof)
-static const uint32_t kTmX = 126, kTmY = 326, kTmZ = 526;
+// first slot of the X / Y / Z edge nodes of a tile: multiples of 8 (three pad slots after the 125 vertices).  The four
+// edges a row of four cells needs along the edges' own axis are 8 doubles = one 64-byte sector, and with the blocks on
+// sector boundaries the four lanes of such a row read ONE sector (K3's roof is the texture-data path, whose work is the
+// number of sectors an instruction touches: 31 per 64-lane load with the vertices packed to 125 and rows straddling)
+static const uint32_t kTmX = 128, kTmY = 328, kTmZ = 528;
 // Slot kTmFlags of a tile holds 64 bits (stored in the double's place): bit (lk 4 + lj) 4 + li is set iff one of the
 // 32 coefficients of the tile's cell (li, lj, lk) is DBL_MAX ("no value").  K3 tests that bit instead of comparing
 // all 32 coefficients at each of its thousand quadrature points per node.
-static const uint32_t kTmFlags = 726;
+static const uint32_t kTmFlags = 728;
 // slots (tile-local) of the 32 nodes of the cell with tile-local coordinates (li, lj, lk), in the order of
 // cell_node_indices(); pairs (2m, 2m+1) are adjacent as there
 DG_HD void tile_node_slots(uint32_t li, uint32_t lj, uint32_t lk, uint32_t out[32])
