@@ -184,6 +184,15 @@ struct PreparedRanges
 				return true;
 		return false;
 	}
+	void forget(const void* p, size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (size_t i = 0; i < ranges.size();)
+			if (ranges[i].first < (uintptr_t)p + bytes && (uintptr_t)p < ranges[i].first + ranges[i].second)
+				ranges.erase(ranges.begin() + (long)i);
+			else
+				++i;
+	}
 	void add(const void* p, size_t bytes)
 	{
 		std::lock_guard<std::mutex> lock(mutex);
@@ -299,6 +308,7 @@ bool prepare_host_piece(HostTarget& T, size_t lo, size_t hi)
 	if (hipHostRegister(base, bytes, hipHostRegisterPortable) != hipSuccess)
 	{
 		(void)hipGetLastError();
+		g_prepared.forget(T.out, T.bytes); // (an address range remembered from an earlier call may have been freed and mapped anew)
 		return false;
 	}
 	T.registered.push_back(base);

@@ -125,6 +125,8 @@ void dg_mesh_destroy(dg_mesh* mesh);
 /* out[l - node_begin] = (invert ? -1 : 1) * signed_distance(indexToNodePosition(l)) for
  * l in [node_begin, node_end); nodes whose pred_mask byte (indexed l - node_begin, nullable)
  * is 0 receive DG_NO_VALUE, mirroring the SamplePredicate branch (:814-817). */
+/* (`out` is scratch from the moment of the call: the direct form touches and pins it before the first result arrives,
+ * so a call that returns an error may leave it partly overwritten.) */
 dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 							  uint64_t node_end, const uint8_t* pred_mask, double* out);
 dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
