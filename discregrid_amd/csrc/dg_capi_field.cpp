@@ -526,7 +526,35 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	L.brick_blocking = env_int("DG_K3_BLOCKED", 1, 0, 1);
 	P.lds_waves = env_int("DG_K3_LDS", 0, 0, 3); // experiment: coefficients staged through LDS (measured slower)
 	const bool unreduced_field = dev.cells == nullptr && dev.cell_map == nullptr;
-	if (unreduced_field && env_int("DG_K3_PAIRS", 2, 0, 3) != 0 && P.lds_waves == 0)
+	// Whole lattice of an unreduced field: row-block waves on the x-major copy (k_density_rows; DG_K3_ROWS=0: the cube-shaped
+	// waves of k_density_pairs on the tile-major copy, 1..5: lane shapes, dg_layout.h row_shape_lanes()).  The copy (Y and Z
+	// classes with x fastest, 0.57 x the field) and the per-cell "no value" bits are stream-ordered scratch of this launch.
+	int rows_idx = -1;
+	const int rows_shape = env_int("DG_K3_ROWS", 1, 0, 5);
+	if (unreduced_field && rows_shape != 0 && node_begin == 0 && node_end == total && P.lds_waves == 0 && env_int("DG_K3_PAIRS", 2, 0, 3) != 0)
+	{
+		const size_t copy_bytes = ((size_t)dg::xmajor_doubles(dev.res) * sizeof(double) + 255) & ~(size_t)255;
+		const size_t flag_bytes = (size_t)dev.res[2] * dev.res[1] * dg::xmajor_flag_words(dev.res) * sizeof(uint64_t);
+		void* d_rows = nullptr;
+		rows_idx = sdf->tile_scratch.acquire(copy_bytes + flag_bytes, st, &d_rows);
+		if (rows_idx >= 0 && dg::launch_xmajor_copy(dev, static_cast<double*>(d_rows), st) == hipSuccess)
+		{
+			dev.xmajor = static_cast<const double*>(d_rows);
+			dev.xmajor_flags = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_rows) + copy_bytes);
+			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 2, 1, 64), (uint32_t)env_int("DG_K3_RB1", 8, 1, 64),
+									   (uint32_t)env_int("DG_K3_RB2", 8, 1, 64)};
+			dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
+		}
+		else
+		{
+			(void)hipGetLastError(); // without the copy then
+			sdf->tile_scratch.release(rows_idx, st);
+			rows_idx = -1;
+		}
+	}
+	if (rows_idx >= 0)
+		;
+	else if (unreduced_field && env_int("DG_K3_PAIRS", 2, 0, 3) != 0 && P.lds_waves == 0)
 	{
 		dg::pair_bricks(L); // two edge nodes per lane: the pair shares its cell's coefficients two times out of three
 		L.pair_nodes = env_int("DG_K3_PAIRS", 2, 0, 3); // (2 / 3: waves per SIMD asked of the register allocator)
@@ -549,7 +577,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// pass over the field against 1 + 4096 interpolations per integrated node: 128^3 161 -> 135 ms
 	// (DG_K3_TILES=0: off).  Launches over a small part of the lattice are not worth the pass.
 	int tile_idx = -1;
-	if (dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
+	if (rows_idx < 0 && dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
 		env_int("DG_K3_TILES", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
 	{
 		const uint64_t n_tiles = (uint64_t)dev.ntile[0] * dev.ntile[1] * dev.ntile[2];
@@ -566,6 +594,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	}
 	const hipError_t e = dg::launch_density_bricks(L, dev, sdf->n_coeffs, P, st);
 	sdf->tile_scratch.release(tile_idx, st);
+	sdf->tile_scratch.release(rows_idx, st);
 	sdf->flag_scratch.release(flag_idx, st);
 	DG_HIP(e);
 	return DG_OK;

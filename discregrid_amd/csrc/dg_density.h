@@ -33,8 +33,96 @@ struct DensityParams
 	uint16_t kmask[256];
 	int32_t skip_mode;
 	int32_t lds_waves; // device, tile-major copy: > 0: the kernel that stages the coefficients through LDS (waves per SIMD to aim for)
+	// device, x-major copy (k_density_rows): lane shape of a wave's row block (1: 16 x 2 x 2 cells, 2: 32 x 2 x 1, 3: 16 x 4 x 1,
+	// 4: 8 x 4 x 2, 5: 64 x 1 x 1; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
+	// class the wave counts along the three axes with the first wave id of the class
+	int32_t row_shape;
+	uint32_t row_block[3];
+	uint32_t row_waves[4][3];
+	uint32_t row_prefix[5];
 	const uint32_t* unsafe;
 };
+
+// k_density_rows: wave id -> (class, wave coordinates along x, y, z).  The waves of a class fill blocks of
+// row_block[0] x [1] x [2] waves (truncated at the upper faces), blocks in row-major order: the waves an XCD has in
+// flight -- consecutive ids -- integrate over (nearly) the same part of the field at the same time.  A bijection of
+// [row_prefix[c], row_prefix[c + 1]) onto the class's waves, all in wave-uniform integers.
+struct RowWave
+{
+	int cls;
+	uint32_t w[3];
+};
+DG_HD RowWave row_wave_map(const DensityParams& P, uint32_t id)
+{
+	int c = 0;
+	if (id >= P.row_prefix[1]) c = 1;
+	if (id >= P.row_prefix[2]) c = 2;
+	if (id >= P.row_prefix[3]) c = 3;
+	const uint32_t local = id - P.row_prefix[c];
+	const uint32_t n0 = P.row_waves[c][0], n1 = P.row_waves[c][1], n2 = P.row_waves[c][2];
+	const uint32_t B0 = P.row_block[0], B1 = P.row_block[1], B2 = P.row_block[2];
+	const uint32_t slab = n0 * n1 * B2;
+	const uint32_t i2 = local / slab, r = local - i2 * slab;
+	const uint32_t s2 = (n2 - i2 * B2) < B2 ? (n2 - i2 * B2) : B2;
+	const uint32_t row = n0 * B1 * s2;
+	const uint32_t i1 = r / row, r2 = r - i1 * row;
+	const uint32_t s1 = (n1 - i1 * B1) < B1 ? (n1 - i1 * B1) : B1;
+	const uint32_t blk = B0 * s1 * s2;
+	const uint32_t i0 = r2 / blk, r3 = r2 - i0 * blk;
+	const uint32_t s0 = (n0 - i0 * B0) < B0 ? (n0 - i0 * B0) : B0;
+	RowWave m;
+	m.cls = c;
+	m.w[0] = i0 * B0 + r3 % s0;
+	m.w[1] = i1 * B1 + (r3 / s0) % s1;
+	m.w[2] = i2 * B2 + r3 / (s0 * s1);
+	return m;
+}
+
+// the item of `lane` in wave m of lane shape (lx, ly, lz): the vertex (class 0) or cell edge (classes 1..3) that starts at
+// cell-lattice point (i, j, k) -- node A = class coordinates (a, b, s), node B = (a + 1, b, s) for the edge classes --
+// clamped to the lattice (valid = false for the lanes that hang over), and node A's index in the coefficient vector
+struct RowItem
+{
+	bool valid;
+	uint32_t a, b, s;
+	uint64_t node;
+};
+DG_HD RowItem row_lane_item(const RowWave& m, int lane, uint32_t lx, uint32_t ly, uint32_t lz, const uint32_t res[3])
+{
+	const int cls = m.cls;
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	uint32_t i = m.w[0] * lx + (uint32_t)lane % lx, j = m.w[1] * ly + ((uint32_t)lane / lx) % ly, k = m.w[2] * lz + (uint32_t)lane / (lx * ly);
+	const uint32_t ix = nx + (cls == 1 ? 0u : 1u), iy = ny + (cls == 2 ? 0u : 1u), iz = nz + (cls == 3 ? 0u : 1u);
+	RowItem it;
+	it.valid = i < ix && j < iy && k < iz;
+	i = i < ix ? i : ix - 1u;
+	j = j < iy ? j : iy - 1u;
+	k = k < iz ? k : iz - 1u;
+	it.a = i;
+	it.b = j;
+	it.s = k;
+	if (cls == 1)
+		it.a = 2u * i;
+	else if (cls == 2)
+	{
+		it.a = 2u * j;
+		it.b = k;
+		it.s = i;
+	}
+	else if (cls == 3)
+	{
+		it.a = 2u * k;
+		it.b = i;
+		it.s = j;
+	}
+	uint32_t D[3];
+	class_dims(cls, res, D);
+	const uint64_t nv = (uint64_t)(nx + 1) * (ny + 1) * (nz + 1);
+	const uint64_t nex = 2ull * nx * (ny + 1) * (nz + 1), ney = 2ull * (nx + 1) * ny * (nz + 1);
+	const uint64_t off = cls == 0 ? 0ull : (cls == 1 ? nv : (cls == 2 ? nv + nex : nv + nex + ney));
+	it.node = off + ((uint64_t)it.s * D[1] + it.b) * D[0] + it.a;
+	return it;
+}
 
 // CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector
 DG_HD double cubic_kernel_k(double radius)
@@ -184,10 +272,14 @@ DG_HD double density_integral_t(const FieldDev& F, const DensityParams& P, const
 						// phi = sum_q cf[q] * N[q] in q order; every N[q] is formed right where it is
 						// consumed (same products as shape_functions(), no 32-entry array kept live)
 						// "no value" coefficients: one flag bit per cell in the tile-major copy, else 32 compares
+						// (the x-major copy: one bit per cell if its producer supplied them)
+						const bool cell_flags = MODE == kFieldTileMajor || (MODE == kFieldXMajor && F.xmajor_flags != nullptr);
 						bool ok = (MODE == kFieldTileMajor) ? !tile_cell_has_novalue(F.tile_major, F.ntile, ax.mi, ay.mi, az.mi) : true;
+						if (MODE == kFieldXMajor && cell_flags)
+							ok = !xmajor_cell_has_novalue(F, ax.mi, ay.mi, az.mi);
 						double phi = 0.0;
 #define DG_ACC(q, n)                                   \
-	if (MODE != kFieldTileMajor)                       \
+	if (!cell_flags)                                   \
 		ok = ok && (cf[q] != NOVAL);                   \
 	phi += cf[q] * (n);
 						DG_ACC(0, fac * mxmy * mz)
@@ -253,6 +345,7 @@ DG_HD double density_integral(const FieldDev& F, const DensityParams& P, const d
 	const bool unreduced = (F.cells == nullptr) && (F.cell_map == nullptr);
 	switch (field_mode(F))
 	{
+	case kFieldXMajor: return density_integral_t<true, kFieldXMajor>(F, P, x);       // (unreduced fields only)
 	case kFieldTileMajor: return density_integral_t<true, kFieldTileMajor>(F, P, x); // (unreduced fields only)
 	case kFieldCellMajor: return unreduced ? density_integral_t<true, kFieldCellMajor>(F, P, x) : density_integral_t<false, kFieldCellMajor>(F, P, x);
 	case kFieldTable: return density_integral_t<false, kFieldTable>(F, P, x);

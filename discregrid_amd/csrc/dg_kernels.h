@@ -332,6 +332,8 @@ hipError_t launch_unpack_ranks(const UnpackParams& p, hipStream_t stream);
 hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, uint64_t n_coeffs, const DensityParams& p,
 								 hipStream_t stream);
 hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream);
+// the x-major copy of the Y and Z edge classes (dg_lattice.h): xmajor_doubles(f.res) doubles
+hipError_t launch_xmajor_copy(const FieldDev& f, double* d_out, hipStream_t stream);
 // f.ntile must be set; d_out: n_tiles * kTmNodes doubles
 hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_out, hipStream_t stream);
 // K2 over the cell-major copy of a field (f.cell_major set), queries in any order, no binning

@@ -1097,7 +1097,7 @@ __device__ __forceinline__ double k3_cell_value(const FieldDev& F, const double 
 	const double fac = 1.0 / 64.0 * (9.0 * (x2y2 + az.t2) - 19.0);
 	double phi = 0.0;
 #define DG_ACC(q, n)                                   \
-	if (MODE != kFieldTileMajor)                       \
+	if (MODE != kFieldTileMajor && MODE != kFieldXMajor) \
 		ok = ok && (cf[q] != NOVAL);                   \
 	phi += cf[q] * (n);
 	DG_ACC(0, fac * mxmy * mz)
@@ -1216,6 +1216,8 @@ __device__ __forceinline__ void k3_pair_integral(const FieldDev& F, const Densit
 					fetch_cell<MODE>(F, ax.mi, ay.mi, az.mi, F.res[1] * F.res[0] * az.mi + F.res[0] * ay.mi + ax.mi, cf);
 					if (MODE == kFieldTileMajor && has_noval)
 						ok = !tile_cell_has_novalue(F.tile_major, F.ntile, ax.mi, ay.mi, az.mi);
+					if (MODE == kFieldXMajor && has_noval)
+						ok = !xmajor_cell_has_novalue(F, ax.mi, ay.mi, az.mi);
 					da = k3_cell_value<MODE>(F, cf, ok, ax, ay, az);
 				}
 				if (want_b && !shared)
@@ -1224,6 +1226,8 @@ __device__ __forceinline__ void k3_pair_integral(const FieldDev& F, const Densit
 					ok = true;
 					if (MODE == kFieldTileMajor && has_noval)
 						ok = !tile_cell_has_novalue(F.tile_major, F.ntile, bx.mi, by.mi, bz.mi);
+					if (MODE == kFieldXMajor && has_noval)
+						ok = !xmajor_cell_has_novalue(F, bx.mi, by.mi, bz.mi);
 				}
 				if (want_b)
 					db = k3_cell_value<MODE>(F, cf, ok, bx, by, bz);
@@ -1247,10 +1251,12 @@ __device__ __forceinline__ void k3_pair_integral(const FieldDev& F, const Densit
 	*out_b = P.rho0 * res_b;
 }
 
+template <int MODE>
+__device__ __forceinline__ void k3_pair_wave(const SampleParams& L, const FieldDev& F, const DensityParams& P, int cls, int lane, bool valid_a,
+											   bool valid_b, int64_t out_a, int64_t out_b, const double xa[3], const double xb[3]);
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void k_density_pairs(const SampleParams L, const FieldDev F, const DensityParams P)
 {
-	const double NOVAL = 1.7976931348623157e308;
 	uint32_t blk;
 	if (!logical_block(L, blockIdx.x, &blk))
 		return;
@@ -1277,11 +1283,21 @@ __global__ __launch_bounds__(64, WAVES) void k_density_pairs(const SampleParams 
 	double xa[3], xb[3];
 	node_position(na.cls, na.a, na.b, na.s, L.dmin, L.cell, xa);
 	node_position(nb.cls, nb.a, nb.b, nb.s, L.dmin, L.cell, xb);
+	k3_pair_wave<MODE>(L, F, P, cls, lane, na.valid, nb.valid, na.out_idx, nb.out_idx, xa, xb);
+}
+
+// the work of one wave of K3's two-nodes-per-lane kernels once every lane knows its nodes: cls (wave-uniform) names the
+// axis along which A and B differ; lane 0 must hold the lowest, lane 63 the highest z of the wave
+template <int MODE>
+__device__ __forceinline__ void k3_pair_wave(const SampleParams& L, const FieldDev& F, const DensityParams& P, int cls, int lane, bool valid_a,
+											   bool valid_b, int64_t out_a, int64_t out_b, const double xa[3], const double xb[3])
+{
+	const double NOVAL = 1.7976931348623157e308;
 	double va = NOVAL, vb = NOVAL;
 	bool need_a = false, need_b = false;
-	if (na.valid && (L.mask == nullptr || L.mask[na.out_idx] != 0))
+	if (valid_a && (L.mask == nullptr || L.mask[out_a] != 0))
 		need_a = density_prefilter(F, P, xa, &va);
-	if (nb.valid && (L.mask == nullptr || L.mask[nb.out_idx] != 0))
+	if (valid_b && (L.mask == nullptr || L.mask[out_b] != 0))
 		need_b = density_prefilter(F, P, xb, &vb);
 	if (__ballot(need_a || need_b) != 0ull)
 	{
@@ -1324,10 +1340,79 @@ __global__ __launch_bounds__(64, WAVES) void k_density_pairs(const SampleParams 
 		if (need_b)
 			vb = rb;
 	}
-	if (na.valid)
-		L.out[na.out_idx] = va;
-	if (nb.valid)
-		L.out[nb.out_idx] = vb;
+	if (valid_a)
+		L.out[out_a] = va;
+	if (valid_b)
+		L.out[out_b] = vb;
+}
+
+// ---- K3 in row blocks (unreduced fields, whole lattice) --------------------------------------------------------------
+// k_density_pairs sits on the texture path (profiles/r03_k3_vmem_pmc.txt: TD busy 0.96, VALU 0.55): its waves are cubes
+// of 4 x 4 x 4 cells, so every 64-lane load is sixteen runs of four lanes = 64 bytes that straddle a sector (or a tile)
+// boundary three times out of four -- 31 sectors of 64 bytes touched per instruction where 16 hold the data.  The texture
+// path's work is the sector count.  Here a wave is a ROW block: LX cells along x (16), LY x LZ = 2 x 2 rows, every lane
+// again the node (vertex class) or the two nodes of the cell edge (edge classes) at its cell -- whichever axis the edge
+// runs along, the lanes of a row sit a cell apart along x.  With the x-major copy of the Y and Z classes (dg_lattice.h)
+// all sixteen pair loads of a cell are 256-byte runs along x: 19 sectors per instruction.  Same per-lane arithmetic as
+// k_density_pairs (k3_pair_wave), same bits.
+template <int MODE, int LX, int LY, int LZ, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_density_rows(const SampleParams L, const FieldDev F, const DensityParams P)
+{
+	static_assert(LX * LY * LZ == 64, "one wave");
+	uint32_t blk;
+	if (!logical_block(L, blockIdx.x, &blk))
+		return;
+	if (blk >= P.row_prefix[4])
+		return;
+	const RowWave m = row_wave_map(P, blk);
+	const int lane = (int)(threadIdx.x & 63u);
+	const int cls = m.cls; // wave-uniform
+	const RowItem it = row_lane_item(m, lane, (uint32_t)LX, (uint32_t)LY, (uint32_t)LZ, F.res);
+	double xa[3], xb[3];
+	node_position(cls, it.a, it.b, it.s, L.dmin, L.cell, xa);
+	node_position(cls, cls != 0 ? it.a + 1u : it.a, it.b, it.s, L.dmin, L.cell, xb);
+	k3_pair_wave<MODE>(L, F, P, cls, lane, it.valid, it.valid && cls != 0, (int64_t)it.node, (int64_t)it.node + 1, xa, xb);
+}
+
+// the x-major copy (dg_lattice.h): one thread per pair of the copy, contiguous 16-byte writes, reads a plane apart
+__global__ __launch_bounds__(256) void k_xmajor_copy(const FieldDev F, uint32_t n_pairs, double* __restrict__ out)
+{
+	for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < n_pairs; e += gridDim.x * 256u)
+	{
+		const double* src = F.coeffs + xmajor_pair_node(e, F.res);
+		double2 v;
+		v.x = src[0];
+		v.y = src[1];
+		*(double2*)(out + 2 * (size_t)e) = v;
+	}
+}
+// the "no value" bit of every cell, one wave per 64 cells of a row; only if k_field_check found such a value at all
+// (flag bit 1) -- k_density_rows does not read the bits otherwise
+__global__ __launch_bounds__(256) void k_xmajor_flags(const FieldDev F, const uint32_t* __restrict__ field_flags, uint64_t* __restrict__ out)
+{
+	if ((field_flags[0] & 2u) == 0u)
+		return;
+	const uint32_t words = xmajor_flag_words(F.res);
+	const uint64_t total = (uint64_t)F.res[2] * F.res[1] * words;
+	const int lane = (int)(threadIdx.x & 63u);
+	for (uint64_t w = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6); w < total; w += (uint64_t)gridDim.x * 4u)
+	{
+		const uint32_t wi = (uint32_t)(w % words), row = (uint32_t)(w / words);
+		const uint32_t j = row % F.res[1], k = row / F.res[1];
+		const uint32_t i = wi * 64u + (uint32_t)lane;
+		bool nov = false;
+		if (i < F.res[0])
+		{
+			double cf[32];
+			fetch_cell<kFieldXMajor>(F, i, j, k, 0u, cf);
+#pragma unroll
+			for (int q = 0; q < 32; ++q)
+				nov = nov || (cf[q] == 1.7976931348623157e308);
+		}
+		const unsigned long long bits = __ballot(nov);
+		if (lane == 0)
+			out[w] = bits;
+	}
 }
 
 // ---- K3 with the coefficients staged through LDS (unreduced fields) ---------------------------------------------------
@@ -1918,6 +2003,25 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 	const bool unreduced = f.cells == nullptr && f.cell_map == nullptr; // staged evaluator
 	switch (field_mode(f))
 	{
+	case kFieldXMajor:
+	{
+		// row blocks over the whole lattice (dg_layout.h layout_density_rows()); the per-cell "no value" bits first
+		if (p.row_shape == 0 || !unreduced)
+			return hipErrorInvalidValue;
+		if (f.xmajor_flags != nullptr && p.unsafe != nullptr)
+			hipLaunchKernelGGL(k_xmajor_flags, dim3(2048), dim3(256), 0, stream, f, p.unsafe, const_cast<uint64_t*>(f.xmajor_flags));
+#define DG_K3_ROWS(LX, LY, LZ) hipLaunchKernelGGL((k_density_rows<kFieldXMajor, LX, LY, LZ, 2>), grid, block, 0, stream, layout, f, p)
+		switch (p.row_shape)
+		{
+		case 2: DG_K3_ROWS(32, 2, 1); break;
+		case 3: DG_K3_ROWS(16, 4, 1); break;
+		case 4: DG_K3_ROWS(8, 4, 2); break;
+		case 5: DG_K3_ROWS(64, 1, 1); break;
+		default: DG_K3_ROWS(16, 2, 2); break;
+		}
+#undef DG_K3_ROWS
+		break;
+	}
 	case kFieldTileMajor:
 		// pair_nodes: two edge nodes per lane (the layout counts double bricks: dg_layout.h pair_bricks()); lds_waves > 0:
 		// the experiment that stages the coefficients through LDS (DG_K3_LDS)
@@ -1948,6 +2052,16 @@ hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_ou
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 64ull);
 	hipLaunchKernelGGL(k_expand_tiles, dim3(blocks), dim3(256), 0, stream, f, n_tiles, d_out);
 	hipLaunchKernelGGL(k_tile_flags, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, stream, n_tiles, d_out);
+	return hipGetLastError();
+}
+
+hipError_t launch_xmajor_copy(const FieldDev& f, double* d_out, hipStream_t stream)
+{
+	const uint64_t n_pairs = xmajor_doubles(f.res) / 2;
+	if (n_pairs == 0 || n_pairs > 0xffffffffull)
+		return n_pairs == 0 ? hipSuccess : hipErrorInvalidValue;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_pairs + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_xmajor_copy, dim3(blocks), dim3(256), 0, stream, f, (uint32_t)n_pairs, d_out);
 	return hipGetLastError();
 }
 

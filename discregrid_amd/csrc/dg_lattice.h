@@ -331,6 +331,11 @@ struct FieldDev
 	// tiles in x-fastest order, ntile[d] = ceil(res[d] / 4).
 	const double* tile_major;
 	uint32_t ntile[3];
+	// Optional x-major copy of the Y and Z edge classes of an UNREDUCED field (see "x-major copy" below): with it
+	// all 16 coefficient pairs of a cell lie in rows that run along x.  xmajor_flags: one "no value" bit per cell
+	// (nullable; valid only where the producer says so).
+	const double* xmajor = nullptr;
+	const uint64_t* xmajor_flags = nullptr;
 };
 // Where the 32 coefficients of a cell come from (FieldDev): the kernels are instantiated per mode, so that each
 // has ONE load sequence (a runtime switch makes the compiler merge the variants into 32 separate 8-byte loads).
@@ -340,10 +345,48 @@ enum FieldMode : int
 	kFieldTable = 1,     // cell table (reduced / loaded fields): 32 indexed 8-byte loads
 	kFieldCellMajor = 2, // cell-major copy: 256 contiguous bytes
 	kFieldTileMajor = 3, // tile-major copy (unreduced fields): 16 x 16-byte pairs within one 5.9 KB tile
+	kFieldXMajor = 4,    // V and X classes from the reference layout, Y and Z from the x-major copy: 16 pairs in 16 rows along x
 };
 DG_HD int field_mode(const FieldDev& F)
 {
+	if (F.xmajor)
+		return kFieldXMajor;
 	return F.tile_major ? kFieldTileMajor : (F.cell_major ? kFieldCellMajor : (F.cells ? kFieldTable : kFieldClosed));
+}
+
+// ---- x-major copy of the Y and Z edge classes (K3) -------------------------------------------------------------
+// The reference numbers the Y edges y-fastest ((2j+h, k, i)) and the Z edges z-fastest ((2k+h, i, j)): lanes that sit
+// side by side along x read them a plane apart.  K3's lanes do sit side by side along x (k_density_rows: a wave is a
+// row block of 16 x 2 x 2 cells), so that the vertex and X-edge pairs of a wave -- x-fastest in the reference layout
+// already -- come in 256-byte runs; the x-major copy gives the other two classes the same property at 1.0 x their
+// memory: Y'[k][j][i][h] (k <= nz, j < ny, i <= nx) followed by Z'[k][j][i][h] (k < nz, j <= ny, i <= nx).
+// Same values, same arithmetic: bit-identical results.
+DG_HD uint64_t xmajor_y_pairs(const uint32_t res[3]) { return (uint64_t)(res[2] + 1) * res[1] * (res[0] + 1); }
+DG_HD uint64_t xmajor_z_pairs(const uint32_t res[3]) { return (uint64_t)res[2] * (res[1] + 1) * (res[0] + 1); }
+DG_HD uint64_t xmajor_doubles(const uint32_t res[3]) { return 2 * (xmajor_y_pairs(res) + xmajor_z_pairs(res)); }
+// global node index (reference order) of the FIRST node (h = 0) of pair `pair` of the copy
+DG_HD uint32_t xmajor_pair_node(uint64_t pair, const uint32_t res[3])
+{
+	const uint32_t nx = res[0], ny = res[1], nz = res[2];
+	const uint32_t nv = (nx + 1) * (ny + 1) * (nz + 1);
+	const uint32_t nex = nx * (ny + 1) * (nz + 1);
+	const uint32_t ney = (nx + 1) * ny * (nz + 1);
+	const uint64_t ny_pairs = xmajor_y_pairs(res);
+	if (pair < ny_pairs)
+	{
+		const uint32_t i = (uint32_t)(pair % (nx + 1)), j = (uint32_t)((pair / (nx + 1)) % ny), k = (uint32_t)(pair / ((uint64_t)(nx + 1) * ny));
+		return nv + 2 * nex + 2 * (ny * (nz + 1) * i + ny * k + j);
+	}
+	pair -= ny_pairs;
+	const uint32_t i = (uint32_t)(pair % (nx + 1)), j = (uint32_t)((pair / (nx + 1)) % (ny + 1)), k = (uint32_t)(pair / ((uint64_t)(nx + 1) * (ny + 1)));
+	return nv + 2 * nex + 2 * ney + 2 * (nz * (nx + 1) * j + nz * i + k);
+}
+// words per row of the per-cell "no value" bits: bit i & 63 of word (k ny + j) xmajor_flag_words(res) + (i >> 6)
+DG_HD uint32_t xmajor_flag_words(const uint32_t res[3]) { return (res[0] + 63u) / 64u; }
+DG_HD bool xmajor_cell_has_novalue(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k)
+{
+	const uint64_t w = F.xmajor_flags[((size_t)k * F.res[1] + j) * xmajor_flag_words(F.res) + (i >> 6)];
+	return ((w >> (i & 63u)) & 1ull) != 0ull;
 }
 template <int MODE>
 DG_HD void fetch_cell(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k, uint32_t row, double cf[32])
@@ -365,6 +408,29 @@ DG_HD void fetch_cell(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k, uin
 #endif
 		for (int q = 0; q < 32; ++q)
 			cf[q] = F.coeffs[r[q]];
+	}
+	else if (MODE == kFieldXMajor)
+	{
+		// rows along x: 4 vertex rows and 4 X-edge rows of the reference layout, 2 + 2 rows of the copy read at i and i + 1
+		const uint32_t nx = F.res[0], ny = F.res[1], nz = F.res[2];
+		const double* v = F.coeffs + ((size_t)(nx + 1) * (ny + 1) * k + (size_t)(nx + 1) * j + i);
+		const size_t vj = nx + 1, vk = (size_t)(nx + 1) * (ny + 1);
+		const double* ex = F.coeffs + (size_t)(nx + 1) * (ny + 1) * (nz + 1) + 2 * ((size_t)nx * (ny + 1) * k + (size_t)nx * j + i);
+		const size_t xj = 2 * (size_t)nx, xk = 2 * (size_t)nx * (ny + 1);
+		const double* ey = F.xmajor + 2 * (((size_t)k * ny + j) * (nx + 1) + i);
+		const size_t yk = 2 * (size_t)ny * (nx + 1);
+		const double* ez = F.xmajor + 2 * xmajor_y_pairs(F.res) + 2 * (((size_t)k * (ny + 1) + j) * (nx + 1) + i);
+		const size_t zj = 2 * (size_t)(nx + 1);
+		const double* src[16] = {v, v + vj, v + vk, v + vk + vj, ex, ex + xk, ex + xj, ex + xk + xj,
+								 ey, ey + 2, ey + yk, ey + yk + 2, ez, ez + zj, ez + 2, ez + zj + 2};
+#if defined(__HIP__)
+#pragma unroll
+#endif
+		for (int m = 0; m < 16; ++m)
+		{
+			cf[2 * m] = src[m][0];
+			cf[2 * m + 1] = src[m][1];
+		}
 	}
 	else
 	{
@@ -538,6 +604,7 @@ DG_HD double interpolate_point(const FieldDev& F, const double x[3], double g[3]
 {
 	switch (field_mode(F))
 	{
+	case kFieldXMajor: return interpolate_point_mode<GRAD, kFieldXMajor>(F, x, g);
 	case kFieldTileMajor: return interpolate_point_mode<GRAD, kFieldTileMajor>(F, x, g);
 	case kFieldCellMajor: return interpolate_point_mode<GRAD, kFieldCellMajor>(F, x, g);
 	case kFieldTable: return interpolate_point_mode<GRAD, kFieldTable>(F, x, g);

@@ -316,7 +316,45 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 		}
 	P.skip_mode = 0;
 	P.lds_waves = 0;
+	P.row_shape = 0;
 	P.unsafe = nullptr;
+}
+// lanes of a wave of k_density_rows along x, y, z (DensityParams::row_shape)
+inline void row_shape_lanes(int shape, uint32_t l[3])
+{
+	l[0] = shape == 2 ? 32u : (shape == 4 ? 8u : (shape == 5 ? 64u : 16u));
+	l[1] = shape == 3 || shape == 4 ? 4u : (shape == 5 ? 1u : 2u);
+	l[2] = shape == 1 || shape == 4 ? 2u : 1u;
+}
+// K3 in row blocks over the WHOLE lattice: waves per class and their first ids; returns the number of waves
+// (block: waves along x / y / z of the blocks consecutive ids fill)
+inline uint64_t layout_density_rows(DensityParams& P, SampleParams& L, const uint32_t res[3], int shape, const uint32_t block[3])
+{
+	uint32_t l[3];
+	row_shape_lanes(shape, l);
+	P.row_shape = shape;
+	uint64_t prefix = 0;
+	for (int c = 0; c < 4; ++c)
+	{
+		const uint32_t items[3] = {res[0] + (c == 1 ? 0u : 1u), res[1] + (c == 2 ? 0u : 1u), res[2] + (c == 3 ? 0u : 1u)};
+		P.row_prefix[c] = (uint32_t)prefix;
+		uint64_t n = 1;
+		for (int d = 0; d < 3; ++d)
+		{
+			P.row_waves[c][d] = (items[d] + l[d] - 1) / l[d];
+			n *= P.row_waves[c][d];
+		}
+		prefix += n;
+	}
+	P.row_prefix[4] = (uint32_t)prefix;
+	for (int d = 0; d < 3; ++d)
+		P.row_block[d] = std::max(1u, block[d]);
+	L.total_bricks = prefix;
+	L.n_blocks = (uint32_t)prefix;
+	L.pair_nodes = 0;
+	L.xcd_chunk = 0;
+	finish_blocks(L);
+	return prefix;
 }
 // may the zero-weight points be skipped for this coefficient? (host mirror of k_field_check)
 inline bool density_value_unsafe(double c) { return c != 1.7976931348623157e308 && !(std::fabs(c) < 1.0e290); }

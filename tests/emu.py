@@ -284,8 +284,21 @@ def udiv_mismatches(n, d):
 
 
 def set_tile_major(on=1):
-    """K2 / K3 bodies read unreduced fields through a tile-major copy (dg_lattice.h) built as k_expand_tiles does."""
+    """K2 / K3 bodies read unreduced fields through a tile-major copy (dg_lattice.h) built as k_expand_tiles does
+    (on = 2: through the x-major copy of the Y and Z classes, built as k_xmajor_copy / k_xmajor_flags do)."""
     lib().emu_set_tile_major(int(on))
+
+
+def density_rows_cover(res, shape, block):
+    """hits per node of one emulated k_density_rows launch over the whole lattice, and its wave count."""
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    block = np.ascontiguousarray(block, dtype=np.uint32)
+    hits = np.zeros(T.n_nodes(res), dtype=np.uint32)
+    L = lib()
+    L.emu_density_rows_cover.restype = C.c_uint64
+    L.emu_density_rows_cover.argtypes = [T.c_up, C.c_int, T.c_up, C.c_void_p]
+    waves = int(L.emu_density_rows_cover(T.up(res), int(shape), T.up(block), hits.ctypes.data_as(C.c_void_p)))
+    return hits, waves
 
 
 def set_heavy(slots=0xffffffff, work=0):

@@ -1189,7 +1189,7 @@ void emu_unpack_ranks(const uint32_t res[3], int nranks, const double* gathered,
 			field[unpack_dest(U, (uint32_t)r, off)] = gathered[(uint64_t)r * stride + off];
 }
 
-int g_emu_tiles = 0; // 1: emu_interpolate / emu_density_map read an (unreduced) field through a tile-major copy
+int g_emu_tiles = 0; // 1: emu_interpolate / emu_density_map read an (unreduced) field through a tile-major copy, 2: through the x-major copy
 void emu_set_tile_major(int on) { g_emu_tiles = on; }
 // the tile-major copy exactly as k_expand_tiles builds it
 static std::vector<double> build_tiles(FieldDev& F)
@@ -1222,6 +1222,68 @@ static std::vector<double> build_tiles(FieldDev& F)
 	}
 	return t;
 }
+// the x-major copy of the Y and Z classes and the per-cell "no value" bits exactly as k_xmajor_copy / k_xmajor_flags build them
+struct XMajorCopy
+{
+	std::vector<double> pairs;
+	std::vector<uint64_t> flags;
+};
+static void build_xmajor(FieldDev& F, XMajorCopy& X)
+{
+	const uint64_t n_pairs = xmajor_doubles(F.res) / 2;
+	X.pairs.resize(2 * n_pairs + 2);
+	for (uint64_t e = 0; e < n_pairs; ++e)
+	{
+		const uint32_t node = xmajor_pair_node(e, F.res);
+		X.pairs[2 * e] = F.coeffs[node];
+		X.pairs[2 * e + 1] = F.coeffs[node + 1];
+	}
+	F.xmajor = X.pairs.data();
+	const uint32_t words = xmajor_flag_words(F.res);
+	X.flags.assign((size_t)F.res[2] * F.res[1] * words, 0ull);
+	for (uint32_t k = 0; k < F.res[2]; ++k)
+		for (uint32_t j = 0; j < F.res[1]; ++j)
+			for (uint32_t i = 0; i < F.res[0]; ++i)
+			{
+				double cf[32];
+				fetch_cell<kFieldXMajor>(F, i, j, k, 0u, cf);
+				bool nov = false;
+				for (int q = 0; q < 32; ++q)
+					nov = nov || (cf[q] == 1.7976931348623157e308);
+				if (nov)
+					X.flags[((size_t)k * F.res[1] + j) * words + (i >> 6)] |= 1ull << (i & 63u);
+			}
+	F.xmajor_flags = X.flags.data();
+}
+// every wave and lane of a k_density_rows launch (dg_layout.h layout_density_rows(), logical_block(), row_wave_map(),
+// row_lane_item()): hits[node] += 1 for every node a valid lane owns; returns the number of waves
+uint64_t emu_density_rows_cover(const uint32_t res[3], int shape, const uint32_t block[3], uint32_t* hits)
+{
+	DensityParams P;
+	SampleParams L;
+	std::memset(&L, 0, sizeof(L));
+	std::memset(&P, 0, sizeof(P));
+	const uint64_t waves = layout_density_rows(P, L, res, shape, block);
+	uint32_t l[3];
+	row_shape_lanes(shape, l);
+	for (uint32_t b = 0; b < L.blocks_per_xcd * 8u; ++b)
+	{
+		uint32_t blk;
+		if (!logical_block(L, b, &blk) || blk >= P.row_prefix[4])
+			continue;
+		const RowWave m = row_wave_map(P, blk);
+		for (int lane = 0; lane < 64; ++lane)
+		{
+			const RowItem it = row_lane_item(m, lane, l[0], l[1], l[2], res);
+			if (!it.valid)
+				continue;
+			hits[it.node] += 1;
+			if (m.cls != 0)
+				hits[it.node + 1] += 1;
+		}
+	}
+	return waves;
+}
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)
@@ -1242,11 +1304,14 @@ void emu_interpolate(const double domain[6], const double cell[3], const double 
 	F.tile_major = nullptr;
 	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
 	std::vector<double> tiles;
-	if (g_emu_tiles && !cells && !cell_map)
+	XMajorCopy xm;
+	if (g_emu_tiles == 1 && !cells && !cell_map)
 	{
 		tiles = build_tiles(F);
 		F.tile_major = tiles.data();
 	}
+	if (g_emu_tiles == 2 && !cells && !cell_map)
+		build_xmajor(F, xm);
 #pragma omp parallel for schedule(static)
 	for (long long q = 0; q < (long long)n; ++q)
 	{
@@ -1365,11 +1430,14 @@ void emu_density_map(const double domain[6], const double cell[3], const double 
 	F.tile_major = nullptr;
 	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
 	std::vector<double> tiles;
-	if (g_emu_tiles && !cells && !cell_map)
+	XMajorCopy xm;
+	if (g_emu_tiles == 1 && !cells && !cell_map)
 	{
 		tiles = build_tiles(F);
 		F.tile_major = tiles.data();
 	}
+	if (g_emu_tiles == 2 && !cells && !cell_map)
+		build_xmajor(F, xm);
 	DensityParams P;
 	std::vector<double> w;
 	init_density_params(P, h, rho0, cell, band, w);

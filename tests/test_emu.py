@@ -414,6 +414,52 @@ def test_tile_major_copy_is_the_same_field(golden):
         emu.set_tile_major(0)
 
 
+def test_xmajor_copy_is_the_same_field(golden):
+    """The x-major copy of the Y and Z edge classes (dg_lattice.h: K3's row-block kernel reads all 16 coefficient pairs of a
+    cell from rows along x) addresses exactly the reference's nodes: same bits from K2's and K3's bodies, "no value"
+    coefficients answered by its one bit per cell."""
+    rng = np.random.default_rng(31)
+    try:
+        for res in ([4, 4, 4], [5, 7, 3], [9, 2, 6], [1, 1, 1], [70, 2, 3]):
+            dom = np.array([-1.0, -0.5, 0.0, 1.5, 1.0, 2.0])
+            coeffs = rng.normal(size=T.n_nodes(res))
+            P = rng.uniform(dom[:3] - 0.1, dom[3:] + 0.1, size=(3000, 3))
+            emu.set_tile_major(0)
+            a, ga = emu.interpolate(dom, res, coeffs, P, grad=True)
+            emu.set_tile_major(2)
+            b, gb = emu.interpolate(dom, res, coeffs, P, grad=True)
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(ga, gb)
+        dom, res = golden["ico8_domain"], golden["ico8_res"]
+        coeffs = golden["ico8_coeffs"]
+        emu.set_tile_major(0)
+        d0 = emu.density_map(dom, res, coeffs, 0.1, 1000.0, begin=0, end=600)
+        emu.set_tile_major(2)
+        d1 = emu.density_map(dom, res, coeffs, 0.1, 1000.0, begin=0, end=600)
+        np.testing.assert_array_equal(d0, d1)
+        c2 = coeffs.copy()
+        c2[::41] = DBL_MAX
+        emu.set_tile_major(0)
+        e0 = emu.density_map(dom, res, c2, 0.1, 1000.0, begin=0, end=600)
+        emu.set_tile_major(2)
+        e1 = emu.density_map(dom, res, c2, 0.1, 1000.0, begin=0, end=600)
+        np.testing.assert_array_equal(e0, e1)
+        assert (e0 != d0).any()
+    finally:
+        emu.set_tile_major(0)
+
+
+@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5])
+def test_row_block_waves_own_every_node_once(shape):
+    """k_density_rows: wave ids -> row blocks (blocked order, XCD chunks) -> lanes -> nodes is a partition of the lattice for
+    every lane shape, block shape and resolution (no multiples of anything included)."""
+    for res, block in (([8, 8, 8], [2, 8, 8]), ([5, 7, 3], [2, 8, 8]), ([33, 3, 5], [1, 2, 3]), ([1, 1, 1], [4, 4, 4]),
+                       ([17, 9, 20], [3, 1, 64]), ([70, 4, 2], [2, 2, 2])):
+        hits, waves = emu.density_rows_cover(res, shape, block)
+        assert waves > 0
+        assert (hits == 1).all(), (res, block, np.unique(hits))
+
+
 def test_scalar_division_by_launch_constants_is_exact():
     """The brick map divides by launch constants with a host-made reciprocal (dg_kernels.h: udiv_by): exact
     quotient and remainder for every 32-bit dividend and every divisor >= 1, including the corners."""

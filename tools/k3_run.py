@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--sweep", default="", help="';'-separated settings, each 'NAME=v,NAME=v': one measurement per setting")
     a = ap.parse_args()
     import torch
     import dgtest as T
@@ -35,25 +36,33 @@ def main():
     out = torch.empty(n, dtype=torch.float64, device="cuda")
     fld.density_map_nodes_device(0.1, 1000.0, True, 0, min(n, 1 << 18), out.data_ptr(), stream=s)
     torch.cuda.synchronize()
-    ms = []
-    for _ in range(a.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fld.density_map_nodes_device(0.1, 1000.0, True, 0, n, out.data_ptr(), stream=s)
-        e1.record()
-        torch.cuda.synchronize()
-        ms.append(e0.elapsed_time(e1))
-    res = {"res": a.res, "ms": ms, "best_ms": min(ms)}
-    if a.check:
-        gold = np.load(os.path.join(ROOT, "tests", "golden", "lattice_digests.npz"))
-        key = "density%d_digest" % a.res
-        if key in gold:
-            got = T.block_digests(out.cpu().numpy())
-            res["mismatching_blocks"] = int((got != gold[key]).any(axis=1).sum())
-        else:
-            res["mismatching_blocks"] = None
-    print(json.dumps(res))
-
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "lattice_digests.npz"))
+    key = "density%d_digest" % a.res
+    for setting in (a.sweep.split(";") if a.sweep else [""]):
+        names = []
+        for kv in filter(None, setting.split(",")):
+            name, v = kv.split("=")
+            os.environ[name] = v
+            names.append(name)
+        out.fill_(-1.0)
+        ms = []
+        for _ in range(a.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fld.density_map_nodes_device(0.1, 1000.0, True, 0, n, out.data_ptr(), stream=s)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        res = {"res": a.res, "setting": setting, "ms": [round(m, 2) for m in ms], "best_ms": min(ms)}
+        if a.check:
+            if key in gold:
+                got = T.block_digests(out.cpu().numpy())
+                res["mismatching_blocks"] = int((got != gold[key]).any(axis=1).sum())
+            else:
+                res["mismatching_blocks"] = None
+        print(json.dumps(res), flush=True)
+        for name in names:
+            del os.environ[name]
 
 if __name__ == "__main__":
     main()
