@@ -293,7 +293,8 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "interpolations in the reference's count" % n_nodes}
     counters, _ = load_counters()
     k3c = ((counters or {}).get("workloads", {}).get("k3") or {})
-    k3k = next((v for k, v in k3c.items() if k.startswith("k_density_pairs")), None) or \
+    k3k = next((v for k, v in k3c.items() if k.startswith("k_density_rows")), None) or \
+        next((v for k, v in k3c.items() if k.startswith("k_density_pairs")), None) or \
         next((v for k, v in k3c.items() if k.startswith("k_density_bricks")), None)
     out_secondary["k3_density_map"]["roofline"] = None if k3k is None else {
         "bound": "vector memory pipeline (texture address / data units: every lane gathers the 256 B of its cell at each quadrature point) "

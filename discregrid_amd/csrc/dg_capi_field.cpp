@@ -530,7 +530,9 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// waves of k_density_pairs on the tile-major copy, 1..5: lane shapes, dg_layout.h row_shape_lanes()).  The copy (Y and Z
 	// classes with x fastest, 0.57 x the field) and the per-cell "no value" bits are stream-ordered scratch of this launch.
 	int rows_idx = -1;
-	const int rows_shape = env_int("DG_K3_ROWS", 1, 0, 5);
+	int rows_shape = env_int("DG_K3_ROWS", 1, 0, 4);
+	if (rows_shape == 2 || rows_shape == 3)
+		rows_shape = 1; // (lane shapes measured slower are not instantiated)
 	if (unreduced_field && rows_shape != 0 && node_begin == 0 && node_end == total && P.lds_waves == 0 && env_int("DG_K3_PAIRS", 2, 0, 3) != 0)
 	{
 		const size_t copy_bytes = ((size_t)dg::xmajor_doubles(dev.res) * sizeof(double) + 255) & ~(size_t)255;
@@ -541,9 +543,10 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		{
 			dev.xmajor = static_cast<const double*>(d_rows);
 			dev.xmajor_flags = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_rows) + copy_bytes);
-			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 2, 1, 64), (uint32_t)env_int("DG_K3_RB1", 8, 1, 64),
+			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 64), (uint32_t)env_int("DG_K3_RB1", 16, 1, 64),
 									   (uint32_t)env_int("DG_K3_RB2", 8, 1, 64)};
 			dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
+			P.row_waves3 = env_int("DG_K3_WAVES3", 1, 0, 1); // (3 waves per SIMD: 256^3 0.666 -> 0.618 s; the spilled registers belong to the prefilter)
 		}
 		else
 		{

@@ -33,10 +33,11 @@ struct DensityParams
 	uint16_t kmask[256];
 	int32_t skip_mode;
 	int32_t lds_waves; // device, tile-major copy: > 0: the kernel that stages the coefficients through LDS (waves per SIMD to aim for)
-	// device, x-major copy (k_density_rows): lane shape of a wave's row block (1: 16 x 2 x 2 cells, 2: 32 x 2 x 1, 3: 16 x 4 x 1,
-	// 4: 8 x 4 x 2, 5: 64 x 1 x 1; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
+	// device, x-major copy (k_density_rows): lane shape of a wave's row block (1: 16 x 2 x 2 cells, 4: 8 x 4 x 2 -- measured
+	// slower: 2: 32 x 2 x 1, 3: 16 x 4 x 1, 5: 64 x 1 x 1, kept for the partition test --; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
 	// class the wave counts along the three axes with the first wave id of the class
 	int32_t row_shape;
+	int32_t row_waves3; // k_density_rows: 1: the instantiation whose register budget allows three waves per SIMD
 	uint32_t row_block[3];
 	uint32_t row_waves[4][3];
 	uint32_t row_prefix[5];

@@ -2010,13 +2010,14 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 			return hipErrorInvalidValue;
 		if (f.xmajor_flags != nullptr && p.unsafe != nullptr)
 			hipLaunchKernelGGL(k_xmajor_flags, dim3(2048), dim3(256), 0, stream, f, p.unsafe, const_cast<uint64_t*>(f.xmajor_flags));
-#define DG_K3_ROWS(LX, LY, LZ) hipLaunchKernelGGL((k_density_rows<kFieldXMajor, LX, LY, LZ, 2>), grid, block, 0, stream, layout, f, p)
+#define DG_K3_ROWS(LX, LY, LZ)                                                                                          \
+	if (p.row_waves3)                                                                                                   \
+		hipLaunchKernelGGL((k_density_rows<kFieldXMajor, LX, LY, LZ, 3>), grid, block, 0, stream, layout, f, p);       \
+	else                                                                                                                \
+		hipLaunchKernelGGL((k_density_rows<kFieldXMajor, LX, LY, LZ, 2>), grid, block, 0, stream, layout, f, p)
 		switch (p.row_shape)
 		{
-		case 2: DG_K3_ROWS(32, 2, 1); break;
-		case 3: DG_K3_ROWS(16, 4, 1); break;
 		case 4: DG_K3_ROWS(8, 4, 2); break;
-		case 5: DG_K3_ROWS(64, 1, 1); break;
 		default: DG_K3_ROWS(16, 2, 2); break;
 		}
 #undef DG_K3_ROWS

@@ -317,6 +317,7 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 	P.skip_mode = 0;
 	P.lds_waves = 0;
 	P.row_shape = 0;
+	P.row_waves3 = 0;
 	P.unsafe = nullptr;
 }
 // lanes of a wave of k_density_rows along x, y, z (DensityParams::row_shape)
