@@ -98,6 +98,46 @@ def test_density_map_without_predicate_on_a_bigger_grid(dg):
     np.testing.assert_array_equal(f.density_map_nodes(n, 0.2, 1000.0, False), got)
 
 
+def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatch):
+    """Whole-lattice launches over an unreduced field take k_density_rows (row-block waves on the x-major copy of the Y / Z
+    classes); DG_K3_ROWS=0 is k_density_pairs on the tile-major copy.  Same bits from both lane shapes, both register budgets
+    and the pair kernel, on resolutions that are no multiples of the lane shape, with a node mask, and on fields spoilt with
+    "no value" (answered by the copy's one bit per cell), NaN and Inf coefficients (no skipping of zero-weight points) --
+    checked against the host emulation of the product's arithmetic."""
+    import emu
+    V, F = T.icosphere(8)
+    dom = T.oracle_default_domain(V)
+    rng = np.random.default_rng(11)
+    for res, h in (([21, 7, 10], 0.3), ([5, 35, 3], 0.25), ([40, 36, 33], 0.2)):
+        grid = dg.grid_desc(dom[:3], dom[3:], res)
+        sdf = dg.Mesh(V, F).sample_nodes(grid)
+        n = dg.n_nodes(grid)
+        spoilt = sdf.copy()
+        spoilt[rng.integers(0, n, size=max(3, n // 3000))] = DBL_MAX
+        worse = spoilt.copy()
+        worse[rng.integers(0, n, size=3)] = np.nan
+        worse[rng.integers(0, n, size=3)] = np.inf
+        mask = (np.arange(n) % 7 != 0).astype(np.uint8)
+        for name, coeffs in (("clean", sdf), ("no value", spoilt), ("nan / inf", worse)):
+            f = dg.Field(grid, coeffs)
+            got = {}
+            for tag, env in (("rows", {}), ("rows 8x4x2", {"DG_K3_ROWS": "4"}), ("rows, 2 waves", {"DG_K3_WAVES3": "0"}),
+                             ("rows, other blocks", {"DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}), ("pairs", {"DG_K3_ROWS": "0"})):
+                for k_, v_ in env.items():
+                    monkeypatch.setenv(k_, v_)
+                got[tag] = (f.density_map_nodes(n, h, 1000.0, True), f.density_map_nodes(n, h, 1000.0, False, mask=mask))
+                for k_ in env:
+                    monkeypatch.delenv(k_)
+            for tag in got:
+                np.testing.assert_array_equal(got[tag][0], got["pairs"][0], err_msg="%s %s %s" % (res, name, tag))
+                np.testing.assert_array_equal(got[tag][1], got["pairs"][1], err_msg="%s %s %s (mask)" % (res, name, tag))
+            assert (got["rows"][1][mask == 0] == DBL_MAX).all()
+            if res[0] != 40:   # (the emulator walks every quadrature point of every node on the host)
+                want = emu.density_map(dom, res, coeffs, h, 1000.0, band=True)
+                np.testing.assert_array_equal(got["rows"][0], want, err_msg="%s %s" % (res, name))
+            f.close()
+
+
 def test_generate_density_map_cli(tmp_path):
     """GenerateDensityMap on the golden SDF files == the files the reference's tool flow writes
     (addFunction with predicate, both reduceField calls, save), byte for byte."""
