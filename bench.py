@@ -297,8 +297,9 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         next((v for k, v in k3c.items() if k.startswith("k_density_pairs")), None) or \
         next((v for k, v in k3c.items() if k.startswith("k_density_bricks")), None)
     out_secondary["k3_density_map"]["roofline"] = None if k3k is None else {
-        "bound": "vector memory pipeline (texture address / data units: every lane gathers the 256 B of its cell at each quadrature point) "
-                 "+ f64 VALU, latency-bound at 2-3 waves per SIMD",
+        "bound": "vector memory pipeline (texture address / data units: every lane gathers the 256 B of its cell at each quadrature point, "
+                 "in rows along x since round 3: 19 instead of 31 sectors per load instruction) and f64 VALU, neither saturated: "
+                 "latency-bound at the 3 waves per SIMD its registers allow",
         "achieved": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]), "peak": 1.0,
         "unit": "busy fraction of the busiest unit (TA / TD / VALU)",
         "frac": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]),

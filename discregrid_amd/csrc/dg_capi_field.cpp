@@ -526,14 +526,14 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	L.brick_blocking = env_int("DG_K3_BLOCKED", 1, 0, 1);
 	P.lds_waves = env_int("DG_K3_LDS", 0, 0, 3); // experiment: coefficients staged through LDS (measured slower)
 	const bool unreduced_field = dev.cells == nullptr && dev.cell_map == nullptr;
-	// Whole lattice of an unreduced field: row-block waves on the x-major copy (k_density_rows; DG_K3_ROWS=0: the cube-shaped
+	// An eighth of the lattice or more of an unreduced field: row-block waves on the x-major copy (k_density_rows; DG_K3_ROWS=0: the cube-shaped
 	// waves of k_density_pairs on the tile-major copy, 1..5: lane shapes, dg_layout.h row_shape_lanes()).  The copy (Y and Z
 	// classes with x fastest, 0.57 x the field) and the per-cell "no value" bits are stream-ordered scratch of this launch.
 	int rows_idx = -1;
 	int rows_shape = env_int("DG_K3_ROWS", 1, 0, 4);
 	if (rows_shape == 2 || rows_shape == 3)
 		rows_shape = 1; // (lane shapes measured slower are not instantiated)
-	if (unreduced_field && rows_shape != 0 && node_begin == 0 && node_end == total && P.lds_waves == 0 && env_int("DG_K3_PAIRS", 2, 0, 3) != 0)
+	if (unreduced_field && rows_shape != 0 && (node_end - node_begin) * 8 >= total && P.lds_waves == 0 && env_int("DG_K3_PAIRS", 2, 0, 3) != 0)
 	{
 		const size_t copy_bytes = ((size_t)dg::xmajor_doubles(dev.res) * sizeof(double) + 255) & ~(size_t)255;
 		const size_t flag_bytes = (size_t)dev.res[2] * dev.res[1] * dg::xmajor_flag_words(dev.res) * sizeof(uint64_t);
@@ -546,6 +546,8 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 64), (uint32_t)env_int("DG_K3_RB1", 16, 1, 64),
 									   (uint32_t)env_int("DG_K3_RB2", 8, 1, 64)};
 			dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
+			P.row_node_begin = node_begin;
+			P.row_node_end = node_end;
 			P.row_waves3 = env_int("DG_K3_WAVES3", 1, 0, 1); // (3 waves per SIMD: 256^3 0.666 -> 0.618 s; the spilled registers belong to the prefilter)
 		}
 		else

@@ -37,6 +37,7 @@ struct DensityParams
 	// slower: 2: 32 x 2 x 1, 3: 16 x 4 x 1, 5: 64 x 1 x 1, kept for the partition test --; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
 	// class the wave counts along the three axes with the first wave id of the class
 	int32_t row_shape;
+	uint64_t row_node_begin, row_node_end; // k_density_rows: the launch's node range (out[l - row_node_begin]); lanes outside idle
 	int32_t row_waves3; // k_density_rows: 1: the instantiation whose register budget allows three waves per SIMD
 	uint32_t row_block[3];
 	uint32_t row_waves[4][3];

@@ -1371,7 +1371,10 @@ __global__ __launch_bounds__(64, WAVES) void k_density_rows(const SampleParams L
 	double xa[3], xb[3];
 	node_position(cls, it.a, it.b, it.s, L.dmin, L.cell, xa);
 	node_position(cls, cls != 0 ? it.a + 1u : it.a, it.b, it.s, L.dmin, L.cell, xb);
-	k3_pair_wave<MODE>(L, F, P, cls, lane, it.valid, it.valid && cls != 0, (int64_t)it.node, (int64_t)it.node + 1, xa, xb);
+	// (a launch over a node range: the waves cover the whole lattice, lanes whose node lies outside the range idle)
+	const bool in_a = it.valid && it.node >= P.row_node_begin && it.node < P.row_node_end;
+	const bool in_b = it.valid && cls != 0 && it.node + 1 >= P.row_node_begin && it.node + 1 < P.row_node_end;
+	k3_pair_wave<MODE>(L, F, P, cls, lane, in_a, in_b, (int64_t)(it.node - P.row_node_begin), (int64_t)(it.node + 1 - P.row_node_begin), xa, xb);
 }
 
 // the x-major copy (dg_lattice.h): one thread per pair of the copy, contiguous 16-byte writes, reads a plane apart

@@ -348,6 +348,8 @@ inline uint64_t layout_density_rows(DensityParams& P, SampleParams& L, const uin
 		prefix += n;
 	}
 	P.row_prefix[4] = (uint32_t)prefix;
+	P.row_node_begin = 0;
+	P.row_node_end = ~0ull;
 	for (int d = 0; d < 3; ++d)
 		P.row_block[d] = std::max(1u, block[d]);
 	L.total_bricks = prefix;

@@ -132,6 +132,10 @@ def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatc
                 np.testing.assert_array_equal(got[tag][0], got["pairs"][0], err_msg="%s %s %s" % (res, name, tag))
                 np.testing.assert_array_equal(got[tag][1], got["pairs"][1], err_msg="%s %s %s (mask)" % (res, name, tag))
             assert (got["rows"][1][mask == 0] == DBL_MAX).all()
+            # node ranges: an eighth of the lattice or more stays with the row kernel (lanes outside the range idle), less goes to the pair kernel
+            for b, e in ((n // 3, n - 5), (n // 2, n // 2 + n // 7), (17, 17 + n // 20)):
+                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, b, e), got["pairs"][0][b:e], err_msg="%s %s [%d, %d)" % (res, name, b, e))
+                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False, b, e, mask=mask[b:e]), got["pairs"][1][b:e])
             if res[0] != 40:   # (the emulator walks every quadrature point of every node on the host)
                 want = emu.density_map(dom, res, coeffs, h, 1000.0, band=True)
                 np.testing.assert_array_equal(got["rows"][0], want, err_msg="%s %s" % (res, name))
