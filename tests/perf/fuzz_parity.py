@@ -93,6 +93,13 @@ def main():
             k3 = fk.density_map_nodes(len(sdf), h, 1000.0, band, b, e)
             w3 = T.oracle_density_map(dom, res, sdf, h, 1000.0, band, b, e)
             ok = ok and np.array_equal(k3, w3, equal_nan=True)
+            # the whole lattice goes through the row-block kernel (k_density_rows), a small slice through the pair kernel:
+            # the slice of the one == the oracle, and the whole == the pair kernel's whole (DG_K3_ROWS=0)
+            full = fk.density_map_nodes(len(sdf), h, 1000.0, band)
+            os.environ["DG_K3_ROWS"] = "0"
+            full_pairs = fk.density_map_nodes(len(sdf), h, 1000.0, band)
+            del os.environ["DG_K3_ROWS"]
+            ok = ok and np.array_equal(full[b:e], w3, equal_nan=True) and np.array_equal(full, full_pairs, equal_nan=True)
             k3_rounds[0] += 1
         rounds += 1
         nodes += len(got)
