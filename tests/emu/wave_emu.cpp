@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../discregrid_amd/csrc/dg_build.h"
@@ -222,6 +223,35 @@ struct FastLane
 	int cnt;
 	int list[kFastListCap + 1];
 };
+// design study (EMU_DEPTH_HIST=1): pair steps of the filtered traversal by depth of the node in the tree
+int g_depth_hist_on = getenv("EMU_DEPTH_HIST") != nullptr;
+static std::vector<int> g_pair_depth;
+static uint64_t g_depth_hist[64];
+static void depth_hist_note(const MeshDev& M, int cur)
+{
+	static std::mutex mu;
+	std::lock_guard<std::mutex> lock(mu);
+	if (g_pair_depth.empty())
+	{
+		g_pair_depth.assign((size_t)M.n_positions + 8, -1); // (more than enough: pair records < positions)
+		std::vector<std::pair<int, int>> open(1, std::make_pair(M.root_info, 0));
+		while (!open.empty())
+		{
+			const std::pair<int, int> t = open.back();
+			open.pop_back();
+			if (t.first < 0)
+				continue;
+			if ((size_t)t.first >= g_pair_depth.size())
+				g_pair_depth.resize((size_t)t.first + 1, -1);
+			g_pair_depth[(size_t)t.first] = t.second;
+			open.push_back(std::make_pair(M.pairs[t.first].info[0], t.second + 1));
+			open.push_back(std::make_pair(M.pairs[t.first].info[1], t.second + 1));
+		}
+	}
+	const int d = g_pair_depth[(size_t)cur];
+	g_depth_hist[d < 0 ? 63 : (d > 62 ? 62 : d)]++;
+}
+extern "C" void emu_depth_hist(uint64_t* out /*64*/) { for (int i = 0; i < 64; ++i) out[i] = g_depth_hist[i]; }
 thread_local std::vector<std::pair<int,int>> g_leaf_log; // (first, cnt) of the leaves a traversal visited (design studies)
 int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowBuf* ovf)
 {
@@ -314,6 +344,8 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 		{
 			const PairRec& pr = M.pairs[cur];
 			st.pair_steps++;
+			if (g_depth_hist_on)
+				depth_hist_note(M, cur);
 			float lbl[64], lbr[64];
 			bool anyl = false, anyr = false;
 			int pref = 0, act = 0;
