@@ -504,8 +504,8 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		if (it == sdf->wtabs.end())
 		{
 			void* d_w = nullptr;
-			DG_HIP(hipMalloc(&d_w, 4096 * sizeof(double)));
-			const hipError_t e = hipMemcpy(d_w, w.data(), 4096 * sizeof(double), hipMemcpyHostToDevice);
+			DG_HIP(hipMalloc(&d_w, w.size() * sizeof(double)));
+			const hipError_t e = hipMemcpy(d_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice);
 			if (e != hipSuccess)
 			{
 				(void)hipFree(d_w);
@@ -545,7 +545,13 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 			dev.xmajor_flags = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_rows) + copy_bytes);
 			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 64), (uint32_t)env_int("DG_K3_RB1", 16, 1, 64),
 									   (uint32_t)env_int("DG_K3_RB2", 8, 1, 64)};
-			dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
+			// round 4: one lane per lattice POINT with its seven nodes (k_density_cells, dg_density_cells.h: 3 cell fetches per 7
+			// nodes and quadrature point instead of 5, one sweep of the field instead of one per node class); DG_K3_CELLS=0: the
+			// row-block kernel with one node / edge per lane
+			if (env_int("DG_K3_CELLS", 1, 0, 1) != 0 && dg::k3c_geometry_fits(dev.res))
+				dg::layout_density_cells(P, L, sdf->grid.resolution, block);
+			else
+				dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
 			P.row_node_begin = node_begin;
 			P.row_node_end = node_end;
 			P.row_waves3 = env_int("DG_K3_WAVES3", 1, 0, 1); // (3 waves per SIMD: 256^3 0.666 -> 0.618 s; the spilled registers belong to the prefilter)

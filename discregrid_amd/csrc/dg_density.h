@@ -36,6 +36,7 @@ struct DensityParams
 	// device, x-major copy (k_density_rows): lane shape of a wave's row block (1: 16 x 2 x 2 cells, 4: 8 x 4 x 2 -- measured
 	// slower: 2: 32 x 2 x 1, 3: 16 x 4 x 1, 5: 64 x 1 x 1, kept for the partition test --; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
 	// class the wave counts along the three axes with the first wave id of the class
+	// 6 (kRowShapeCells): k_density_cells -- a lane owns a lattice POINT with its seven nodes, waves of 16 x 2 x 2 points (dg_density_cells.h)
 	int32_t row_shape;
 	uint64_t row_node_begin, row_node_end; // k_density_rows: the launch's node range (out[l - row_node_begin]); lanes outside idle
 	int32_t row_waves3; // k_density_rows: 1: the instantiation whose register budget allows three waves per SIMD
@@ -45,6 +46,7 @@ struct DensityParams
 	const uint32_t* unsafe;
 };
 
+static const int kRowShapeCells = 6;
 // k_density_rows: wave id -> (class, wave coordinates along x, y, z).  The waves of a class fill blocks of
 // row_block[0] x [1] x [2] waves (truncated at the upper faces), blocks in row-major order: the waves an XCD has in
 // flight -- consecutive ids -- integrate over (nearly) the same part of the field at the same time.  A bijection of

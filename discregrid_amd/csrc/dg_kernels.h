@@ -508,3 +508,5 @@ hipError_t launch_signed_distance(const SampleParams& p, const TileGrid* tiles, 
 
 
 } // namespace dg
+
+#include "dg_density_cells.h" // K3, one lane per lattice point (needs SampleParams)

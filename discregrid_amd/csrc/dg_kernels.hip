@@ -1377,6 +1377,118 @@ __global__ __launch_bounds__(64, WAVES) void k_density_rows(const SampleParams L
 	k3_pair_wave<MODE>(L, F, P, cls, lane, in_a, in_b, (int64_t)(it.node - P.row_node_begin), (int64_t)(it.node + 1 - P.row_node_begin), xa, xb);
 }
 
+
+// ---- K3, one lane per lattice point (dg_density_cells.h) ----------------------------------------------------------------
+// The wave context of k3c_lane() on the device: ballots, and the LDS tables of the axis states of the shifted coordinates.
+// Producers: the X states of (variant v, lane x) come from the lane (x, y = v, z = 0), the Y states of (v, lane y) from
+// the lane (x = v, y, z = 0), the Z states from lanes 0..5 for one k after the other -- each the pure function
+// k3_axis_entry() of a coordinate that depends on the lattice index along that axis only, i.e. the value the consuming
+// lane would compute itself.  One wave per workgroup: the barriers cost nothing and fence the compiler.
+struct K3WaveDev
+{
+	K3Axis* sX; // [2][16]    (variant, lane x)
+	K3Axis* sY; // [2][2]     (variant, lane y)
+	K3Axis* sZ; // [16][3][2] (k, variant: lattice point / node A / node B, lane z)
+	uint32_t* sZb; // [16][2] (k, lane z): k3c_axis_bits() of the z axis
+	double* sR; // [7][64]    the seven sums of every lane (registers are what this kernel is short of)
+	int lane, ix, iy, iz;
+	__device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
+	__device__ __forceinline__ void acc_init()
+	{
+#pragma unroll
+		for (int n = 0; n < 7; ++n)
+			sR[n * 64 + lane] = 0.0;
+	}
+	__device__ __forceinline__ void acc_add(int n, double t) { sR[n * 64 + lane] += t; }
+	__device__ __forceinline__ double acc_get(int n) const { return sR[n * 64 + lane]; }
+	__device__ __forceinline__ void set_x(const FieldDev& F, double a, double b)
+	{
+		const K3Axis e = k3_axis_entry(F, 0, iy == 0 ? a : b);
+		__syncthreads();
+		if (iz == 0)
+			sX[iy * 16 + ix] = e;
+		__syncthreads();
+	}
+	__device__ __forceinline__ void set_y(const FieldDev& F, double a, double b)
+	{
+		const K3Axis e = k3_axis_entry(F, 1, ix == 0 ? a : b);
+		__syncthreads();
+		if (iz == 0 && ix < 2)
+			sY[ix * 2 + iy] = e;
+		__syncthreads();
+	}
+	__device__ __forceinline__ void set_z(const FieldDev& F, const DensityParams& P, const SampleParams& L, const RowWave& m, double, double, double)
+	{
+		const int v = lane >> 1, s = lane & 1; // lanes 0..5
+		uint32_t kz = m.w[2] * (uint32_t)kK3cLz + (uint32_t)s;
+		kz = kz <= F.res[2] ? kz : F.res[2];
+		double z = L.dmin[2] + L.cell[2] * (double)kz;
+		if (v == 1)
+			z = z + 1.0 / 3.0 * L.cell[2];
+		else if (v == 2)
+			z = z + 2.0 / 3.0 * L.cell[2];
+		DG_NOUNROLL
+		for (int k = 0; k < 16; ++k)
+		{
+			const K3Axis e = k3_axis_entry(F, 2, z + P.xi[k]);
+			if (lane < 6)
+				sZ[k * 6 + lane] = e; // (k * 3 + v) * 2 + s
+		}
+		__syncthreads();
+		// the z axis' verdict on the seven nodes (k3c_axis_bits()) for every k and lane z, once
+		if (lane < 32)
+		{
+			const int k = lane >> 1, sl = lane & 1;
+			const K3Axis* z = sZ + k * 6 + sl;
+			sZb[lane] = k3c_axis_bits(kK3cZ0, kK3cZA, kK3cZB, z[0].mi, z[0].inside != 0u, z[2].mi, z[2].inside != 0u, z[4].mi, z[4].inside != 0u);
+		}
+		__syncthreads();
+	}
+	__device__ __forceinline__ uint32_t z_bits(const FieldDev&, const DensityParams&, int k) const { return sZb[k * 2 + iz]; }
+	__device__ __forceinline__ K3Axis x_var(const FieldDev&, int v) const { return sX[v * 16 + ix]; }
+	__device__ __forceinline__ K3Axis y_var(const FieldDev&, int v) const { return sY[v * 2 + iy]; }
+	__device__ __forceinline__ K3Axis z_var(const FieldDev&, const DensityParams&, int k, int v) const { return sZ[(k * 3 + v) * 2 + iz]; }
+	__device__ __forceinline__ void x_id(const FieldDev&, int v, uint32_t* mi, bool* in) const
+	{
+		*mi = sX[v * 16 + ix].mi;
+		*in = sX[v * 16 + ix].inside != 0u;
+	}
+	__device__ __forceinline__ void y_id(const FieldDev&, int v, uint32_t* mi, bool* in) const
+	{
+		*mi = sY[v * 2 + iy].mi;
+		*in = sY[v * 2 + iy].inside != 0u;
+	}
+	__device__ __forceinline__ void z_id(const FieldDev&, const DensityParams&, int k, int v, uint32_t* mi, bool* in) const
+	{
+		*mi = sZ[(k * 3 + v) * 2 + iz].mi;
+		*in = sZ[(k * 3 + v) * 2 + iz].inside != 0u;
+	}
+};
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_density_cells(const SampleParams L, const FieldDev F, const DensityParams P, const K3CellsGeom G)
+{
+	__shared__ K3Axis sX[2 * 16], sY[2 * 2], sZ[16 * 3 * 2];
+	__shared__ double sR[7 * 64];
+	__shared__ uint32_t sZb[16 * 2];
+	uint32_t blk;
+	if (!logical_block(L, blockIdx.x, &blk))
+		return;
+	if (blk >= P.row_prefix[4])
+		return;
+	const RowWave m = row_wave_map(P, blk);
+	K3WaveDev w;
+	w.sX = sX;
+	w.sY = sY;
+	w.sZ = sZ;
+	w.sR = sR;
+	w.sZb = sZb;
+	w.lane = (int)(threadIdx.x & 63u);
+	w.ix = w.lane & 15;
+	w.iy = (w.lane >> 4) & 1;
+	w.iz = w.lane >> 5;
+	k3c_lane(w, L, F, P, G, m, w.lane);
+}
+
 // the x-major copy (dg_lattice.h): one thread per pair of the copy, contiguous 16-byte writes, reads a plane apart
 __global__ __launch_bounds__(256) void k_xmajor_copy(const FieldDev F, uint32_t n_pairs, double* __restrict__ out)
 {
@@ -2013,6 +2125,17 @@ hipError_t launch_density_bricks(const SampleParams& layout, const FieldDev& f, 
 			return hipErrorInvalidValue;
 		if (f.xmajor_flags != nullptr && p.unsafe != nullptr)
 			hipLaunchKernelGGL(k_xmajor_flags, dim3(2048), dim3(256), 0, stream, f, p.unsafe, const_cast<uint64_t*>(f.xmajor_flags));
+		if (p.row_shape == kRowShapeCells) // one lane per lattice point, all seven nodes of the point (dg_density_cells.h)
+		{
+			if (f.xmajor_flags == nullptr || !k3c_geometry_fits(f.res))
+				return hipErrorInvalidValue;
+			const K3CellsGeom g = k3c_geometry(f);
+			if (p.row_waves3)
+				hipLaunchKernelGGL((k_density_cells<3>), grid, block, 0, stream, layout, f, p, g);
+			else
+				hipLaunchKernelGGL((k_density_cells<2>), grid, block, 0, stream, layout, f, p, g);
+			break;
+		}
 #define DG_K3_ROWS(LX, LY, LZ)                                                                                          \
 	if (p.row_waves3)                                                                                                   \
 		hipLaunchKernelGGL((k_density_rows<kFieldXMajor, LX, LY, LZ, 3>), grid, block, 0, stream, layout, f, p);       \

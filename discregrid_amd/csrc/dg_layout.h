@@ -299,11 +299,18 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 		P.w[i] = kGaussW[i];
 	}
 	const double k = cubic_kernel_k(h);
-	wtab_host.resize(4096);
+	// [0, 4096): W(xi_i, xi_j, xi_k); [4096, 8192): the weight products (w_i * w_j) * w_k as the kernels' loops form them
+	// (k_density_cells reads them as scalars instead of keeping w_i w_j in vector registers)
+	wtab_host.resize(8192);
 	for (int i = 0; i < 16; ++i)
 		for (int j = 0; j < 16; ++j)
 			for (int kk = 0; kk < 16; ++kk)
+			{
 				wtab_host[(i * 16 + j) * 16 + kk] = cubic_kernel_W(P.xi[i], P.xi[j], P.xi[kk], h, k, HostSqrt());
+				const double wi = P.w[i];
+				const double wij = wi * P.w[j];
+				wtab_host[4096 + (i * 16 + j) * 16 + kk] = wij * P.w[kk];
+			}
 	P.wtab = nullptr;
 	for (int i = 0; i < 16; ++i)
 		for (int j = 0; j < 16; ++j)
@@ -358,6 +365,34 @@ inline uint64_t layout_density_rows(DensityParams& P, SampleParams& L, const uin
 	L.xcd_chunk = 0;
 	finish_blocks(L);
 	return prefix;
+}
+// K3 with one lane per lattice point (k_density_cells): waves of 16 x 2 x 2 points over the (n + 1)^3 point lattice, ids in
+// blocks of `block` waves like layout_density_rows() (one "class" holds every wave); returns the number of waves
+inline uint64_t layout_density_cells(DensityParams& P, SampleParams& L, const uint32_t res[3], const uint32_t block[3])
+{
+	const uint32_t l[3] = {(uint32_t)kK3cLx, (uint32_t)kK3cLy, (uint32_t)kK3cLz};
+	P.row_shape = kRowShapeCells;
+	uint64_t n = 1;
+	for (int d = 0; d < 3; ++d)
+	{
+		P.row_waves[0][d] = (res[d] + 1 + l[d] - 1) / l[d];
+		n *= P.row_waves[0][d];
+		for (int c = 1; c < 4; ++c)
+			P.row_waves[c][d] = 0;
+	}
+	P.row_prefix[0] = 0;
+	for (int c = 1; c <= 4; ++c)
+		P.row_prefix[c] = (uint32_t)n;
+	P.row_node_begin = 0;
+	P.row_node_end = ~0ull;
+	for (int d = 0; d < 3; ++d)
+		P.row_block[d] = std::max(1u, block[d]);
+	L.total_bricks = n;
+	L.n_blocks = (uint32_t)n;
+	L.pair_nodes = 0;
+	L.xcd_chunk = 0;
+	finish_blocks(L);
+	return n;
 }
 // may the zero-weight points be skipped for this coefficient? (host mirror of k_field_check)
 inline bool density_value_unsafe(double c) { return c != 1.7976931348623157e308 && !(std::fabs(c) < 1.0e290); }

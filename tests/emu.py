@@ -301,6 +301,32 @@ def density_rows_cover(res, shape, block):
     return hits, waves
 
 
+def density_cells(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, mask=None, block=(1, 16, 8)):
+    """One emulated k_density_cells launch (a lane owns a lattice point with its seven nodes, dg_density_cells.h) over the
+    node range: the values and, per node, how many lanes wrote it."""
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    block = np.ascontiguousarray(block, dtype=np.uint32)
+    cell = np.empty(3)
+    inv = np.empty(3)
+    T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    if end is None:
+        end = T.n_nodes(res)
+    out = np.empty(end - begin)
+    hits = np.zeros(end - begin, dtype=np.uint32)
+    L = lib()
+    L.emu_density_cells.restype = None
+    L.emu_density_cells.argtypes = [T.c_dp, T.c_dp, T.c_dp, T.c_up, T.c_dp, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint64,
+                                    C.c_void_p, T.c_up, T.c_dp, C.c_void_p]
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    L.emu_density_cells(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), h, rho0, int(band), begin, end,
+                        mask.ctypes.data_as(C.c_void_p) if mask is not None else None, T.up(block), T.dp(out),
+                        hits.ctypes.data_as(C.c_void_p))
+    return out, hits
+
+
 def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
     slots = 0 disables the split; the defaults size slots and budget as the product does."""

@@ -1316,6 +1316,102 @@ uint64_t emu_density_rows_cover(const uint32_t res[3], int shape, const uint32_t
 	}
 	return waves;
 }
+extern int g_density_skip;
+// K3 with one lane per lattice point (dg_density_cells.h) on the host: every wave and lane of a k_density_cells launch over
+// [begin, end) -- layout_density_cells(), logical_block(), row_wave_map(), k3c_lane() with the host's wave context (the
+// table entries computed where they are read).  out[l - begin]; hits[l - begin] += 1 for every node a lane writes (the
+// caller checks "exactly once").  mask (nullable) is indexed like out.
+void emu_density_cells(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
+					   const double* coeffs, double h, double rho0, int band, uint64_t begin, uint64_t end, const uint8_t* mask,
+					   const uint32_t block[3], double* out, uint32_t* hits)
+{
+	FieldDev F;
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = domain[d];
+		F.dmax[d] = domain[3 + d];
+		F.cell[d] = cell[d];
+		F.inv_cell[d] = inv_cell[d];
+		F.res[d] = res[d];
+	}
+	F.coeffs = coeffs;
+	F.cells = nullptr;
+	F.cell_map = nullptr;
+	F.cell_major = nullptr;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
+	XMajorCopy xm;
+	build_xmajor(F, xm);
+	DensityParams P;
+	std::vector<double> w;
+	init_density_params(P, h, rho0, cell, band, w);
+	P.wtab = w.data();
+	uint32_t flags = 0;
+	{
+		dg::ClassGeom cg[4];
+		const uint64_t n_coeffs = dg::class_geometry(res, cg);
+		for (uint64_t i = 0; i < n_coeffs; ++i)
+		{
+			if (density_value_unsafe(coeffs[i]))
+				flags |= 1u;
+			if (coeffs[i] == 1.7976931348623157e308)
+				flags |= 2u;
+		}
+	}
+	P.skip_mode = (h >= 1.0e-12 && g_density_skip) ? 2 : 0;
+	P.unsafe = &flags;
+	SampleParams L;
+	std::memset(&L, 0, sizeof(L));
+	for (int d = 0; d < 3; ++d)
+	{
+		L.dmin[d] = domain[d];
+		L.cell[d] = cell[d];
+	}
+	layout_density_cells(P, L, res, block);
+	P.row_node_begin = begin;
+	P.row_node_end = end;
+	L.mask = mask;
+	L.out = out;
+	const K3CellsGeom G = k3c_geometry(F);
+	const uint32_t grid = L.blocks_per_xcd * 8u;
+	for (uint64_t l = 0; l < end - begin; ++l)
+		out[l] = -7.0; // (no node value is negative: 0, a density, or DBL_MAX)
+#pragma omp parallel for schedule(dynamic, 4)
+	for (long long b = 0; b < (long long)grid; ++b)
+	{
+		uint32_t blk;
+		if (!logical_block(L, (uint32_t)b, &blk) || blk >= P.row_prefix[4])
+			continue;
+		const RowWave m = row_wave_map(P, blk);
+		for (int lane = 0; lane < 64; ++lane)
+		{
+			K3HostWave hw;
+			k3c_lane(hw, L, F, P, G, m, lane);
+		}
+	}
+	// a second pass that only records which nodes the launch's lanes own (valid lanes' nodes inside the range)
+	for (uint32_t b = 0; b < grid; ++b)
+	{
+		uint32_t blk;
+		if (!logical_block(L, b, &blk) || blk >= P.row_prefix[4])
+			continue;
+		const RowWave m = row_wave_map(P, blk);
+		for (int lane = 0; lane < 64; ++lane)
+		{
+			uint32_t i = m.w[0] * (uint32_t)kK3cLx + ((uint32_t)lane & 15u), j = m.w[1] * (uint32_t)kK3cLy + (((uint32_t)lane >> 4) & 1u),
+					 k = m.w[2] * (uint32_t)kK3cLz + ((uint32_t)lane >> 5);
+			const bool valid = i <= res[0] && j <= res[1] && k <= res[2];
+			i = std::min(i, res[0]);
+			j = std::min(j, res[1]);
+			k = std::min(k, res[2]);
+			const K3PointNodes pn = k3c_point_nodes(res, i, j, k, valid);
+			for (int e = 0; e < 4; ++e)
+				for (uint64_t s = 0; s < (e == 0 ? 1u : 2u); ++s)
+					if (pn.valid[e] && pn.node[e] + s >= begin && pn.node[e] + s < end)
+						hits[pn.node[e] + s - begin] += 1;
+		}
+	}
+}
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)

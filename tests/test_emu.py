@@ -460,6 +460,60 @@ def test_row_block_waves_own_every_node_once(shape):
         assert (hits == 1).all(), (res, block, np.unique(hits))
 
 
+def test_point_lanes_with_seven_nodes_equal_the_per_node_body(golden):
+    """k_density_cells (dg_density_cells.h): a lane owns a lattice point with its seven nodes, evaluates the points that share a
+    cell from one fetch and takes the axis states of the shifted coordinates from tables.  Every node of the lattice is written
+    exactly once, and with the bits of the per-node body (density_prefilter + density_integral) -- on lattices that are no
+    multiples of the wave shape, support radii from a fraction of a cell to several cells (the seven points then spread over
+    one to four cells), with and without the node predicate, node ranges, masks, and fields spoilt with "no value", NaN and
+    Inf coefficients (the latter evaluate every one of the 4096 points)."""
+    rng = np.random.default_rng(77)
+    dom, res = golden["ico8_domain"], [int(r) for r in golden["ico8_res"]]
+    coeffs = golden["ico8_coeffs"]
+    n = T.n_nodes(res)
+    cases = [(dom, res, coeffs, 0.1, True), (dom, res, coeffs, 0.23, False)]
+    V, F = T.icosphere(4)
+    d2 = T.oracle_default_domain(V)
+    for r2, h in (([5, 7, 3], 0.3), ([17, 2, 4], 0.08), ([1, 1, 1], 0.5), ([3, 18, 2], 0.6)):
+        c2 = T.OracleMesh(V, F).sample_nodes(d2, r2)
+        cases.append((d2, r2, c2, h, True))
+        cases.append((d2, r2, c2, h, False))
+    emu.set_tile_major(2)
+    try:
+        for ci, (dm, rs, cf, h, band) in enumerate(cases):
+            nn = T.n_nodes(rs)
+            want = emu.density_map(dm, rs, cf, h, 1000.0, band=band)
+            got, hits = emu.density_cells(dm, rs, cf, h, 1000.0, band=band, block=(1 + ci % 3, 2, 5))
+            assert (hits == 1).all(), (rs, np.unique(hits))
+            np.testing.assert_array_equal(got, want, err_msg="%s h=%g band=%s" % (rs, h, band))
+            assert ((got != 0.0) & (got != DBL_MAX)).sum() > 0
+            # a node range (lanes outside idle) and a mask
+            b, e = nn // 3, nn - 2
+            got_r, hits_r = emu.density_cells(dm, rs, cf, h, 1000.0, band=band, begin=b, end=e)
+            assert (hits_r == 1).all()
+            np.testing.assert_array_equal(got_r, want[b:e])
+            mask = (np.arange(nn) % 5 != 0).astype(np.uint8)
+            got_m, _ = emu.density_cells(dm, rs, cf, h, 1000.0, band=band, mask=mask)
+            np.testing.assert_array_equal(got_m[mask == 1], want[mask == 1])
+            assert (got_m[mask == 0] == DBL_MAX).all()
+        # spoilt fields
+        for rs, h in (([5, 7, 3], 0.3), ([9, 4, 6], 0.2)):
+            cf = T.OracleMesh(V, F).sample_nodes(d2, rs)
+            nn = T.n_nodes(rs)
+            spoilt = cf.copy()
+            spoilt[rng.integers(0, nn, size=6)] = DBL_MAX
+            worse = spoilt.copy()
+            worse[rng.integers(0, nn, size=2)] = np.nan
+            worse[rng.integers(0, nn, size=2)] = np.inf
+            for name, c in (("no value", spoilt), ("nan / inf", worse)):
+                want = emu.density_map(d2, rs, c, h, 1000.0, band=True)
+                got, hits = emu.density_cells(d2, rs, c, h, 1000.0, band=True)
+                assert (hits == 1).all()
+                np.testing.assert_array_equal(got, want, err_msg="%s %s" % (rs, name))
+    finally:
+        emu.set_tile_major(0)
+
+
 def test_scalar_division_by_launch_constants_is_exact():
     """The brick map divides by launch constants with a host-made reciprocal (dg_kernels.h: udiv_by): exact
     quotient and remainder for every 32-bit dividend and every divisor >= 1, including the corners."""

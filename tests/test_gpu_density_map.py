@@ -99,11 +99,12 @@ def test_density_map_without_predicate_on_a_bigger_grid(dg):
 
 
 def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatch):
-    """Whole-lattice launches over an unreduced field take k_density_rows (row-block waves on the x-major copy of the Y / Z
-    classes); DG_K3_ROWS=0 is k_density_pairs on the tile-major copy.  Same bits from both lane shapes, both register budgets
-    and the pair kernel, on resolutions that are no multiples of the lane shape, with a node mask, and on fields spoilt with
-    "no value" (answered by the copy's one bit per cell), NaN and Inf coefficients (no skipping of zero-weight points) --
-    checked against the host emulation of the product's arithmetic."""
+    """Whole-lattice launches over an unreduced field take k_density_cells (round 4: a lane owns a lattice point with its seven
+    nodes, waves of 16 x 2 x 2 points on the x-major copy of the Y / Z classes); DG_K3_CELLS=0 is k_density_rows (one node or
+    edge per lane), DG_K3_ROWS=0 k_density_pairs on the tile-major copy.  Same bits from all of them, from both register
+    budgets, other block shapes and lane shapes, on resolutions that are no multiples of the lane shape, with a node mask, and
+    on fields spoilt with "no value" (answered by the copy's one bit per cell), NaN and Inf coefficients (no skipping of
+    zero-weight points) -- checked against the host emulation of the product's arithmetic."""
     import emu
     V, F = T.icosphere(8)
     dom = T.oracle_default_domain(V)
@@ -121,8 +122,12 @@ def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatc
         for name, coeffs in (("clean", sdf), ("no value", spoilt), ("nan / inf", worse)):
             f = dg.Field(grid, coeffs)
             got = {}
-            for tag, env in (("rows", {}), ("rows 8x4x2", {"DG_K3_ROWS": "4"}), ("rows, 2 waves", {"DG_K3_WAVES3": "0"}),
-                             ("rows, other blocks", {"DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}), ("pairs", {"DG_K3_ROWS": "0"})):
+            for tag, env in (("cells", {}), ("cells, 2 waves", {"DG_K3_WAVES3": "0"}),
+                             ("cells, other blocks", {"DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}),
+                             ("rows", {"DG_K3_CELLS": "0"}), ("rows 8x4x2", {"DG_K3_CELLS": "0", "DG_K3_ROWS": "4"}),
+                             ("rows, 2 waves", {"DG_K3_CELLS": "0", "DG_K3_WAVES3": "0"}),
+                             ("rows, other blocks", {"DG_K3_CELLS": "0", "DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}),
+                             ("pairs", {"DG_K3_ROWS": "0"})):
                 for k_, v_ in env.items():
                     monkeypatch.setenv(k_, v_)
                 got[tag] = (f.density_map_nodes(n, h, 1000.0, True), f.density_map_nodes(n, h, 1000.0, False, mask=mask))
@@ -131,14 +136,14 @@ def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatc
             for tag in got:
                 np.testing.assert_array_equal(got[tag][0], got["pairs"][0], err_msg="%s %s %s" % (res, name, tag))
                 np.testing.assert_array_equal(got[tag][1], got["pairs"][1], err_msg="%s %s %s (mask)" % (res, name, tag))
-            assert (got["rows"][1][mask == 0] == DBL_MAX).all()
-            # node ranges: an eighth of the lattice or more stays with the row kernel (lanes outside the range idle), less goes to the pair kernel
+            assert (got["cells"][1][mask == 0] == DBL_MAX).all()
+            # node ranges: an eighth of the lattice or more stays with the point kernel (lanes outside the range idle), less goes to the pair kernel
             for b, e in ((n // 3, n - 5), (n // 2, n // 2 + n // 7), (17, 17 + n // 20)):
                 np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, b, e), got["pairs"][0][b:e], err_msg="%s %s [%d, %d)" % (res, name, b, e))
                 np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False, b, e, mask=mask[b:e]), got["pairs"][1][b:e])
             if res[0] != 40:   # (the emulator walks every quadrature point of every node on the host)
                 want = emu.density_map(dom, res, coeffs, h, 1000.0, band=True)
-                np.testing.assert_array_equal(got["rows"][0], want, err_msg="%s %s" % (res, name))
+                np.testing.assert_array_equal(got["cells"][0], want, err_msg="%s %s" % (res, name))
             f.close()
 
 
