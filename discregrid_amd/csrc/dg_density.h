@@ -22,7 +22,9 @@ struct DensityParams
 	int band_predicate; // apply the node predicate of main.cpp:119-133
 	double xi[16];      // quadrature offsets  c0*abscissa + c1 = h*a + 0.0
 	double w[16];       // weights
-	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k
+	const double* wtab; // 4096 values W(xi_i, xi_j, xi_k), index (i*16 + j)*16 + k (+ 4096 weight products, dg_layout.h init_density_params())
+	double rcp_h;       // RN(1 / h): the correctly rounded reciprocal, for k3c_div_h()
+	int32_t fast_div;   // h allows the division-free d / h (k_density_cells, fields without NaN / Inf / huge values only)
 	// Quadrature points outside the kernel's support (|xi| > h: 3088 of the 4096 points) contribute
 	// w * (gamma * 0.0) = +0.0 to a sum of non-negative terms, i.e. nothing -- provided gamma is
 	// finite, which holds whenever every coefficient other than DBL_MAX is finite and below 1e290.

@@ -103,6 +103,16 @@ inline K3CellsGeom k3c_geometry(const FieldDev& F)
 	return G;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DG_K3C_OPAQUE(v) asm volatile("" : "+v"(v))
+#define DG_K3C_OPAQUE_D(v) asm volatile("" : "+v"(v))
+// a wave-uniform address of launch-constant data: through the scalar cache into scalar registers
+#define DG_K3C_ULOAD(p) (*(const __attribute__((address_space(4))) double*)(uintptr_t)(p))
+#else
+#define DG_K3C_OPAQUE(v) (void)(v)
+#define DG_K3C_OPAQUE_D(v) (void)(v)
+#define DG_K3C_ULOAD(p) (*(p))
+#endif
 // 24-bit multiply-add in 32-bit offsets (one VALU instruction on the device; k3c_geometry_fits() keeps the operands in range)
 DG_HD uint32_t k3c_mad(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -196,10 +206,50 @@ DG_HD double k3c_value(const double cf[32], bool ok, const K3Axis& ax, const K3A
 #undef DG_ACC
 	return ok ? phi : NOVAL;
 }
-// one term of the quadrature sum: wijk * (gamma(d) * W)  (main.cpp:104-110, gauss_quadrature.cpp:5953)
+// d / h, correctly rounded, without the division: q0 = RN(d y), y = RN(1 / h); one residual correction makes q1 faithful
+// (q0 is within 2 ulps, so q0 + (d - h q0) y differs from d / h by < 2^-104 relative), and a second one is Markstein's
+// theorem (a faithful quotient corrected with the exact residual and the correctly rounded reciprocal IS the correctly rounded
+// quotient; divisors with an all-ones significand excluded: DensityParams::fast_div).  The residuals are exact as long as
+// nothing under- or overflows: the caller guarantees d == 0 or 1e-280 <= |d| <= 1e300 and 1e-12 <= h <= 1e12
+// (tests/test_emu.py checks 2 x 10^8 quotients, half of them built to sit next to rounding boundaries, against the division).
+DG_HD double k3c_div_h(double d, double h, double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	const double q0 = d * y;
+	const double r0 = __builtin_fma(-h, q0, d);
+	const double q1 = __builtin_fma(r0, y, q0);
+	const double r1 = __builtin_fma(-h, q1, d);
+	return __builtin_fma(r1, y, q1);
+#else
+	const double q0 = d * y;
+	const double r0 = std::fma(-h, q0, d);
+	const double q1 = std::fma(r0, y, q0);
+	const double r1 = std::fma(-h, q1, d);
+	return std::fma(r1, y, q1);
+#endif
+}
+// (|d| <= 1e300 holds for every value of a field k_field_check passed; "no value" sums are beyond h and take gamma = 0)
+DG_HD bool k3c_div_h_unsafe(double d) { return __builtin_fabs(d) < 1.0e-280 && d != 0.0; }
+// one term of the quadrature sum: wijk * (gamma(d) * W)  (main.cpp:104-110, gauss_quadrature.cpp:5953); FAST: the launch
+// may use k3c_div_h() (a compile-time choice: as a run-time one it makes the compiler carry some twenty lane masks
+// around the k loop)
+template <bool FAST>
 DG_HD double k3c_term(const DensityParams& P, double d, double wijk, double wv)
 {
-	const double gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
+	double gamma;
+	if (FAST)
+	{
+		double q = k3c_div_h(d, P.h, P.rcp_h);
+		if (k3c_div_h_unsafe(d))
+		{
+			double dd = d;
+			DG_K3C_OPAQUE_D(dd); // (keeps the division out of line: speculated, it would cost more than it saves)
+			q = dd / P.h;
+		}
+		gamma = (d > P.h) ? 0.0 : 1.0 - q;
+	}
+	else
+		gamma = (d > P.h) ? 0.0 : 1.0 - d / P.h;
 	return wijk * (gamma * wv);
 }
 
@@ -240,14 +290,6 @@ DG_HD void k3c_coords(const SampleParams& L, int d, uint32_t idx, double* x0, do
 	*xa = *x0 + 1.0 / 3.0 * L.cell[d];
 	*xb = *x0 + 2.0 / 3.0 * L.cell[d];
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DG_K3C_OPAQUE(v) asm volatile("" : "+v"(v))
-// a wave-uniform address of launch-constant data: through the scalar cache into scalar registers
-#define DG_K3C_ULOAD(p) (*(const __attribute__((address_space(4))) double*)(uintptr_t)(p))
-#else
-#define DG_K3C_OPAQUE(v) (void)(v)
-#define DG_K3C_ULOAD(p) (*(p))
-#endif
 // Which of a lane's seven nodes depend on which coordinate: node bits 0 V, 1 / 2 X edge A / B, 3 / 4 Y edge, 5 / 6 Z edge.
 // Along x the nodes V, YA, YB, ZA, ZB sit at the lattice point's own coordinate (mask 0x79), XA / XB at the shifted ones.
 static const uint32_t kK3cX0 = 0x79u, kK3cXA = 0x02u, kK3cXB = 0x04u;
@@ -268,7 +310,7 @@ DG_HD bool k3c_cell_ok(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k)
 	const uint64_t w = F.xmajor_flags[word];
 	return ((w >> (i & 63u)) & 1ull) == 0ull;
 }
-template <class W>
+template <bool FAST, class W>
 DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const DensityParams& P, const K3CellsGeom& G, bool has_noval,
 						  bool skip, uint32_t li, uint32_t lj, uint32_t need, double res[7])
 {
@@ -343,14 +385,12 @@ DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const 
 				double cf[32];
 				bool ok = true;
 #define DG_K3C_EVAL(mask, n, AX, AY, AZ)                                   \
-	if (w.any(mask))                                                      \
+	if (mask)                                                             \
 	{                                                                     \
-		if (mask)                                                         \
-		{                                                                 \
-			const double d_ = k3c_value(cf, ok, AX, AY, AZ);              \
-			w.acc_add(n, k3c_term(P, d_, wijk, wv));                      \
-		}                                                                 \
+		const double d_ = k3c_value(cf, ok, AX, AY, AZ);                  \
+		w.acc_add(n, k3c_term<FAST>(P, d_, wijk, wv));                 \
 	}
+#define DG_K3C_IF(mask) if (w.any(mask)) if (mask)
 				// ---- the cell of the lattice point ----
 				if (w.any(g != 0u))
 				{
@@ -360,36 +400,39 @@ DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const 
 						if (has_noval)
 							ok = k3c_cell_ok(F, X0.mi, Y0.mi, Z0.mi);
 					}
-					DG_K3C_EVAL((g & 1u) != 0u, 0, X0, Y0, Z0)
-					if (w.any((g & kK3cXA) != 0u))
+					DG_K3C_IF((g & 1u) != 0u)
+					{
+						DG_K3C_EVAL(true, 0, X0, Y0, Z0)
+					}
+					DG_K3C_IF((g & kK3cXA) != 0u)
 					{
 						const K3Axis XA = w.x_var(F, 0);
-						DG_K3C_EVAL((g & kK3cXA) != 0u, 1, XA, Y0, Z0)
+						DG_K3C_EVAL(true, 1, XA, Y0, Z0)
 					}
-					if (w.any((g & kK3cXB) != 0u))
+					DG_K3C_IF((g & kK3cXB) != 0u)
 					{
 						const K3Axis XB = w.x_var(F, 1);
-						DG_K3C_EVAL((g & kK3cXB) != 0u, 2, XB, Y0, Z0)
+						DG_K3C_EVAL(true, 2, XB, Y0, Z0)
 					}
-					if (w.any((g & kK3cYA) != 0u))
+					DG_K3C_IF((g & kK3cYA) != 0u)
 					{
 						const K3Axis YA = w.y_var(F, 0);
-						DG_K3C_EVAL((g & kK3cYA) != 0u, 3, X0, YA, Z0)
+						DG_K3C_EVAL(true, 3, X0, YA, Z0)
 					}
-					if (w.any((g & kK3cYB) != 0u))
+					DG_K3C_IF((g & kK3cYB) != 0u)
 					{
 						const K3Axis YB = w.y_var(F, 1);
-						DG_K3C_EVAL((g & kK3cYB) != 0u, 4, X0, YB, Z0)
+						DG_K3C_EVAL(true, 4, X0, YB, Z0)
 					}
-					if (w.any((g & kK3cZA) != 0u))
+					DG_K3C_IF((g & kK3cZA) != 0u)
 					{
 						const K3Axis ZA = w.z_var(F, P, k, 1);
-						DG_K3C_EVAL((g & kK3cZA) != 0u, 5, X0, Y0, ZA)
+						DG_K3C_EVAL(true, 5, X0, Y0, ZA)
 					}
-					if (w.any((g & kK3cZB) != 0u))
+					DG_K3C_IF((g & kK3cZB) != 0u)
 					{
 						const K3Axis ZB = w.z_var(F, P, k, 2);
-						DG_K3C_EVAL((g & kK3cZB) != 0u, 6, X0, Y0, ZB)
+						DG_K3C_EVAL(true, 6, X0, Y0, ZB)
 					}
 				}
 				const uint32_t rest = act & ~g;
@@ -421,15 +464,15 @@ DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const 
 			if (has_noval)                                                                                                         \
 				ok = OKCELL;                                                                                                       \
 		}                                                                                                                          \
-		if (w.any(mB))                                                                                                             \
+		DG_K3C_IF(mB)                                                                                                              \
 		{                                                                                                                          \
 			const K3Axis VB = VAR_B;                                                                                               \
-			DG_K3C_EVAL(mB, NB, AXB, AYB, AZB)                                                                                     \
+			DG_K3C_EVAL(true, NB, AXB, AYB, AZB)                                                                                   \
 		}                                                                                                                          \
-		if (w.any(mA))                                                                                                             \
+		DG_K3C_IF(mA)                                                                                                              \
 		{                                                                                                                          \
 			const K3Axis VA = VAR_A;                                                                                               \
-			DG_K3C_EVAL(mA, NA, AXA, AYA, AZA)                                                                                     \
+			DG_K3C_EVAL(true, NA, AXA, AYA, AZA)                                                                                   \
 		}                                                                                                                          \
 		r_ = mA ? 0u : (r_ & MA_);                                                                                                 \
 	}
@@ -456,6 +499,7 @@ DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const 
 				}
 #undef DG_K3C_NEIGHBOUR
 #undef DG_K3C_EVAL
+#undef DG_K3C_IF
 			}
 		}
 	}
@@ -514,12 +558,18 @@ DG_HD void k3c_lane(W& w, const SampleParams& L, const FieldDev& F, const Densit
 	}
 	if (!w.any(need != 0u))
 		return;
-	const uint32_t flags = P.unsafe ? P.unsafe[0] : 2u; // bit 0: NaN / Inf / huge values, bit 1: "no value" coefficients
+	// bit 0: NaN / Inf / huge values, bit 1: "no value" coefficients.  One word for the whole launch: told to the compiler
+	// (uniform()), or every branch on it becomes a lane mask carried around the loops
+	const uint32_t flags = w.uniform(P.unsafe ? P.unsafe[0] : 2u);
 	const bool has_noval = (flags & 2u) != 0u; // (answered by the x-major copy's one bit per cell: the launch supplies F.xmajor_flags)
 	const bool skip = P.skip_mode == 1 || (P.skip_mode == 2 && (flags & 1u) == 0u);
 	w.set_z(F, P, L, m, x0[2], xa[2], xb[2]);
 	double res[7];
-	k3c_quadrature(w, L, F, P, G, has_noval, skip, i, j, need, res);
+	// (skip: the field holds no NaN / Inf / huge value, k_field_check -- what k3c_div_h() needs as well)
+	if (skip && P.fast_div != 0)
+		k3c_quadrature<true>(w, L, F, P, G, has_noval, skip, i, j, need, res);
+	else
+		k3c_quadrature<false>(w, L, F, P, G, has_noval, skip, i, j, need, res);
 	// (the node indices again: not kept across the quadrature)
 	uint32_t i2 = i, j2 = j, k2 = k;
 	DG_K3C_OPAQUE(i2);
@@ -551,6 +601,7 @@ struct K3HostWave
 	double z_[3] = {0.0, 0.0, 0.0};
 	double acc_[7];
 	bool any(bool b) const { return b; }
+	uint32_t uniform(uint32_t v) const { return v; }
 	void acc_init()
 	{
 		for (int n = 0; n < 7; ++n)

@@ -1392,7 +1392,8 @@ struct K3WaveDev
 	uint32_t* sZb; // [16][2] (k, lane z): k3c_axis_bits() of the z axis
 	double* sR; // [7][64]    the seven sums of every lane (registers are what this kernel is short of)
 	int lane, ix, iy, iz;
-	__device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
+	__device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+	__device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 	__device__ __forceinline__ void acc_init()
 	{
 #pragma unroll

@@ -321,6 +321,13 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 					m |= 1u << kk;
 			P.kmask[i * 16 + j] = (uint16_t)m;
 		}
+	P.rcp_h = 1.0 / h;
+	{
+		// k3c_div_h(): Markstein's correction needs RN(1 / h) (the line above) and excludes divisors whose significand is all ones
+		uint64_t bits;
+		std::memcpy(&bits, &h, sizeof(bits));
+		P.fast_div = (h >= 1.0e-12 && h <= 1.0e12 && (bits & 0xfffffffffffffull) != 0xfffffffffffffull) ? 1 : 0;
+	}
 	P.skip_mode = 0;
 	P.lds_waves = 0;
 	P.row_shape = 0;

@@ -327,6 +327,14 @@ def density_cells(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, ma
     return out, hits
 
 
+def div_h_mismatches(h, n, seed):
+    """quotients of k3c_div_h() (dg_density_cells.h: d / h without the division) that differ from d / h."""
+    L = lib()
+    L.emu_div_h_check.restype = C.c_uint64
+    L.emu_div_h_check.argtypes = [C.c_double, C.c_uint64, C.c_uint64]
+    return int(L.emu_div_h_check(float(h), int(n), int(seed)))
+
+
 def set_heavy(slots=0xffffffff, work=0):
     """Heavy-brick settings of the emulated K1 launches (dg_kernels.h: overflow_slots_for(), kHeavyWork);
     slots = 0 disables the split; the defaults size slots and budget as the product does."""

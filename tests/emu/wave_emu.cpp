@@ -1412,6 +1412,56 @@ void emu_density_cells(const double domain[6], const double cell[3], const doubl
 		}
 	}
 }
+// k3c_div_h() against the division: n random numerators per call -- uniform bit patterns in the allowed range, values
+// around h, and numerators built so that the quotient lands next to a rounding boundary (q = m + ulp / 2 for a random m,
+// d = RN(q h) and its neighbours).  Returns the number of quotients that differ from d / h.
+uint64_t emu_div_h_check(double h, uint64_t n, uint64_t seed)
+{
+	const double y = 1.0 / h;
+	uint64_t bad = 0;
+	uint64_t s = seed * 0x9e3779b97f4a7c15ull + 1;
+	auto next = [&s]() {
+		s ^= s << 13;
+		s ^= s >> 7;
+		s ^= s << 17;
+		return s;
+	};
+	for (uint64_t t = 0; t < n; ++t)
+	{
+		double d;
+		const uint64_t r = next();
+		const int kind = (int)(r & 3u);
+		if (kind == 0)
+		{
+			// any exponent in [-900, 900], random significand and sign
+			const int e = (int)(next() % 1801) - 900;
+			const double m = 1.0 + (double)(next() >> 12) * 0x1p-52;
+			d = std::ldexp((next() & 1u) ? -m : m, e);
+		}
+		else if (kind == 1)
+		{
+			d = h * (((double)(next() >> 11) * 0x1p-53) * 4.0 - 2.0); // [-2h, 2h)
+		}
+		else
+		{
+			// quotient next to a midpoint between two doubles
+			const int e = (int)(next() % 41) - 20;
+			const double m = std::ldexp(1.0 + (double)(next() >> 12) * 0x1p-52, e);
+			const long double mid = (long double)m + (long double)std::ldexp(0x1p-53, e);
+			d = (double)(mid * (long double)h);
+			const int step = (int)(next() % 5) - 2;
+			for (int q = 0; q < (step < 0 ? -step : step); ++q)
+				d = std::nextafter(d, step < 0 ? -INFINITY : INFINITY);
+			if (next() & 1u)
+				d = -d;
+		}
+		if (k3c_div_h_unsafe(d) || !(std::fabs(d) <= 1.0e300))
+			continue;
+		if (k3c_div_h(d, h, y) != d / h)
+			++bad;
+	}
+	return bad;
+}
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)

@@ -514,6 +514,16 @@ def test_point_lanes_with_seven_nodes_equal_the_per_node_body(golden):
         emu.set_tile_major(0)
 
 
+def test_division_free_quotient_by_the_support_radius_is_the_division():
+    """k_density_cells forms gamma = 1 - d / h with a multiplication by RN(1 / h) and two residual corrections
+    (dg_density_cells.h k3c_div_h(): Markstein's theorem).  Same bits as the division for 10^7 numerators per support
+    radius -- random over the whole admitted range, around h, and next to rounding boundaries of the quotient."""
+    rng = np.random.default_rng(9)
+    hs = [0.1, 0.05, 0.2, 0.3, 1.0 / 3.0, 0.0123456789, 1.0, 2.5e-3, 7.0, 1.0e-12, 1.0e12] + list(rng.uniform(1e-3, 2.0, 9))
+    for t, h in enumerate(hs):
+        assert emu.div_h_mismatches(h, 10_000_000 if t < 4 else 2_000_000, 100 + t) == 0, h
+
+
 def test_scalar_division_by_launch_constants_is_exact():
     """The brick map divides by launch constants with a host-made reciprocal (dg_kernels.h: udiv_by): exact
     quotient and remainder for every 32-bit dividend and every divisor >= 1, including the corners."""
