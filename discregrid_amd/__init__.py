@@ -67,6 +67,7 @@ SYMBOLS = {
     "dg_grid_n_cells": (C.c_uint64, [C.POINTER(GridDesc)]),
     "dg_mesh_create": (C.c_int, [_dp, C.c_size_t, _u32p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dg_mesh_get_info": (C.c_int, [C.c_void_p, C.POINTER(MeshInfo)]),
+    "dg_mesh_device": (C.c_int, [C.c_void_p]),
     "dg_mesh_destroy": (None, [C.c_void_p]),
     "dg_sdf_sample_nodes": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_uint64, C.c_uint64, _u8p, _dp]),
     "dg_sdf_sample_nodes_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_uint64, C.c_uint64,
@@ -227,6 +228,10 @@ class Mesh:
         i = MeshInfo()
         _check(self._lib.dg_mesh_get_info(self.handle, C.byref(i)))
         return {k: getattr(i, k) for k, _ in MeshInfo._fields_}
+
+    def device(self):
+        """dg_mesh_device: the handle's device, -1 for a host-only handle (no HIP device / DG_FORCE_CPU=1)."""
+        return int(self._lib.dg_mesh_device(self.handle))
 
     def last_heavy_bricks(self):
         """dg_mesh_last_heavy_bricks: (bricks over budget, bricks actually split) of the last launch."""

@@ -10,6 +10,7 @@
 // same .cdf file GenerateSDF writes.  With --steps K the sampling step is repeated K times after one
 // warm-up and the parent prints one JSON line: whole-job Mnodes/s = nodes * K / max over ranks of the
 // time of the K steps (the figure bench.py reports for N GPUs).
+#include <algorithm>
 #include <Discregrid/All>
 
 #include <fcntl.h>
@@ -262,12 +263,13 @@ int main(int argc, char* argv[])
 		const pid_t pid = wait(&st);
 		if (pid < 0)
 			break;
+		// (a reaped pid may be handed to an unrelated process at any moment: only ranks still running are ever signalled)
+		kids.erase(std::remove(kids.begin(), kids.end(), pid), kids.end());
 		if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0))
 		{
 			if (failed++ == 0)
 				for (pid_t k : kids)
-					if (k != pid)
-						kill(k, SIGTERM);
+					kill(k, SIGTERM);
 		}
 	}
 	std::remove(id_file.c_str());

@@ -136,7 +136,7 @@ CubicLagrangeDiscreteGrid::CubicLagrangeDiscreteGrid(CubicLagrangeDiscreteGrid&&
 	  m_last_reduce_used_gpu(other.m_last_reduce_used_gpu)
 {
 	// the heap buffers of the field vectors moved with them, so copies in flight keep writing to the right place
-	other.m_dev.reset(new (std::nothrow) DeviceCache);
+	other.m_dev.reset(new DeviceCache); // (never null: every member function dereferences it)
 	other.m_nodes.clear();
 	other.m_cells.clear();
 	other.m_cell_map.clear();
@@ -157,7 +157,7 @@ CubicLagrangeDiscreteGrid& CubicLagrangeDiscreteGrid::operator=(CubicLagrangeDis
 		m_last_sampling_s = other.m_last_sampling_s;
 		m_last_used_gpu = other.m_last_used_gpu;
 		m_last_reduce_used_gpu = other.m_last_reduce_used_gpu;
-		other.m_dev.reset(new (std::nothrow) DeviceCache);
+		other.m_dev.reset(new DeviceCache); // (never null: every member function dereferences it)
 		other.m_nodes.clear();
 		other.m_cells.clear();
 		other.m_cell_map.clear();
@@ -309,7 +309,40 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 	const auto t_sample = clock::now();
 	MeshSDF const* sdf = func.target<MeshSDF>();
 	m_last_used_gpu = false;
-	if (sdf != nullptr && sdf->distance != nullptr)
+	// A failure below must leave the grid as it was: the three vectors lose the entry pushed above, the device
+	// bookkeeping of the field that never came to be is dropped, and m_n_fields was not touched yet.
+	struct Unwind
+	{
+		CubicLagrangeDiscreteGrid* g;
+		bool armed = true;
+		~Unwind()
+		{
+			if (!armed)
+				return;
+			const std::size_t id = g->m_nodes.size() - 1;
+			{
+				std::lock_guard<std::mutex> lock(g->m_dev->mutex);
+				if (id < g->m_dev->fields.size() && g->m_dev->fields[id])
+				{
+					dg_field_destroy(g->m_dev->fields[id]); // (joins a copy job that still writes into the host vector)
+					g->m_dev->fields[id] = nullptr;
+				}
+				if (id < g->m_dev->pending.size())
+					g->m_dev->pending[id] = 0;
+			}
+			g->m_nodes.pop_back();
+			g->m_cells.pop_back();
+			g->m_cell_map.pop_back();
+		}
+	} unwind{this};
+	// The typed functor on a host-only mesh handle (no HIP device, or DG_FORCE_CPU=1): the reference's OpenMP node loop
+	// (:806-831) over the per-point query -- the product's own BVH and arithmetic on the calling threads, the bits of
+	// the kernel (tests/test_host_api.py).  DG_REQUIRE_GPU=1 refuses instead (a deployment that must not degrade silently).
+	const bool host_only_mesh = sdf != nullptr && sdf->distance != nullptr && sdf->distance->deviceMesh() != nullptr &&
+								dg_mesh_device(static_cast<const dg_mesh*>(sdf->distance->deviceMesh())) < 0;
+	if (host_only_mesh && env_flag("DG_REQUIRE_GPU", 0) != 0)
+		throw std::runtime_error("CubicLagrangeDiscreteGrid::addFunction: no HIP device for the MeshSDF functor and DG_REQUIRE_GPU=1");
+	if (sdf != nullptr && sdf->distance != nullptr && !host_only_mesh)
 	{
 		// GPU path.  The predicate is opaque host code: evaluate it into a byte mask first.
 		std::vector<uint8_t> mask;
@@ -378,8 +411,8 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 	}
 	else
 	{
-		// Arbitrary callable: can only run on the host (same loop as the reference, :806-831,
-		// with a dynamic schedule because the cost per node is very uneven).
+		// Arbitrary callable (or the typed functor without a device: its operator() is the per-point query): can only run
+		// on the host (same loop as the reference, :806-831, with a dynamic schedule because the cost per node is very uneven).
 		std::atomic_uint counter(0u);
 		auto t0 = clock::now();
 #pragma omp parallel for schedule(dynamic, 256)
@@ -423,6 +456,7 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 		if (m_dev->pending.size() < m_nodes.size())
 			m_dev->pending.resize(m_nodes.size(), 0);
 	}
+	unwind.armed = false;
 	return static_cast<unsigned int>(m_n_fields++);
 }
 

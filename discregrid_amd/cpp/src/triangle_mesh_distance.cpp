@@ -52,7 +52,8 @@ void TriangleMeshDistance::constructFlat(const std::vector<double>& v, const std
 	impl->all.push_back(impl->mesh);
 	// DG_DEVICES = "all" or a comma-separated list of device ordinals: replicate the mesh there so that
 	// CubicLagrangeDiscreteGrid::addFunction can spread the node lattice over those GPUs
-	if (const char* env = std::getenv("DG_DEVICES"))
+	const char* env_devices = dg_mesh_device(impl->mesh) < 0 ? nullptr : std::getenv("DG_DEVICES"); // (a host-only handle has no replicas)
+	if (const char* env = env_devices)
 	{
 		int count = 0, current = 0;
 		dg_device_count(&count);
@@ -121,6 +122,31 @@ void TriangleMeshDistance::signed_distance(const double* xyz, std::size_t n, dou
 		throw std::runtime_error("DistanceTriangleMesh error: not constructed.");
 	}
 	static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bits");
+	if (dg_mesh_device(m_impl->mesh) < 0)
+	{
+		// host-only handle (no HIP device / DG_FORCE_CPU=1): the per-point query on every core, same bits as the kernel
+		bool ok = true;
+#pragma omp parallel for schedule(dynamic, 64) reduction(&& : ok)
+		for (long long i = 0; i < (long long)n; ++i)
+		{
+			int32_t tri = -1, ent = -1;
+			double np[3] = {0.0, 0.0, 0.0};
+			ok = ok && dg_signed_distance_point(m_impl->mesh, xyz + 3 * i, distance + i, &tri, &ent, np) == DG_OK;
+			if (triangle_id)
+				triangle_id[i] = tri;
+			if (nearest_entity)
+				nearest_entity[i] = ent;
+			if (nearest_point)
+			{
+				nearest_point[3 * i] = np[0];
+				nearest_point[3 * i + 1] = np[1];
+				nearest_point[3 * i + 2] = np[2];
+			}
+		}
+		if (!ok)
+			fail("TriangleMeshDistance::signed_distance");
+		return;
+	}
 	if (dg_signed_distance(m_impl->mesh, xyz, n, distance, reinterpret_cast<int32_t*>(triangle_id),
 						   reinterpret_cast<int32_t*>(nearest_entity), nearest_point) != DG_OK)
 		fail("TriangleMeshDistance::signed_distance");

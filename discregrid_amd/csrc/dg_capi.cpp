@@ -174,9 +174,22 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	*out = nullptr;
 	if (!verts || !tris || n_vertices == 0 || n_triangles == 0)
 		return fail(DG_ERR_INVALID, "empty triangle list"); // reference: message + exit(-1), TriangleMeshDistance.h:338-341
-	dg_status s = require_device();
-	if (s != DG_OK)
-		return s;
+	// Without a HIP device (or under DG_FORCE_CPU=1) the handle is HOST-ONLY: BVH, pseudonormals and filter records are
+	// built as always and kept in host memory, dg_signed_distance_point() -- the reference's per-point signed_distance,
+	// TriangleMeshDistance.h:269-328 -- works, and every entry point that would launch a kernel returns
+	// DG_ERR_NO_DEVICE (dg_mesh_device() tells).  What a caller does then is its decision: the C++ host API runs the
+	// reference's OpenMP node loop over the point query (cpp/src/cubic_lagrange_discrete_grid.cpp), like the reference
+	// does everywhere (cubic_lagrange_discrete_grid.cpp:806-831).
+	bool host_only = env_int("DG_FORCE_CPU", 0, 0, 1) != 0;
+	if (!host_only)
+	{
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+		{
+			(void)hipGetLastError();
+			host_only = true;
+		}
+	}
 
 	auto t0 = std::chrono::high_resolution_clock::now();
 	dg::MeshBuild B;
@@ -200,7 +213,13 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	const size_t tb = B.tris.size() * sizeof(dg::TriPacket);
 	const size_t pb = B.pn.size() * sizeof(double);
 	const size_t ab = B.tri_approx.size() * sizeof(dg::TriApproxPair);
-	hipError_t e = hipGetDevice(&m->device);
+	hipError_t e = hipSuccess;
+	if (host_only)
+		m->device = -1;
+	else
+		e = hipGetDevice(&m->device);
+	if (!host_only)
+	{
 	if (e == hipSuccess) e = hipMalloc(&m->d_pairs, std::max<size_t>(nb, 128));
 	if (e == hipSuccess) e = hipMalloc(&m->d_tri_pairs, sb);
 	if (e == hipSuccess) e = hipMalloc(&m->d_tris, tb);
@@ -211,6 +230,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	if (e == hipSuccess) e = hipMemcpy(m->d_tri_pairs, B.tri_pairs.data(), sb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_tris, B.tris.data(), tb, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(m->d_pn, B.pn.data(), pb, hipMemcpyHostToDevice);
+	}
 	if (e != hipSuccess)
 	{
 		dg_mesh_destroy(m);
@@ -246,12 +266,14 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->info.n_bvh_nodes = 2 * B.pairs.size() + 1;
 	m->info.bvh_depth = B.depth;
 	m->info.not_watertight = B.not_watertight;
-	m->info.device_bytes = nb + tb + pb + sb + ab;
+	m->info.device_bytes = host_only ? 0 : nb + tb + pb + sb + ab;
 	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
 	m->host = std::move(B);
 	*out = m;
 	return DG_OK;
 }
+
+int dg_mesh_device(const dg_mesh* mesh) { return mesh ? mesh->device : -1; }
 
 dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info)
 {
@@ -265,6 +287,11 @@ void dg_mesh_destroy(dg_mesh* m)
 {
 	if (!m)
 		return;
+	if (m->device < 0) // host-only handle: nothing of it lives in the HIP runtime
+	{
+		delete m;
+		return;
+	}
 	DeviceGuard guard(m->device);
 	if (m->d_pairs) (void)hipFree(m->d_pairs);
 	if (m->d_tri_pairs) (void)hipFree(m->d_tri_pairs);

@@ -529,7 +529,16 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// An eighth of the lattice or more of an unreduced field: row-block waves on the x-major copy (k_density_rows; DG_K3_ROWS=0: the cube-shaped
 	// waves of k_density_pairs on the tile-major copy, 1..5: lane shapes, dg_layout.h row_shape_lanes()).  The copy (Y and Z
 	// classes with x fastest, 0.57 x the field) and the per-cell "no value" bits are stream-ordered scratch of this launch.
+	// (scratch slots go back to their pools on EVERY way out of this function: a slot left busy is never handed out again)
+	struct SlotGuard
+	{
+		ScratchPool& pool;
+		int& idx;
+		hipStream_t st;
+		~SlotGuard() { pool.release(idx, st); }
+	};
 	int rows_idx = -1;
+	SlotGuard rows_guard{sdf->tile_scratch, rows_idx, st};
 	int rows_shape = env_int("DG_K3_ROWS", 1, 0, 4);
 	if (rows_shape == 2 || rows_shape == 3)
 		rows_shape = 1; // (lane shapes measured slower are not instantiated)
@@ -573,6 +582,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
 	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
 	int flag_idx = -1; // the flag k_field_check writes belongs to this launch (stream-ordered scratch)
+	SlotGuard flag_guard{sdf->flag_scratch, flag_idx, st};
 	const bool skip_points = env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12;
 	// (always: besides the values that forbid the skip, k_field_check reports whether the field holds "no value" coefficients at all)
 	{
@@ -588,6 +598,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// pass over the field against 1 + 4096 interpolations per integrated node: 128^3 161 -> 135 ms
 	// (DG_K3_TILES=0: off).  Launches over a small part of the lattice are not worth the pass.
 	int tile_idx = -1;
+	SlotGuard tile_guard{sdf->tile_scratch, tile_idx, st};
 	if (rows_idx < 0 && dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
 		env_int("DG_K3_TILES", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
 	{
@@ -603,11 +614,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 				(void)hipGetLastError(); // without the copy then
 		}
 	}
-	const hipError_t e = dg::launch_density_bricks(L, dev, sdf->n_coeffs, P, st);
-	sdf->tile_scratch.release(tile_idx, st);
-	sdf->tile_scratch.release(rows_idx, st);
-	sdf->flag_scratch.release(flag_idx, st);
-	DG_HIP(e);
+	DG_HIP(dg::launch_density_bricks(L, dev, sdf->n_coeffs, P, st));
 	return DG_OK;
 }
 

@@ -1296,6 +1296,9 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 	s = require_device();
 	if (s != DG_OK)
 		return s;
+	for (int i = 0; i < n_meshes; ++i)
+		if (meshes[i]->device < 0)
+			return fail(DG_ERR_NO_DEVICE, "meshes[%d] is a host-only handle (dg_mesh_device() < 0)", i);
 	// chunks are dealt round-robin: thin interleaved pieces equalise the very uneven cost per node
 	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / (10ull * (uint64_t)n_meshes), 1u << 21), 1u << 25);
 	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);

@@ -183,6 +183,9 @@ struct DeviceGuard
 	DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 #define DG_ON_DEVICE_OF(handle)                                                                       \
+	if ((handle)->device < 0)                                                                         \
+		return fail(DG_ERR_NO_DEVICE, "host-only mesh handle (created without a HIP device or under DG_FORCE_CPU=1): " \
+									  "only dg_signed_distance_point works on it; this library has no CPU path for batches"); \
 	DeviceGuard device_guard_((handle)->device);                                                      \
 	if (device_guard_.err != hipSuccess)                                                              \
 		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))

@@ -8,8 +8,9 @@
 // the bits K1 / K1p produce.  Read-only on immutable data: no locks, any number of concurrent callers.
 //
 // This is the per-point evaluator of the host API (like the scalar interpolate of dg_lattice.h), not a
-// substitute for the kernels: batches go to dg_signed_distance / dg_sdf_sample_nodes, and a mesh handle
-// cannot be created without a HIP device.  Compile with -ffp-contract=off.
+// substitute for the kernels: batches go to dg_signed_distance / dg_sdf_sample_nodes.  It is also all a HOST-ONLY mesh
+// handle can do (dg_mesh_create without a HIP device, dg_mesh_device() == -1): the C++ host API then runs the reference's
+// OpenMP node loop over it.  Compile with -ffp-contract=off.
 #include "dg_capi_internal.h"
 #include "dg_host_query.h"
 

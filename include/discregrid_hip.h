@@ -39,8 +39,9 @@
  * through device memory and synchronise before returning.  All work runs on the HIP
  * device that is current on the calling thread (hipSetDevice / dg_set_device).
  *
- * There is NO CPU fallback: without a HIP device every compute entry point returns
- * DG_ERR_NO_DEVICE.
+ * There is NO CPU fallback behind this ABI: without a HIP device every compute entry point returns
+ * DG_ERR_NO_DEVICE.  (What does work without one: the grid helpers, dg_mesh_create as a host-only handle and the
+ * per-point query dg_signed_distance_point -- see dg_mesh_device().)
  *
  * Sentinel: DG_NO_VALUE == std::numeric_limits<double>::max() marks "no value" exactly
  * like the reference (cubic_lagrange_discrete_grid.cpp:817, 982, 994, 1017).
@@ -119,6 +120,12 @@ uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
 dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
 						 dg_mesh** out);
 dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info);
+/* The device the handle's arrays live on, or -1 for a HOST-ONLY handle: dg_mesh_create on a machine without a HIP device (or
+ * under DG_FORCE_CPU=1) still builds the BVH and the pseudonormals and keeps them in host memory, so that
+ * dg_signed_distance_point() -- the reference's per-point TriangleMeshDistance::signed_distance,
+ * TriangleMeshDistance.h:252-267, 269-328 -- works wherever the reference works; every entry point that would launch a
+ * kernel returns DG_ERR_NO_DEVICE for such a handle. */
+int dg_mesh_device(const dg_mesh* mesh);
 void dg_mesh_destroy(dg_mesh* mesh);
 
 /* ---- K1: SDF node sampling --------------------------------------------------------------- */

@@ -10,11 +10,18 @@
 //   host_api_driver evalsplit  in.cdf pts.bin out.bin     determineShapeFunctions + split interpolate
 //   host_api_driver flow       mesh.obj "rx ry rz" h pts.bin prefix   GPU: addFunction -> addDensityMap -> batches ->
 //                                                         host reads -> copies / moves -> reduceField x 2 -> .cdf / .cdm
+//   host_api_driver fault      mesh.obj out.cdf           a MeshSDF addFunction that FAILS (host-only mesh under DG_REQUIRE_GPU=1: run
+//                                                         with DG_FORCE_CPU=1 DG_REQUIRE_GPU=1) must leave the grid as it was:
+//                                                         nFields, the next field's id and data, save; exit code 0 = all held
+//   host_api_driver cpu        mesh.obj "rx ry rz" pts.bin out.bin  MeshSDF addFunction + batched signed_distance on whatever the box
+//                                                         has (no device / DG_FORCE_CPU=1: the host loops); out.bin = [used_gpu,
+//                                                         0, coefficients..., the batched distances of the points...]
 //   host_api_driver gpu        mesh.obj pts.bin out.bin   GPU: MeshSDF addFunction (with a predicate
 //                                                         on field 1), batched vs scalar interpolate,
 //                                                         batched vs single signed_distance
 #include <Discregrid/All>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +29,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -46,6 +54,77 @@ int main(int argc, char** argv)
 	if (argc < 2)
 		return 2;
 	const std::string cmd = argv[1];
+	if (cmd == "fault" && argc == 4)
+	{
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		Eigen::AlignedBox3d dom(Eigen::Vector3d(-1.6, -1.6, -0.6), Eigen::Vector3d(1.6, 1.6, 0.6));
+		CubicLagrangeDiscreteGrid g(dom, {{6, 5, 4}});
+		auto poly = [](Eigen::Vector3d const& p) { return 1.0 + p[0] - 2.0 * p[1] + 0.5 * p[2] * p[0]; };
+		const unsigned int id0 = g.addFunction(poly);
+		bool threw = false;
+		try
+		{
+			g.addFunction(MeshSDF{&md, false});
+		}
+		catch (std::exception const& e)
+		{
+			threw = true;
+			std::cout << "addFunction failed as arranged: " << e.what() << std::endl;
+		}
+		if (!threw)
+		{
+			std::cout << "the MeshSDF addFunction did not fail (run with DG_FORCE_CPU=1 DG_REQUIRE_GPU=1)" << std::endl;
+			return 3;
+		}
+		if (id0 != 0u || g.nFields() != 1u)
+			return 4;
+		// the next field gets the id that indexes what it wrote
+		const unsigned int id1 = g.addFunction([&](Eigen::Vector3d const& p) { return 2.0 * poly(p); });
+		if (id1 != 1u || g.nFields() != 2u || g.nodeData(1).size() != g.nodeData(0).size())
+			return 5;
+		for (std::size_t l = 0; l < g.nodeData(0).size(); ++l)
+			if (g.nodeData(1)[l] != 2.0 * g.nodeData(0)[l])
+				return 6;
+		const Eigen::Vector3d x(0.3, -0.2, 0.1);
+		if (g.interpolate(1, x) != 2.0 * g.interpolate(0, x))
+			return 7;
+		g.save(argv[3]);
+		CubicLagrangeDiscreteGrid h{std::string(argv[3])};
+		if (h.nFields() != 2u || h.nodeData(1) != g.nodeData(1))
+			return 8;
+		return 0;
+	}
+	if (cmd == "cpu" && argc == 6)
+	{
+		TriangleMesh mesh{std::string(argv[2])};
+		TriangleMeshDistance md(mesh);
+		Eigen::AlignedBox3d dom;
+		dom.setEmpty();
+		for (auto const& x : mesh.vertices())
+			dom.extend(x);
+		dom.max() += 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		dom.min() -= 1.0e-3 * dom.diagonal().norm() * Eigen::Vector3d::Ones();
+		std::array<unsigned int, 3> res;
+		{
+			std::istringstream in(argv[3]);
+			in >> res[0] >> res[1] >> res[2];
+		}
+		CubicLagrangeDiscreteGrid g(dom, res);
+		g.addFunction(MeshSDF{&md, false});
+		std::vector<double> out;
+		out.push_back(g.lastAddFunctionUsedGpu() ? 1.0 : 0.0);
+		out.push_back(0.0);
+		out.insert(out.end(), g.nodeData(0).begin(), g.nodeData(0).end());
+		const std::vector<double> xyz = read_doubles(argv[4]);
+		std::vector<std::array<double, 3>> pts;
+		for (std::size_t l = 0; l + 2 < xyz.size(); l += 3)
+			pts.push_back({{xyz[l], xyz[l + 1], xyz[l + 2]}});
+		for (auto const& r : md.signed_distance(pts))
+			out.push_back(r.distance);
+		write_doubles(argv[5], out);
+		return 0;
+	}
 	if (cmd == "roundtrip" && argc == 4)
 	{
 		CubicLagrangeDiscreteGrid g{std::string(argv[2])};

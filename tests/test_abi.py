@@ -85,15 +85,23 @@ def test_invalid_arguments_are_reported(dg):
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
 def test_no_device_fails_loudly(dg):
-    """No CPU path: on a machine without a HIP device compute entry points return
-    DG_ERR_NO_DEVICE instead of silently computing on the host."""
+    """No CPU path behind the ABI: on a machine without a HIP device every entry point that would launch a kernel returns
+    DG_ERR_NO_DEVICE instead of silently computing on the host.  What works without one (round 4): a HOST-ONLY
+    mesh handle (BVH + pseudonormals in host memory, dg_mesh_device() == -1) and the per-point query on it -- the
+    reference's TriangleMeshDistance::signed_distance(point) -- with the bits of the oracle."""
     assert dg.device_count() == 0
-    V, F = T.box_mesh()
-    with pytest.raises(dg.DiscregridError) as e:
-        dg.Mesh(V, F)
-    assert e.value.status == dg.DG_ERR_NO_DEVICE
-    assert "no CPU path" in str(e.value)
-    g = dg.grid_desc([0] * 3, [1] * 3, [2, 2, 2])
+    V, F = T.torus()
+    m = dg.Mesh(V, F)
+    assert m.device() == -1 and m.info()["device_bytes"] == 0 and m.info()["n_triangles"] == len(F)
+    g = dg.grid_desc([-1.5] * 3, [1.5] * 3, [3, 3, 3])
+    for call in (lambda: m.sample_nodes(g), lambda: m.signed_distance(np.zeros((4, 3)))):
+        with pytest.raises(dg.DiscregridError) as e:
+            call()
+        assert e.value.status == dg.DG_ERR_NO_DEVICE
+        assert "no CPU path" in str(e.value)
+    P = np.random.default_rng(4).uniform(-1.5, 1.5, size=(300, 3))
+    got = np.array([m.signed_distance_point(p) for p in P])
+    np.testing.assert_array_equal(got, T.OracleMesh(V, F).signed_distance(P))
     with pytest.raises(dg.DiscregridError) as e:
         dg.Field(g, np.zeros(dg.n_nodes(g)))
     assert e.value.status == dg.DG_ERR_NO_DEVICE

@@ -124,3 +124,69 @@ def test_headers_compile_standalone(tmp_path):
         src.write_text("#include <%s>\nint main() { return 0; }\n" % h)
         subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I" + inc,
                                "-I" + os.path.join(CPP, "third_party", "eigen_min"), str(src)])
+
+
+def _no_gpu_env():
+    """the C++ API without a HIP device: on the build box there is none; on a GPU box DG_FORCE_CPU=1 makes the mesh handle
+    host-only (include/discregrid_hip.h dg_mesh_device())."""
+    return dict(os.environ, DG_FORCE_CPU="1")
+
+
+def test_generate_sdf_cli_without_a_device_reproduces_box_cdf(driver, tmp_path):
+    """without a HIP device the typed MeshSDF functor falls back to the reference's OpenMP node loop over the
+    per-point query (the product's own BVH and arithmetic on the host).  GenerateSDF -r "5 5 5" box.obj still writes the
+    reference's box.cdf, byte for byte."""
+    exe = os.path.join(CPP, "build", "GenerateSDF")
+    obj = str(tmp_path / "box.obj")
+    V, F = T.box_mesh()
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "box.cdf")
+    log = subprocess.check_output([exe, "-r", "5 5 5", "-o", out, obj], env=_no_gpu_env()).decode()
+    assert "Construction took" in log and "DONE" in log
+    assert read(out) == read(os.path.join(T.GOLDEN, "box.cdf"))
+
+
+def test_unchanged_reference_caller_and_typed_functor_without_a_device(driver, tmp_path):
+    """tests/cpp/unchanged_caller.cpp (the body of the reference's GenerateSDF with the reference's own lambda) and the typed
+    MeshSDF functor on a box without a GPU: same coefficients from both, equal to the oracle bit for bit; the batched
+    signed_distance falls back to the per-point query as well."""
+    exe = os.path.join(T.ROOT, "tests", "cpp", "build", "unchanged_caller")
+    V, F = T.torus()
+    obj = str(tmp_path / "torus.obj")
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, "lambda", obj, "9 7 8", out], env=_no_gpu_env())
+    got = np.fromfile(out)
+    n = int(got[0])
+    assert n == T.n_nodes([9, 7, 8]) and got[3] == 0.0          # lambda path == typed path
+    dom = T.oracle_default_domain(V)
+    om = T.OracleMesh(V, F)
+    np.testing.assert_array_equal(got[4:], om.sample_nodes(dom, [9, 7, 8]))
+    out2 = str(tmp_path / "cpu.bin")
+    n2 = T.n_nodes([6, 5, 7])
+    P = T.oracle_node_positions(dom, [6, 5, 7])[(np.arange(1000) * 7919) % n2] + np.array([0.01, -0.02, 0.005])
+    pts = str(tmp_path / "pts.bin")
+    P.tofile(pts)
+    subprocess.check_call([driver, "cpu", obj, "6 5 7", pts, out2], env=_no_gpu_env())
+    got = np.fromfile(out2)
+    assert got[0] == 0.0                                        # lastAddFunctionUsedGpu() == false
+    want = om.sample_nodes(dom, [6, 5, 7])
+    np.testing.assert_array_equal(got[2:2 + n2], want)
+    np.testing.assert_array_equal(got[2 + n2:], om.signed_distance(P))
+
+
+def test_a_failed_addfunction_leaves_the_grid_consistent(driver, tmp_path):
+    """A MeshSDF addFunction that throws (here: host-only mesh under DG_REQUIRE_GPU=1) unwinds the entries it pushed:
+    nFields() is unchanged, the next addFunction returns the id that indexes its data, scalar interpolate and save / load see
+    exactly the fields that exist (round-3 review: the GPU branch threw after the push_backs without popping)."""
+    V, F = T.torus()
+    obj = str(tmp_path / "torus.obj")
+    T.write_obj(obj, V, F)
+    out = str(tmp_path / "two_fields.cdf")
+    r = subprocess.run([driver, "fault", obj, out], env=dict(os.environ, DG_FORCE_CPU="1", DG_REQUIRE_GPU="1"),
+                       stdout=subprocess.PIPE)
+    assert r.returncode == 0, (r.returncode, r.stdout.decode())
+    assert b"failed as arranged" in r.stdout
+    g = T.read_cdf(out)
+    assert len(g["nodes"]) == 2
+    np.testing.assert_array_equal(g["nodes"][1], 2.0 * g["nodes"][0])
