@@ -380,10 +380,13 @@ def main():
                     help="N > 1: issue the all-gather in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
                     help="run the N > 1 protocol (communicator, shards, all-gather, unpack) even at N = 1 (self-test)")
-    ap.add_argument("--exchange", choices=["slabs", "inplace", "inplace-p2p", "to-root"], default="slabs",
-                    help="N > 1: slabs = interleaved 4-plane slabs, packed buffers, all-gather, unpack (default); inplace = contiguous "
-                         "chunks cut by measured cost, sampled into place and exchanged with grouped broadcasts (no unpack pass, no "
-                         "scratch); inplace-p2p: the same with send / recv pairs; to-root: only rank 0 gets the whole field")
+    ap.add_argument("--exchange", choices=["auto", "slabs", "inplace", "inplace-p2p", "copy", "to-root"], default="auto",
+                    help="N > 1: auto (default) = time slabs, inplace, inplace-p2p and copy during the warm-up (after the cost "
+                         "rebalance of the in-place forms) and run the timed steps with the fastest; slabs = interleaved 4-plane "
+                         "slabs, packed buffers, all-gather, unpack; inplace = contiguous chunks cut by measured cost, sampled into "
+                         "place and exchanged with grouped broadcasts (no unpack pass, no scratch); inplace-p2p: the same with "
+                         "send / recv pairs; copy: the same chunks pushed into the peers' fields by the copy engines (HIP IPC + "
+                         "hipMemcpyAsync, no collective kernel beside the sampling); to-root: only rank 0 gets the whole field")
     ap.add_argument("--python-gather", action="store_true",
                     help="N > 1: drive the pieces from here with torch.distributed's all_gather instead of the library's "
                          "dg_sdf_sample_allgather_device (A/B, and the one-GPU self-test)")
@@ -428,9 +431,12 @@ def main():
     s = stream.cuda_stream
 
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
-    comm = None
+    comm = None          # the library's RCCL communicator
+    comm_ext = None      # one-GPU self-test: the library's communicator with gloo as its control plane (copy form only)
     pieces = 1
-    inplace = sharded and args.exchange != "slabs"
+    comm_note = None
+    launch_nodes = n_nodes
+    exchange_report = None
     if sharded:
         pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
         vworld = pieces * world
@@ -440,7 +446,6 @@ def main():
             c, stride = dg.shard_layout(grid, p * world + rank, vworld)
             counts.append(c)
         launch_nodes = sum(counts)
-        comm_note = None
         if not args.python_gather:
             # the library's own RCCL communicator: rank 0's unique id travels through torch.distributed.  Should the
             # library's communicator not come up on some rank (it never ran with more than one rank on the boxes this
@@ -468,29 +473,32 @@ def main():
             if int(failed.item()) != 0:
                 comm = None
                 comm_note = "library communicator unavailable (%s)" % (comm_note or "on another rank")
-        if comm is None and not inplace:
-            # piece p of this rank = shard of virtual rank p*world + rank in a (pieces*world)-way deal of the
-            # 4-plane slabs; `gathered` is exactly the buffer a single all-gather among pieces*world ranks
-            # would produce and the unpack kernel is unchanged
+        elif selftest:
+            def _ag(mine):
+                t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+                outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t)
+                return [bytes(o.numpy().tobytes()) for o in outs]
+            comm_ext = dg.Comm.external(rank, world, _ag, dist.barrier)
+        # python-driven slabs (no library communicator): buffers
+        gathered = mine = unpack_stream = None
+        if comm is None:
             gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
             mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
             unpack_stream = torch.cuda.Stream()
-    else:
-        launch_nodes = n_nodes
-        comm_note = None
-
-    plane_cost = [None]            # inplace: relative cost per plane of every class (None: uniform), refined from measured times
-    ex_flags = 0
-    if inplace:
-        ex_flags = dg.EXCHANGE_INPLACE | (dg.EXCHANGE_P2P if args.exchange == "inplace-p2p" else 0) | \
-            (dg.EXCHANGE_TO_ROOT if args.exchange == "to-root" else 0)
         cg_D = [(res[0] + 1, res[1] + 1, res[2] + 1), (2 * res[0], res[1] + 1, res[2] + 1), (2 * res[1], res[2] + 1, res[0] + 1),
                 (2 * res[2], res[0] + 1, res[1] + 1)]      # class dims (fastest, middle, slowest = k, k, i, j)
         cg_off = np.concatenate([[0], np.cumsum([int(np.prod(d)) for d in cg_D])])
 
+    plane_cost = [None]            # in-place forms: relative cost per plane of every class (None: uniform), refined from measured times
+    FLAGS = {"inplace": dg.EXCHANGE_INPLACE, "inplace-p2p": dg.EXCHANGE_INPLACE | dg.EXCHANGE_P2P,
+             "to-root": dg.EXCHANGE_INPLACE | dg.EXCHANGE_TO_ROOT, "copy": dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY}
+    last_python_ms = [None]
+
     def rebalance(piece_ms):
         """piece_ms[r][p]: sampling time of piece p on rank r -> plane costs: every plane of the chunks of virtual rank
-        v = p * world + r gets (time of that launch / its nodes) x (nodes of the plane)."""
+        v = p * world + r gets (time of that launch / its nodes) x (nodes of the plane).  Every rank computes this from the
+        SAME gathered times, so every rank cuts the lattice the same way."""
         cuts = dg.chunk_layout(grid, vworld, plane_cost[0])
         cost = [np.zeros(d[2], dtype=np.float32) for d in cg_D]
         for r in range(world):
@@ -520,58 +528,120 @@ def main():
                 for c in range(4):
                     a = int(cg_off[c]) + int(cuts[c][vo]) * cg_D[c][0] * cg_D[c][1]
                     b = int(cg_off[c]) + int(cuts[c][vo + 1]) * cg_D[c][0] * cg_D[c][1]
-                    if b > a and (args.exchange != "to-root" or True):
+                    if b > a:
                         dist.broadcast(field[a:b], src=o)
         torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in times]
+        last_python_ms[0] = [a.elapsed_time(b) for a, b in times]
+
+    def run_form(form):
+        """one step of the sharded protocol in the given exchange form (enqueued on `stream`)"""
+        if form in FLAGS:
+            c = comm if comm is not None else (comm_ext if form == "copy" else None)
+            if c is not None:
+                c.sample_exchange_device(mesh, grid, field.data_ptr(), pieces=pieces, flags=FLAGS[form], root=0, plane_cost=plane_cost[0],
+                                         stream=s)
+            else:
+                python_inplace_step()
+        elif comm is not None:
+            comm.sample_allgather_device(mesh, grid, field.data_ptr(), pieces=pieces, stream=s)
+        else:
+            for p in range(pieces):
+                mp = mine[p * stride:(p + 1) * stride]
+                mesh.sample_shard_device(grid, p * world + rank, vworld, mp.data_ptr(), stream=s)
+                # the collective's stream waits for the kernel just enqueued; this stream goes on with piece p+1
+                work = dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp, async_op=True)
+                with torch.cuda.stream(unpack_stream):
+                    work.wait()          # unpack_stream waits for gather p, not the host
+                    dg.unpack_shard_range_device(grid, vworld, gathered.data_ptr(), stride, p * world, (p + 1) * world,
+                                                 field.data_ptr(), stream=unpack_stream.cuda_stream)
+            stream.wait_stream(unpack_stream)
+
+    def piece_times(form):
+        """this rank's sampling time per piece of the step just run (None where the form does not report it)"""
+        c = comm if comm is not None else (comm_ext if form == "copy" else None)
+        if c is not None:
+            return c.last_chunk_ms(pieces)
+        return last_python_ms[0] if form in FLAGS else None
+
+    def share_and_rebalance(form):
+        torch.cuda.synchronize()
+        ms = piece_times(form)
+        mine_ms = torch.tensor(ms, dtype=torch.float32, device="cpu" if selftest else "cuda")
+        all_ms = [torch.empty_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        rebalance([t.cpu().tolist() for t in all_ms])
+
+    def trial(form, steps=2):
+        """max over ranks of the mean step time of `steps` steps in this form (None if any rank failed)"""
+        failed = torch.zeros(1, dtype=torch.int32, device="cpu" if selftest else "cuda")
+        note = None
+        dt = 0.0
+        try:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_form(form)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps * 1e3
+        except Exception as exc:  # noqa: BLE001 (reported on the line; the form is out of the race)
+            note = "%s: %s" % (type(exc).__name__, str(exc)[:160])
+            failed += 1
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if selftest else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return (None if int(failed.item()) else float(t.item())), note
+
+    form = args.exchange if sharded else None
+    if sharded and form == "auto" and world == 1:
+        form = "slabs"    # (--force-shard-path on one GPU: nothing to choose)
+    if sharded and form == "auto":
+        # Measure, do not guess: none of the exchange forms has ever run on more than one GPU where this was developed.
+        # Uniform cuts first (two steps, which also give the in-place forms their cost weights), then every form twice.
+        ms_by_form, errors = {}, {}
+        for cand in ("slabs", "inplace", "inplace-p2p", "copy"):
+            if cand in FLAGS:
+                plane_cost[0] = None
+                ok = True
+                for _ in range(2):       # settle the cost-weighted cuts of this form
+                    t_, note = trial(cand, 1)
+                    if t_ is None:
+                        ok = False
+                        errors[cand] = note or "failed on another rank"
+                        break
+                    share_and_rebalance(cand)
+                if not ok:
+                    continue
+            t_, note = trial(cand, 2)
+            if t_ is None:
+                errors[cand] = note or "failed on another rank"
+            else:
+                ms_by_form[cand] = t_
+        if not ms_by_form:
+            raise SystemExit("no exchange form ran: %s" % errors)
+        form = min(ms_by_form, key=ms_by_form.get)
+        exchange_report = {"chosen": form, "ms_by_form": ms_by_form, "errors": errors or None,
+                           "how": "warm-up: 2 steps per form (max over ranks), in-place forms after 2 cost-rebalancing steps"}
+        plane_cost[0] = None
+    inplace = sharded and form in FLAGS
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record(stream)
-        if inplace and comm is not None:
-            comm.sample_exchange_device(mesh, grid, field.data_ptr(), pieces=pieces, flags=ex_flags, root=0, plane_cost=plane_cost[0],
-                                        stream=s)
-            if i is not None:
-                ev[i][1].record(stream)
-        elif inplace:
-            python_inplace_step()
-            if i is not None:
-                ev[i][1].record(stream)
-        elif sharded and comm is not None:
-            comm.sample_allgather_device(mesh, grid, field.data_ptr(), pieces=pieces, stream=s)
-            if i is not None:
-                ev[i][1].record(stream)    # the call makes `stream` wait for the last unpack
-        elif sharded:
-            for p in range(pieces):
-                mp = mine[p * stride:(p + 1) * stride]
-                mesh.sample_shard_device(grid, p * world + rank, vworld, mp.data_ptr(), stream=s)
-                # the collective's stream waits for the kernel just enqueued; this stream goes on with piece p+1
-                work = dist.all_gather_into_tensor(gathered[p * world * stride:(p + 1) * world * stride], mp,
-                                                   async_op=True)
-                with torch.cuda.stream(unpack_stream):
-                    work.wait()          # unpack_stream waits for gather p, not the host
-                    dg.unpack_shard_range_device(grid, vworld, gathered.data_ptr(), stride, p * world, (p + 1) * world,
-                                                 field.data_ptr(), stream=unpack_stream.cuda_stream)
-            stream.wait_stream(unpack_stream)
-            if i is not None:
-                ev[i][1].record(stream)
+        if sharded:
+            run_form(form)
         else:
             mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
-            if i is not None:
-                ev[i][1].record(stream)
+        if i is not None:
+            ev[i][1].record(stream)    # (the sharded calls make `stream` wait for the complete field)
 
     for w in range(args.warmup):
         step()
         if inplace and world > 1:
             # cost-weighted cuts: every rank's sampling times of the step just run, shared, turned into plane costs
-            torch.cuda.synchronize()
-            ms = comm.last_chunk_ms(pieces) if comm is not None else python_inplace_step()
-            mine_ms = torch.tensor(ms, dtype=torch.float32, device="cuda")
-            all_ms = [torch.empty_like(mine_ms) for _ in range(world)]
-            dist.all_gather(all_ms, mine_ms)
-            rebalance([t.cpu().tolist() for t in all_ms])
+            share_and_rebalance(form)
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -590,6 +660,21 @@ def main():
         elapsed = float(tmax.item())
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_rank = None
+    rccl_nranks = None
+    if sharded and world > 1:
+        # what the last timed step looked like on every rank: sampling time per piece and the part of the exchange the
+        # sampling did not hide (a bad scaling number must be readable from the line)
+        c = comm if comm is not None else (comm_ext if form == "copy" else None)
+        ms = piece_times(form) or [float("nan")] * pieces
+        wait = c.last_exchange_wait_ms() if c is not None else float("nan")
+        mine_t = torch.tensor(list(ms) + [wait], dtype=torch.float32, device="cpu" if selftest else "cuda")
+        all_t = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        per_rank = {"sample_ms": [[round(float(x), 3) for x in t.cpu().tolist()[:-1]] for t in all_t],
+                    "exchange_wait_ms": [round(float(t.cpu().tolist()[-1]), 3) for t in all_t]}
+        if comm is not None:
+            rccl_nranks = comm.info()["rccl_nranks"]
     # sanity of the result that was just timed (cheap, outside the timed region)
     probe = field[:: max(1, n_nodes // 1000)].cpu().numpy()
     assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0
@@ -597,7 +682,7 @@ def main():
         ref = torch.empty_like(field)
         mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
         torch.cuda.synchronize()
-        if args.exchange != "to-root" or rank == 0 or comm is None:
+        if form != "to-root" or rank == 0 or comm is None:
             assert torch.equal(ref, field), "the sharded protocol's field differs from the direct launch"
 
     if rank == 0:
@@ -621,8 +706,11 @@ def main():
                              % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
                                 else "dg_sdf_sample_allgather_device (RCCL inside the library)")) if not inplace else
                             ("contiguous chunks cut by measured cost, sampled in place, %s in %d piece(s) by %s"
-                             % (args.exchange, pieces, "torch.distributed broadcasts (python)" if comm is None
-                                else "dg_sdf_sample_exchange_device (RCCL inside the library)")),
+                             % (form, pieces, "torch.distributed broadcasts (python)" if (comm is None and not (form == "copy" and comm_ext))
+                                else ("dg_sdf_sample_exchange_device (%s)" % ("peer copies on the copy engines, HIP IPC"
+                                                                              if form == "copy" else "RCCL inside the library")))),
+                # every multi-rank figure of this path is UNVERIFIED on hardware until a driver-run SCALE file exists
+                "exchange": (dict(exchange_report or {"chosen": form}, per_rank=per_rank, rccl_nranks=rccl_nranks) if sharded else None),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {
@@ -665,6 +753,8 @@ def main():
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
+    if comm_ext is not None:
+        comm_ext.close()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -95,6 +95,9 @@ SYMBOLS = {
     "dg_sdf_sample_exchange_device": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_comm_last_chunk_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "dg_comm_last_exchange_wait_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "dg_comm_create_external": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dg_comm_get_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
                                   C.POINTER(C.c_void_p)]),
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -320,7 +323,16 @@ def sample_nodes_multi(meshes, grid, begin=0, end=None, invert=False, mask=None)
     return out
 
 
-EXCHANGE_INPLACE, EXCHANGE_P2P, EXCHANGE_TO_ROOT = 1, 2, 4
+EXCHANGE_INPLACE, EXCHANGE_P2P, EXCHANGE_TO_ROOT, EXCHANGE_COPY = 1, 2, 4, 8
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("rccl_nranks", C.c_int32),
+                ("registered_fields", C.c_int32)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 def _plane_cost_arg(plane_cost):
@@ -397,6 +409,47 @@ class Comm:
         _check(self._lib.dg_comm_create(buf, rank, nranks, C.byref(h)))
         self.handle = h
         self.rank, self.nranks = rank, nranks
+
+    @classmethod
+    def external(cls, rank, nranks, allgather, barrier):
+        """dg_comm_create_external: a communicator whose two small host-side collectives the caller supplies (RCCL-free; runs
+        EXCHANGE_INPLACE | EXCHANGE_COPY only).  allgather(mine: bytes) -> list of every rank's bytes; barrier() -> None."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+
+        def _ag(mine, out, nbytes, _user):
+            try:
+                parts = allgather(C.string_at(mine, nbytes))
+                assert len(parts) == nranks and all(len(b) == nbytes for b in parts)
+                C.memmove(out, b"".join(parts), nbytes * nranks)
+                return 0
+            except Exception:  # noqa: BLE001 (reported through the status code)
+                return 1
+
+        def _bar(_user):
+            try:
+                barrier()
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        self._callbacks = (ALLGATHER_FN(_ag), BARRIER_FN(_bar))   # kept alive with the handle
+        h = C.c_void_p()
+        _check(self._lib.dg_comm_create_external(rank, nranks, C.cast(self._callbacks[0], C.c_void_p), C.cast(self._callbacks[1], C.c_void_p),
+                                                 None, C.byref(h)))
+        self.handle = h
+        self.rank, self.nranks = rank, nranks
+        return self
+
+    def info(self):
+        i = CommInfo()
+        _check(self._lib.dg_comm_get_info(self.handle, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in CommInfo._fields_}
+
+    def last_exchange_wait_ms(self):
+        ms = C.c_float(0.0)
+        _check(self._lib.dg_comm_last_exchange_wait_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -8,10 +8,14 @@
 // exactly that one.
 #include "dg_capi_internal.h"
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <dlfcn.h>
+#include <map>
 #include <memory>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 namespace
 {
@@ -22,6 +26,8 @@ struct Rccl
 	decltype(&ncclCommInitRank) CommInitRank = nullptr;
 	decltype(&ncclCommDestroy) CommDestroy = nullptr;
 	decltype(&ncclAllGather) AllGather = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;
 	decltype(&ncclBroadcast) Broadcast = nullptr;
 	decltype(&ncclSend) Send = nullptr;
 	decltype(&ncclRecv) Recv = nullptr;
@@ -49,13 +55,15 @@ Rccl* rccl()
 		R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
 		R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.lib, "ncclAllGather"));
 		R.Broadcast = reinterpret_cast<decltype(R.Broadcast)>(dlsym(R.lib, "ncclBroadcast"));
+		R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(dlsym(R.lib, "ncclAllReduce"));
+		R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.lib, "ncclCommCount"));
 		R.Send = reinterpret_cast<decltype(R.Send)>(dlsym(R.lib, "ncclSend"));
 		R.Recv = reinterpret_cast<decltype(R.Recv)>(dlsym(R.lib, "ncclRecv"));
 		R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(dlsym(R.lib, "ncclGroupStart"));
 		R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(dlsym(R.lib, "ncclGroupEnd"));
 		R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
 		if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather || !R.GetErrorString || !R.Broadcast || !R.Send || !R.Recv ||
-			!R.GroupStart || !R.GroupEnd)
+			!R.GroupStart || !R.GroupEnd || !R.AllReduce || !R.CommCount)
 			R.error = "librccl.so.1 lacks an expected symbol";
 	});
 	return R.error.empty() ? &R : nullptr;
@@ -68,10 +76,42 @@ dg_status rccl_unavailable()
 }
 } // namespace
 
+// one peer's view of a registered field: the allocation its process exported, opened here
+struct PeerField
+{
+	std::vector<char*> base;   // [nranks]: peer r's d_field in THIS process' address space (own rank: the local pointer)
+	std::vector<void*> opened; // what hipIpcOpenMemHandle returned (closed with the communicator)
+	uint64_t bytes = 0;
+};
+struct IpcRecord // what travels through the control plane when a field is registered
+{
+	hipIpcMemHandle_t handle;
+	uint64_t offset; // of d_field inside the exported allocation
+	uint64_t bytes;
+	uint64_t alloc_bytes; // size of that allocation
+	int32_t device;
+	int32_t pid;
+};
 struct dg_comm
 {
 	ncclComm_t comm = nullptr;
 	bool owned = false;
+	// control plane without RCCL (dg_comm_create_external): small host-blocking collectives supplied by the caller
+	dg_comm_allgather_fn ext_allgather = nullptr;
+	dg_comm_barrier_fn ext_barrier = nullptr;
+	void* ext_user = nullptr;
+	// DG_EXCHANGE_COPY: one copy stream per peer (the chunks are pushed by the copy engines), the fields whose peers
+	// are known, a device word for the stream-ordered barriers of the RCCL control plane
+	std::vector<hipStream_t> copy_streams;
+	std::vector<hipEvent_t> copy_done;
+	std::map<const void*, PeerField> peer_fields;
+	int* d_token = nullptr;
+	hipEvent_t entered = nullptr, started = nullptr;
+	uint64_t cuts_hash = 0; // of the last cost-weighted cuts every rank agreed on
+	bool cuts_checked = false;
+	hipEvent_t t_last_sampled = nullptr, t_complete = nullptr; // timing: end of this rank's last sampling launch / field complete
+	bool wait_timed = false;
+	std::map<std::string, void*> opened_handles; // (pid, handle) -> mapping: an allocation is opened once however many fields live in it
 	int rank = 0, nranks = 1, device = -1;
 	hipStream_t gather = nullptr, unpack = nullptr; // the exchange and the unpack run beside the caller's stream
 	std::vector<hipEvent_t> sampled, gathered;      // per piece
@@ -109,6 +149,12 @@ static dg_status comm_finish_setup(dg_comm* c)
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->gather, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->unpack, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->entered, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->started, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreate(&c->t_last_sampled);
+	if (e == hipSuccess) e = hipEventCreate(&c->t_complete);
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_token), 256);
+	if (e == hipSuccess) e = hipMemset(c->d_token, 0, 256);
 	if (e != hipSuccess)
 		return fail(DG_ERR_HIP, "dg_comm: %s", hipGetErrorString(e));
 	return DG_OK;
@@ -222,6 +268,54 @@ dg_status dg_comm_adopt(void* nccl_comm, int rank, int nranks, dg_comm** out)
 	return DG_OK;
 }
 
+dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn allgather, dg_comm_barrier_fn barrier, void* user,
+								  dg_comm** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!allgather || !barrier || nranks < 1 || nranks > dg::kMaxRanks || rank < 0 || rank >= nranks)
+		return fail(DG_ERR_INVALID, "null callback, or rank %d / nranks %d out of range (max %d ranks)", rank, nranks, dg::kMaxRanks);
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	dg_comm* c = new (std::nothrow) dg_comm;
+	if (!c)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	c->rank = rank;
+	c->nranks = nranks;
+	c->ext_allgather = allgather;
+	c->ext_barrier = barrier;
+	c->ext_user = user;
+	s = comm_finish_setup(c);
+	if (s != DG_OK)
+	{
+		dg_comm_destroy(c);
+		return s;
+	}
+	*out = c;
+	return DG_OK;
+}
+
+dg_status dg_comm_get_info(dg_comm* comm, dg_comm_info* info)
+{
+	if (!comm || !info)
+		return fail(DG_ERR_INVALID, "null argument");
+	info->rank = comm->rank;
+	info->nranks = comm->nranks;
+	info->device = comm->device;
+	info->rccl_nranks = -1;
+	info->registered_fields = (int32_t)comm->peer_fields.size();
+	if (comm->comm)
+	{
+		Rccl* R = rccl();
+		int n = 0;
+		if (R && R->CommCount(comm->comm, &n) == ncclSuccess)
+			info->rccl_nranks = n;
+	}
+	return DG_OK;
+}
+
 void dg_comm_destroy(dg_comm* c)
 {
 	if (!c)
@@ -237,6 +331,21 @@ void dg_comm_destroy(dg_comm* c)
 	for (hipEvent_t e : c->t_begin) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->t_end) (void)hipEventDestroy(e);
 	if (c->done) (void)hipEventDestroy(c->done);
+	for (hipStream_t cs : c->copy_streams)
+		if (cs)
+		{
+			(void)hipStreamSynchronize(cs);
+			(void)hipStreamDestroy(cs);
+		}
+	for (hipEvent_t e : c->copy_done)
+		if (e) (void)hipEventDestroy(e);
+	for (auto& kv : c->opened_handles)
+		(void)hipIpcCloseMemHandle(kv.second);
+	if (c->entered) (void)hipEventDestroy(c->entered);
+	if (c->started) (void)hipEventDestroy(c->started);
+	if (c->t_last_sampled) (void)hipEventDestroy(c->t_last_sampled);
+	if (c->t_complete) (void)hipEventDestroy(c->t_complete);
+	if (c->d_token) (void)hipFree(c->d_token);
 	if (c->gather) (void)hipStreamDestroy(c->gather);
 	if (c->unpack) (void)hipStreamDestroy(c->unpack);
 	if (c->d_mine) (void)hipFree(c->d_mine);
@@ -275,6 +384,8 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
 	Rccl* R = rccl();
 	if (!R)
 		return rccl_unavailable();
+	if (!comm->comm)
+		return fail(DG_ERR_INVALID, "a communicator with an external control plane runs DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY only");
 	if (mesh->device != comm->device)
 		return fail(DG_ERR_INVALID, "mesh lives on device %d, the communicator on device %d", mesh->device, comm->device);
 	const int N = comm->nranks;
@@ -332,8 +443,328 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
 		if (s != DG_OK)
 			return s;
 	}
+	DG_HIP(hipEventRecord(comm->t_last_sampled, st));
 	DG_HIP(hipEventRecord(comm->done, comm->unpack));
 	DG_HIP(hipStreamWaitEvent(st, comm->done, 0)); // the field is complete in the order of the caller's stream
+	DG_HIP(hipEventRecord(comm->t_complete, st));
+	comm->wait_timed = true;
+	comm->last_pieces = pieces;
+	return DG_OK;
+}
+
+// ---- DG_EXCHANGE_COPY: the control plane (small, host-blocking collectives) ---------------------------------------------
+static dg_status ctrl_allgather(dg_comm* c, const void* mine, void* all, size_t bytes)
+{
+	if (c->ext_allgather)
+	{
+		if (c->ext_allgather(mine, all, bytes, c->ext_user) != 0)
+			return fail(DG_ERR_HIP, "the caller's allgather failed");
+		return DG_OK;
+	}
+	Rccl* R = rccl();
+	if (!R || !c->comm)
+		return rccl_unavailable();
+	void* d = nullptr;
+	DG_HIP(hipMalloc(&d, bytes * (size_t)(c->nranks + 1)));
+	char* dall = static_cast<char*>(d) + bytes;
+	hipError_t e = hipMemcpyAsync(d, mine, bytes, hipMemcpyHostToDevice, c->gather);
+	ncclResult_t r = ncclSuccess;
+	if (e == hipSuccess)
+		r = R->AllGather(d, dall, bytes, ncclUint8, c->comm, c->gather);
+	if (e == hipSuccess && r == ncclSuccess)
+		e = hipMemcpyAsync(all, dall, bytes * (size_t)c->nranks, hipMemcpyDeviceToHost, c->gather);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(c->gather);
+	(void)hipFree(d);
+	if (r != ncclSuccess)
+		return fail(DG_ERR_HIP, "ncclAllGather (control plane): %s", R->GetErrorString(r));
+	DG_HIP(e);
+	return DG_OK;
+}
+// one word all-reduced on the communicator's stream: stream-ordered, a few microseconds of one CU
+static dg_status rccl_stream_barrier(dg_comm* c)
+{
+	Rccl* R = rccl();
+	if (!R || !c->comm)
+		return rccl_unavailable();
+	const ncclResult_t r = R->AllReduce(c->d_token, c->d_token + 16, 1, ncclInt, ncclSum, c->comm, c->gather);
+	if (r != ncclSuccess)
+		return fail(DG_ERR_HIP, "ncclAllReduce (barrier): %s", R->GetErrorString(r));
+	return DG_OK;
+}
+// DG_COMM_DEBUG=1: one line per protocol stage on stderr (where does a rank wait?)
+static void comm_trace(const dg_comm* c, const char* what, int p = -1)
+{
+	static const int on = env_int("DG_COMM_DEBUG", 0, 0, 1);
+	if (!on)
+		return;
+	const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	std::fprintf(stderr, "[dg_comm %.6f rank %d/%d] %s%s%s\n", t, c->rank, c->nranks, what, p >= 0 ? " piece " : "", p >= 0 ? std::to_string(p).c_str() : "");
+	std::fflush(stderr);
+}
+// host-blocking barrier of the control plane
+static dg_status ctrl_barrier_host(dg_comm* c)
+{
+	if (c->ext_barrier)
+	{
+		if (c->ext_barrier(c->ext_user) != 0)
+			return fail(DG_ERR_HIP, "the caller's barrier failed");
+		return DG_OK;
+	}
+	dg_status s = rccl_stream_barrier(c);
+	if (s != DG_OK)
+		return s;
+	DG_HIP(hipStreamSynchronize(c->gather));
+	return DG_OK;
+}
+// the peers' views of d_field (collective and host-blocking on first use of the pointer)
+static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, PeerField** out)
+{
+	auto it = c->peer_fields.find(d_field);
+	if (it != c->peer_fields.end() && it->second.bytes >= bytes)
+	{
+		*out = &it->second;
+		return DG_OK;
+	}
+	const int N = c->nranks;
+	IpcRecord mine;
+	std::memset(&mine, 0, sizeof(mine));
+	PeerField pf;
+	pf.base.assign((size_t)N, nullptr);
+	pf.base[(size_t)c->rank] = reinterpret_cast<char*>(d_field);
+	pf.bytes = bytes;
+	if (N > 1)
+	{
+		void* base = nullptr;
+		size_t size = 0;
+		DG_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_field));
+		comm_trace(c, "  address range known");
+		DG_HIP(hipIpcGetMemHandle(&mine.handle, base));
+		comm_trace(c, "  handle exported");
+		mine.offset = (uint64_t)(reinterpret_cast<char*>(d_field) - static_cast<char*>(base));
+		mine.bytes = bytes;
+		mine.alloc_bytes = size;
+		mine.device = c->device;
+		mine.pid = (int32_t)getpid();
+		std::vector<IpcRecord> all((size_t)N);
+		dg_status s = ctrl_allgather(c, &mine, all.data(), sizeof(IpcRecord));
+		if (s != DG_OK)
+			return s;
+		comm_trace(c, "  handles gathered");
+		// Measured on the MI355X box of this round (ROCm 7.2, dmabuf IPC, several processes on one device):
+		// hipIpcOpenMemHandle never returns for an allocation above 2 GiB (1.9 GB: fine with 2, 3 and 4 processes; 3.8 GB: hangs
+		// with 2).  Every rank sees every record, so all of them refuse together instead of one of them hanging
+		// (DG_IPC_MAX_MB raises the limit where the platform is known to cope).
+		const uint64_t max_alloc = (uint64_t)env_int("DG_IPC_MAX_MB", 2047, 1, 1 << 30) << 20;
+		for (int r = 0; r < N; ++r)
+			if (all[(size_t)r].alloc_bytes > max_alloc)
+				return fail(DG_ERR_INVALID, "DG_EXCHANGE_COPY: the field of rank %d lives in an allocation of %.2f GB; opening allocations above %llu MB "
+											"through HIP IPC hung on the platform this was developed on (set DG_IPC_MAX_MB to try)", r,
+							(double)all[(size_t)r].alloc_bytes * 1e-9, (unsigned long long)(max_alloc >> 20));
+		// The ranks open each other's allocations ONE RANK AT A TIME (DG_IPC_STAGGER=0: all at once): four processes that
+		// opened each other's handles simultaneously never returned from hipIpcOpenMemHandle on the box this was developed
+		// on (two did), and the set-up happens once per field.
+		const bool stagger = env_int("DG_IPC_STAGGER", 1, 0, 1) != 0;
+		for (int turn = 0; turn < (stagger ? N : 1); ++turn)
+		{
+		if (stagger)
+		{
+			s = ctrl_barrier_host(c);
+			if (s != DG_OK)
+				return s;
+		}
+		if (stagger && turn != c->rank)
+			continue;
+		for (int r = 0; r < N; ++r)
+		{
+			if (r == c->rank)
+				continue;
+			const IpcRecord& rec = all[(size_t)r];
+			if (rec.bytes != bytes)
+				return fail(DG_ERR_INVALID, "rank %d registered %llu bytes for this field, this rank %llu", r, (unsigned long long)rec.bytes,
+							(unsigned long long)bytes);
+			if (rec.pid == mine.pid)
+				return fail(DG_ERR_INVALID, "ranks %d and %d live in one process: DG_EXCHANGE_COPY is one process per rank", r, c->rank);
+			std::string key(reinterpret_cast<const char*>(&rec.pid), sizeof(rec.pid));
+			key.append(reinterpret_cast<const char*>(&rec.handle), sizeof(rec.handle));
+			auto oh = c->opened_handles.find(key);
+			void* p = nullptr;
+			if (oh != c->opened_handles.end())
+				p = oh->second;
+			else
+			{
+				const hipError_t e = hipIpcOpenMemHandle(&p, rec.handle, hipIpcMemLazyEnablePeerAccess);
+				if (e != hipSuccess)
+					return fail(DG_ERR_HIP, "hipIpcOpenMemHandle (field of rank %d, device %d): %s", r, rec.device, hipGetErrorString(e));
+				c->opened_handles.emplace(key, p);
+				comm_trace(c, "  opened the field of rank", r);
+			}
+			pf.base[(size_t)r] = static_cast<char*>(p) + rec.offset;
+		}
+		}
+		if (stagger)
+		{
+			s = ctrl_barrier_host(c);
+			if (s != DG_OK)
+				return s;
+		}
+	}
+	PeerField& slot = c->peer_fields[d_field];
+	slot = std::move(pf);
+	*out = &slot;
+	return DG_OK;
+}
+static uint64_t hash_cuts(const uint32_t cuts[4][dg::kMaxRanks + 1], int V)
+{
+	uint64_t h = 1469598103934665603ull;
+	for (int c = 0; c < 4; ++c)
+		for (int v = 0; v <= V; ++v)
+		{
+			h ^= cuts[c][v];
+			h *= 1099511628211ull;
+		}
+	return h;
+}
+
+static dg_status exchange_copy(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
+							   const float* const plane_cost[4], double* d_field, hipStream_t st)
+{
+	const int N = comm->nranks;
+	const bool ext = comm->ext_allgather != nullptr;
+	pieces = std::max(1, std::min(pieces, dg::kMaxRanks / N));
+	const int V = pieces * N;
+	while ((int)comm->copy_streams.size() < N)
+	{
+		hipStream_t cs = nullptr;
+		hipEvent_t ce = nullptr;
+		// (highest priority: a queue of their own, so that the pushes are not serialised behind the sampling launches)
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		DG_HIP(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi));
+		comm->copy_streams.push_back(cs);
+		DG_HIP(hipEventCreateWithFlags(&ce, hipEventDisableTiming));
+		comm->copy_done.push_back(ce);
+	}
+	PeerField* pf = nullptr;
+	comm_trace(comm, "register_field");
+	dg_status s = register_field(comm, d_field, dg_grid_n_nodes(grid) * sizeof(double), &pf);
+	if (s != DG_OK)
+		return s;
+	comm_trace(comm, "registered");
+	uint32_t cuts[4][dg::kMaxRanks + 1];
+	dg::chunk_planes(grid->resolution, V, plane_cost, cuts);
+	// every rank derives the cuts from its own copy of plane_cost: make sure they agree (once per change)
+	if (N > 1)
+	{
+		const uint64_t h = hash_cuts(cuts, V);
+		if (!comm->cuts_checked || h != comm->cuts_hash)
+		{
+			std::vector<uint64_t> all((size_t)N);
+			comm_trace(comm, "cuts changed: hash allgather");
+			s = ctrl_allgather(comm, &h, all.data(), sizeof(h));
+			if (s != DG_OK)
+				return s;
+			for (int r = 0; r < N; ++r)
+				if (all[(size_t)r] != h)
+					return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank %d: plane_cost must hold the same values on every rank", r,
+								comm->rank);
+			comm->cuts_hash = h;
+			comm->cuts_checked = true;
+		}
+	}
+	dg::ClassGeom cg[4];
+	dg::class_geometry(grid->resolution, cg);
+	DG_HIP(piece_events(comm, pieces));
+	auto chunk_off = [&](int c, int v) { return (size_t)(cg[c].off + (uint64_t)cuts[c][v] * cg[c].D[0] * cg[c].D[1]) * sizeof(double); };
+	auto chunk_bytes = [&](int c, int v) { return (size_t)(cuts[c][v + 1] - cuts[c][v]) * cg[c].D[0] * cg[c].D[1] * sizeof(double); };
+	// barrier 1: every rank's stream has reached this call, i.e. nothing reads its field any more -- it may be written
+	if (N > 1)
+	{
+		if (ext)
+		{
+			comm_trace(comm, "barrier 1: stream sync");
+			DG_HIP(hipStreamSynchronize(st));
+			comm_trace(comm, "barrier 1: enter");
+			if (comm->ext_barrier(comm->ext_user) != 0)
+				return fail(DG_ERR_HIP, "the caller's barrier failed");
+			comm_trace(comm, "barrier 1: left");
+		}
+		else
+		{
+			DG_HIP(hipEventRecord(comm->entered, st));
+			DG_HIP(hipStreamWaitEvent(comm->gather, comm->entered, 0));
+			s = rccl_stream_barrier(comm);
+			if (s != DG_OK)
+				return s;
+			DG_HIP(hipEventRecord(comm->started, comm->gather));
+			for (int d = 0; d < N; ++d)
+				if (d != comm->rank)
+					DG_HIP(hipStreamWaitEvent(comm->copy_streams[(size_t)d], comm->started, 0));
+		}
+	}
+	for (int p = 0; p < pieces; ++p)
+	{
+		const int v = p * N + comm->rank;
+		uint32_t qb[4], qe[4];
+		for (int c = 0; c < 4; ++c)
+		{
+			qb[c] = cuts[c][v];
+			qe[c] = cuts[c][v + 1];
+		}
+		DG_HIP(hipEventRecord(comm->t_begin[(size_t)p], st));
+		s = dg_sdf_sample_planes_device(mesh, grid, invert, qb, qe, d_field, st);
+		if (s != DG_OK)
+			return s;
+		DG_HIP(hipEventRecord(comm->t_end[(size_t)p], st));
+		DG_HIP(hipEventRecord(comm->sampled[(size_t)p], st));
+		comm_trace(comm, "sampling enqueued", p);
+		// this rank's chunks of piece p, pushed into every peer's field by the copy engines while piece p + 1 is sampled
+		for (int k = 1; k < N; ++k)
+		{
+			const int d = (comm->rank + k) % N; // (every rank starts with its right neighbour: no peer is everybody's first target)
+			hipStream_t cs = comm->copy_streams[(size_t)d];
+			DG_HIP(hipStreamWaitEvent(cs, comm->sampled[(size_t)p], 0));
+			for (int c = 0; c < 4; ++c)
+			{
+				const size_t len = chunk_bytes(c, v);
+				if (len)
+					DG_HIP(hipMemcpyAsync(pf->base[(size_t)d] + chunk_off(c, v), reinterpret_cast<char*>(d_field) + chunk_off(c, v), len,
+										  hipMemcpyDeviceToDevice, cs));
+			}
+		}
+	}
+	DG_HIP(hipEventRecord(comm->t_last_sampled, st));
+	// barrier 2: this rank's pushes are complete -> every rank's pushes are complete -> the field is whole
+	if (N > 1)
+	{
+		for (int d = 0; d < N; ++d)
+			if (d != comm->rank)
+				DG_HIP(hipEventRecord(comm->copy_done[(size_t)d], comm->copy_streams[(size_t)d]));
+		if (ext)
+		{
+			comm_trace(comm, "barrier 2: waiting for the pushes");
+			for (int d = 0; d < N; ++d)
+				if (d != comm->rank)
+					DG_HIP(hipEventSynchronize(comm->copy_done[(size_t)d]));
+			comm_trace(comm, "barrier 2: enter");
+			if (comm->ext_barrier(comm->ext_user) != 0)
+				return fail(DG_ERR_HIP, "the caller's barrier failed");
+			comm_trace(comm, "barrier 2: left");
+		}
+		else
+		{
+			for (int d = 0; d < N; ++d)
+				if (d != comm->rank)
+					DG_HIP(hipStreamWaitEvent(comm->gather, comm->copy_done[(size_t)d], 0));
+			s = rccl_stream_barrier(comm);
+			if (s != DG_OK)
+				return s;
+			DG_HIP(hipEventRecord(comm->done, comm->gather));
+			DG_HIP(hipStreamWaitEvent(st, comm->done, 0));
+		}
+	}
+	DG_HIP(hipEventRecord(comm->t_complete, st));
+	comm->wait_timed = true;
 	comm->last_pieces = pieces;
 	return DG_OK;
 }
@@ -341,6 +772,19 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
 dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
 										int flags, int root, const float* const plane_cost[4], double* d_field, void* stream)
 {
+	if ((flags & DG_EXCHANGE_COPY) != 0)
+	{
+		if (flags != (DG_EXCHANGE_COPY | DG_EXCHANGE_INPLACE))
+			return fail(DG_ERR_INVALID, "DG_EXCHANGE_COPY goes with DG_EXCHANGE_INPLACE and nothing else");
+		if (!mesh || !grid || !comm || !d_field)
+			return fail(DG_ERR_INVALID, "null argument");
+		if (!valid_grid(grid))
+			return fail(DG_ERR_INVALID, "invalid grid");
+		if (mesh->device != comm->device)
+			return fail(DG_ERR_INVALID, "mesh lives on device %d, the communicator on device %d", mesh->device, comm->device);
+		DG_ON_DEVICE_OF(mesh);
+		return exchange_copy(mesh, grid, invert, comm, pieces, plane_cost, d_field, static_cast<hipStream_t>(stream));
+	}
 	if ((flags & DG_EXCHANGE_INPLACE) == 0)
 	{
 		if (flags != 0)
@@ -354,6 +798,8 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
 	Rccl* R = rccl();
 	if (!R)
 		return rccl_unavailable();
+	if (!comm->comm)
+		return fail(DG_ERR_INVALID, "a communicator with an external control plane runs DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY only");
 	if (mesh->device != comm->device)
 		return fail(DG_ERR_INVALID, "mesh lives on device %d, the communicator on device %d", mesh->device, comm->device);
 	const int N = comm->nranks;
@@ -417,7 +863,10 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
 			return fail(DG_ERR_HIP, "in-place exchange of piece %d: %s", p, R->GetErrorString(r));
 		DG_HIP(hipEventRecord(comm->gathered[(size_t)p], comm->gather));
 	}
+	DG_HIP(hipEventRecord(comm->t_last_sampled, st));
 	DG_HIP(hipStreamWaitEvent(st, comm->gathered[(size_t)pieces - 1], 0)); // (one stream: the last piece's event covers all)
+	DG_HIP(hipEventRecord(comm->t_complete, st));
+	comm->wait_timed = true;
 	comm->last_pieces = pieces;
 	return DG_OK;
 }
@@ -434,6 +883,18 @@ dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces)
 		DG_HIP(hipEventElapsedTime(&ms[p], comm->t_begin[(size_t)p], comm->t_end[(size_t)p]));
 	}
 	*n_pieces = n;
+	return DG_OK;
+}
+
+dg_status dg_comm_last_exchange_wait_ms(dg_comm* comm, float* ms)
+{
+	if (!comm || !ms)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!comm->wait_timed)
+		return fail(DG_ERR_INVALID, "no exchange call on this communicator yet");
+	DG_ON_DEVICE_OF(comm);
+	DG_HIP(hipEventSynchronize(comm->t_complete));
+	DG_HIP(hipEventElapsedTime(ms, comm->t_last_sampled, comm->t_complete));
 	return DG_OK;
 }
 

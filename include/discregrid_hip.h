@@ -215,12 +215,28 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
  * thin slabs balance the uneven cost per node by construction; contiguous chunks need the cuts to follow the cost:
  * plane_cost[c] (nullable) holds a relative cost for each plane of class c along its slowest index (k, k, i, j) --
  * e.g. the times dg_comm_last_chunk_ms() reported for the previous call, spread over the planes of each chunk.
+ * plane_cost must hold the SAME values on every rank (share the measured times first): each rank derives the cuts from it
+ * by itself, and ranks that disagree about the cuts post transfers that do not match -- a hang or a corrupted field.
  * DG_EXCHANGE_TO_ROOT: only rank `root` ends up with the whole field (the others keep their own chunks): every other
  * GPU then SENDS its 1 / nranks of the field instead of receiving (nranks - 1) / nranks of it.  flags == 0 is
  * dg_sdf_sample_allgather_device (interleaved slabs, packed buffers, all-gather, unpack).  No reference counterpart. */
 #define DG_EXCHANGE_INPLACE 1
 #define DG_EXCHANGE_P2P 2
 #define DG_EXCHANGE_TO_ROOT 4
+/* DG_EXCHANGE_COPY (with DG_EXCHANGE_INPLACE): the chunks are PUSHED into the peers' fields by the copy engines -- one
+ * hipMemcpyAsync per chunk and peer on a copy stream per peer, into the peer's d_field opened through HIP IPC -- so that
+ * no collective kernel competes with the sampling kernel for the compute units (K1 fills 0.95 of the VALU issue slots of
+ * all 256 CUs; the RCCL forms run their copy kernels beside it).  The first call with a given d_field is collective and
+ * host-blocking (the ranks exchange IPC handles of the allocations behind their d_field; the pointer must then stay
+ * allocated until dg_comm_destroy); every call brackets the pushes with two barriers ("every rank's stream has reached
+ * this call: its field may be written", "every rank's pushes have landed") -- one-word all-reduces on the communicator's
+ * stream with RCCL, host-blocking calls of the caller's barrier with an external control plane (below).  plane_cost must
+ * be the SAME array on every rank (true for all in-place forms: the cuts decide who sends what; this form checks a hash
+ * of the cuts across the ranks whenever they change and fails on a mismatch).  Limit found on the development platform
+ * (ROCm 7.2, dmabuf IPC): hipIpcOpenMemHandle does not return for allocations above 2 GiB, so fields living in larger
+ * allocations are REFUSED (every rank gets DG_ERR_INVALID; DG_IPC_MAX_MB overrides) -- 256 x 256 x 512 is the largest
+ * lattice of the bench that passes.  UNVERIFIED on more than one device. */
+#define DG_EXCHANGE_COPY 8
 /* cuts[c * (nchunks + 1) + v], v = 0..nchunks: first plane of chunk v of class c (class order V, X, Y, Z); host only */
 dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts);
 /* planes [plane_begin[c], plane_end[c]) of every class, sampled into their places in d_field (the WHOLE vector) */
@@ -228,9 +244,28 @@ dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* g
 									  const uint32_t plane_end[4], double* d_field, void* stream);
 dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
 										int flags, int root, const float* const plane_cost[4], double* d_field, void* stream);
+/* A communicator WITHOUT RCCL for DG_EXCHANGE_COPY (whose data path is peer copies): the two small host-side collectives
+ * it needs come from the caller -- MPI, a TCP store, torch.distributed's gloo backend (tests/test_gpu_multirank.py drives
+ * several ranks on ONE GPU this way, which RCCL refuses).  allgather(mine, all, bytes, user): all[r * bytes ...] = rank r's
+ * `mine`, returns 0; barrier(user): returns 0 once every rank has called it.  Both are called from the thread that calls
+ * dg_sdf_sample_exchange_device, in the same order on every rank.  Only DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY runs on
+ * such a communicator, and the call blocks the host until the exchange is complete. */
+typedef int (*dg_comm_allgather_fn)(const void* mine, void* all, size_t bytes, void* user);
+typedef int (*dg_comm_barrier_fn)(void* user);
+dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn allgather, dg_comm_barrier_fn barrier, void* user,
+								  dg_comm** out);
+typedef struct dg_comm_info {
+	int32_t rank, nranks, device;
+	int32_t rccl_nranks; /* ncclCommCount() of the wrapped communicator; -1: external control plane */
+	int32_t registered_fields; /* d_field pointers whose peers are mapped (DG_EXCHANGE_COPY) */
+} dg_comm_info;
+dg_status dg_comm_get_info(dg_comm* comm, dg_comm_info* info);
 /* device time of this rank's sampling launches of the most recent dg_sdf_sample_exchange_device / _allgather_device
  * call on `comm`, one value per piece (waits for that call); *n_pieces in: capacity of ms, out: pieces */
 dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces);
+/* how long the caller's stream had to wait, after this rank's last sampling launch of the most recent exchange call, until
+ * the field was complete (the part of the exchange the sampling did not hide); waits for that call */
+dg_status dg_comm_last_exchange_wait_ms(dg_comm* comm, float* ms);
 
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both

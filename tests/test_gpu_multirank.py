@@ -76,7 +76,7 @@ def test_sharded_protocol_with_several_ranks_on_one_gpu(world, pieces):
     env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(T.ROOT, "bench.py"), "--gpus", str(world),
-           "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--pieces", str(pieces)]
+           "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--pieces", str(pieces), "--exchange", "slabs"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -85,7 +85,7 @@ def test_sharded_protocol_with_several_ranks_on_one_gpu(world, pieces):
     assert "pipelined in %d piece" % pieces in rec["config"]["sharding"]
 
 
-@pytest.mark.parametrize("exchange", ["inplace", "inplace-p2p", "to-root"])
+@pytest.mark.parametrize("exchange", ["inplace", "inplace-p2p", "to-root", "copy"])
 def test_library_inplace_exchange_one_rank(exchange):
     """dg_sdf_sample_exchange_device (contiguous chunks cut by dg_chunk_layout, sampled straight into the field,
     grouped ncclBroadcast / ncclSend + ncclRecv, no unpack) through the library's own RCCL communicator with a world
@@ -108,10 +108,67 @@ def test_inplace_exchange_with_several_ranks_on_one_gpu(world, pieces):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(T.ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "2",
            "--pieces", str(pieces), "--exchange", "inplace"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == world and "contiguous chunks" in rec["config"]["sharding"]
+
+
+def _torchrun(world, script, *args, env=None, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script] + [str(a) for a in args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env or dict(os.environ))
+
+
+@pytest.mark.parametrize("world,res,pieces", [(2, "61 47 53", 3), (3, "40 36 33", 2), (4, "61 47 53", 2), (4, "256 256 512", 2)])
+def test_copy_exchange_with_several_ranks_on_one_gpu(world, res, pieces):
+    """DG_EXCHANGE_COPY inside the library with several PROCESSES sharing the one GPU (tests/perf/copy_exchange_worker.py): the
+    communicator's control plane is gloo (dg_comm_create_external: RCCL refuses two ranks on one device), everything else is what
+    runs on a multi-GPU node -- IPC handles of the ranks' fields exchanged and opened (one rank at a time), cuts agreed on by hash
+    (ranks that disagree are told so), barrier, every rank's chunks pushed into every peer's field with hipMemcpyAsync on a copy
+    stream per peer while the next piece is sampled, barrier; four steps with changing cost-weighted cuts.  Every rank asserts
+    field == direct launch, bit for bit.  The last case is the largest lattice of the bench whose field (1.9 GB) the platform's IPC
+    opens.  (One device: the copies do not cross xGMI.  UNVERIFIED on more than one GPU.)"""
+    out = _torchrun(world, os.path.join(T.ROOT, "tests", "perf", "copy_exchange_worker.py"), res, pieces)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    recs = [json.loads(l) for l in out.stdout.replace("}{", "}\n{").splitlines() if l.startswith("{")]
+    assert len(recs) == world and all(r["ok"] and r["mismatch_caught"] and r["registered_fields"] == 1 and r["rccl_nranks"] == -1 for r in recs), recs
+
+
+def test_copy_exchange_refuses_allocations_the_platform_cannot_open():
+    """hipIpcOpenMemHandle never returned for allocations above 2 GiB on the development box: every rank refuses such a field
+    together (instead of one of them hanging), and bench.py's exchange race then goes on without the copy form."""
+    out = _torchrun(2, os.path.join(T.ROOT, "tests", "perf", "copy_exchange_worker.py"), "61 47 53", 2, env=dict(os.environ, DG_IPC_MAX_MB="1"))
+    assert out.returncode != 0 and "opening allocations above 1 MB" in out.stdout + out.stderr
+
+
+def test_copy_exchange_in_bench_with_two_ranks_on_one_gpu():
+    """bench.py --exchange copy as the driver would run it at N = 2 (256 x 256 x 512 per rank pair), gloo control plane."""
+    env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1")
+    out = _torchrun(2, os.path.join(T.ROOT, "bench.py"), "--gpus", 2, "--steps", 2, "--warmup", 2, "--pieces", 4, "--exchange", "copy", env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and "peer copies on the copy engines" in rec["config"]["sharding"]
+    ex = rec["config"]["exchange"]
+    assert ex["chosen"] == "copy" and len(ex["per_rank"]["sample_ms"]) == 2 and len(ex["per_rank"]["exchange_wait_ms"]) == 2
+    assert all(len(r) == 4 and all(t > 0 for t in r) for r in ex["per_rank"]["sample_ms"])
+
+
+def test_exchange_auto_times_every_form_and_explains_itself():
+    """bench.py's default for N > 1: every exchange form is timed during the warm-up (two ranks on the one GPU here, gloo
+    stand-ins for RCCL), the timed steps run with the winner, and the line carries the timings per form, the sampling time
+    per rank and piece and the exchange time the sampling did not hide; the field equals the direct launch on every rank."""
+    env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pieces", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ex = rec["config"]["exchange"]
+    assert set(ex["ms_by_form"]) == {"slabs", "inplace", "inplace-p2p", "copy"} and not ex["errors"], ex
+    assert ex["chosen"] == min(ex["ms_by_form"], key=ex["ms_by_form"].get)
+    assert len(ex["per_rank"]["sample_ms"]) == 2
 
 
 def test_sample_planes_and_chunk_layout():
