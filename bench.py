@@ -168,18 +168,22 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         T.write_obj(obj, V, F)
         try:
             j = json.loads(subprocess.check_output([exe, "addfunction", obj, " ".join(map(str, res)), "4"], timeout=300).decode())
-            best = min(j["calls"][1:], key=lambda c: c["device_ready_s"])
+            best = min(j["calls"][1:], key=lambda c: c["total_s"])
             out["addfunction_e2e"] = {
-                "value": n_nodes / best["device_ready_s"] / 1e6, "unit": "Mnodes/s",
+                # value / ratio_to_kernel: until the HOST vector is complete -- what the reference guarantees when addFunction
+                # returns (comparable with rounds 1 and 2); the device-side figures are secondary
+                "value": n_nodes / best["total_s"] / 1e6, "unit": "Mnodes/s",
+                "host_ready_ms": best["total_s"] * 1e3, "ratio_to_kernel": best["total_s"] * 1e3 / kernel_ms,
                 "return_ms": best["return_s"] * 1e3, "device_ready_ms": best["device_ready_s"] * 1e3,
-                "host_ready_ms": best["total_s"] * 1e3, "first_call_ms": j["calls"][0]["total_s"] * 1e3,
-                "ratio_to_kernel": best["device_ready_s"] * 1e3 / kernel_ms,
-                "ratio_to_kernel_host_ready": best["total_s"] * 1e3 / kernel_ms,
+                "ratio_to_kernel_device_ready": best["device_ready_s"] * 1e3 / kernel_ms,
+                "first_call_ms": j["calls"][0]["total_s"] * 1e3,
                 "what": "CubicLagrangeDiscreteGrid::addFunction(MeshSDF) on a fresh grid (C++, the best of calls 2-4; the first call of a "
-                        "process also sets up streams and buffers).  The field is produced into a device array its handle owns; the call "
-                        "returns once the work is enqueued (return_ms); device_ready_ms = until a GPU-side consumer of the WHOLE field (a "
-                        "batched interpolate) has run -- what a following addDensityMap / batched query waits for; host_ready_ms = until the "
-                        "host vector is complete (waitForHostData: what the first scalar interpolate / save waits for)"}
+                        "process also sets up streams and buffers).  host_ready_ms (= value) = until the host vector is complete "
+                        "(waitForHostData: what the first scalar interpolate / save / nodeData waits for, and what the reference's "
+                        "addFunction means by returning).  The field is produced into a device array its handle owns, in four chunks whose "
+                        "copies run under the following chunks; the call itself returns once the work is enqueued (return_ms), and "
+                        "device_ready_ms = until a GPU-side consumer of the WHOLE field (a batched interpolate) has run -- what a "
+                        "following addDensityMap / batched query waits for"}
         except Exception as e:  # noqa: BLE001  (a missing / failing driver must not void the headline number)
             out["addfunction_e2e"] = {"error": str(e)[:200]}
     else:
@@ -239,6 +243,27 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
             ms = timed(torch, stream, fn, 5)
             bytes_q = 312 if g else 288
             k2["%s_%s_cell_major" % (name, "grad" if g else "value")] = {
+                "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    fld.drop_cell_major()
+    # ... and with the BAND-LIMITED cell-major copy (round 4, dg_field_build_cell_major_band): rows only for the cells that reach into
+    # |phi| <= 2h + cell diagonal -- what SPH boundary handling and GenerateDensityMap query -- the plain gather for the rest, one launch
+    diag = float(np.linalg.norm((dom[3:] - dom[:3]) / np.array(res, dtype=np.float64)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    band_rows = fld.build_cell_major_band(-(0.2 + diag), 0.2 + diag, s)
+    torch.cuda.synchronize()
+    k2["band_copy"] = {"build_ms": (time.perf_counter() - t0) * 1e3, "band": [-(0.2 + diag), 0.2 + diag], "rows": band_rows,
+                       "fraction_of_cells": band_rows / float(np.prod(res)),
+                       "copy_bytes": band_rows * 256 + 4 * int(np.prod(res)), "copy_bytes_over_field_bytes": (band_rows * 256 + 4 * int(np.prod(res))) / (8.0 * n_nodes)}
+    for name, Q in (("uniform", P), ("shell", S)):
+        if len(Q) < nq:
+            continue
+        for g in (False, True):
+            fn = (lambda Q=Q, g=g: fld.interpolate_device(Q.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
+            fn()
+            ms = timed(torch, stream, fn, 5)
+            bytes_q = 312 if g else 288
+            k2["%s_%s_band_copy" % (name, "grad" if g else "value")] = {
                 "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     fld.drop_cell_major()
     # queries that arrive sorted by cell (what a caller with spatially sorted particles hands over), plain layout

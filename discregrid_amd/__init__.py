@@ -40,7 +40,7 @@ class FieldInfo(C.Structure):
     _fields_ = [("n_coeffs", C.c_uint64), ("n_cell_rows", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("d_coeffs", C.c_void_p), ("device", C.c_int32), ("owns_coefficients", C.c_int32),
                 ("has_cell_major", C.c_int32), ("has_tile_major", C.c_int32), ("immutable", C.c_int32),
-                ("host_copy_pending", C.c_int32)]
+                ("host_copy_pending", C.c_int32), ("band_rows", C.c_uint64)]
 
 
 class ShardInfo(C.Structure):
@@ -113,6 +113,7 @@ SYMBOLS = {
     "dg_reduction_to_field": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_field_build_cell_major": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_field_drop_cell_major": (C.c_int, [C.c_void_p]),
+    "dg_field_build_cell_major_band": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_uint64)]),
     "dg_field_build_tile_major": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_field_drop_tile_major": (C.c_int, [C.c_void_p]),
     "dg_interpolate_batch": (C.c_int, [C.c_void_p, _dp, C.c_uint64, _dp, _dp]),
@@ -560,6 +561,12 @@ class Field:
 
     def drop_cell_major(self):
         _check(self._lib.dg_field_drop_cell_major(self.handle))
+
+    def build_cell_major_band(self, lo, hi, stream=0):
+        """dg_field_build_cell_major_band: 256-byte rows for the cells whose coefficients reach into [lo, hi]; returns the row count."""
+        rows = C.c_uint64(0)
+        _check(self._lib.dg_field_build_cell_major_band(self.handle, float(lo), float(hi), C.c_void_p(stream), C.byref(rows)))
+        return int(rows.value)
 
     def build_tile_major(self, stream=0):
         _check(self._lib.dg_field_build_tile_major(self.handle, C.c_void_p(stream)))

@@ -123,6 +123,9 @@ public:
 	// chain further device work; nullptr never (throws if the GPU call fails).
 	void* deviceField(unsigned int field_id) const;
 	// Seconds spent in the last addFunction call (whole call) and in its node-sampling stage.
+	// wall time of the last addFunction CALL and of its sampling part.  With the typed MeshSDF functor in the default lazy mode
+	// the call returns when the work is enqueued: these exclude the kernels and the copy into the host vector
+	// (waitForHostData() / the first host reader waits for that; DG_LAZY_HOST=0 makes the call itself wait, as the reference does)
 	double lastAddFunctionSeconds() const { return m_last_total_s; }
 	double lastSamplingSeconds() const { return m_last_sampling_s; }
 	bool lastAddFunctionUsedGpu() const { return m_last_used_gpu; }

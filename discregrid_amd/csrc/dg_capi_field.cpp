@@ -141,6 +141,12 @@ void dg_field_destroy(dg_field* f)
 			(void)hipFree(p);
 	if (f->d_cell_major)
 		(void)hipFree(f->d_cell_major);
+	if (f->d_band_rows)
+		(void)hipFree(f->d_band_rows);
+	if (f->d_band_map)
+		(void)hipFree(f->d_band_map);
+	if (f->band_ready)
+		(void)hipEventDestroy(f->band_ready);
 	if (f->d_tile_major)
 		(void)hipFree(f->d_tile_major);
 	if (f->cell_major_ready)
@@ -250,14 +256,78 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 		return fail(DG_ERR_INVALID, "null argument");
 	std::lock_guard<std::mutex> lock(field->copy_mutex);
 	field->auto_copy_tried = true; // the caller decided against the copy: K2 does not bring it back by itself
-	if (field->d_cell_major)
+	if (field->d_cell_major || field->d_band_rows)
 	{
 		DG_ON_DEVICE_OF(field);
 		DG_HIP(hipDeviceSynchronize());
-		(void)hipFree(field->d_cell_major);
+		if (field->d_cell_major) (void)hipFree(field->d_cell_major);
 		field->d_cell_major = nullptr;
 		field->dev.cell_major = nullptr;
+		if (field->d_band_rows) (void)hipFree(field->d_band_rows);
+		if (field->d_band_map) (void)hipFree(field->d_band_map);
+		field->d_band_rows = field->d_band_map = nullptr;
+		field->dev.band_rows = nullptr;
+		field->dev.band_map = nullptr;
+		field->band_rows = 0;
 	}
+	return DG_OK;
+}
+
+// The band-limited cell-major copy: rows only for the cells whose coefficients reach into [lo, hi].
+dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, void* stream, uint64_t* rows_out)
+{
+	if (!field || !(lo <= hi))
+		return fail(DG_ERR_INVALID, "null field or an empty band");
+	std::lock_guard<std::mutex> lock(field->copy_mutex);
+	if (field->d_band_rows || field->n_rows == 0)
+	{
+		if (rows_out)
+			*rows_out = field->band_rows;
+		return DG_OK;
+	}
+	if (field->n_rows >= 0xffffffffull)
+		return fail(DG_ERR_INVALID, "too many cell rows for a 32-bit row map");
+	DG_ON_DEVICE_OF(field);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	DG_HIP(wait_produced(field, st));
+	const uint64_t n = field->n_rows;
+	void *d_flag = nullptr, *d_pos = nullptr, *d_tmp = nullptr, *d_map = nullptr, *d_rows = nullptr;
+	size_t tmp_bytes = 0;
+	hipError_t e = hipMalloc(&d_flag, n * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc(&d_pos, (n + 1) * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc(&d_map, n * sizeof(uint32_t));
+	if (e == hipSuccess) e = dg::band_scan(static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), n, nullptr, &tmp_bytes, st);
+	if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 256));
+	if (e == hipSuccess) e = dg::launch_band_flags(field->dev, n, lo, hi, static_cast<uint32_t*>(d_flag), st);
+	if (e == hipSuccess) e = dg::band_scan(static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), n, d_tmp, &tmp_bytes, st);
+	uint32_t last_pos = 0, last_flag = 0;
+	if (e == hipSuccess) e = hipMemcpyAsync(&last_pos, static_cast<uint32_t*>(d_pos) + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(&last_flag, static_cast<uint32_t*>(d_flag) + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st); // (building a copy is a one-off: the row count has to reach the host)
+	const uint64_t rows = (uint64_t)last_pos + last_flag;
+	if (e == hipSuccess) e = hipMalloc(&d_rows, std::max<uint64_t>(rows, 1) * 32 * sizeof(double));
+	if (e == hipSuccess && !field->band_ready) e = hipEventCreateWithFlags(&field->band_ready, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = dg::launch_band_expand(field->dev, n, static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), static_cast<uint32_t*>(d_map),
+								   static_cast<double*>(d_rows), st);
+	if (e == hipSuccess) e = hipEventRecord(field->band_ready, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st); // the scratch below is freed right away
+	(void)hipFree(d_flag);
+	(void)hipFree(d_pos);
+	(void)hipFree(d_tmp);
+	if (e != hipSuccess)
+	{
+		(void)hipFree(d_map);
+		(void)hipFree(d_rows);
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "band-limited cell-major copy: %s", hipGetErrorString(e));
+	}
+	field->d_band_rows = d_rows;
+	field->d_band_map = d_map;
+	field->band_rows = rows;
+	field->dev.band_rows = static_cast<const double*>(d_rows);
+	field->dev.band_map = static_cast<const uint32_t*>(d_map);
+	if (rows_out)
+		*rows_out = rows;
 	return DG_OK;
 }
 
@@ -283,6 +353,7 @@ dg_status dg_field_get_info(const dg_field* field, dg_field_info* info)
 	{
 		std::lock_guard<std::mutex> lock(field->copy_mutex);
 		info->has_cell_major = field->d_cell_major != nullptr;
+		info->band_rows = field->band_rows;
 		info->has_tile_major = field->d_tile_major != nullptr;
 		info->immutable = field->immutable;
 	}
@@ -294,6 +365,7 @@ dg_status dg_field_get_info(const dg_field* field, dg_field_info* info)
 	if (field->owned[1]) bytes += field->n_rows * 32 * sizeof(uint32_t);
 	if (field->owned[2]) bytes += dg_grid_n_cells(&field->grid) * sizeof(uint32_t);
 	if (info->has_cell_major) bytes += field->n_rows * 256ull;
+	if (field->d_band_rows) bytes += info->band_rows * 256ull + field->n_rows * sizeof(uint32_t);
 	if (info->has_tile_major)
 		bytes += (uint64_t)field->dev.ntile[0] * field->dev.ntile[1] * field->dev.ntile[2] * dg::kTmNodes * sizeof(double);
 	info->device_bytes = bytes;
@@ -552,12 +624,16 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		{
 			dev.xmajor = static_cast<const double*>(d_rows);
 			dev.xmajor_flags = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_rows) + copy_bytes);
-			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 64), (uint32_t)env_int("DG_K3_RB1", 16, 1, 64),
-									   (uint32_t)env_int("DG_K3_RB2", 8, 1, 64)};
+			// waves along x / y / z of the blocks consecutive wave ids fill.  The point-lane kernel likes them tall in z: the
+			// quadrature's innermost loop sweeps z, so the waves of a tall block read what their z-neighbours read a step ago
+			// (256^3: 1 x 16 x 8 470 ms, 1 x 12 x 8 466, 1 x 2 x 64 464, 1 x 3 x 43 458; 1 x 24 x 8 490)
+			const bool cells_kernel = env_int("DG_K3_CELLS", 1, 0, 1) != 0 && dg::k3c_geometry_fits(dev.res);
+			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 256), (uint32_t)env_int("DG_K3_RB1", cells_kernel ? 3 : 16, 1, 256),
+									   (uint32_t)env_int("DG_K3_RB2", cells_kernel ? 43 : 8, 1, 256)};
 			// round 4: one lane per lattice POINT with its seven nodes (k_density_cells, dg_density_cells.h: 3 cell fetches per 7
 			// nodes and quadrature point instead of 5, one sweep of the field instead of one per node class); DG_K3_CELLS=0: the
 			// row-block kernel with one node / edge per lane
-			if (env_int("DG_K3_CELLS", 1, 0, 1) != 0 && dg::k3c_geometry_fits(dev.res))
+			if (cells_kernel)
 				dg::layout_density_cells(P, L, sdf->grid.resolution, block);
 			else
 				dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
@@ -629,7 +705,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	const bool big = n >= (1u << 18) && field->n_coeffs * sizeof(double) >= (32u << 20);
 	dg::FieldDev dev;
-	hipEvent_t copy_ready = nullptr;
+	hipEvent_t copy_ready = nullptr, band_ready = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(field->copy_mutex);
 		// A field whose coefficients this library owns (dg_field_create: they cannot change) that gets a large batch and
@@ -657,6 +733,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 			copy_ready = field->tile_major_ready;
 		else if (field->d_cell_major)
 			copy_ready = field->cell_major_ready;
+		band_ready = field->d_band_rows ? field->band_ready : nullptr;
 	}
 	DG_HIP(wait_produced(field, st));
 	if (copy_ready) // the copy may still be being built on another stream
@@ -666,6 +743,15 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	if (dev.cell_major != nullptr && dev.tile_major == nullptr && env_int("DG_K2_ROWS", 1, 0, 1) != 0)
 	{
 		DG_HIP(dg::launch_interpolate_rows(dev, d_xyz, n, d_phi, d_grad, st));
+		return DG_OK;
+	}
+	// A field with a band-limited cell-major copy (and no full one): rows for the queries inside the band, the plain gather
+	// for the others, in one launch, queries in any order (DG_K2_BAND=0: ignore the copy)
+	if (dev.band_rows != nullptr && dev.cell_major == nullptr && dev.tile_major == nullptr && env_int("DG_K2_BAND", 1, 0, 1) != 0)
+	{
+		if (band_ready)
+			DG_HIP(hipStreamWaitEvent(st, band_ready, 0));
+		DG_HIP(dg::launch_interpolate_band(dev, d_xyz, n, d_phi, d_grad, st));
 		return DG_OK;
 	}
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in

@@ -395,10 +395,9 @@ void schedule_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end
 	cuts.push_back(node_end);
 }
 // chunk sizes of the direct form as fractions of the range (DG_HOST_DIRECT_FRACTIONS="0.1,0.2,...": experiments)
-std::vector<double> direct_fractions()
+std::vector<double> parse_fractions(std::vector<double> f, const char* env_name)
 {
-	std::vector<double> f = {0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03};
-	if (const char* e = std::getenv("DG_HOST_DIRECT_FRACTIONS"))
+	if (const char* e = std::getenv(env_name))
 	{
 		std::vector<double> g;
 		double sum = 0;
@@ -424,6 +423,13 @@ std::vector<double> direct_fractions()
 	}
 	return f;
 }
+std::vector<double> direct_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "DG_HOST_DIRECT_FRACTIONS"); }
+// dg_sdf_sample_field: ONE profile for callers that read the field on the device next and for callers that wait for the
+// host vector (round 4).  The copy engine moves 57 GB/s, K1 produces 64 GB/s: the copy must start early and never run
+// dry, so the chunks are fine and shrink towards the end (the last copy is what the host waits for after the last kernel).
+// Measured at 256^3 on one stream (ms until the field is complete on the device / in the host vector; one launch then
+// eight copy pieces: 16.4 / 34.7): 3 chunks 17.2 / 27.2, 4 chunks 19.0 / 25.3, 5 chunks 18.1 / 23.1, these seven 18.3 / 21.6.
+std::vector<double> field_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "DG_FIELD_FRACTIONS"); }
 } // namespace
 
 // One array of a pipelined host-pointer call: read from the host (`in`) or written back to it (`out`),
@@ -1102,10 +1108,10 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	std::vector<uint64_t> cuts, copy_cuts;
 	if (host_out == nullptr || n < (1u << 22))
 		cuts = {0, n};
-	else if (!host_first)
+	else if (!host_first && env_int("DG_FIELD_ONE_LAUNCH", 0, 0, 1) != 0)
 	{
-		// one launch (no chunk tails, nothing else on the device while it runs); the copy follows in eight pieces so that
-		// the registration of piece i + 1 runs under the copy of piece i
+		// (round 3's lazy form, kept for A/B: one launch, no chunk tails; the copy follows in eight pieces so that the
+		// registration of piece i + 1 runs under the copy of piece i -- host vector complete 2.4 x the kernel time after the call)
 		cuts = {0, n};
 		const uint64_t pieces = std::max<uint64_t>(1, std::min<uint64_t>(8, (n * sizeof(double)) >> 24));
 		for (uint64_t i = 0; i <= pieces; ++i)
@@ -1118,10 +1124,9 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 	}
 	else
 	{
-		// the chunk profile of the direct form: the copy of chunk i can only start when chunk i is sampled, so fine
-		// chunks keep the copy engine busy (three chunks: host-ready 35 instead of 27 ms at 256^3 [MI355X]) at the
-		// price of a kernel tail each (~0.4 ms) for consumers on the device
-		schedule_cuts(grid->resolution, 0, n, direct_fractions(), cuts);
+		// the copy of chunk i can only start when chunk i is sampled and runs under the sampling of chunk i + 1
+		// (field_fractions() above; host_first is a hint without effect since round 4: one policy serves both kinds of caller)
+		schedule_cuts(grid->resolution, 0, n, field_fractions(), cuts);
 	}
 	hipEvent_t dbg0 = nullptr, dbg1 = nullptr;
 	if (debug)
@@ -1145,12 +1150,29 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		job->after_kernel = !copy_cuts.empty();
 	}
 	hipError_t e = hipSuccess;
+	// The chunks alternate between the field's stream and a second one (DG_FIELD_STREAMS=1: one stream): launches on one
+	// stream run strictly one after the other, and every chunk then ends with a tail of a few waves running alone
+	// (~0.3 ms x 7 chunks for consumers on the device); on two streams the next chunk's waves fill the tail.
+	hipStream_t second = nullptr;
+	hipEvent_t second_done = nullptr;
+	if (cuts.size() > 2 && env_int("DG_FIELD_STREAMS", 2, 1, 2) == 2)
+	{
+		if (g_streams.take(mesh->device, 0, &second) != hipSuccess)
+			second = nullptr;
+		if (second && hipEventCreateWithFlags(&second_done, hipEventDisableTiming) != hipSuccess)
+		{
+			g_streams.give(mesh->device, 0, second);
+			second = nullptr;
+		}
+	}
+	size_t launch_no = 0;
 	for (size_t k = 0; k + 1 < cuts.size() && e == hipSuccess && s == DG_OK; ++k)
 	{
 		if (cuts[k + 1] == cuts[k])
 			continue;
+		hipStream_t chunk_stream = (second && (launch_no++ & 1u)) ? second : f->producer_stream;
 		s = dg_sdf_sample_nodes_device(mesh, grid, invert, cuts[k], cuts[k + 1], d_mask ? d_mask + cuts[k] : nullptr, d_c + cuts[k],
-									   f->producer_stream);
+									   chunk_stream);
 		// the segments of the host copy: the chunk itself, or (one launch) the pieces of copy_cuts behind the whole launch
 		const std::vector<uint64_t> segs = copy_cuts.empty() ? std::vector<uint64_t>{cuts[k], cuts[k + 1]} : copy_cuts;
 		for (size_t g = 0; g + 1 < segs.size() && s == DG_OK && job && e == hipSuccess; ++g)
@@ -1163,9 +1185,19 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 				if (job->seg.empty())
 					job->seg.push_back(segs[g] * sizeof(double));
 				job->seg.push_back(segs[g + 1] * sizeof(double));
-				e = hipEventRecord(ev, f->producer_stream);
+				e = hipEventRecord(ev, chunk_stream);
 			}
 		}
+	}
+	if (second)
+	{
+		// the field is complete when both streams are through: the field's stream waits for the second one
+		if (e == hipSuccess && s == DG_OK) e = hipEventRecord(second_done, second);
+		if (e == hipSuccess && s == DG_OK) e = hipStreamWaitEvent(f->producer_stream, second_done, 0);
+		if (e != hipSuccess || s != DG_OK)
+			(void)hipStreamSynchronize(second);
+		(void)hipEventDestroy(second_done); // (released by the runtime once the recorded work has completed)
+		g_streams.give(mesh->device, 0, second);
 	}
 	if (e == hipSuccess && s == DG_OK) e = hipEventRecord(f->produced, f->producer_stream);
 	if (e != hipSuccess || s != DG_OK)

@@ -131,6 +131,10 @@ struct dg_field
 	void* owned[3] = {nullptr, nullptr, nullptr};
 	void* d_tile_major = nullptr;
 	void* d_cell_major = nullptr;
+	void* d_band_rows = nullptr; // band-limited cell-major copy (dg_field_build_cell_major_band): rows and row map
+	void* d_band_map = nullptr;
+	uint64_t band_rows = 0;
+	hipEvent_t band_ready = nullptr;
 	hipEvent_t cell_major_ready = nullptr; // recorded behind k_expand_cells: launches on other streams wait for it
 	hipEvent_t tile_major_ready = nullptr; // the same for k_expand_tiles (one event per copy: they may be built on different streams)
 	// A field whose coefficients a kernel of this library produces (dg_sdf_sample_field, dg_density_map_field): the

@@ -981,6 +981,128 @@ __global__ __launch_bounds__(64) void k_interpolate_rows(const FieldDev F, const
 	}
 }
 
+// K2 over a field with a BAND-LIMITED cell-major copy (FieldDev::band_rows / band_map): k_interpolate_rows for the queries
+// whose cell has a row in the copy -- the wave fetches those rows together, four whole rows per load instruction, owners
+// read them from LDS --, and in the same launch the plain gather (closed-form indices or the cell table) for the lanes
+// whose cell has none.  A load group whose owner has no row (or no query) is switched off, so a batch that lives in the
+// band moves 256 B per query and a batch far from it moves what the plain kernel moves plus 4 B of map.  Same
+// locate_query / evaluate_cell statements as every other K2 path: same bits.
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(64) void k_interpolate_band(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+														   double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	__shared__ double rows[64 * kRowStride];
+	const int lane = (int)threadIdx.x;
+	const int sub = lane & 15, grp = lane >> 4;
+	for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n; base += (uint64_t)gridDim.x * 64u)
+	{
+		const uint64_t gid = base + (uint64_t)lane;
+		const bool have = gid < n;
+		double x[3] = {0.0, 0.0, 0.0};
+		if (have)
+		{
+			x[0] = xyz[3 * gid];
+			x[1] = xyz[3 * gid + 1];
+			x[2] = xyz[3 * gid + 2];
+		}
+		CellQuery q = locate_query(F, x);
+		q.valid = q.valid && have;
+		const uint32_t my_row = q.valid ? F.band_map[q.row] : 0xffffffffu;
+		const bool mapped = my_row != 0xffffffffu;
+		__syncthreads(); // the previous round's rows have been read
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const int owner = 4 * k + grp;
+			const uint32_t r = (uint32_t)__shfl((int)my_row, owner);
+			if (r != 0xffffffffu)
+			{
+				const double2 v = *reinterpret_cast<const double2*>(F.band_rows + 32 * (size_t)r + 2 * sub);
+				rows[owner * kRowStride + 2 * sub] = v.x;
+				rows[owner * kRowStride + 2 * sub + 1] = v.y;
+			}
+		}
+		__syncthreads();
+		double cf[32];
+		if (mapped)
+		{
+#pragma unroll
+			for (int j = 0; j < 32; ++j)
+				cf[j] = rows[lane * kRowStride + j];
+		}
+		else if (q.valid)
+			fetch_cell<MODE>(F, q.mi[0], q.mi[1], q.mi[2], q.row, cf);
+		double g[3] = {0.0, 0.0, 0.0};
+		double phi = 1.7976931348623157e308;
+		if (q.valid)
+			phi = evaluate_cell<GRAD>(cf, q.xi, q.c0, g);
+		if (have)
+		{
+			phi_out[gid] = phi;
+			if (GRAD)
+			{
+				grad_out[3 * gid] = g[0];
+				grad_out[3 * gid + 1] = g[1];
+				grad_out[3 * gid + 2] = g[2];
+			}
+		}
+	}
+}
+// the band copy's builders: (1) per cell row, does any value the cell's 32 coefficients span reach into [lo, hi]?
+// (min <= hi and max >= lo: a cell that straddles a thin band counts); (2) after a scan of the flags: rows and map
+__device__ __forceinline__ void band_cell_indices(const FieldDev& F, uint64_t row, uint32_t idx[32])
+{
+	if (F.cells)
+	{
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			idx[j] = F.cells[32 * row + j];
+	}
+	else
+	{
+		const uint32_t n01 = F.res[0] * F.res[1];
+		const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+		cell_node_indices(r % F.res[0], r / F.res[0], k, F.res, idx);
+	}
+}
+__global__ __launch_bounds__(256) void k_band_flags(const FieldDev F, uint64_t n_rows, double lo, double hi, uint32_t* __restrict__ flag)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= n_rows)
+		return;
+	uint32_t idx[32];
+	band_cell_indices(F, row, idx);
+	double mn = F.coeffs[idx[0]], mx = mn;
+#pragma unroll
+	for (int j = 1; j < 32; ++j)
+	{
+		const double v = F.coeffs[idx[j]];
+		mn = v < mn ? v : mn;
+		mx = v > mx ? v : mx;
+	}
+	flag[row] = (mn <= hi && mx >= lo) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_band_expand(const FieldDev F, uint64_t n_rows, const uint32_t* __restrict__ flag,
+													   const uint32_t* __restrict__ pos, uint32_t* __restrict__ map, double* __restrict__ out)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= n_rows)
+		return;
+	if (!flag[row])
+	{
+		map[row] = 0xffffffffu;
+		return;
+	}
+	const uint32_t r = pos[row];
+	map[row] = r;
+	uint32_t idx[32];
+	band_cell_indices(F, row, idx);
+	double* o = out + 32 * (size_t)r;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		o[j] = F.coeffs[idx[j]];
+}
+
 // Builds the cell-major copy of a field (FieldDev::cell_major): one thread per cell row.
 __global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t n_rows, double* __restrict__ out)
 {
@@ -2190,6 +2312,41 @@ hipError_t launch_xmajor_copy(const FieldDev& f, double* d_out, hipStream_t stre
 		return n_pairs == 0 ? hipSuccess : hipErrorInvalidValue;
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_pairs + 255) / 256, 256ull * 64ull);
 	hipLaunchKernelGGL(k_xmajor_copy, dim3(blocks), dim3(256), 0, stream, f, (uint32_t)n_pairs, d_out);
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 63) / 64, 256ull * 64ull);
+	const bool table = f.cells != nullptr;
+#define DG_K2_BAND(G, M) hipLaunchKernelGGL((k_interpolate_band<G, M>), dim3(blocks), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad)
+	if (d_grad && table) DG_K2_BAND(true, kFieldTable);
+	else if (d_grad) DG_K2_BAND(true, kFieldClosed);
+	else if (table) DG_K2_BAND(false, kFieldTable);
+	else DG_K2_BAND(false, kFieldClosed);
+#undef DG_K2_BAND
+	return hipGetLastError();
+}
+hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_band_flags, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, lo, hi, d_flag);
+	return hipGetLastError();
+}
+// exclusive scan of the flags (rocPRIM); tmp: scratch of *tmp_bytes (query with d_tmp == nullptr)
+hipError_t band_scan(const uint32_t* d_flag, uint32_t* d_pos, uint64_t n_rows, void* d_tmp, size_t* tmp_bytes, hipStream_t stream)
+{
+	return rocprim::exclusive_scan(d_tmp, *tmp_bytes, d_flag, d_pos, 0u, (size_t)n_rows, rocprim::plus<uint32_t>(), stream);
+}
+hipError_t launch_band_expand(const FieldDev& f, uint64_t n_rows, const uint32_t* d_flag, const uint32_t* d_pos, uint32_t* d_map, double* d_rows,
+							  hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_band_expand, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, d_flag, d_pos, d_map, d_rows);
 	return hipGetLastError();
 }
 

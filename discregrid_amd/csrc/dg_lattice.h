@@ -336,6 +336,12 @@ struct FieldDev
 	// (nullable; valid only where the producer says so).
 	const double* xmajor = nullptr;
 	const uint64_t* xmajor_flags = nullptr;
+	// Optional BAND-LIMITED cell-major copy (round 4): 256-byte rows like cell_major, but only for the cell rows whose
+	// coefficients reach into a value band [lo, hi] (SPH boundary handling and GenerateDensityMap query the shell
+	// |phi| < 2h around the surface: 10-20 % of the cells, i.e. less than 1 x the field instead of 4.6 x).
+	// band_map[row] = index of the row in band_rows, or 0xffffffff: queries into such cells gather from the field.
+	const double* band_rows = nullptr;
+	const uint32_t* band_map = nullptr;
 };
 // Where the 32 coefficients of a cell come from (FieldDev): the kernels are instantiated per mode, so that each
 // has ONE load sequence (a runtime switch makes the compiler merge the variants into 32 separate 8-byte loads).

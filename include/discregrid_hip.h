@@ -289,6 +289,7 @@ typedef struct dg_field_info {
 	int32_t has_cell_major, has_tile_major;
 	int32_t immutable;         /* dg_field_set_immutable */
 	int32_t host_copy_pending; /* the asynchronous copy into the caller's host array has not been collected yet */
+	uint64_t band_rows;        /* rows of the band-limited cell-major copy (0: none), dg_field_build_cell_major_band */
 } dg_field_info;
 dg_status dg_field_get_info(const dg_field* field, dg_field_info* info);
 /* An ATTACHED device array (dg_field_attach_device) may change between calls, so batched queries never build the
@@ -307,10 +308,10 @@ dg_status dg_field_set_immutable(dg_field* field, int immutable);
  * piece by piece from a worker thread), consumers on the device start when the last kernel ends, and
  * dg_field_host_wait() blocks until host_out is complete (dg_field_destroy waits too).  host_out must stay
  * allocated until then and is scratch from the moment of the call.  pred_mask (host, nullable, one byte per node)
- * works as in dg_sdf_sample_nodes.  host_first chooses what finishes first [MI355X, 256^3]: != 0: the lattice is
- * sampled in seven chunks whose copies run under the following chunks -- the host array is complete after 22 ms,
- * consumers on the device start after 18.8 ms; 0: ONE launch -- consumers on the device start after 15 ms (the
- * kernel's own time), the copy follows and completes after 32 ms. */
+ * works as in dg_sdf_sample_nodes.  host_first is a hint without effect since round 4: ONE chunk profile serves callers
+ * that read on the device next and callers that wait for the host vector -- seven chunks that shrink towards the end,
+ * launched alternately on two streams so that a chunk's last waves do not run alone (DG_FIELD_STREAMS=1: one stream);
+ * DG_FIELD_FRACTIONS="f0,f1,..." overrides, DG_FIELD_ONE_LAUNCH=1 with host_first == 0 is round 3's single launch. */
 dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
 							  double* host_out, int host_first, dg_field** out);
 /* K3 over the whole lattice of `sdf` into a NEW device-resident field on the same grid (the density map the
@@ -338,7 +339,16 @@ dg_status dg_field_host_wait(dg_field* field);
  * itself on the first batch of >= 2^18 queries, up to DG_K2_AUTO_CELL_MAJOR_MB megabytes (default 16384; 0: never)
  * and a quarter of the free device memory -- unless dg_field_drop_cell_major was called on the field. */
 dg_status dg_field_build_cell_major(dg_field* field, void* stream);
-dg_status dg_field_drop_cell_major(dg_field* field);
+dg_status dg_field_drop_cell_major(dg_field* field); /* (drops the band-limited copy below as well) */
+/* The same rows for a VALUE BAND only: a cell row gets its 256 contiguous bytes if the values its 32 coefficients span reach
+ * into [lo, hi] (min <= hi and max >= lo), every other cell stays where it is; a 4-byte map per cell row tells which.
+ * dg_interpolate_batch* then serves queries into mapped cells from their rows (fetched cooperatively like the full copy's)
+ * and, in the same launch, all others by the plain gather -- queries in any order, no sort.  SPH boundary handling and
+ * GenerateDensityMap (cmd/generate_density_map/main.cpp:99,125-132) query the shell |phi| < 2h around the surface: for
+ * [-(2h + cell diagonal), 2h + cell diagonal] the copy holds 10-20 % of the cells -- less than 1 x the field instead of 4.6 x.
+ * One-off and host-blocking (the row count has to reach the host); *rows (nullable): rows in the copy.  A field that also
+ * has the full or the tile-major copy uses that.  The coefficients must not change afterwards.  No reference counterpart. */
+dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, void* stream, uint64_t* rows);
 /* Optional, for UNREDUCED fields: builds (once, asynchronously on `stream`) a tile-major device copy --
  * for every tile of 4x4x4 cells all the nodes its cells reference, 736 contiguous doubles -- that
  * dg_interpolate_batch* and dg_density_map_nodes* then read.  The reference layout [V|X|Y|Z] puts a cell's

@@ -175,13 +175,16 @@ def cell_order(dom, res):
 
 
 @pytest.mark.parametrize("path", ["cell_major_rows", "cell_major_per_lane", "owned_auto_copy", "tile_major",
-                                  "cell_sorted_input", "cell_sorted_input_cell_major", "no_binning"])
+                                  "cell_sorted_input", "cell_sorted_input_cell_major", "no_binning", "band_copy", "band_copy_thin"])
 def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, path, monkeypatch):
     """The same 2 x 3 x 10 digest blocks through EVERY other K2 path that carries a quoted number
     (secondary.k2_interpolate on the bench line): the cooperative row kernel on the cell-major copy
     (k_interpolate_rows: the 18 Gq/s figure), the per-lane kernels on that copy, an OWNED field that builds the
     copy by itself on its first large batch, the tile-major copy, cell-sorted input (the device-side "already
-    ordered" decision; results un-permuted before digesting) on both layouts, and the unbinned gather."""
+    ordered" decision; results un-permuted before digesting) on both layouts, the unbinned gather, and (round 4) the
+    band-limited cell-major copy: rows for the cells that reach into |phi| <= 2h + cell diagonal (every shell query takes the
+    row path, four uniform queries in five the gather, in one launch) and for a band so thin that most shell queries
+    straddle it or miss it."""
     import torch
     V, F, dom, mesh, grid, field = ico256
     P, S = config5_points
@@ -200,6 +203,15 @@ def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, pat
         order = cell_order(dom, [256] * 3)
     if path == "no_binning":
         monkeypatch.setenv("DG_K2_BINNING", "0")
+    if path.startswith("band_copy"):
+        n_cells = 256 ** 3
+        diag = float(np.linalg.norm((np.asarray(dom[3:]) - np.asarray(dom[:3])) / 256.0))
+        band = (2 * 0.1 + diag) if path == "band_copy" else 0.02
+        rows = fld.build_cell_major_band(-band, band, stream=torch.cuda.current_stream().cuda_stream)
+        info = fld.info()
+        print("%s: |phi| <= %.4f -> %d of %d cell rows (%.1f %%), copy + map %.2f GB against %.2f GB of field"
+              % (path, band, rows, n_cells, 100.0 * rows / n_cells, (rows * 256 + n_cells * 4) / 1e9, len(field) * 8 / 1e9))
+        assert info["band_rows"] == rows and 0 < rows < (0.25 if path == "band_copy" else 0.05) * n_cells
     _check_config5(gold, _device_evaluator(torch, fld, order), P, S, path)
     if path == "owned_auto_copy":
         assert fld.has_cell_major(), "the owned field did not build its cell-major copy on a 10 M batch"

@@ -229,6 +229,21 @@ def test_interpolate_vs_golden(dg, golden, name, monkeypatch):
     f.drop_tile_major()
     f.drop_cell_major()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
+    # band-limited cell-major copy (round 4): rows for the cells that reach into a value band, the plain gather for the others
+    # in the same launch -- wide, narrow and empty bands, any batch size, dropped again
+    fin = coeffs[coeffs != DBL_MAX]
+    for lo, hi in ((-0.05, 0.05), (float(np.median(fin)), float(fin.max())), (float(fin.max()) + 1.0, float(fin.max()) + 2.0),
+                   (float(fin.min()) - 1.0, float(fin.max()) + 1.0)):
+        rows = f.build_cell_major_band(lo, hi)
+        assert f.info()["band_rows"] == rows and 0 <= rows <= int(np.prod(res))
+        phi4, grad4 = f.interpolate(P, grad=True)
+        np.testing.assert_array_equal(phi4, phi)
+        np.testing.assert_array_equal(grad4, grad)
+        for m in (1, 63, 65, 1000):
+            np.testing.assert_array_equal(f.interpolate(P[:m]), golden[name + "_phi"][:m])
+        f.drop_cell_major()
+        assert f.info()["band_rows"] == 0
+    assert rows == int(np.prod(res))            # (the last band holds every value: every cell has a row)
     # table mode, removed cells, DBL_MAX coefficients
     cells = T.oracle_cell_table(res)
     cmap = np.arange(len(cells), dtype=np.uint32)
@@ -246,6 +261,11 @@ def test_interpolate_vs_golden(dg, golden, name, monkeypatch):
     a2, ga2 = f2.interpolate(P, grad=True)
     np.testing.assert_array_equal(a2, a)
     np.testing.assert_array_equal(ga2, ga)
+    f2.drop_cell_major()
+    f2.build_cell_major_band(-0.1, 0.1)      # the band copy of a table-mode field with removed cells and "no value" coefficients
+    a3, ga3 = f2.interpolate(P, grad=True)
+    np.testing.assert_array_equal(a3, a)
+    np.testing.assert_array_equal(ga3, ga)
     with pytest.raises(dg.DiscregridError):
         f2.build_tile_major()   # unreduced fields only
 

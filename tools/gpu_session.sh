@@ -1,0 +1,34 @@
+#!/bin/bash
+# one measuring session on the GPU box (run through gpurun): the legs named on the command line, outputs under gpurun_out/$TAG
+#   bash tools/gpu_session.sh TAG leg [leg ...]     legs: addfn k3blocks k3pmc gputests bench multirank collect
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+python -c "import torch" 2>/dev/null
+for leg in "$@"; do
+  case $leg in
+    addfn)   # C++ addFunction(MeshSDF) at 256^3: return / device-ready / host-ready per chunk profile
+      python - > /tmp/ico71.log 2>&1 <<'PY'
+import sys; sys.path.insert(0, "tests"); import dgtest as T
+V, F = T.icosphere(71); T.write_obj("/tmp/ico71.obj", V, F)
+PY
+      for prof in "" "0.10,0.20,0.35,0.35" "0.08,0.14,0.22,0.28,0.28" "0.12,0.28,0.60" "0.22,0.22,0.20,0.16,0.11,0.06,0.03" "one"; do
+        if [ "$prof" = one ]; then export DG_FIELD_ONE_LAUNCH=1; unset DG_FIELD_FRACTIONS; elif [ -n "$prof" ]; then export DG_FIELD_FRACTIONS=$prof; fi
+        echo "profile '${prof:-default}':" >> $OUT/addfn.txt
+        timeout 120 tests/cpp/build/unchanged_caller addfunction /tmp/ico71.obj "256 256 256" 5 >> $OUT/addfn.txt 2>> $OUT/addfn.err
+        echo >> $OUT/addfn.txt
+      done
+      unset DG_FIELD_FRACTIONS DG_FIELD_ONE_LAUNCH
+      cat $OUT/addfn.txt ;;
+    k3blocks)
+      timeout 400 python tools/k3_run.py --res 256 --steps 2 --check --sweep "DG_K3_RB1=16,DG_K3_RB2=8;DG_K3_RB1=8,DG_K3_RB2=8;DG_K3_RB1=12,DG_K3_RB2=8;DG_K3_RB1=24,DG_K3_RB2=8;DG_K3_RB1=16,DG_K3_RB2=4;DG_K3_RB1=8,DG_K3_RB2=4;DG_K3_RB1=2,DG_K3_RB2=64;DG_K3_RB1=3,DG_K3_RB2=43;DG_K3_RB1=64,DG_K3_RB2=2;DG_K3_RB0=4,DG_K3_RB1=8,DG_K3_RB2=4;DG_K3_RB0=2,DG_K3_RB1=16,DG_K3_RB2=4;DG_K3_RB0=17,DG_K3_RB1=3,DG_K3_RB2=3" > $OUT/k3_blocks_256.jsonl 2> $OUT/k3_blocks.err
+      cat $OUT/k3_blocks_256.jsonl ;;
+    gputests)
+      timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/gputests.log 2>&1; tail -5 $OUT/gputests.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json ;;
+    collect)
+      timeout 2400 bash profiles/collect.sh ${TAG} all > $OUT/collect.log 2>&1; tail -25 $OUT/collect.log ;;
+    *) echo "unknown leg $leg" ;;
+  esac
+done
