@@ -318,13 +318,18 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "interpolations in the reference's count" % n_nodes}
     counters, _ = load_counters()
     k3c = ((counters or {}).get("workloads", {}).get("k3") or {})
-    k3k = next((v for k, v in k3c.items() if k.startswith("k_density_rows")), None) or \
-        next((v for k, v in k3c.items() if k.startswith("k_density_pairs")), None) or \
-        next((v for k, v in k3c.items() if k.startswith("k_density_bricks")), None)
+    k3name = next((k for k in k3c if k.startswith("k_density_cells")), None) or next((k for k in k3c if k.startswith("k_density_rows")), None) or \
+        next((k for k in k3c if k.startswith("k_density_pairs")), None) or next((k for k in k3c if k.startswith("k_density_bricks")), None)
+    k3k = k3c.get(k3name) if k3name else None
     out_secondary["k3_density_map"]["roofline"] = None if k3k is None else {
-        "bound": "vector memory pipeline (texture address / data units: every lane gathers the 256 B of its cell at each quadrature point, "
-                 "in rows along x since round 3: 19 instead of 31 sectors per load instruction) and f64 VALU, neither saturated: "
-                 "latency-bound at the 3 waves per SIMD its registers allow",
+        "kernel": k3name,
+        "bound": "f64 VALU issue and the vector memory pipeline together (round 4, k_density_cells: a lane owns a lattice point with its seven "
+                 "nodes -- 3 cell fetches of 256 B per 7 nodes and quadrature point instead of 5, one sweep of the field for all node "
+                 "classes; both units near 0.85-0.9 busy at the 3 waves per SIMD the registers allow)",
+        # what the launch has to move at least (field read once + x-major copy of the Y / Z classes written and read + result written)
+        # against what the HBM counters saw
+        "compulsory_bytes": int(8 * n_nodes * (1 + 2 * 0.57 + 1)), "traffic": k3k.get("hbm_bytes_per_launch"),
+        "arith_frac": k3k.get("arith_frac"), "salu_slot_frac": k3k.get("salu_slot_frac"),
         "achieved": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]), "peak": 1.0,
         "unit": "busy fraction of the busiest unit (TA / TD / VALU)",
         "frac": max(k3k.get("td_busy") or 0.0, k3k.get("ta_busy") or 0.0, k3k["valu_busy"]),
@@ -718,6 +723,8 @@ def main():
             "metric": "Mnodes/s SDF sampling (256³ grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
             "value": n_nodes * args.steps / elapsed / 1e6,
             "unit": "Mnodes/s",
+            "value_is": "the sampling step with the result left in HBM (at N > 1: incl. the exchange that leaves the whole field on every GPU); "
+                        "SURVEY 8(d)'s metric incl. the D2H into the host vector is value_with_d2h / addfunction_e2e",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -763,6 +770,12 @@ def main():
                 # (rocprofv3 PMC passes cannot run inside the driver's bench); kernel_ms is measured live
                 "replayed": True, "counters_sha": (counters or {}).get("csrc_sha256"),
                 "per_brick": k1.get("per_brick") if k1 else None,
+                # frac above is UTILISATION of the vector issue slots; these say how much of it is arithmetic and how full the scalar unit is:
+                # arith_frac = (f32 + f64 arithmetic instructions) / all vector instructions (the rest: compares, selects, moves, integer);
+                # salu_slot_frac = (SALU + SMEM instructions) / (256 CUs x kernel cycles), one scalar issue slot per cycle and CU
+                "arith_frac": (k1 or {}).get("arith_frac") or ((((k1 or {}).get("per_brick") or {}).get("valu_f32", 0) + ((k1 or {}).get("per_brick") or {}).get("valu_f64", 0)) /
+                                                                 ((k1 or {}).get("per_brick") or {}).get("valu") if ((k1 or {}).get("per_brick") or {}).get("valu") else None),
+                "salu_slot_frac": (k1 or {}).get("salu_slot_frac"),
                 # informational only: bytes the REFERENCE's traversal would move for these nodes / this kernel's time
                 "algorithmic_bytes_per_node": balg["bytes_per_node"],
                 "algorithmic_gbs": balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9,

@@ -5,6 +5,8 @@
 // gfx950 device every compute entry point fails with DG_ERR_NO_DEVICE.
 #include "dg_capi_internal.h"
 
+#include <dlfcn.h>
+
 thread_local std::string g_error;
 thread_local double g_last_ms = -1.0;
 
@@ -19,6 +21,50 @@ dg_status fail(dg_status s, const char* fmt, ...)
 	return s;
 }
 
+
+// ---- ROCTx (dlopen'ed) ---------------------------------------------------------------------------------
+namespace
+{
+struct Roctx
+{
+	int (*push)(const char*) = nullptr;
+	int (*pop)() = nullptr;
+	Roctx()
+	{
+		if (const char* e = std::getenv("DG_ROCTX"))
+			if (std::atoi(e) == 0)
+				return;
+		void* lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib)
+			lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib)
+			return;
+		push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+		pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+		if (!push || !pop)
+			push = nullptr, pop = nullptr;
+	}
+};
+Roctx& roctx()
+{
+	static Roctx r;
+	return r;
+}
+} // namespace
+TraceRange::TraceRange(const char* name)
+{
+	Roctx& r = roctx();
+	if (r.push)
+	{
+		r.push(name);
+		on = true;
+	}
+}
+TraceRange::~TraceRange()
+{
+	if (on)
+		roctx().pop();
+}
 
 dg_status require_device()
 {
@@ -472,6 +518,7 @@ static hipError_t launch_k1(const dg_mesh* mesh, dg::SampleParams& P, hipStream_
 dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream)
 {
+	TraceRange trace_range_("dg K1 sample_nodes");
 	if (!mesh || !grid || !d_out)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))
@@ -497,6 +544,7 @@ dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* gr
 dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
 									int32_t* d_tri, int32_t* d_entity, double* d_nearest, void* stream)
 {
+	TraceRange trace_range_("dg K1p signed_distance");
 	if (!mesh || (n && (!d_xyz || !d_dist)))
 		return fail(DG_ERR_INVALID, "null argument");
 	if (n == 0)
@@ -570,6 +618,7 @@ dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_sha
 dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
 									 double* d_packed, void* stream)
 {
+	TraceRange trace_range_("dg K1 sample_shard");
 	if (!mesh || !grid || !d_packed)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))
@@ -606,6 +655,7 @@ dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* co
 dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint32_t plane_begin[4],
 									  const uint32_t plane_end[4], double* d_field, void* stream)
 {
+	TraceRange trace_range_("dg K1 sample_planes");
 	if (!mesh || !grid || !plane_begin || !plane_end || !d_field)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))
@@ -626,6 +676,7 @@ dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* g
 dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 								  double* d_field, void* stream)
 {
+	TraceRange trace_range_("dg U unpack_shards");
 	if (!grid || !d_gathered || !d_field)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))
@@ -648,6 +699,7 @@ dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const do
 dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 									   int rank_begin, int rank_end, double* d_field, void* stream)
 {
+	TraceRange trace_range_("dg U unpack_shard_range");
 	if (!grid || !d_gathered || !d_field)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!valid_grid(grid))

@@ -537,6 +537,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
 									  double* d_out, void* stream)
 {
+	TraceRange trace_range_("dg K3 density_map");
 	if (!sdf || !d_out)
 		return fail(DG_ERR_INVALID, "null argument");
 	if (!(support_radius > 0.0))
@@ -697,6 +698,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
 									  double* d_grad, void* stream)
 {
+	TraceRange trace_range_("dg K2 interpolate");
 	if (!field || (n && (!d_xyz || !d_phi)))
 		return fail(DG_ERR_INVALID, "null argument");
 	if (n == 0)

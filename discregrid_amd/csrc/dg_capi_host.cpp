@@ -1150,12 +1150,13 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		job->after_kernel = !copy_cuts.empty();
 	}
 	hipError_t e = hipSuccess;
-	// The chunks alternate between the field's stream and a second one (DG_FIELD_STREAMS=1: one stream): launches on one
-	// stream run strictly one after the other, and every chunk then ends with a tail of a few waves running alone
-	// (~0.3 ms x 7 chunks for consumers on the device); on two streams the next chunk's waves fill the tail.
+	// DG_FIELD_STREAMS=2: the chunks alternate between the field's stream and a second one, so that a chunk's last waves
+	// (and its two small heavy-brick kernels) do not run alone.  Measured at 256^3: 18.5 / 21.7 ms (device / host complete)
+	// against 18.6 / 21.8 on one stream -- nothing: the 2.2 ms the chunks cost a consumer on the device against one launch
+	// (16.3 ms) are not tails.  Off by default.
 	hipStream_t second = nullptr;
 	hipEvent_t second_done = nullptr;
-	if (cuts.size() > 2 && env_int("DG_FIELD_STREAMS", 2, 1, 2) == 2)
+	if (cuts.size() > 2 && env_int("DG_FIELD_STREAMS", 1, 1, 2) == 2)
 	{
 		if (g_streams.take(mesh->device, 0, &second) != hipSuccess)
 			second = nullptr;

@@ -194,6 +194,17 @@ struct DeviceGuard
 	if (device_guard_.err != hipSuccess)                                                              \
 		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))
 
+// ROCTx ranges around the launches of the device entry points (tracing): `rocprofv3 --marker-trace` shows
+// "dg K1 sample_nodes" / "dg K2 interpolate" / "dg K3 density_map" / "dg U unpack" around the kernels they enqueue.
+// libroctx64 is bound at run time (no hard dependency; DG_ROCTX=0: off); without a tool attached a range costs a call.
+struct TraceRange
+{
+	explicit TraceRange(const char* name);
+	~TraceRange();
+	TraceRange(const TraceRange&) = delete;
+	TraceRange& operator=(const TraceRange&) = delete;
+	bool on = false;
+};
 bool recycle_field_buffer(void* p, size_t bytes, int device); // dg_capi_host.cpp
 void recycle_stream(int device, hipStream_t s);               // dg_capi_host.cpp: an idle stream for the next produced field
 // collects the field's host copy job, if any (dg_capi_host.cpp); returns its status

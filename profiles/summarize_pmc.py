@@ -125,6 +125,7 @@ def main():
                 e["valu_busy"] = cs["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc)
             if "SQ_WAVES" in cs and cs["SQ_WAVES"] > 0:
                 wv = cs["SQ_WAVES"]
+                e["waves"] = wv
                 e["per_wave"] = {n_: cs[c_] / wv for n_, c_ in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("smem", "SQ_INSTS_SMEM"),
                                                               ("lds", "SQ_INSTS_LDS")) if c_ in cs}
                 f64 = sum(cs.get(c_, 0.0) for c_ in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
@@ -135,6 +136,12 @@ def main():
                     e["per_wave"]["valu_f32"] = f32 / wv
                 if "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"] > 0:
                     e["wait_inst_any_frac"] = cs.get("SQ_WAIT_INST_ANY", 0.0) / cs["SQ_WAVE_CYCLES"]
+                # efficiency, not utilisation: the share of the issued vector instructions that is floating-point arithmetic,
+                # and the share of the scalar unit's issue slots (one per cycle and CU, 256 CUs) that scalar ALU + memory instructions fill
+                if (f64 or f32) and cs.get("SQ_INSTS_VALU", 0) > 0:
+                    e["arith_frac"] = (f64 + f32) / cs["SQ_INSTS_VALU"]
+                if "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"] > 0 and "SQ_INSTS_SALU" in cs:
+                    e["salu_slot_frac"] = (cs["SQ_INSTS_SALU"] + cs.get("SQ_INSTS_SMEM", 0.0)) / (256.0 * cs["GRBM_GUI_ACTIVE"] / 8.0)
             if "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"] > 0:
                 cyc = cs["GRBM_GUI_ACTIVE"] / 8.0
                 if "TA_TA_BUSY_sum" in cs:   # 256 texture-address / texture-data units, one per CU

@@ -211,7 +211,8 @@ def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, pat
         info = fld.info()
         print("%s: |phi| <= %.4f -> %d of %d cell rows (%.1f %%), copy + map %.2f GB against %.2f GB of field"
               % (path, band, rows, n_cells, 100.0 * rows / n_cells, (rows * 256 + n_cells * 4) / 1e9, len(field) * 8 / 1e9))
-        assert info["band_rows"] == rows and 0 < rows < (0.25 if path == "band_copy" else 0.05) * n_cells
+        # (h = 0.1 on a unit sphere in a box that hugs it: the shell is THICK -- 57 % of the cells; a band of +-0.02: a few per cent)
+        assert info["band_rows"] == rows and 0 < rows < (0.65 if path == "band_copy" else 0.12) * n_cells
     _check_config5(gold, _device_evaluator(torch, fld, order), P, S, path)
     if path == "owned_auto_copy":
         assert fld.has_cell_major(), "the owned field did not build its cell-major copy on a 10 M batch"

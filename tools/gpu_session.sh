@@ -12,16 +12,20 @@ for leg in "$@"; do
 import sys; sys.path.insert(0, "tests"); import dgtest as T
 V, F = T.icosphere(71); T.write_obj("/tmp/ico71.obj", V, F)
 PY
-      for prof in "" "0.10,0.20,0.35,0.35" "0.08,0.14,0.22,0.28,0.28" "0.12,0.28,0.60" "0.22,0.22,0.20,0.16,0.11,0.06,0.03" "one"; do
-        if [ "$prof" = one ]; then export DG_FIELD_ONE_LAUNCH=1; unset DG_FIELD_FRACTIONS; elif [ -n "$prof" ]; then export DG_FIELD_FRACTIONS=$prof; fi
+      for prof in "" "streams1" "0.08,0.14,0.22,0.28,0.28" "0.16,0.16,0.16,0.16,0.14,0.10,0.07,0.05" "one"; do
+        unset DG_FIELD_FRACTIONS DG_FIELD_ONE_LAUNCH DG_FIELD_STREAMS
+        if [ "$prof" = one ]; then export DG_FIELD_ONE_LAUNCH=1; elif [ "$prof" = streams1 ]; then export DG_FIELD_STREAMS=1; elif [ -n "$prof" ]; then export DG_FIELD_FRACTIONS=$prof; fi
         echo "profile '${prof:-default}':" >> $OUT/addfn.txt
         timeout 120 tests/cpp/build/unchanged_caller addfunction /tmp/ico71.obj "256 256 256" 5 >> $OUT/addfn.txt 2>> $OUT/addfn.err
         echo >> $OUT/addfn.txt
       done
-      unset DG_FIELD_FRACTIONS DG_FIELD_ONE_LAUNCH
+      unset DG_FIELD_FRACTIONS DG_FIELD_ONE_LAUNCH DG_FIELD_STREAMS
       cat $OUT/addfn.txt ;;
+    k2band)  # parity of the band copy, then the config-5 digests through it
+      timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "interpolate_vs_golden" > $OUT/k2band_parity.log 2>&1; tail -3 $OUT/k2band_parity.log
+      timeout 900 python -m pytest tests/test_gpu_digests.py -x -q -m gpu -s -k "band_copy" > $OUT/k2band_digests.log 2>&1; grep "band_copy\|passed\|failed" $OUT/k2band_digests.log | tail -6 ;;
     k3blocks)
-      timeout 400 python tools/k3_run.py --res 256 --steps 2 --check --sweep "DG_K3_RB1=16,DG_K3_RB2=8;DG_K3_RB1=8,DG_K3_RB2=8;DG_K3_RB1=12,DG_K3_RB2=8;DG_K3_RB1=24,DG_K3_RB2=8;DG_K3_RB1=16,DG_K3_RB2=4;DG_K3_RB1=8,DG_K3_RB2=4;DG_K3_RB1=2,DG_K3_RB2=64;DG_K3_RB1=3,DG_K3_RB2=43;DG_K3_RB1=64,DG_K3_RB2=2;DG_K3_RB0=4,DG_K3_RB1=8,DG_K3_RB2=4;DG_K3_RB0=2,DG_K3_RB1=16,DG_K3_RB2=4;DG_K3_RB0=17,DG_K3_RB1=3,DG_K3_RB2=3" > $OUT/k3_blocks_256.jsonl 2> $OUT/k3_blocks.err
+      timeout 400 python tools/k3_run.py --res 256 --steps 2 --check --sweep "DG_K3_RB1=3,DG_K3_RB2=43;DG_K3_RB1=3,DG_K3_RB2=129;DG_K3_RB1=1,DG_K3_RB2=129;DG_K3_RB1=2,DG_K3_RB2=129;DG_K3_RB1=4,DG_K3_RB2=32;DG_K3_RB1=6,DG_K3_RB2=22;DG_K3_RB1=3,DG_K3_RB2=65;DG_K3_RB1=3,DG_K3_RB2=26;DG_K3_RB0=2,DG_K3_RB1=3,DG_K3_RB2=22" > $OUT/k3_blocks_256.jsonl 2> $OUT/k3_blocks.err
       cat $OUT/k3_blocks_256.jsonl ;;
     gputests)
       timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/gputests.log 2>&1; tail -5 $OUT/gputests.log ;;
