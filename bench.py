@@ -254,7 +254,8 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
     torch.cuda.synchronize()
     k2["band_copy"] = {"build_ms": (time.perf_counter() - t0) * 1e3, "band": [-(0.2 + diag), 0.2 + diag], "rows": band_rows,
                        "fraction_of_cells": band_rows / float(np.prod(res)),
-                       "copy_bytes": band_rows * 256 + 4 * int(np.prod(res)), "copy_bytes_over_field_bytes": (band_rows * 256 + 4 * int(np.prod(res))) / (8.0 * n_nodes)}
+                       "copy_bytes": band_rows * 256 + 12 * (int(np.prod(res)) // 64 + 1),
+                       "copy_bytes_over_field_bytes": (band_rows * 256 + 12 * (int(np.prod(res)) // 64 + 1)) / (8.0 * n_nodes)}
     for name, Q in (("uniform", P), ("shell", S)):
         if len(Q) < nq:
             continue

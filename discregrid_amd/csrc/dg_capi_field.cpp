@@ -267,7 +267,8 @@ dg_status dg_field_drop_cell_major(dg_field* field)
 		if (field->d_band_map) (void)hipFree(field->d_band_map);
 		field->d_band_rows = field->d_band_map = nullptr;
 		field->dev.band_rows = nullptr;
-		field->dev.band_map = nullptr;
+		field->dev.band_bits = nullptr;
+		field->dev.band_rank = nullptr;
 		field->band_rows = 0;
 	}
 	return DG_OK;
@@ -291,11 +292,12 @@ dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, 
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	DG_HIP(wait_produced(field, st));
 	const uint64_t n = field->n_rows;
-	void *d_flag = nullptr, *d_pos = nullptr, *d_tmp = nullptr, *d_map = nullptr, *d_rows = nullptr;
+	void *d_flag = nullptr, *d_pos = nullptr, *d_tmp = nullptr, *d_map = nullptr, *d_rows = nullptr; // d_map: bit words, then rank words
+	const uint64_t words = (n + 63) / 64;
 	size_t tmp_bytes = 0;
 	hipError_t e = hipMalloc(&d_flag, n * sizeof(uint32_t));
 	if (e == hipSuccess) e = hipMalloc(&d_pos, (n + 1) * sizeof(uint32_t));
-	if (e == hipSuccess) e = hipMalloc(&d_map, n * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc(&d_map, words * (sizeof(uint64_t) + sizeof(uint32_t)));
 	if (e == hipSuccess) e = dg::band_scan(static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), n, nullptr, &tmp_bytes, st);
 	if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 256));
 	if (e == hipSuccess) e = dg::launch_band_flags(field->dev, n, lo, hi, static_cast<uint32_t*>(d_flag), st);
@@ -308,8 +310,8 @@ dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, 
 	if (e == hipSuccess) e = hipMalloc(&d_rows, std::max<uint64_t>(rows, 1) * 32 * sizeof(double));
 	if (e == hipSuccess && !field->band_ready) e = hipEventCreateWithFlags(&field->band_ready, hipEventDisableTiming);
 	if (e == hipSuccess)
-		e = dg::launch_band_expand(field->dev, n, static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), static_cast<uint32_t*>(d_map),
-								   static_cast<double*>(d_rows), st);
+		e = dg::launch_band_expand(field->dev, n, static_cast<uint32_t*>(d_flag), static_cast<uint32_t*>(d_pos), static_cast<uint64_t*>(d_map),
+								   reinterpret_cast<uint32_t*>(static_cast<uint64_t*>(d_map) + words), static_cast<double*>(d_rows), st);
 	if (e == hipSuccess) e = hipEventRecord(field->band_ready, st);
 	if (e == hipSuccess) e = hipStreamSynchronize(st); // the scratch below is freed right away
 	(void)hipFree(d_flag);
@@ -325,7 +327,8 @@ dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, 
 	field->d_band_map = d_map;
 	field->band_rows = rows;
 	field->dev.band_rows = static_cast<const double*>(d_rows);
-	field->dev.band_map = static_cast<const uint32_t*>(d_map);
+	field->dev.band_bits = static_cast<const uint64_t*>(d_map);
+	field->dev.band_rank = reinterpret_cast<const uint32_t*>(static_cast<const uint64_t*>(d_map) + words);
 	if (rows_out)
 		*rows_out = rows;
 	return DG_OK;
@@ -365,7 +368,7 @@ dg_status dg_field_get_info(const dg_field* field, dg_field_info* info)
 	if (field->owned[1]) bytes += field->n_rows * 32 * sizeof(uint32_t);
 	if (field->owned[2]) bytes += dg_grid_n_cells(&field->grid) * sizeof(uint32_t);
 	if (info->has_cell_major) bytes += field->n_rows * 256ull;
-	if (field->d_band_rows) bytes += info->band_rows * 256ull + field->n_rows * sizeof(uint32_t);
+	if (field->d_band_rows) bytes += info->band_rows * 256ull + (field->n_rows + 63) / 64 * 12ull;
 	if (info->has_tile_major)
 		bytes += (uint64_t)field->dev.ntile[0] * field->dev.ntile[1] * field->dev.ntile[2] * dg::kTmNodes * sizeof(double);
 	info->device_bytes = bytes;

@@ -501,8 +501,8 @@ inline void bin_scratch_assign(BinScratch& S, void* mem, const size_t off[6], ui
 hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream);
 hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream);
 hipError_t band_scan(const uint32_t* d_flag, uint32_t* d_pos, uint64_t n_rows, void* d_tmp, size_t* tmp_bytes, hipStream_t stream);
-hipError_t launch_band_expand(const FieldDev& f, uint64_t n_rows, const uint32_t* d_flag, const uint32_t* d_pos, uint32_t* d_map, double* d_rows,
-							  hipStream_t stream);
+hipError_t launch_band_expand(const FieldDev& f, uint64_t n_rows, const uint32_t* d_flag, const uint32_t* d_pos, uint64_t* d_bits, uint32_t* d_rank,
+							  double* d_rows, hipStream_t stream);
 hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
 									 const BinScratch& scratch, hipStream_t stream);
 // K1p: p.pts describes the points and outputs, p.total_bricks etc. come from layout_points().  The

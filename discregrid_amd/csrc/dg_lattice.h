@@ -339,10 +339,27 @@ struct FieldDev
 	// Optional BAND-LIMITED cell-major copy (round 4): 256-byte rows like cell_major, but only for the cell rows whose
 	// coefficients reach into a value band [lo, hi] (SPH boundary handling and GenerateDensityMap query the shell
 	// |phi| < 2h around the surface: 10-20 % of the cells, i.e. less than 1 x the field instead of 4.6 x).
-	// band_map[row] = index of the row in band_rows, or 0xffffffff: queries into such cells gather from the field.
+	// Which cell rows have one: one bit per cell row (band_bits, 64 rows per word) and the number of rows before each word
+	// (band_rank) -- 12 bytes per 64 cells, 3 MB at 256^3: the look-up of a query stays in the L2s instead of costing a sector
+	// of HBM traffic per query as a 4-byte-per-cell map would.  Queries into cells without a row gather from the field.
 	const double* band_rows = nullptr;
-	const uint32_t* band_map = nullptr;
+	const uint64_t* band_bits = nullptr;
+	const uint32_t* band_rank = nullptr;
 };
+// index of cell row `row` in the band copy, 0xffffffff if it has none
+DG_HD uint32_t band_row_of(const FieldDev& F, uint32_t row)
+{
+	const uint64_t bits = F.band_bits[row >> 6];
+	const uint32_t b = row & 63u;
+	if (((bits >> b) & 1ull) == 0ull)
+		return 0xffffffffu;
+	const uint64_t below = bits & ((1ull << b) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+	return F.band_rank[row >> 6] + (uint32_t)__popcll(below);
+#else
+	return F.band_rank[row >> 6] + (uint32_t)__builtin_popcountll(below);
+#endif
+}
 // Where the 32 coefficients of a cell come from (FieldDev): the kernels are instantiated per mode, so that each
 // has ONE load sequence (a runtime switch makes the compiler merge the variants into 32 separate 8-byte loads).
 enum FieldMode : int

@@ -342,7 +342,7 @@ dg_status dg_field_host_wait(dg_field* field);
 dg_status dg_field_build_cell_major(dg_field* field, void* stream);
 dg_status dg_field_drop_cell_major(dg_field* field); /* (drops the band-limited copy below as well) */
 /* The same rows for a VALUE BAND only: a cell row gets its 256 contiguous bytes if the values its 32 coefficients span reach
- * into [lo, hi] (min <= hi and max >= lo), every other cell stays where it is; a 4-byte map per cell row tells which.
+ * into [lo, hi] (min <= hi and max >= lo), every other cell stays where it is; one bit per cell row (+ a running count per 64) tells which.
  * dg_interpolate_batch* then serves queries into mapped cells from their rows (fetched cooperatively like the full copy's)
  * and, in the same launch, all others by the plain gather -- queries in any order, no sort.  SPH boundary handling and
  * GenerateDensityMap (cmd/generate_density_map/main.cpp:99,125-132) query the shell |phi| < 2h around the surface: for
