@@ -338,6 +338,12 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         "valu_busy": k3k["valu_busy"], "hbm_frac": k3k["hbm_frac"], "l2_hit_rate": k3k["l2_hit_rate"],
         "valu_per_wave": k3k["per_wave"]["valu"], "kernel_ms_when_profiled": k3k["kernel_ms"], "replayed": True,
         "td_cycles_per_load_instruction": k3k.get("td_cycles_per_load_instruction")}
+    k2bc = ((counters or {}).get("workloads", {}).get("k2b") or {})
+    k2bk = next((v for k, v in k2bc.items() if k.startswith("k_interpolate_band<false")), None)
+    k2["roofline_band_kernel"] = None if k2bk is None else {
+        "bound": "hbm", "achieved": k2bk["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2bk["hbm_frac"],
+        "traffic": k2bk["hbm_bytes_per_launch"], "algorithmic_bytes": 288 * nq, "replayed": True,
+        "what": "k_interpolate_band, 10 M shell queries (value), through the band-limited cell-major copy"}
     k2c = ((counters or {}).get("workloads", {}).get("k2r") or {})
     k2k = next((v for k, v in k2c.items() if k.startswith("k_interpolate_rows<false")), None)
     k2["roofline_rows_kernel"] = None if k2k is None else {
@@ -648,6 +654,8 @@ def main():
                 errors[cand] = note or "failed on another rank"
             else:
                 ms_by_form[cand] = t_
+            if rank == 0:   # (stderr: a later form that hangs must not take the evidence of the earlier ones with it)
+                print("bench.py exchange race: %s -> %s" % (cand, ("%.3f ms / step" % t_) if t_ is not None else errors[cand]), file=sys.stderr, flush=True)
         if not ms_by_form:
             raise SystemExit("no exchange form ran: %s" % errors)
         form = min(ms_by_form, key=ms_by_form.get)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence on the GPU box (run through gpurun) and turns it into the committed
 # summaries:
-#   profiles/collect.sh <tag> [k1|k2|k2r|k3|u|all]   (k2r: K2's row kernel on the cell-major copy)
+#   profiles/collect.sh <tag> [k1|k2|k2r|k2b|k3|u|all]   (k2r: K2's row kernel on the cell-major copy, k2b: on the band-limited copy)
 # Per workload: one --kernel-trace --stats run (kernel durations) and the PMC passes (own runs, counters
 # only -- never combined with a trace).  K1 = the default bench (python bench.py, 256^3 icosphere);
 # K2 / K3 / U = profiles/pmc_workloads.py at BASELINE configs[4] sizes.  Raw databases stay under
@@ -31,10 +31,10 @@ if [ $WHAT = k1 ] || [ $WHAT = all ]; then
   GRP=("${GROUPS_BASE[@]}" "${GROUPS_K1[@]}")
   run_set k1 python bench.py --steps 10 --warmup 2 --no-extras
 fi
-for w in k2 k2r k3 u; do
+for w in k2 k2r k2b k3 u; do
   if [ $WHAT = $w ] || [ $WHAT = all ]; then
     GRP=("${GROUPS_BASE[@]}")
-    if [ $w = k3 ] || [ $w = k2r ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}"); fi
+    if [ $w = k3 ] || [ $w = k2r ] || [ $w = k2b ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}"); fi
     if [ $w = k3 ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}" "${GROUPS_K1[@]}"); fi   # (+ instruction mix and the LDS pipe: k_density_cells keeps its tables and sums there)
     run_set $w python profiles/pmc_workloads.py $w
   fi

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workloads profiles/collect.sh profiles besides the default bench: K2 (batched interpolate), K3 (density
 map) and U (unpack) at BASELINE configs[4] / configs[2] sizes on the 256^3 icosphere field.
-    python profiles/pmc_workloads.py k2|k2r|k3|u
+    python profiles/pmc_workloads.py k2|k2r|k2b|k3|u
 Measurement tooling (uses the test helpers for the mesh and the config-5 query generator)."""
 import os
 import sys
@@ -60,6 +60,26 @@ def main():
         for rep in range(3):
             fld.interpolate_device(P.data_ptr(), nq, phi.data_ptr(), grad.data_ptr(), stream=s)
         torch.cuda.synchronize()
+    elif what == "k2b":
+        # K2 through the BAND-LIMITED cell-major copy: the SPH-like shell |phi| < 2h (every query has a row) and uniform queries
+        # (four in ten gather from the field), unordered, no binning
+        import numpy as np
+        fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
+        diag = float(np.linalg.norm((dom[3:] - dom[:3]) / 256.0))
+        fld.build_cell_major_band(-(0.2 + diag), 0.2 + diag, s)
+        nq = 10_000_000
+        C = torch.from_numpy(T.uniform_points(4321, 26_000_000, dom[:3], dom[3:])).cuda()
+        phic = torch.empty(len(C), dtype=torch.float64, device="cuda")
+        fld.interpolate_device(C.data_ptr(), len(C), phic.data_ptr(), stream=s)
+        S = C[(phic.abs() < 0.2)][:nq].contiguous()
+        del C, phic
+        phi = torch.empty(nq, dtype=torch.float64, device="cuda")
+        grad = torch.empty(3 * nq, dtype=torch.float64, device="cuda")
+        for rep in range(3):
+            fld.interpolate_device(S.data_ptr(), nq, phi.data_ptr(), stream=s)
+        for rep in range(3):
+            fld.interpolate_device(S.data_ptr(), nq, phi.data_ptr(), grad.data_ptr(), stream=s)
+        torch.cuda.synchronize()
     elif what == "k3":
         fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
         dens = torch.empty(n, dtype=torch.float64, device="cuda")
@@ -82,7 +102,7 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(out, field)
     else:
-        raise SystemExit("k2 | k2r | k3 | u")
+        raise SystemExit("k2 | k2r | k2b | k3 | u")
 
 
 if __name__ == "__main__":
