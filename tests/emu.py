@@ -327,6 +327,34 @@ def density_cells(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, ma
     return out, hits
 
 
+def interpolate_band(domain, res, coeffs, lo, hi, P, grad=False, cells=None, cell_map=None):
+    """K2 through a band-limited cell-major copy built on the host (bit / rank words as the device builds them);
+    returns (phi, grad or None, rows in the copy, queries served from the copy)."""
+    domain = np.ascontiguousarray(domain, dtype=np.float64)
+    res = np.ascontiguousarray(res, dtype=np.uint32)
+    cell = np.empty(3)
+    inv = np.empty(3)
+    T.oracle_lib().dgo_grid_header(T.dp(domain), T.up(res), T.dp(cell), T.dp(inv))
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, 3)
+    n_rows = int(np.prod(res.astype(np.int64)))
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.uint32)
+        cell_map = np.ascontiguousarray(cell_map, dtype=np.uint32)
+        n_rows = len(cells.reshape(-1, 32))
+    phi = np.empty(len(P))
+    g = np.empty((len(P), 3)) if grad else None
+    rows = C.c_uint64(0)
+    mapped = C.c_uint64(0)
+    L = lib()
+    L.emu_interpolate_band.restype = None
+    L.emu_interpolate_band.argtypes = [T.c_dp, T.c_dp, T.c_dp, T.c_up, T.c_dp, T.c_up, T.c_up, C.c_uint64, C.c_double, C.c_double, T.c_dp,
+                                       C.c_uint64, T.c_dp, T.c_dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.emu_interpolate_band(T.dp(domain), T.dp(cell), T.dp(inv), T.up(res), T.dp(coeffs), T.up(cells), T.up(cell_map), n_rows, lo, hi, T.dp(P),
+                           len(P), T.dp(phi), T.dp(g) if grad else None, C.byref(rows), C.byref(mapped))
+    return phi, g, int(rows.value), int(mapped.value)
+
+
 def div_h_mismatches(h, n, seed):
     """quotients of k3c_div_h() (dg_density_cells.h: d / h without the division) that differ from d / h."""
     L = lib()

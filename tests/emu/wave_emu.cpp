@@ -1462,6 +1462,99 @@ uint64_t emu_div_h_check(double h, uint64_t n, uint64_t seed)
 	}
 	return bad;
 }
+// The band-limited cell-major copy on the host: flags -> bit / rank words exactly as k_band_flags / the scan / k_band_expand
+// build them, then K2 through band_row_of() -- mapped queries from the copy's rows, the others from the field -- with the
+// product's locate_query / evaluate_cell.  rows_out: number of rows in the copy.
+void emu_interpolate_band(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3], const double* coeffs,
+						  const uint32_t* cells, const uint32_t* cell_map, uint64_t n_rows, double lo, double hi, const double* xyz, uint64_t n,
+						  double* phi, double* grad, uint64_t* rows_out, uint64_t* mapped_out)
+{
+	FieldDev F;
+	for (int d = 0; d < 3; ++d)
+	{
+		F.dmin[d] = domain[d];
+		F.dmax[d] = domain[3 + d];
+		F.cell[d] = cell[d];
+		F.inv_cell[d] = inv_cell[d];
+		F.res[d] = res[d];
+	}
+	F.coeffs = coeffs;
+	F.cells = cells;
+	F.cell_map = cell_map;
+	F.cell_major = nullptr;
+	F.tile_major = nullptr;
+	F.ntile[0] = F.ntile[1] = F.ntile[2] = 0;
+	auto indices = [&](uint64_t row, uint32_t idx[32]) {
+		if (cells)
+			for (int j = 0; j < 32; ++j)
+				idx[j] = cells[32 * row + j];
+		else
+		{
+			const uint32_t n01 = res[0] * res[1];
+			const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+			cell_node_indices(r % res[0], r / res[0], k, res, idx);
+		}
+	};
+	std::vector<uint64_t> bits((n_rows + 63) / 64, 0);
+	std::vector<uint32_t> rank((n_rows + 63) / 64, 0);
+	std::vector<double> rows;
+	uint32_t count = 0;
+	for (uint64_t row = 0; row < n_rows; ++row)
+	{
+		if ((row & 63u) == 0u)
+			rank[row >> 6] = count;
+		uint32_t idx[32];
+		indices(row, idx);
+		double mn = coeffs[idx[0]], mx = mn;
+		for (int j = 1; j < 32; ++j)
+		{
+			const double v = coeffs[idx[j]];
+			mn = v < mn ? v : mn;
+			mx = v > mx ? v : mx;
+		}
+		if (mn <= hi && mx >= lo)
+		{
+			bits[row >> 6] |= 1ull << (row & 63u);
+			for (int j = 0; j < 32; ++j)
+				rows.push_back(coeffs[idx[j]]);
+			++count;
+		}
+	}
+	if (rows.empty())
+		rows.resize(32, 0.0);
+	F.band_rows = rows.data();
+	F.band_bits = bits.data();
+	F.band_rank = rank.data();
+	*rows_out = count;
+	uint64_t mapped = 0;
+	for (uint64_t i = 0; i < n; ++i)
+	{
+		const CellQuery q = locate_query(F, xyz + 3 * i);
+		double g[3] = {0.0, 0.0, 0.0};
+		double v = 1.7976931348623157e308;
+		if (q.valid)
+		{
+			double cf[32];
+			const uint32_t r = band_row_of(F, q.row);
+			if (r != 0xffffffffu)
+			{
+				++mapped;
+				for (int j = 0; j < 32; ++j)
+					cf[j] = F.band_rows[32 * (size_t)r + j];
+			}
+			else if (cells)
+				fetch_cell<kFieldTable>(F, q.mi[0], q.mi[1], q.mi[2], q.row, cf);
+			else
+				fetch_cell<kFieldClosed>(F, q.mi[0], q.mi[1], q.mi[2], q.row, cf);
+			v = grad ? evaluate_cell<true>(cf, q.xi, q.c0, g) : evaluate_cell<false>(cf, q.xi, q.c0, g);
+		}
+		phi[i] = v;
+		if (grad)
+			for (int d = 0; d < 3; ++d)
+				grad[3 * i + d] = g[d];
+	}
+	*mapped_out = mapped;
+}
 void emu_interpolate(const double domain[6], const double cell[3], const double inv_cell[3], const uint32_t res[3],
 					 const double* coeffs, const uint32_t* cells, const uint32_t* cell_map, const double* xyz,
 					 uint64_t n, double* phi, double* grad)

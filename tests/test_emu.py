@@ -514,6 +514,39 @@ def test_point_lanes_with_seven_nodes_equal_the_per_node_body(golden):
         emu.set_tile_major(0)
 
 
+def test_band_limited_copy_data_path_bit_exact(golden):
+    """K2's band-limited cell-major copy (dg_lattice.h band_row_of(): one bit per cell row + a running count per 64 rows): the
+    look-up finds exactly the rows the builder kept, mapped and unmapped queries evaluate to the bits of the plain path (and of
+    the reference's golden values) -- wide, narrow, empty and all-inclusive bands, unreduced and table-mode fields with removed
+    cells and "no value" coefficients, row counts that are no multiples of 64."""
+    for name in ("torus", "box"):
+        dom, res = golden[name + "_domain"], golden[name + "_res"]
+        coeffs, P = golden[name + "_coeffs"], golden[name + "_P"]
+        want_phi, want_grad = golden[name + "_phi"], golden[name + "_grad"]
+        fin = coeffs[coeffs != DBL_MAX]
+        n_cells = int(np.prod(res))
+        seen = set()
+        for lo, hi in ((-0.05, 0.05), (float(np.median(fin)), float(fin.max())), (float(fin.max()) + 1.0, float(fin.max()) + 2.0),
+                       (float(fin.min()) - 1.0, float(fin.max()) + 1.0)):
+            phi, grad, rows, mapped = emu.interpolate_band(dom, res, coeffs, lo, hi, P, grad=True)
+            np.testing.assert_array_equal(phi, want_phi)
+            inside = want_phi != DBL_MAX
+            np.testing.assert_array_equal(grad[inside], want_grad[inside])
+            assert 0 <= rows <= n_cells and mapped <= inside.sum()
+            seen.add(rows)
+        assert 0 in seen and n_cells in seen and len(seen) >= 3
+        cells = T.oracle_cell_table(res)
+        cmap = np.arange(len(cells), dtype=np.uint32)
+        cmap[::3] = 0xFFFFFFFF
+        c2 = coeffs.copy()
+        c2[::7] = DBL_MAX
+        a, ga = emu.interpolate(dom, res, c2, P, grad=True, cells=cells, cell_map=cmap)
+        b, gb, rows, mapped = emu.interpolate_band(dom, res, c2, -0.1, 0.1, P, grad=True, cells=cells, cell_map=cmap)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ga, gb)
+        assert rows > 0
+
+
 def test_division_free_quotient_by_the_support_radius_is_the_division():
     """k_density_cells forms gamma = 1 - d / h with a multiplication by RN(1 / h) and two residual corrections
     (dg_density_cells.h k3c_div_h(): Markstein's theorem).  Same bits as the division for 10^7 numerators per support

@@ -188,3 +188,35 @@ def test_density_map_bigger_lattice_vs_oracle(dg):
         want = T.oracle_density_map(dom, res, sdf, 0.1, 1000.0, True, int(b), int(b) + 64)
         np.testing.assert_array_equal(got[b:b + 64], want)
     assert active > 20000
+
+
+def test_point_lane_kernel_beyond_two_gigabytes_of_offsets(dg, monkeypatch):
+    """k_density_cells addresses a cell by 32-bit byte offsets on scalar row bases.  At 512^3 the X class alone is 2.16 GB and the
+    x-major copy of the Y / Z classes 2 x 2.15 GB: offsets beyond 2^31 must be taken as UNSIGNED by the load.  Node ranges at
+    the far end of every class (where the offsets are largest), point-lane kernel == row-block kernel, bit for bit."""
+    import torch
+    V, F = T.icosphere(24)
+    dom = T.oracle_default_domain(V)
+    res = [512, 512, 512]
+    grid = dg.grid_desc(dom[:3], dom[3:], res)
+    n = dg.n_nodes(grid)
+    s = torch.cuda.current_stream().cuda_stream
+    sdf = torch.empty(n, dtype=torch.float64, device="cuda")
+    dg.Mesh(V, F).sample_nodes_device(grid, 0, n, sdf.data_ptr(), stream=s)
+    fld = dg.Field(grid, d_coeffs=sdf.data_ptr(), n_coeffs=n)
+    nv = 513 ** 3
+    ne2 = 2 * 512 * 513 * 513
+    m = n // 8 + 1000                      # (an eighth of the lattice or more: the whole-lattice kernels)
+    outs = {}
+    for begin in (nv + ne2 - m, nv + 2 * ne2 - m, n - m):      # the ends of the X, Y and Z classes
+        for tag, cells in (("cells", "1"), ("rows", "0")):
+            monkeypatch.setenv("DG_K3_CELLS", cells)
+            out = torch.full((m,), -1.0, dtype=torch.float64, device="cuda")
+            fld.density_map_nodes_device(0.05, 1000.0, True, begin, begin + m, out.data_ptr(), stream=s)
+            torch.cuda.synchronize()
+            outs[tag] = out
+        monkeypatch.delenv("DG_K3_CELLS")
+        assert torch.equal(outs["cells"], outs["rows"]), begin
+        got = outs["cells"]
+        assert int(((got != DBL_MAX) & (got != 0.0)).sum().item()) > 100000      # (the band is there: real quadratures ran)
+    fld.close()

@@ -27,6 +27,9 @@ PY
     k3blocks)
       timeout 400 python tools/k3_run.py --res 256 --steps 2 --check --sweep "DG_K3_RB1=3,DG_K3_RB2=43;DG_K3_RB1=3,DG_K3_RB2=129;DG_K3_RB1=1,DG_K3_RB2=129;DG_K3_RB1=2,DG_K3_RB2=129;DG_K3_RB1=4,DG_K3_RB2=32;DG_K3_RB1=6,DG_K3_RB2=22;DG_K3_RB1=3,DG_K3_RB2=65;DG_K3_RB1=3,DG_K3_RB2=26;DG_K3_RB0=2,DG_K3_RB1=3,DG_K3_RB2=22" > $OUT/k3_blocks_256.jsonl 2> $OUT/k3_blocks.err
       cat $OUT/k3_blocks_256.jsonl ;;
+    k3big)   # 512^3: parity of the point-lane kernel at offsets beyond 2^31, then its time
+      timeout 900 python -m pytest tests/test_gpu_density_map.py -x -q -m gpu -k "beyond_two_gigabytes" > $OUT/k3big.log 2>&1; tail -4 $OUT/k3big.log
+      timeout 600 python tools/k3_run.py --res 512 --steps 1 --sweep "DG_K3_CELLS=1;DG_K3_CELLS=0" > $OUT/k3_512.jsonl 2> $OUT/k3_512.err; cat $OUT/k3_512.jsonl ;;
     gputests)
       timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/gputests.log 2>&1; tail -5 $OUT/gputests.log ;;
     bench)
