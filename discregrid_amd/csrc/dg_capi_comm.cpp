@@ -812,6 +812,25 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	uint32_t cuts[4][dg::kMaxRanks + 1];
 	dg::chunk_planes(grid->resolution, V, plane_cost, cuts);
+	// every rank derives the cuts from its own copy of plane_cost; ranks that disagree would post transfers that do not match
+	// (a hang or a corrupted field): whenever the cuts change, their hash goes round once and a mismatch fails the call
+	if (N > 1 && plane_cost != nullptr)
+	{
+		const uint64_t h = hash_cuts(cuts, V);
+		if (!comm->cuts_checked || h != comm->cuts_hash)
+		{
+			std::vector<uint64_t> all((size_t)N);
+			const dg_status hs = ctrl_allgather(comm, &h, all.data(), sizeof(h));
+			if (hs != DG_OK)
+				return hs;
+			for (int r = 0; r < N; ++r)
+				if (all[(size_t)r] != h)
+					return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank %d: plane_cost must hold the same values on every rank", r,
+								comm->rank);
+			comm->cuts_hash = h;
+			comm->cuts_checked = true;
+		}
+	}
 	dg::ClassGeom cg[4];
 	dg::class_geometry(grid->resolution, cg);
 	DG_HIP(piece_events(comm, pieces));

@@ -628,12 +628,13 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 		{
 			dev.xmajor = static_cast<const double*>(d_rows);
 			dev.xmajor_flags = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_rows) + copy_bytes);
-			// waves along x / y / z of the blocks consecutive wave ids fill.  The point-lane kernel likes them tall in z: the
-			// quadrature's innermost loop sweeps z, so the waves of a tall block read what their z-neighbours read a step ago
-			// (256^3: 1 x 16 x 8 470 ms, 1 x 12 x 8 466, 1 x 2 x 64 464, 1 x 3 x 43 458; 1 x 24 x 8 490)
+			// waves along x / y / z of the blocks consecutive wave ids fill, fitted by counter (profiles/r04_k3_blocks_pmc.txt, 256^3,
+			// kernel ms / L2 hit rate): 1 x 16 x 8 472 / 0.890, 1 x 12 x 8 466 / 0.894, 1 x 8 x 8 468 / 0.853, 1 x 6 x 22 462 / 0.899,
+			// 1 x 3 x 43 467 / 0.864, 1 x 2 x 64 465 / 0.816, 1 x 8 x 16 489 / 0.911 -- moderately tall in z: the quadrature's
+			// innermost loop sweeps z, so the waves of a block read what their z-neighbours read a step ago
 			const bool cells_kernel = env_int("DG_K3_CELLS", 1, 0, 1) != 0 && dg::k3c_geometry_fits(dev.res);
-			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 256), (uint32_t)env_int("DG_K3_RB1", cells_kernel ? 3 : 16, 1, 256),
-									   (uint32_t)env_int("DG_K3_RB2", cells_kernel ? 43 : 8, 1, 256)};
+			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 256), (uint32_t)env_int("DG_K3_RB1", cells_kernel ? 6 : 16, 1, 256),
+									   (uint32_t)env_int("DG_K3_RB2", cells_kernel ? 22 : 8, 1, 256)};
 			// round 4: one lane per lattice POINT with its seven nodes (k_density_cells, dg_density_cells.h: 3 cell fetches per 7
 			// nodes and quadrature point instead of 5, one sweep of the field instead of one per node class); DG_K3_CELLS=0: the
 			// row-block kernel with one node / edge per lane
