@@ -66,13 +66,13 @@ def main():
         import numpy as np
         fld = dg.Field(grid, d_coeffs=field.data_ptr(), n_coeffs=n)
         diag = float(np.linalg.norm((dom[3:] - dom[:3]) / 256.0))
-        fld.build_cell_major_band(-(0.2 + diag), 0.2 + diag, s)
         nq = 10_000_000
         C = torch.from_numpy(T.uniform_points(4321, 26_000_000, dom[:3], dom[3:])).cuda()
         phic = torch.empty(len(C), dtype=torch.float64, device="cuda")
-        fld.interpolate_device(C.data_ptr(), len(C), phic.data_ptr(), stream=s)
+        fld.interpolate_device(C.data_ptr(), len(C), phic.data_ptr(), stream=s)     # (plain path: the band copy does not exist yet)
         S = C[(phic.abs() < 0.2)][:nq].contiguous()
         del C, phic
+        fld.build_cell_major_band(-(0.2 + diag), 0.2 + diag, s)    # from here on k_interpolate_band sees the shell batches only
         phi = torch.empty(nq, dtype=torch.float64, device="cuda")
         grad = torch.empty(3 * nq, dtype=torch.float64, device="cuda")
         for rep in range(3):
