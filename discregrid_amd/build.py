@@ -19,7 +19,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 SOURCES_HIP = ["dg_kernels.hip"]
 SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_build.cpp"]
-HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_host_query.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
+HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_host_query.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
 
 
 def _stale():
@@ -42,9 +42,9 @@ def build(force=False, verbose=False, defines=(), out=None):
 
 # headers each source includes (directly or not): an object is rebuilt only when one of these is newer
 DEPS = {
-    "dg_kernels.hip": ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h"],
-    "dg_build.cpp": ["dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h"],
-    "dg_host_query.cpp": ["dg_host_query.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_capi_internal.h", "dg_layout.h",
+    "dg_kernels.hip": ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h"],
+    "dg_build.cpp": ["dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h"],
+    "dg_host_query.cpp": ["dg_host_query.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_capi_internal.h", "dg_layout.h",
                           os.path.join("..", "..", "include", "discregrid_hip.h")],
 }
 

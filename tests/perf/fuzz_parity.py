@@ -76,6 +76,16 @@ def main():
         same_field = np.array_equal(got, want)
         if same_field:
             ok = ok and np.array_equal(phi, wphi) and np.array_equal(grad[inside], wgrad[inside])
+        # K2 through a band-limited cell-major copy with a random band (round 4): the same bits
+        if rounds % 3 == 0:
+            fin = got[np.isfinite(got) & (got != np.finfo(np.float64).max)]
+            if len(fin):
+                lo_b = float(rng.uniform(fin.min() - 0.1, fin.max() + 0.1))
+                hi_b = lo_b + float(rng.uniform(0.0, 1.0)) * float(fin.max() - fin.min() + 1e-9)
+                f.build_cell_major_band(lo_b, hi_b)
+                phi_b, grad_b = f.interpolate(Q, grad=True)
+                ok = ok and np.array_equal(phi_b, phi) and np.array_equal(grad_b, grad)
+                f.drop_cell_major()
         # K3 on a slice of the lattice, now and then on a field spoilt with NaN / Inf / huge / DBL_MAX values
         # (those must take the evaluate-every-point path and still match the oracle, NaNs included)
         if rounds % 4 == 0 and len(got) > 64:
@@ -93,13 +103,17 @@ def main():
             k3 = fk.density_map_nodes(len(sdf), h, 1000.0, band, b, e)
             w3 = T.oracle_density_map(dom, res, sdf, h, 1000.0, band, b, e)
             ok = ok and np.array_equal(k3, w3, equal_nan=True)
-            # the whole lattice goes through the row-block kernel (k_density_rows), a small slice through the pair kernel:
-            # the slice of the one == the oracle, and the whole == the pair kernel's whole (DG_K3_ROWS=0)
+            # the whole lattice goes through the point-lane kernel (k_density_cells, round 4), a small slice through the pair kernel:
+            # the slice of the one == the oracle, and the whole == the row-block kernel's and the pair kernel's whole
             full = fk.density_map_nodes(len(sdf), h, 1000.0, band)
+            os.environ["DG_K3_CELLS"] = "0"
+            full_rows = fk.density_map_nodes(len(sdf), h, 1000.0, band)
+            del os.environ["DG_K3_CELLS"]
             os.environ["DG_K3_ROWS"] = "0"
             full_pairs = fk.density_map_nodes(len(sdf), h, 1000.0, band)
             del os.environ["DG_K3_ROWS"]
-            ok = ok and np.array_equal(full[b:e], w3, equal_nan=True) and np.array_equal(full, full_pairs, equal_nan=True)
+            ok = ok and np.array_equal(full[b:e], w3, equal_nan=True) and np.array_equal(full, full_pairs, equal_nan=True) and \
+                np.array_equal(full, full_rows, equal_nan=True)
             k3_rounds[0] += 1
         rounds += 1
         nodes += len(got)
