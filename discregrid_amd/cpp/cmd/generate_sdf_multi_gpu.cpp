@@ -48,7 +48,7 @@ struct Options
 	Eigen::AlignedBox3d domain;
 	bool invert = false;
 	int gpus = 1, pieces = 4, steps = 1;
-	int exchange = 0; // flags of dg_sdf_sample_exchange_device (--inplace, --p2p)
+	int exchange = 0; // flags of dg_sdf_sample_exchange_device (--inplace, --p2p, --copy)
 	std::string output, input;
 };
 
@@ -181,7 +181,7 @@ int main(int argc, char* argv[])
 		if (a == "-h" || a == "--help")
 		{
 			std::cout << "Usage: " << argv[0]
-					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p] [--steps k] [-o out.cdf] mesh.obj"
+					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p | --copy] [--steps k] [-o out.cdf] mesh.obj"
 					  << std::endl;
 			return 0;
 		}
@@ -206,6 +206,8 @@ int main(int argc, char* argv[])
 			opt.exchange |= DG_EXCHANGE_INPLACE;
 		else if (a == "--p2p") // ... exchanged with send / recv pairs instead
 			opt.exchange |= DG_EXCHANGE_INPLACE | DG_EXCHANGE_P2P;
+		else if (a == "--copy") // ... pushed into the peers' fields by the copy engines (HIP IPC), no collective kernel
+			opt.exchange = DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY;
 		else if (a == "--steps")
 		{
 			opt.steps = std::atoi(value().c_str());

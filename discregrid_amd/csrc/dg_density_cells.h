@@ -276,13 +276,6 @@ DG_HD K3PointNodes k3c_point_nodes(const uint32_t res[3], uint32_t i, uint32_t j
 	return n;
 }
 
-// The quadrature of one lane.  W is the wave context: any(b) (device: ballot), the tables of the shifted coordinates'
-// axis states (set_x / x_var, set_y / y_var, z_var) -- LDS on the device, computed on demand by the host emulator from
-// the same pure function k3_axis_entry() on the same coordinates.
-//   li, lj          the lattice point's indices along x and y (its coordinates are recomputed where they are needed: the
-//                   kernel is short of registers, and three instructions per i / (i, j) level are nothing)
-//   need            bit n: node n needs the quadrature
-//   res[n]          the sums (before * c0prod, * rho0)
 // the coordinates of lattice index `idx` along axis d and of the two edge nodes behind it: node_position()
 DG_HD void k3c_coords(const SampleParams& L, int d, uint32_t idx, double* x0, double* xa, double* xb)
 {
@@ -310,6 +303,13 @@ DG_HD bool k3c_cell_ok(const FieldDev& F, uint32_t i, uint32_t j, uint32_t k)
 	const uint64_t w = F.xmajor_flags[word];
 	return ((w >> (i & 63u)) & 1ull) == 0ull;
 }
+// The quadrature of one lane.  W is the wave context: any(b) (device: ballot), the tables of the shifted coordinates'
+// axis states (set_x / x_var, set_y / y_var, z_var) -- LDS on the device, computed on demand by the host emulator from
+// the same pure function k3_axis_entry() on the same coordinates.
+//   li, lj          the lattice point's indices along x and y (its coordinates are recomputed where they are needed: the
+//                   kernel is short of registers, and three instructions per i / (i, j) level are nothing)
+//   need            bit n: node n needs the quadrature
+//   res[n]          the sums (before * c0prod, * rho0)
 template <bool FAST, class W>
 DG_HD void k3c_quadrature(W& w, const SampleParams& L, const FieldDev& F, const DensityParams& P, const K3CellsGeom& G, bool has_noval,
 						  bool skip, uint32_t li, uint32_t lj, uint32_t need, double res[7])
