@@ -180,7 +180,7 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "what": "CubicLagrangeDiscreteGrid::addFunction(MeshSDF) on a fresh grid (C++, the best of calls 2-4; the first call of a "
                         "process also sets up streams and buffers).  host_ready_ms (= value) = until the host vector is complete "
                         "(waitForHostData: what the first scalar interpolate / save / nodeData waits for, and what the reference's "
-                        "addFunction means by returning).  The field is produced into a device array its handle owns, in four chunks whose "
+                        "addFunction means by returning).  The field is produced into a device array its handle owns, in seven chunks whose "
                         "copies run under the following chunks; the call itself returns once the work is enqueued (return_ms), and "
                         "device_ready_ms = until a GPU-side consumer of the WHOLE field (a batched interpolate) has run -- what a "
                         "following addDensityMap / batched query waits for"}

@@ -30,6 +30,9 @@ PY
     k3big)   # 512^3: parity of the point-lane kernel at offsets beyond 2^31, then its time
       timeout 900 python -m pytest tests/test_gpu_density_map.py -x -q -m gpu -k "beyond_two_gigabytes" > $OUT/k3big.log 2>&1; tail -4 $OUT/k3big.log
       timeout 600 python tools/k3_run.py --res 512 --steps 1 --sweep "DG_K3_CELLS=1;DG_K3_CELLS=0" > $OUT/k3_512.jsonl 2> $OUT/k3_512.err; cat $OUT/k3_512.jsonl ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+      timeout 600 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu -k "cpp_multi_gpu_tool" > $OUT/tool.log 2>&1; tail -2 $OUT/tool.log ;;
     gputests)
       timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/gputests.log 2>&1; tail -5 $OUT/gputests.log ;;
     bench)
