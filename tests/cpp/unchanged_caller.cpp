@@ -86,7 +86,8 @@ int main(int argc, char** argv)
 		sdf.addFunction(MeshSDF{&md, false}, false);
 		const double t_typed = now() - t0;
 		// (the GPU suite insists on the device path; the no-device test of tests/test_host_api.py runs under DG_FORCE_CPU=1)
-		const bool want_gpu = std::getenv("DG_FORCE_CPU") == nullptr;
+		const char* visible = std::getenv("HIP_VISIBLE_DEVICES");
+		const bool want_gpu = std::getenv("DG_FORCE_CPU") == nullptr && !(visible != nullptr && visible[0] == '\0');
 		if (sdf.lastAddFunctionUsedGpu() != want_gpu)
 			return 4;
 		auto const& a = sdf.nodeData(0);

@@ -126,13 +126,16 @@ def test_headers_compile_standalone(tmp_path):
                                "-I" + os.path.join(CPP, "third_party", "eigen_min"), str(src)])
 
 
-def _no_gpu_env():
-    """the C++ API without a HIP device: on the build box there is none; on a GPU box DG_FORCE_CPU=1 makes the mesh handle
-    host-only (include/discregrid_hip.h dg_mesh_device())."""
+def _no_gpu_env(how="force"):
+    """the C++ API without a HIP device: on the build box there is none; on a GPU box either DG_FORCE_CPU=1 makes the mesh
+    handle host-only (include/discregrid_hip.h dg_mesh_device()) or HIP_VISIBLE_DEVICES= hides the devices from the runtime."""
+    if how == "hidden":
+        return dict(os.environ, HIP_VISIBLE_DEVICES="")
     return dict(os.environ, DG_FORCE_CPU="1")
 
 
-def test_generate_sdf_cli_without_a_device_reproduces_box_cdf(driver, tmp_path):
+@pytest.mark.parametrize("how", ["force", "hidden"])
+def test_generate_sdf_cli_without_a_device_reproduces_box_cdf(driver, tmp_path, how):
     """without a HIP device the typed MeshSDF functor falls back to the reference's OpenMP node loop over the
     per-point query (the product's own BVH and arithmetic on the host).  GenerateSDF -r "5 5 5" box.obj still writes the
     reference's box.cdf, byte for byte."""
@@ -141,12 +144,13 @@ def test_generate_sdf_cli_without_a_device_reproduces_box_cdf(driver, tmp_path):
     V, F = T.box_mesh()
     T.write_obj(obj, V, F)
     out = str(tmp_path / "box.cdf")
-    log = subprocess.check_output([exe, "-r", "5 5 5", "-o", out, obj], env=_no_gpu_env()).decode()
+    log = subprocess.check_output([exe, "-r", "5 5 5", "-o", out, obj], env=_no_gpu_env(how)).decode()
     assert "Construction took" in log and "DONE" in log
     assert read(out) == read(os.path.join(T.GOLDEN, "box.cdf"))
 
 
-def test_unchanged_reference_caller_and_typed_functor_without_a_device(driver, tmp_path):
+@pytest.mark.parametrize("how", ["force", "hidden"])
+def test_unchanged_reference_caller_and_typed_functor_without_a_device(driver, tmp_path, how):
     """tests/cpp/unchanged_caller.cpp (the body of the reference's GenerateSDF with the reference's own lambda) and the typed
     MeshSDF functor on a box without a GPU: same coefficients from both, equal to the oracle bit for bit; the batched
     signed_distance falls back to the per-point query as well."""
@@ -155,7 +159,7 @@ def test_unchanged_reference_caller_and_typed_functor_without_a_device(driver, t
     obj = str(tmp_path / "torus.obj")
     T.write_obj(obj, V, F)
     out = str(tmp_path / "out.bin")
-    subprocess.check_call([exe, "lambda", obj, "9 7 8", out], env=_no_gpu_env())
+    subprocess.check_call([exe, "lambda", obj, "9 7 8", out], env=_no_gpu_env(how))
     got = np.fromfile(out)
     n = int(got[0])
     assert n == T.n_nodes([9, 7, 8]) and got[3] == 0.0          # lambda path == typed path
@@ -167,7 +171,7 @@ def test_unchanged_reference_caller_and_typed_functor_without_a_device(driver, t
     P = T.oracle_node_positions(dom, [6, 5, 7])[(np.arange(1000) * 7919) % n2] + np.array([0.01, -0.02, 0.005])
     pts = str(tmp_path / "pts.bin")
     P.tofile(pts)
-    subprocess.check_call([driver, "cpu", obj, "6 5 7", pts, out2], env=_no_gpu_env())
+    subprocess.check_call([driver, "cpu", obj, "6 5 7", pts, out2], env=_no_gpu_env(how))
     got = np.fromfile(out2)
     assert got[0] == 0.0                                        # lastAddFunctionUsedGpu() == false
     want = om.sample_nodes(dom, [6, 5, 7])
