@@ -12,7 +12,7 @@ for leg in "$@"; do
 import sys; sys.path.insert(0, "tests"); import dgtest as T
 V, F = T.icosphere(71); T.write_obj("/tmp/ico71.obj", V, F)
 PY
-      for prof in "" "streams1" "0.08,0.14,0.22,0.28,0.28" "0.16,0.16,0.16,0.16,0.14,0.10,0.07,0.05" "one"; do
+      for prof in ${ADDFN_PROFILES:-"" "0.1,0.1,0.1,0.1,0.1,0.1,0.1,0.1,0.1,0.1" "0.14,0.13,0.12,0.11,0.10,0.10,0.09,0.08,0.07,0.06" "0.12,0.12,0.12,0.12,0.11,0.11,0.10,0.09,0.07,0.04" "0.18,0.17,0.16,0.14,0.12,0.10,0.07,0.04,0.02" "0.10,0.12,0.13,0.13,0.12,0.11,0.10,0.08,0.06,0.03,0.02"}; do
         unset DG_FIELD_FRACTIONS DG_FIELD_ONE_LAUNCH DG_FIELD_STREAMS
         if [ "$prof" = one ]; then export DG_FIELD_ONE_LAUNCH=1; elif [ "$prof" = streams1 ]; then export DG_FIELD_STREAMS=1; elif [ -n "$prof" ]; then export DG_FIELD_FRACTIONS=$prof; fi
         echo "profile '${prof:-default}':" >> $OUT/addfn.txt
