@@ -34,9 +34,12 @@ struct Roctx
 		if (const char* e = std::getenv("DG_ROCTX"))
 			if (std::atoi(e) == 0)
 				return;
-		void* lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
-		if (!lib)
-			lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+		// rocprofv3 (--marker-trace) listens to the ROCTx of the rocprofiler SDK; the older libroctx64 is what roctracer-based
+		// tools see.  Same entry points: take the first that loads.
+		void* lib = nullptr;
+		for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+			if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
+				break;
 		if (!lib)
 			return;
 		push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));

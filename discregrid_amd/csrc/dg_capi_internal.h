@@ -196,7 +196,8 @@ struct DeviceGuard
 
 // ROCTx ranges around the launches of the device entry points (tracing): `rocprofv3 --marker-trace` shows
 // "dg K1 sample_nodes" / "dg K2 interpolate" / "dg K3 density_map" / "dg U unpack" around the kernels they enqueue.
-// libroctx64 is bound at run time (no hard dependency; DG_ROCTX=0: off); without a tool attached a range costs a call.
+// The ROCTx library (the rocprofiler SDK's, else libroctx64) is bound at run time (no hard dependency; DG_ROCTX=0: off);
+// without a tool attached a range costs a call.
 struct TraceRange
 {
 	explicit TraceRange(const char* name);
