@@ -68,8 +68,8 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "discregrid_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        # (not the host-only sources: the copy pipeline, the CPU point query and the RCCL glue do not change what the kernels do)
-        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp"):
+        # (not the host-only sources: the copy pipeline, the CPU point query and the exchange glue do not change what the kernels do)
+        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_capi_vmm.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
@@ -406,24 +406,90 @@ def cpu_baseline_k2_k3(T, dom, res, field, h, rho0):
     return out
 
 
+def user_facing_scalars(out):
+    """The figures an API user sees, as plain scalars INSIDE `roofline` (the driver's record keeps config / roofline / cpu_baseline
+    of the line and drops the nested secondary / addfunction_e2e objects)."""
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return d
+    k2 = get(out, "secondary", "k2_interpolate") or {}
+    k3 = get(out, "secondary", "k3_density_map") or {}
+    k1 = get(out, "secondary", "k1") or {}
+    traffic, compulsory = get(k3, "roofline", "traffic"), get(k3, "roofline", "compulsory_bytes")
+    return {
+        "d2h_mnodes_s": get(out, "value_with_d2h", "value"),            # SURVEY 8(d)'s metric: K1 + D2H into the caller's host vector
+        "host_ready_ms": get(out, "addfunction_e2e", "host_ready_ms"),   # C++ addFunction(MeshSDF) until the host vector is complete
+        "device_ready_ms": get(out, "addfunction_e2e", "device_ready_ms"),
+        "k2_rows_frac": get(k2, "uniform_value_cell_major", "hbm_frac_algorithmic"),   # 10 M uniform queries, cell-major copy: 288 B / query / 8 TB/s
+        "k2_band_frac": get(k2, "shell_value_band_copy", "hbm_frac_algorithmic"),      # 10 M shell queries, band-limited copy
+        "k2_band_uniform_gq_s": get(k2, "uniform_value_band_copy", "gq_s"),            # ... and uniform queries through the same copy (43 % miss the band)
+        "k2_plain_frac": get(k2, "uniform_value", "hbm_frac_algorithmic"),             # plain layout incl. the on-device binning
+        "k3_seconds": get(k3, "seconds"),                                              # density map of the 256^3 SDF, whole lattice
+        "k3_td_busy": get(k3, "roofline", "td_busy"),
+        "k3_traffic_over_compulsory": (traffic / compulsory) if traffic and compulsory else None,
+        "k1_bunny128_ms": get(k1, "bunny128", "ms"), "k1_bunny256_ms": get(k1, "bunny256", "ms"),
+        "k1_dragon256_ms": get(k1, "dragon256", "ms"), "k1_ico512_ms": get(k1, "ico512", "ms"),
+    }
+
+
+class Watchdog:
+    """N > 1: no exchange form has ever run on more than one GPU where this was developed, and a rank that fails inside a
+    collective leaves its peers waiting for ever.  Every candidate form therefore runs under a deadline: when it expires, rank 0
+    prints the line of the best form measured SO FAR (saying which form was cut off) and every rank leaves at once -- a scaling
+    run returns a number as long as one form completed."""
+
+    def __init__(self, seconds, rank, state):
+        self.seconds, self.rank, self.state, self.timer = seconds, rank, state, None
+
+    def _fire(self, what):
+        if self.rank == 0:
+            line = self.state.get("line")
+            if line is not None:
+                line["config"]["exchange"]["watchdog"] = "%s did not complete within %d s; the forms measured before it are reported" % (what, self.seconds)
+                print(json.dumps(line), flush=True)
+            print("bench.py watchdog: %s did not complete within %d s%s" % (what, self.seconds, "" if line else "; nothing was measured before it"),
+                  file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(0 if self.state.get("line") is not None or self.rank != 0 else 3)
+
+    def arm(self, what):
+        import threading
+        self.disarm()
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire, [what])
+            self.timer.daemon = True
+            self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=28.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed K1 steps (profiling runs)")
     ap.add_argument("--pieces", type=int, default=4,
-                    help="N > 1: issue the all-gather in this many pieces, overlapped with the sampling kernel")
+                    help="N > 1: issue the exchange in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
                     help="run the N > 1 protocol (communicator, shards, all-gather, unpack) even at N = 1 (self-test)")
-    ap.add_argument("--exchange", choices=["auto", "slabs", "inplace", "inplace-p2p", "copy", "to-root"], default="auto",
-                    help="N > 1: auto (default) = time slabs, inplace, inplace-p2p and copy during the warm-up (after the cost "
-                         "rebalance of the in-place forms) and run the timed steps with the fastest; slabs = interleaved 4-plane "
+    ap.add_argument("--exchange", choices=["auto", "host", "slabs", "inplace", "inplace-p2p", "copy", "to-root"], default="auto",
+                    help="N > 1: auto (default) = run --warmup + --steps steps of EVERY form, each under --form-timeout, and report the "
+                         "fastest (the others' times are on the line).  host = every rank copies its chunks into a shared-memory host "
+                         "vector (no RCCL, no device IPC: cannot fail for lack of either; measured first); slabs = interleaved 4-plane "
                          "slabs, packed buffers, all-gather, unpack; inplace = contiguous chunks cut by measured cost, sampled into "
                          "place and exchanged with grouped broadcasts (no unpack pass, no scratch); inplace-p2p: the same with "
-                         "send / recv pairs; copy: the same chunks pushed into the peers' fields by the copy engines (HIP IPC + "
-                         "hipMemcpyAsync, no collective kernel beside the sampling); to-root: only rank 0 gets the whole field")
+                         "send / recv pairs; copy: the same chunks pushed into the peers' fields by the copy engines (fields from "
+                         "dg_comm_field_alloc, mapped by the peers chunk by chunk; no collective kernel beside the sampling); "
+                         "to-root: only rank 0 gets the whole field")
+    ap.add_argument("--form-timeout", type=int, default=120, help="N > 1: seconds a candidate form may take before the run is cut short")
     ap.add_argument("--python-gather", action="store_true",
                     help="N > 1: drive the pieces from here with torch.distributed's all_gather instead of the library's "
                          "dg_sdf_sample_allgather_device (A/B, and the one-GPU self-test)")
@@ -453,10 +519,18 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if selftest:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # The bench's OWN collectives (barriers, max over ranks, shared timings) act on CPU tensors and go through gloo: they
+        # must work whatever state RCCL is in.  RCCL is what the library's communicator uses (dg_comm_create, the product),
+        # and what torch.distributed falls back to for CUDA tensors if that communicator cannot be created.
+        dist.init_process_group("gloo" if selftest else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+
+    def ctl_barrier():
+        dist.all_reduce(torch.zeros(1))
+
+    def ctl_max(x):
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     V, F = T.icosphere(71)
     dom = dg.default_domain(V)            # cmd/generate_sdf/main.cpp:83-91
@@ -470,10 +544,13 @@ def main():
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
     comm = None          # the library's RCCL communicator
     comm_ext = None      # one-GPU self-test: the library's communicator with gloo as its control plane (copy form only)
+    hostf = [None]       # the shared-memory host vector of the "host" form (opened on first use)
+    copy_field = [None]  # the field of the "copy" form: an array of dg_comm_field_alloc (mappable by the peers whatever its size)
     pieces = 1
     comm_note = None
     launch_nodes = n_nodes
-    exchange_report = None
+    state = {"line": None}
+    dog = Watchdog(args.form_timeout if world > 1 else 0, rank, state)
     if sharded:
         pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
         vworld = pieces * world
@@ -483,53 +560,58 @@ def main():
             c, stride = dg.shard_layout(grid, p * world + rank, vworld)
             counts.append(c)
         launch_nodes = sum(counts)
-        if not args.python_gather:
-            # the library's own RCCL communicator: rank 0's unique id travels through torch.distributed.  Should the
-            # library's communicator not come up on some rank (it never ran with more than one rank on the boxes this
-            # was developed on), EVERY rank takes the torch.distributed form below -- same kernels, same bytes on the
-            # links -- and the line says so; a scaling run is not lost to the plumbing.
-            failed = torch.zeros(1, dtype=torch.int32, device="cuda")
-            try:
-                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(dg.Comm.unique_id()), dtype=torch.uint8))
-            except Exception as exc:  # noqa: BLE001 (reported on the line)
-                comm_note = "%s: %s" % (type(exc).__name__, exc)
-                failed += 1
-            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-            if int(failed.item()) == 0:
-                dist.broadcast(uid, 0)
-                try:
-                    if os.environ.get("DG_BENCH_BREAK_LIBRARY_COMM") == "1":   # (tests: exercise the way out)
-                        raise RuntimeError("simulated failure of dg_comm_create")
-                    comm = dg.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-                except Exception as exc:  # noqa: BLE001
-                    comm_note = "%s: %s" % (type(exc).__name__, exc)
-                    failed += 1
-                dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-            if int(failed.item()) != 0:
-                comm = None
-                comm_note = "library communicator unavailable (%s)" % (comm_note or "on another rank")
-        elif selftest:
-            def _ag(mine):
-                t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
-                outs = [torch.empty_like(t) for _ in range(world)]
-                dist.all_gather(outs, t)
-                return [bytes(o.numpy().tobytes()) for o in outs]
-            comm_ext = dg.Comm.external(rank, world, _ag, dist.barrier)
-        # python-driven slabs (no library communicator): buffers
-        gathered = mine = unpack_stream = None
-        if comm is None:
-            gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
-            mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
-            unpack_stream = torch.cuda.Stream()
         cg_D = [(res[0] + 1, res[1] + 1, res[2] + 1), (2 * res[0], res[1] + 1, res[2] + 1), (2 * res[1], res[2] + 1, res[0] + 1),
                 (2 * res[2], res[0] + 1, res[1] + 1)]      # class dims (fastest, middle, slowest = k, k, i, j)
         cg_off = np.concatenate([[0], np.cumsum([int(np.prod(d)) for d in cg_D])])
+    gathered = mine = unpack_stream = None
 
-    plane_cost = [None]            # in-place forms: relative cost per plane of every class (None: uniform), refined from measured times
+    def make_comm():
+        """the library's communicator (collective).  Should it not come up on some rank, EVERY rank takes the torch.distributed
+        form of the slabs exchange -- same kernels, same bytes on the links -- and the line says so."""
+        nonlocal comm, comm_ext, comm_note, gathered, mine, unpack_stream
+        if comm is not None or comm_ext is not None or gathered is not None:
+            return
+        if selftest:
+            def _ag(mine_):
+                t = torch.frombuffer(bytearray(mine_), dtype=torch.uint8)
+                outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t)
+                return [bytes(o.numpy().tobytes()) for o in outs]
+            comm_ext = dg.Comm.external(rank, world, _ag, ctl_barrier)
+        elif not args.python_gather:
+            failed = 0
+            uid = [None]
+            try:
+                if rank == 0:
+                    uid[0] = dg.Comm.unique_id()
+            except Exception as exc:  # noqa: BLE001 (reported on the line)
+                comm_note = "%s: %s" % (type(exc).__name__, exc)
+                failed = 1
+            dist.broadcast_object_list(uid, src=0)      # (gloo: rank 0's unique id, or None)
+            if uid[0] is None:
+                failed = 1
+            if ctl_max(failed) == 0:
+                try:
+                    if os.environ.get("DG_BENCH_BREAK_LIBRARY_COMM") == "1":   # (tests: exercise the way out)
+                        raise RuntimeError("simulated failure of dg_comm_create")
+                    comm = dg.Comm(uid[0], rank, world)
+                except Exception as exc:  # noqa: BLE001
+                    comm_note = "%s: %s" % (type(exc).__name__, exc)
+                    failed = 1
+            if ctl_max(failed) != 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                comm_note = "library communicator unavailable (%s)" % (comm_note or "on another rank")
+        if comm is None:     # python-driven slabs (no library communicator): buffers
+            gathered = torch.empty(vworld * stride, dtype=torch.float64, device="cuda")
+            mine = torch.zeros(pieces * stride, dtype=torch.float64, device="cuda")   # packed pieces (+ padding)
+            unpack_stream = torch.cuda.Stream()
+
+    plane_cost = [None]            # chunked forms: relative cost per plane of every class (None: uniform), refined from measured times
     FLAGS = {"inplace": dg.EXCHANGE_INPLACE, "inplace-p2p": dg.EXCHANGE_INPLACE | dg.EXCHANGE_P2P,
              "to-root": dg.EXCHANGE_INPLACE | dg.EXCHANGE_TO_ROOT, "copy": dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY}
+    CHUNKED = set(FLAGS) | {"host"}
     last_python_ms = [None]
 
     def rebalance(piece_ms):
@@ -570,12 +652,51 @@ def main():
         torch.cuda.synchronize()
         last_python_ms[0] = [a.elapsed_time(b) for a, b in times]
 
+    def comm_of(form):
+        return comm if comm is not None else (comm_ext if form == "copy" else None)
+
+    def field_of(form):
+        return copy_field[0] if (form == "copy" and copy_field[0] is not None) else field
+
+    def prepare(form):
+        """what a form needs before its first step (collective: every rank gets here for every candidate)"""
+        if form == "host":
+            if hostf[0] is None:
+                name = [None]
+                if rank == 0:
+                    name[0] = "dg_bench_%d_%d" % (os.getpid(), int(time.time()))
+                if world > 1:
+                    dist.broadcast_object_list(name, src=0)
+                hostf[0] = dg.HostField(name[0], n_nodes, rank, world)
+            return
+        make_comm()
+        if form == "copy" and copy_field[0] is None and comm_of("copy") is not None:
+            # a field the peers can map whatever its size (512^3 is 7.5 GB; whole-allocation IPC stops at 2 GiB here);
+            # if the virtual-memory route is unavailable on ANY rank, every rank keeps its torch allocation
+            arr, failed = None, 0
+            try:
+                arr = comm_of("copy").field_alloc(n_nodes)
+            except Exception as exc:  # noqa: BLE001
+                print("bench.py rank %d: dg_comm_field_alloc failed (%s); the copy form uses the torch allocation" % (rank, exc), file=sys.stderr)
+                failed = 1
+            if sharded and world > 1:
+                failed = ctl_max(failed)
+            if failed == 0:
+                copy_field[0] = torch.as_tensor(arr, device="cuda")
+                copy_field[0].fill_(float("nan"))
+            elif arr is not None:
+                comm_of("copy").field_free(arr)
+
     def run_form(form):
-        """one step of the sharded protocol in the given exchange form (enqueued on `stream`)"""
-        if form in FLAGS:
-            c = comm if comm is not None else (comm_ext if form == "copy" else None)
+        """one step of the sharded protocol in the given exchange form (enqueued on `stream`; "host" blocks)"""
+        if os.environ.get("DG_BENCH_HANG_FORM") == form:    # (tests: a form that never returns, for the watchdog to cut off)
+            time.sleep(1e6)
+        if form == "host":
+            hostf[0].sample(mesh, grid, field.data_ptr(), pieces=pieces, plane_cost=plane_cost[0], stream=s)
+        elif form in FLAGS:
+            c = comm_of(form)
             if c is not None:
-                c.sample_exchange_device(mesh, grid, field.data_ptr(), pieces=pieces, flags=FLAGS[form], root=0, plane_cost=plane_cost[0],
+                c.sample_exchange_device(mesh, grid, field_of(form).data_ptr(), pieces=pieces, flags=FLAGS[form], root=0, plane_cost=plane_cost[0],
                                          stream=s)
             else:
                 python_inplace_step()
@@ -595,145 +716,122 @@ def main():
 
     def piece_times(form):
         """this rank's sampling time per piece of the step just run (None where the form does not report it)"""
-        c = comm if comm is not None else (comm_ext if form == "copy" else None)
+        if form == "host":
+            return hostf[0].last_chunk_ms(pieces)
+        c = comm_of(form)
         if c is not None:
             return c.last_chunk_ms(pieces)
         return last_python_ms[0] if form in FLAGS else None
 
     def share_and_rebalance(form):
         torch.cuda.synchronize()
-        ms = piece_times(form)
-        mine_ms = torch.tensor(ms, dtype=torch.float32, device="cpu" if selftest else "cuda")
+        mine_ms = torch.tensor(piece_times(form), dtype=torch.float32)
         all_ms = [torch.empty_like(mine_ms) for _ in range(world)]
         dist.all_gather(all_ms, mine_ms)
-        rebalance([t.cpu().tolist() for t in all_ms])
+        rebalance([t.tolist() for t in all_ms])
 
-    def trial(form, steps=2):
-        """max over ranks of the mean step time of `steps` steps in this form (None if any rank failed)"""
-        failed = torch.zeros(1, dtype=torch.int32, device="cpu" if selftest else "cuda")
-        note = None
-        dt = 0.0
-        try:
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                run_form(form)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps * 1e3
-        except Exception as exc:  # noqa: BLE001 (reported on the line; the form is out of the race)
-            note = "%s: %s" % (type(exc).__name__, str(exc)[:160])
-            failed += 1
-        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if selftest else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return (None if int(failed.item()) else float(t.item())), note
-
-    form = args.exchange if sharded else None
-    if sharded and form == "auto" and world == 1:
-        form = "slabs"    # (--force-shard-path on one GPU: nothing to choose)
-    if sharded and form == "auto":
-        # Measure, do not guess: none of the exchange forms has ever run on more than one GPU where this was developed.
-        # Uniform cuts first (two steps, which also give the in-place forms their cost weights), then every form twice.
-        ms_by_form, errors = {}, {}
-        for cand in ("slabs", "inplace", "inplace-p2p", "copy"):
-            if cand in FLAGS:
-                plane_cost[0] = None
-                ok = True
-                for _ in range(2):       # settle the cost-weighted cuts of this form
-                    t_, note = trial(cand, 1)
-                    if t_ is None:
-                        ok = False
-                        errors[cand] = note or "failed on another rank"
-                        break
-                    share_and_rebalance(cand)
-                if not ok:
-                    continue
-            t_, note = trial(cand, 2)
-            if t_ is None:
-                errors[cand] = note or "failed on another rank"
-            else:
-                ms_by_form[cand] = t_
-            if rank == 0:   # (stderr: a later form that hangs must not take the evidence of the earlier ones with it)
-                print("bench.py exchange race: %s -> %s" % (cand, ("%.3f ms / step" % t_) if t_ is not None else errors[cand]), file=sys.stderr, flush=True)
-        if not ms_by_form:
-            raise SystemExit("no exchange form ran: %s" % errors)
-        form = min(ms_by_form, key=ms_by_form.get)
-        exchange_report = {"chosen": form, "ms_by_form": ms_by_form, "errors": errors or None,
-                           "how": "warm-up: 2 steps per form (max over ranks), in-place forms after 2 cost-rebalancing steps"}
-        plane_cost[0] = None
-    inplace = sharded and form in FLAGS
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record(stream)
-        if sharded:
-            run_form(form)
+    def check_result(form):
+        """sanity of the result that was just timed (cheap, outside the timed region); in the self-test modes: the whole field
+        against the direct launch, bit for bit"""
+        out = hostf[0].data if form == "host" else None
+        if out is not None:
+            probe = np.array(out[:: max(1, n_nodes // 1000)])
         else:
-            mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
-        if i is not None:
-            ev[i][1].record(stream)    # (the sharded calls make `stream` wait for the complete field)
+            probe = field_of(form)[:: max(1, n_nodes // 1000)].cpu().numpy()
+        assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0, "the field of form %s holds values no signed distance can take" % form
+        if (args.force_shard_path and world == 1) or selftest:
+            ref = torch.empty_like(field)
+            mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
+            torch.cuda.synchronize()
+            if form == "host":
+                assert np.array_equal(out, ref.cpu().numpy()), "the shared host vector differs from the direct launch"
+            elif form != "to-root" or rank == 0 or comm is None:
+                assert torch.equal(ref, field_of(form)), "the sharded protocol's field differs from the direct launch"
 
-    for w in range(args.warmup):
-        step()
-        if inplace and world > 1:
-            # cost-weighted cuts: every rank's sampling times of the step just run, shared, turned into plane costs
-            share_and_rebalance(form)
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def measure(form):
+        """--warmup untimed steps (the chunked forms re-cut the lattice from every rank's measured sampling times after each; at
+        least two such steps), then EXACTLY --steps steps between barrier + synchronize on both sides; max over ranks."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        if sharded:
+            prepare(form)
+            plane_cost[0] = None
+        chunked = sharded and form in CHUNKED and world > 1
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    per_rank = None
-    rccl_nranks = None
-    if sharded and world > 1:
-        # what the last timed step looked like on every rank: sampling time per piece and the part of the exchange the
-        # sampling did not hide (a bad scaling number must be readable from the line)
-        c = comm if comm is not None else (comm_ext if form == "copy" else None)
-        ms = piece_times(form) or [float("nan")] * pieces
-        wait = c.last_exchange_wait_ms() if c is not None else float("nan")
-        mine_t = torch.tensor(list(ms) + [wait], dtype=torch.float32, device="cpu" if selftest else "cuda")
-        all_t = [torch.empty_like(mine_t) for _ in range(world)]
-        dist.all_gather(all_t, mine_t)
-        per_rank = {"sample_ms": [[round(float(x), 3) for x in t.cpu().tolist()[:-1]] for t in all_t],
-                    "exchange_wait_ms": [round(float(t.cpu().tolist()[-1]), 3) for t in all_t]}
-        if comm is not None:
-            rccl_nranks = comm.info()["rccl_nranks"]
-    # sanity of the result that was just timed (cheap, outside the timed region)
-    probe = field[:: max(1, n_nodes // 1000)].cpu().numpy()
-    assert np.isfinite(probe).all() and np.abs(probe).max() < 2.0
-    if (args.force_shard_path and world == 1) or selftest:
-        ref = torch.empty_like(field)
-        mesh.sample_nodes_device(grid, 0, n_nodes, ref.data_ptr(), stream=s)
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record(stream)
+            if sharded:
+                run_form(form)
+            else:
+                mesh.sample_nodes_device(grid, 0, n_nodes, field.data_ptr(), stream=s)
+            if i is not None:
+                ev[i][1].record(stream)    # (the sharded calls make `stream` wait for the complete field)
+
+        for w in range(max(args.warmup, 2 if chunked else 0)):
+            step()
+            if chunked:
+                share_and_rebalance(form)
         torch.cuda.synchronize()
-        if form != "to-root" or rank == 0 or comm is None:
-            assert torch.equal(ref, field), "the sharded protocol's field differs from the direct launch"
+        if sharded:
+            ctl_barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if sharded:
+            ctl_barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if sharded:
+            elapsed = ctl_max(elapsed)
+        r = {"form": form, "elapsed": elapsed, "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in ev])), "per_rank": None}
+        if sharded and world > 1:
+            # what the last timed step looked like on every rank: sampling time per piece and the part of the exchange the
+            # sampling did not hide (a bad scaling number must be readable from the line)
+            c = comm_of(form) if form != "host" else None
+            ms = piece_times(form) or [float("nan")] * pieces
+            wait = c.last_exchange_wait_ms() if c is not None else float("nan")
+            mine_t = torch.tensor(list(ms) + [wait], dtype=torch.float32)
+            all_t = [torch.empty_like(mine_t) for _ in range(world)]
+            dist.all_gather(all_t, mine_t)
+            r["per_rank"] = {"sample_ms": [[round(float(x), 3) for x in t.tolist()[:-1]] for t in all_t],
+                             "exchange_wait_ms": [round(float(t.tolist()[-1]), 3) for t in all_t]}
+        check_result(form)
+        return r
 
-    if rank == 0:
+    def sharding_text(form):
+        if not sharded:
+            return "none"
+        if form == "host":
+            return ("contiguous chunks cut by measured cost; every rank copies its chunks into ONE shared-memory host vector with its own "
+                    "copy engine in %d piece(s) under the sampling, a barrier inside the segment (dg_sdf_sample_to_host_field: no RCCL, no "
+                    "device IPC); the result is the reference's host vector m_nodes[field], not a device-resident field" % pieces)
+        if form not in FLAGS:
+            return ("4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
+                    % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
+                       else "dg_sdf_sample_allgather_device (RCCL inside the library)"))
+        return ("contiguous chunks cut by measured cost, sampled in place, %s in %d piece(s) by %s"
+                % (form, pieces, "torch.distributed broadcasts (python)" if (comm is None and not (form == "copy" and comm_ext))
+                   else ("dg_sdf_sample_exchange_device (%s)" % (("peer copies on the copy engines, fields of dg_comm_field_alloc mapped chunk by chunk"
+                                                                  if copy_field[0] is not None else "peer copies on the copy engines, HIP IPC")
+                                                                 if form == "copy" else "RCCL inside the library"))))
+
+    def build_line(r, exchange_report):
+        """the JSON line for the measured form r (no collectives, no GPU work: the watchdog may call for it at any time)"""
+        form, elapsed, kernel_ms = r["form"], r["elapsed"], r["kernel_ms"]
         balg = load_balg()
         counters, counters_note = load_counters()
         k1 = (counters or {}).get("k1") if world == 1 else None
-        out = {
+        rccl_nranks = comm.info()["rccl_nranks"] if (comm is not None and form not in (None, "host")) else None
+        return {
             "metric": "Mnodes/s SDF sampling (256³ grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
             "value": n_nodes * args.steps / elapsed / 1e6,
             "unit": "Mnodes/s",
-            "value_is": "the sampling step with the result left in HBM (at N > 1: incl. the exchange that leaves the whole field on every GPU); "
-                        "SURVEY 8(d)'s metric incl. the D2H into the host vector is value_with_d2h / addfunction_e2e",
+            "value_is": ("the sampling step with the result left in HBM (at N > 1: incl. the exchange that leaves the whole field on every GPU); "
+                         "SURVEY 8(d)'s metric incl. the D2H into the host vector is roofline.d2h_mnodes_s / value_with_d2h / addfunction_e2e") if form != "host" else
+                        ("the sampling step incl. the copies that assemble the WHOLE coefficient vector in one host vector shared by all ranks "
+                         "(SURVEY 8(d)'s metric: sampling + D2H into m_nodes); no device-resident copy of the whole field"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -742,16 +840,9 @@ def main():
                 "workload": "icosphere nu=71 (100820 tris) SDF node sampling, grid %s = %d nodes"
                             % ("x".join(map(str, res)), n_nodes),
                 "nodes_per_gpu_launch": launch_nodes,
-                "sharding": "none" if not sharded else
-                            ("4-plane slabs round-robin; sample / all_gather / unpack pipelined in %d piece(s) by %s"
-                             % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
-                                else "dg_sdf_sample_allgather_device (RCCL inside the library)")) if not inplace else
-                            ("contiguous chunks cut by measured cost, sampled in place, %s in %d piece(s) by %s"
-                             % (form, pieces, "torch.distributed broadcasts (python)" if (comm is None and not (form == "copy" and comm_ext))
-                                else ("dg_sdf_sample_exchange_device (%s)" % ("peer copies on the copy engines, HIP IPC"
-                                                                              if form == "copy" else "RCCL inside the library")))),
+                "sharding": sharding_text(form),
                 # every multi-rank figure of this path is UNVERIFIED on hardware until a driver-run SCALE file exists
-                "exchange": (dict(exchange_report or {"chosen": form}, per_rank=per_rank, rccl_nranks=rccl_nranks) if sharded else None),
+                "exchange": (dict(exchange_report or {}, chosen=form, per_rank=r["per_rank"], rccl_nranks=rccl_nranks) if sharded else None),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {
@@ -789,21 +880,71 @@ def main():
                 "algorithmic_bytes_per_node": balg["bytes_per_node"],
                 "algorithmic_gbs": balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9,
             },
+            "cpu_baseline": None,
         }
+
+    # ---- which forms, in which order ---------------------------------------------------------------------------------
+    if not sharded:
+        candidates = [None]
+    elif args.exchange != "auto":
+        candidates = [args.exchange]
+    elif world == 1:
+        candidates = ["slabs"]    # (--force-shard-path on one GPU: nothing to choose)
+    else:
+        # Measure, do not guess: none of these has ever run on more than one GPU where this was developed.  "host" first: it needs
+        # nothing but shared memory and each GPU's own copy engine, so a number exists before RCCL or device IPC are touched.
+        candidates = ["host", "slabs", "inplace", "inplace-p2p", "copy"]
+    results, errors = {}, {}
+    best = None
+    for cand in candidates:
+        dog.arm("exchange form %s" % cand)
+        r, note, failed = None, None, 0
+        try:
+            r = measure(cand)
+        except Exception as exc:  # noqa: BLE001 (reported on the line; the form is out of the race)
+            if len(candidates) == 1:
+                raise
+            note = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+            failed = 1
+        if sharded and world > 1:
+            failed = ctl_max(failed)     # (a form that failed on any rank is out on all of them)
+        dog.disarm()
+        if failed:
+            errors[cand] = note or "failed on another rank"
+        else:
+            results[cand] = r
+            if best is None or r["elapsed"] < best["elapsed"]:
+                best = r
+        if rank == 0 and len(candidates) > 1:   # (stderr: a later form that hangs must not take the evidence of the earlier ones with it)
+            print("bench.py exchange race: %s -> %s" % (cand, ("%.3f ms / step" % (r["elapsed"] / args.steps * 1e3)) if not failed else errors[cand]),
+                  file=sys.stderr, flush=True)
+        if rank == 0 and best is not None:
+            report = None if len(candidates) == 1 else {
+                "ms_by_form": {k: v["elapsed"] / args.steps * 1e3 for k, v in results.items()}, "errors": errors or None,
+                "how": "every form: >= 2 cost-rebalancing warm-up steps (chunked forms), --warmup steps, then --steps timed steps between "
+                       "barriers (max over ranks), each form under a %d s watchdog; value = the fastest form" % args.form_timeout}
+            state["line"] = build_line(best, report)
+    if best is None:
+        raise SystemExit("no exchange form ran: %s" % errors)
+
+    if rank == 0:
+        out = state["line"]
+        kernel_ms = best["kernel_ms"]
         if world == 1 and not args.no_extras:
             out.update(extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms))
             out["roofline"]["hbm"]["copy_kernel_gbs"] = out.pop("hbm_copy_gbs")
+            out["roofline"].update(user_facing_scalars(out))
         if world == 1 and args.cpu_seconds > 0 and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(V, F, dom, res, args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if hostf[0] is not None:
+        hostf[0].close()
     if comm is not None:
         comm.close()
     if comm_ext is not None:
         comm_ext.close()
     if sharded:
-        dist.barrier()
+        ctl_barrier()
         dist.destroy_process_group()
 
 

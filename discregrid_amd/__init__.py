@@ -98,6 +98,16 @@ SYMBOLS = {
     "dg_comm_last_exchange_wait_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "dg_comm_create_external": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_comm_get_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dg_comm_field_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "dg_comm_field_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dg_host_field_open": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dg_host_field_data": (C.c_void_p, [C.c_void_p]),
+    "dg_host_field_barrier": (C.c_int, [C.c_void_p]),
+    "dg_host_field_get_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dg_host_field_close": (None, [C.c_void_p]),
+    "dg_sdf_sample_to_host_field": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
+    "dg_host_field_last_chunk_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "dg_field_create": (C.c_int, [C.POINTER(GridDesc), _dp, C.c_uint64, _u32p, C.c_uint64, _u32p,
                                   C.POINTER(C.c_void_p)]),
     "dg_field_attach_device": (C.c_int, [C.POINTER(GridDesc), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -474,6 +484,72 @@ class Comm:
     def sample_allgather_device(self, mesh, grid, d_field, pieces=4, invert=False, stream=0):
         _check(self._lib.dg_sdf_sample_allgather_device(mesh.handle, C.byref(grid), int(invert), self.handle, pieces,
                                                         C.c_void_p(d_field), C.c_void_p(stream)))
+
+    def field_alloc(self, n_doubles):
+        """dg_comm_field_alloc: a device array of hipMemCreate chunks that the peers can map whatever its size; returns a
+        DeviceArray (pointer + __cuda_array_interface__, so torch.as_tensor(a, device="cuda") views it)."""
+        p = C.c_void_p()
+        _check(self._lib.dg_comm_field_alloc(self.handle, n_doubles, C.byref(p)))
+        return DeviceArray(p.value, n_doubles)
+
+    def field_free(self, array):
+        _check(self._lib.dg_comm_field_free(self.handle, C.c_void_p(array.ptr)))
+
+
+class DeviceArray:
+    """n float64 values of device memory the library allocated (not owned by this object)."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+
+    def data_ptr(self):
+        return self.ptr
+
+
+class HostFieldInfo(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("device", C.c_int32), ("registered", C.c_int32), ("n_doubles", C.c_uint64)]
+
+
+class HostField:
+    """dg_host_field: a coefficient vector in POSIX shared memory that all ranks of one node map (the exchange form without
+    collective kernels and without device IPC).  `data` is a numpy view of the shared vector."""
+
+    def __init__(self, name, n_doubles, rank, nranks):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.dg_host_field_open(name.encode(), n_doubles, rank, nranks, C.byref(h)))
+        self.handle = h
+        self.rank, self.nranks = rank, nranks
+        ptr = self._lib.dg_host_field_data(h)
+        self.data = np.ctypeslib.as_array(C.cast(ptr, _dp), shape=(n_doubles,))
+
+    def info(self):
+        i = HostFieldInfo()
+        _check(self._lib.dg_host_field_get_info(self.handle, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in HostFieldInfo._fields_}
+
+    def barrier(self):
+        _check(self._lib.dg_host_field_barrier(self.handle))
+
+    def sample(self, mesh, grid, d_field, pieces=4, plane_cost=None, invert=False, stream=0):
+        arr, keep = _plane_cost_arg(plane_cost)
+        _check(self._lib.dg_sdf_sample_to_host_field(mesh.handle, C.byref(grid), int(invert), self.handle, pieces, arr,
+                                                     C.c_void_p(d_field), C.c_void_p(stream)))
+
+    def last_chunk_ms(self, pieces=64):
+        ms = (C.c_float * pieces)()
+        n = C.c_int(pieces)
+        _check(self._lib.dg_host_field_last_chunk_ms(self.handle, ms, C.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.data = None
+            self._lib.dg_host_field_close(self.handle)
+            self.handle = None
+
+    __del__ = close
 
 
 class Field:

@@ -18,8 +18,8 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 SOURCES_HIP = ["dg_kernels.hip"]
-SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_build.cpp"]
-HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_host_query.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
+SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_build.cpp"]
+HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_host_query.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
 
 
 def _stale():

@@ -7,6 +7,7 @@
 // this library never load it, and a process that already carries an RCCL (PyTorch ships one) keeps
 // exactly that one.
 #include "dg_capi_internal.h"
+#include "dg_capi_vmm.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -85,12 +86,26 @@ struct PeerField
 };
 struct IpcRecord // what travels through the control plane when a field is registered
 {
-	hipIpcMemHandle_t handle;
-	uint64_t offset; // of d_field inside the exported allocation
+	hipIpcMemHandle_t handle; // kind 0: the whole allocation through HIP IPC
+	uint64_t offset; // of d_field inside the exported allocation / mapped range
 	uint64_t bytes;
-	uint64_t alloc_bytes; // size of that allocation
+	uint64_t alloc_bytes; // size of that allocation / range
+	uint64_t chunk;       // kind 1: size of every chunk but the last
+	uint64_t serial;      // kind 1: names the unix socket that serves the chunks' descriptors ("dg_vmm_<pid>_<serial>")
 	int32_t device;
 	int32_t pid;
+	int32_t kind;   // 0: hipIpcMemHandle_t, 1: an array of dg_comm_field_alloc (hipMemCreate chunks, one descriptor each)
+	int32_t status; // 0: exported; otherwise the rank could not export its field and EVERY rank refuses
+	uint32_t n_chunks;
+	uint32_t pad;
+};
+enum
+{
+	kExportOk = 0,
+	kExportNoRange = 1,  // hipMemGetAddressRange failed (not a hipMalloc allocation?)
+	kExportNoHandle = 2, // hipIpcGetMemHandle failed
+	kExportNoFds = 3,    // hipMemExportToShareableHandle failed
+	kExportNoSocket = 4, // the descriptor server could not be started
 };
 struct dg_comm
 {
@@ -105,10 +120,11 @@ struct dg_comm
 	std::vector<hipStream_t> copy_streams;
 	std::vector<hipEvent_t> copy_done;
 	std::map<const void*, PeerField> peer_fields;
-	int* d_token = nullptr;
-	hipEvent_t entered = nullptr, started = nullptr;
-	uint64_t cuts_hash = 0; // of the last cost-weighted cuts every rank agreed on
-	bool cuts_checked = false;
+	int* d_token = nullptr; // device words of the control plane: [0, 256) barrier tokens, [256, kCtrlBytes) small all-gathers
+	hipEvent_t entered = nullptr;
+	std::map<char*, dgvmm::Array> vmm_owned;  // dg_comm_field_alloc: base -> array
+	std::vector<dgvmm::Array> vmm_imported;   // peers' arrays mapped here
+	uint64_t vmm_serial = 0;
 	hipEvent_t t_last_sampled = nullptr, t_complete = nullptr; // timing: end of this rank's last sampling launch / field complete
 	bool wait_timed = false;
 	std::map<std::string, void*> opened_handles; // (pid, handle) -> mapping: an allocation is opened once however many fields live in it
@@ -124,6 +140,7 @@ struct dg_comm
 };
 
 static_assert(DG_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+constexpr size_t kCtrlBytes = 16384;
 
 extern "C"
 {
@@ -150,11 +167,10 @@ static dg_status comm_finish_setup(dg_comm* c)
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->unpack, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->entered, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->started, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreate(&c->t_last_sampled);
 	if (e == hipSuccess) e = hipEventCreate(&c->t_complete);
-	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_token), 256);
-	if (e == hipSuccess) e = hipMemset(c->d_token, 0, 256);
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_token), kCtrlBytes);
+	if (e == hipSuccess) e = hipMemset(c->d_token, 0, kCtrlBytes);
 	if (e != hipSuccess)
 		return fail(DG_ERR_HIP, "dg_comm: %s", hipGetErrorString(e));
 	return DG_OK;
@@ -320,7 +336,7 @@ void dg_comm_destroy(dg_comm* c)
 {
 	if (!c)
 		return;
-	DeviceGuard guard(c->device);
+	DeviceGuard guard(c->device); // (device < 0 -- set-up failed before a device was known -- leaves the current device alone)
 	if (c->gather) (void)hipStreamSynchronize(c->gather);
 	if (c->unpack) (void)hipStreamSynchronize(c->unpack);
 	if (c->owned && c->comm)
@@ -341,8 +357,11 @@ void dg_comm_destroy(dg_comm* c)
 		if (e) (void)hipEventDestroy(e);
 	for (auto& kv : c->opened_handles)
 		(void)hipIpcCloseMemHandle(kv.second);
+	for (dgvmm::Array& a : c->vmm_imported)
+		dgvmm::destroy(a);
+	for (auto& kv : c->vmm_owned)
+		dgvmm::destroy(kv.second);
 	if (c->entered) (void)hipEventDestroy(c->entered);
-	if (c->started) (void)hipEventDestroy(c->started);
 	if (c->t_last_sampled) (void)hipEventDestroy(c->t_last_sampled);
 	if (c->t_complete) (void)hipEventDestroy(c->t_complete);
 	if (c->d_token) (void)hipFree(c->d_token);
@@ -452,7 +471,7 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
 	return DG_OK;
 }
 
-// ---- DG_EXCHANGE_COPY: the control plane (small, host-blocking collectives) ---------------------------------------------
+// ---- the control plane (small, host-blocking collectives) ---------------------------------------------------------------
 static dg_status ctrl_allgather(dg_comm* c, const void* mine, void* all, size_t bytes)
 {
 	if (c->ext_allgather)
@@ -464,9 +483,15 @@ static dg_status ctrl_allgather(dg_comm* c, const void* mine, void* all, size_t 
 	Rccl* R = rccl();
 	if (!R || !c->comm)
 		return rccl_unavailable();
+	// small messages (the hash of the cuts on every exchange call) go through the communicator's own device words
+	const size_t need = ((bytes + 255) / 256 * 256) + bytes * (size_t)c->nranks;
 	void* d = nullptr;
-	DG_HIP(hipMalloc(&d, bytes * (size_t)(c->nranks + 1)));
-	char* dall = static_cast<char*>(d) + bytes;
+	const bool own = need > kCtrlBytes - 256;
+	if (own)
+		DG_HIP(hipMalloc(&d, bytes * (size_t)(c->nranks + 1) + 256));
+	else
+		d = reinterpret_cast<char*>(c->d_token) + 256;
+	char* dall = static_cast<char*>(d) + (bytes + 255) / 256 * 256;
 	hipError_t e = hipMemcpyAsync(d, mine, bytes, hipMemcpyHostToDevice, c->gather);
 	ncclResult_t r = ncclSuccess;
 	if (e == hipSuccess)
@@ -475,7 +500,8 @@ static dg_status ctrl_allgather(dg_comm* c, const void* mine, void* all, size_t 
 		e = hipMemcpyAsync(all, dall, bytes * (size_t)c->nranks, hipMemcpyDeviceToHost, c->gather);
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(c->gather);
-	(void)hipFree(d);
+	if (own)
+		(void)hipFree(d);
 	if (r != ncclSuccess)
 		return fail(DG_ERR_HIP, "ncclAllGather (control plane): %s", R->GetErrorString(r));
 	DG_HIP(e);
@@ -517,7 +543,29 @@ static dg_status ctrl_barrier_host(dg_comm* c)
 	DG_HIP(hipStreamSynchronize(c->gather));
 	return DG_OK;
 }
-// the peers' views of d_field (collective and host-blocking on first use of the pointer)
+
+static dgvmm::Array* owned_array_of(dg_comm* c, const void* p)
+{
+	for (auto& kv : c->vmm_owned)
+		if (static_cast<const char*>(p) >= kv.second.base && static_cast<const char*>(p) < kv.second.base + kv.second.bytes)
+			return &kv.second;
+	return nullptr;
+}
+static const char* export_failure(int status)
+{
+	switch (status)
+	{
+	case kExportNoRange: return "hipMemGetAddressRange failed for its field (not a hipMalloc allocation? allocate the field with dg_comm_field_alloc)";
+	case kExportNoHandle: return "hipIpcGetMemHandle failed for its field (memory from a pool or a virtual-memory range? allocate the field with dg_comm_field_alloc)";
+	case kExportNoFds: return "hipMemExportToShareableHandle failed for the chunks of its field";
+	case kExportNoSocket: return "the unix socket that serves the descriptors of its field could not be opened";
+	default: return "unknown export failure";
+	}
+}
+
+// The peers' views of d_field (collective and host-blocking on first use of the pointer).  Every decision to give up is taken
+// from data EVERY rank holds (the gathered records, then the gathered open statuses), so the ranks fail together: nobody
+// returns early and leaves its peers in a collective.
 static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, PeerField** out)
 {
 	auto it = c->peer_fields.find(d_field);
@@ -535,79 +583,174 @@ static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, Pee
 	pf.bytes = bytes;
 	if (N > 1)
 	{
-		void* base = nullptr;
-		size_t size = 0;
-		DG_HIP(hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_field));
-		comm_trace(c, "  address range known");
-		DG_HIP(hipIpcGetMemHandle(&mine.handle, base));
-		comm_trace(c, "  handle exported");
-		mine.offset = (uint64_t)(reinterpret_cast<char*>(d_field) - static_cast<char*>(base));
+		// -- step 1: export (local; a failure travels in the record instead of ending the call)
+		dgvmm::FdServer server;
 		mine.bytes = bytes;
-		mine.alloc_bytes = size;
 		mine.device = c->device;
 		mine.pid = (int32_t)getpid();
+		if (dgvmm::Array* arr = owned_array_of(c, d_field))
+		{
+			mine.kind = 1;
+			mine.offset = (uint64_t)(reinterpret_cast<char*>(d_field) - arr->base);
+			mine.alloc_bytes = arr->bytes;
+			mine.chunk = arr->chunk;
+			mine.n_chunks = (uint32_t)arr->handles.size();
+			mine.serial = ++c->vmm_serial;
+			std::vector<int> fds;
+			if (dgvmm::export_fds(*arr, fds) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				mine.status = kExportNoFds;
+			}
+			else if (!server.start("dg_vmm_" + std::to_string(mine.pid) + "_" + std::to_string(mine.serial), fds, N - 1))
+			{
+				for (int f : fds)
+					(void)close(f);
+				mine.status = kExportNoSocket;
+			}
+			comm_trace(c, "  chunks exported");
+		}
+		else
+		{
+			void* base = nullptr;
+			size_t size = 0;
+			if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, d_field) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				mine.status = kExportNoRange;
+			}
+			else if (hipIpcGetMemHandle(&mine.handle, base) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				mine.status = kExportNoHandle;
+			}
+			else
+			{
+				mine.offset = (uint64_t)(reinterpret_cast<char*>(d_field) - static_cast<char*>(base));
+				mine.alloc_bytes = size;
+			}
+			comm_trace(c, "  handle exported");
+		}
+		// -- step 2: every rank sees every record
 		std::vector<IpcRecord> all((size_t)N);
 		dg_status s = ctrl_allgather(c, &mine, all.data(), sizeof(IpcRecord));
 		if (s != DG_OK)
 			return s;
-		comm_trace(c, "  handles gathered");
-		// Measured on the MI355X box of this round (ROCm 7.2, dmabuf IPC, several processes on one device):
+		comm_trace(c, "  records gathered");
+		// -- step 3: refuse together
+		// Measured on the MI355X boxes of rounds 4 and 5 (ROCm 7.2, dmabuf IPC, several processes on one device):
 		// hipIpcOpenMemHandle never returns for an allocation above 2 GiB (1.9 GB: fine with 2, 3 and 4 processes; 3.8 GB: hangs
-		// with 2).  Every rank sees every record, so all of them refuse together instead of one of them hanging
-		// (DG_IPC_MAX_MB raises the limit where the platform is known to cope).
+		// with 2).  Larger fields come from dg_comm_field_alloc (chunks of 512 MiB, kind 1); a plain allocation above the limit
+		// is refused (DG_IPC_MAX_MB raises the limit where the platform is known to cope).
 		const uint64_t max_alloc = (uint64_t)env_int("DG_IPC_MAX_MB", 2047, 1, 1 << 30) << 20;
 		for (int r = 0; r < N; ++r)
-			if (all[(size_t)r].alloc_bytes > max_alloc)
-				return fail(DG_ERR_INVALID, "DG_EXCHANGE_COPY: the field of rank %d lives in an allocation of %.2f GB; opening allocations above %llu MB "
-											"through HIP IPC hung on the platform this was developed on (set DG_IPC_MAX_MB to try)", r,
-							(double)all[(size_t)r].alloc_bytes * 1e-9, (unsigned long long)(max_alloc >> 20));
-		// The ranks open each other's allocations ONE RANK AT A TIME (DG_IPC_STAGGER=0: all at once): four processes that
-		// opened each other's handles simultaneously never returned from hipIpcOpenMemHandle on the box this was developed
-		// on (two did), and the set-up happens once per field.
-		const bool stagger = env_int("DG_IPC_STAGGER", 1, 0, 1) != 0;
-		for (int turn = 0; turn < (stagger ? N : 1); ++turn)
 		{
-		if (stagger)
-		{
-			s = ctrl_barrier_host(c);
-			if (s != DG_OK)
-				return s;
-		}
-		if (stagger && turn != c->rank)
-			continue;
-		for (int r = 0; r < N; ++r)
-		{
-			if (r == c->rank)
-				continue;
 			const IpcRecord& rec = all[(size_t)r];
+			if (rec.status != kExportOk)
+				return fail(DG_ERR_HIP, "DG_EXCHANGE_COPY: rank %d: %s", r, export_failure(rec.status));
 			if (rec.bytes != bytes)
 				return fail(DG_ERR_INVALID, "rank %d registered %llu bytes for this field, this rank %llu", r, (unsigned long long)rec.bytes,
 							(unsigned long long)bytes);
-			if (rec.pid == mine.pid)
-				return fail(DG_ERR_INVALID, "ranks %d and %d live in one process: DG_EXCHANGE_COPY is one process per rank", r, c->rank);
-			std::string key(reinterpret_cast<const char*>(&rec.pid), sizeof(rec.pid));
-			key.append(reinterpret_cast<const char*>(&rec.handle), sizeof(rec.handle));
-			auto oh = c->opened_handles.find(key);
-			void* p = nullptr;
-			if (oh != c->opened_handles.end())
-				p = oh->second;
-			else
-			{
-				const hipError_t e = hipIpcOpenMemHandle(&p, rec.handle, hipIpcMemLazyEnablePeerAccess);
-				if (e != hipSuccess)
-					return fail(DG_ERR_HIP, "hipIpcOpenMemHandle (field of rank %d, device %d): %s", r, rec.device, hipGetErrorString(e));
-				c->opened_handles.emplace(key, p);
-				comm_trace(c, "  opened the field of rank", r);
-			}
-			pf.base[(size_t)r] = static_cast<char*>(p) + rec.offset;
+			if (rec.kind == 0 && rec.alloc_bytes > max_alloc)
+				return fail(DG_ERR_INVALID, "DG_EXCHANGE_COPY: the field of rank %d lives in an allocation of %.2f GB; opening allocations above %llu MB "
+											"through HIP IPC hung on the platform this was developed on: allocate the field with dg_comm_field_alloc "
+											"(or set DG_IPC_MAX_MB to try)", r, (double)rec.alloc_bytes * 1e-9, (unsigned long long)(max_alloc >> 20));
+			if (rec.kind == 1 && (rec.n_chunks == 0 || rec.chunk == 0 || rec.offset + rec.bytes > rec.alloc_bytes))
+				return fail(DG_ERR_INVALID, "rank %d sent an inconsistent record for its field", r);
+			for (int q = 0; q < r; ++q)
+				if (all[(size_t)q].pid == rec.pid)
+					return fail(DG_ERR_INVALID, "ranks %d and %d live in one process: DG_EXCHANGE_COPY is one process per rank", q, r);
 		}
-		}
-		if (stagger)
+		// -- step 4: the ranks map each other's fields ONE RANK AT A TIME (DG_IPC_STAGGER=0: all at once): four processes that
+		// opened each other's handles simultaneously never returned from hipIpcOpenMemHandle on the box this was developed
+		// on (two did), and the set-up happens once per field.  A rank whose open fails keeps taking part in the barriers.
+		const bool stagger = env_int("DG_IPC_STAGGER", 1, 0, 1) != 0;
+		uint64_t my_open_status = 0; // 0: every peer mapped; else 1 + the rank whose field could not be mapped
+		std::string my_open_error;
+		dg_status barrier_failure = DG_OK;
+		for (int turn = 0; turn < (stagger ? N : 1); ++turn)
 		{
-			s = ctrl_barrier_host(c);
-			if (s != DG_OK)
-				return s;
+			if (stagger)
+			{
+				s = ctrl_barrier_host(c);
+				if (s != DG_OK)
+				{
+					barrier_failure = s; // (the control plane itself broke: nothing collective can follow)
+					break;
+				}
+			}
+			if (stagger && turn != c->rank)
+				continue;
+			for (int r = 0; r < N && my_open_status == 0; ++r)
+			{
+				if (r == c->rank)
+					continue;
+				const IpcRecord& rec = all[(size_t)r];
+				if (rec.kind == 1)
+				{
+					std::vector<int> fds;
+					std::vector<size_t> sizes;
+					for (uint32_t i = 0; i < rec.n_chunks; ++i)
+						sizes.push_back((size_t)std::min<uint64_t>(rec.chunk, rec.alloc_bytes - (uint64_t)i * rec.chunk));
+					dgvmm::Array imp;
+					hipError_t e = hipSuccess;
+					if (!dgvmm::fetch_fds("dg_vmm_" + std::to_string(rec.pid) + "_" + std::to_string(rec.serial), (int)rec.n_chunks, fds, 30000))
+					{
+						my_open_status = 1 + (uint64_t)r;
+						my_open_error = "could not fetch the descriptors of the field of rank " + std::to_string(r);
+						break;
+					}
+					e = dgvmm::import_fds(imp, fds, sizes, c->device);
+					for (int f : fds)
+						(void)close(f);
+					if (e != hipSuccess)
+					{
+						(void)hipGetLastError();
+						my_open_status = 1 + (uint64_t)r;
+						my_open_error = std::string("mapping the chunks of the field of rank ") + std::to_string(r) + ": " + hipGetErrorString(e);
+						break;
+					}
+					pf.base[(size_t)r] = imp.base + rec.offset;
+					c->vmm_imported.push_back(std::move(imp));
+					comm_trace(c, "  mapped the chunks of rank", r);
+					continue;
+				}
+				std::string key(reinterpret_cast<const char*>(&rec.pid), sizeof(rec.pid));
+				key.append(reinterpret_cast<const char*>(&rec.handle), sizeof(rec.handle));
+				auto oh = c->opened_handles.find(key);
+				void* p = nullptr;
+				if (oh != c->opened_handles.end())
+					p = oh->second;
+				else
+				{
+					const hipError_t e = hipIpcOpenMemHandle(&p, rec.handle, hipIpcMemLazyEnablePeerAccess);
+					if (e != hipSuccess)
+					{
+						(void)hipGetLastError();
+						my_open_status = 1 + (uint64_t)r;
+						my_open_error = std::string("hipIpcOpenMemHandle (field of rank ") + std::to_string(r) + ", device " + std::to_string(rec.device) +
+										"): " + hipGetErrorString(e);
+						break;
+					}
+					c->opened_handles.emplace(key, p);
+					comm_trace(c, "  opened the field of rank", r);
+				}
+				pf.base[(size_t)r] = static_cast<char*>(p) + rec.offset;
+			}
 		}
+		if (barrier_failure != DG_OK)
+			return barrier_failure;
+		// -- step 5: did everybody map everybody?  (also the barrier that ends the set-up: the descriptor servers may stop)
+		std::vector<uint64_t> statuses((size_t)N);
+		s = ctrl_allgather(c, &my_open_status, statuses.data(), sizeof(uint64_t));
+		server.finish();
+		if (s != DG_OK)
+			return s;
+		if (my_open_status != 0)
+			return fail(DG_ERR_HIP, "DG_EXCHANGE_COPY: %s", my_open_error.c_str());
+		for (int r = 0; r < N; ++r)
+			if (statuses[(size_t)r] != 0)
+				return fail(DG_ERR_HIP, "DG_EXCHANGE_COPY: rank %d could not map the field of rank %d", r, (int)(statuses[(size_t)r] - 1));
 	}
 	PeerField& slot = c->peer_fields[d_field];
 	slot = std::move(pf);
@@ -624,6 +767,26 @@ static uint64_t hash_cuts(const uint32_t cuts[4][dg::kMaxRanks + 1], int V)
 			h *= 1099511628211ull;
 		}
 	return h;
+}
+// Every rank derives the cuts from its own copy of plane_cost; ranks that disagree would post transfers that do not match (a
+// hang or a corrupted field).  The hash of the cuts therefore goes round on EVERY exchange call -- a collective every rank
+// enters whatever its arguments look like -- and a mismatch fails the call on all of them.  Host-blocking: the call returns
+// from here once every rank has entered it (8 bytes per rank; the in-place forms serialise their steps on the field anyway).
+static dg_status agree_on_cuts(dg_comm* comm, const uint32_t cuts[4][dg::kMaxRanks + 1], int V)
+{
+	const int N = comm->nranks;
+	if (N <= 1)
+		return DG_OK;
+	const uint64_t h = hash_cuts(cuts, V);
+	std::vector<uint64_t> all((size_t)N);
+	const dg_status s = ctrl_allgather(comm, &h, all.data(), sizeof(h));
+	if (s != DG_OK)
+		return s;
+	for (int r = 0; r < N; ++r)
+		if (all[(size_t)r] != all[0])
+			return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank 0: plane_cost must hold the same values on every rank (this is rank %d)",
+						r, comm->rank);
+	return DG_OK;
 }
 
 static dg_status exchange_copy(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
@@ -653,54 +816,31 @@ static dg_status exchange_copy(const dg_mesh* mesh, const dg_grid_desc* grid, in
 	comm_trace(comm, "registered");
 	uint32_t cuts[4][dg::kMaxRanks + 1];
 	dg::chunk_planes(grid->resolution, V, plane_cost, cuts);
-	// every rank derives the cuts from its own copy of plane_cost: make sure they agree (once per change)
-	if (N > 1)
-	{
-		const uint64_t h = hash_cuts(cuts, V);
-		if (!comm->cuts_checked || h != comm->cuts_hash)
-		{
-			std::vector<uint64_t> all((size_t)N);
-			comm_trace(comm, "cuts changed: hash allgather");
-			s = ctrl_allgather(comm, &h, all.data(), sizeof(h));
-			if (s != DG_OK)
-				return s;
-			for (int r = 0; r < N; ++r)
-				if (all[(size_t)r] != h)
-					return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank %d: plane_cost must hold the same values on every rank", r,
-								comm->rank);
-			comm->cuts_hash = h;
-			comm->cuts_checked = true;
-		}
-	}
 	dg::ClassGeom cg[4];
 	dg::class_geometry(grid->resolution, cg);
 	DG_HIP(piece_events(comm, pieces));
 	auto chunk_off = [&](int c, int v) { return (size_t)(cg[c].off + (uint64_t)cuts[c][v] * cg[c].D[0] * cg[c].D[1]) * sizeof(double); };
 	auto chunk_bytes = [&](int c, int v) { return (size_t)(cuts[c][v + 1] - cuts[c][v]) * cg[c].D[0] * cg[c].D[1] * sizeof(double); };
-	// barrier 1: every rank's stream has reached this call, i.e. nothing reads its field any more -- it may be written
+	// barrier 1: every rank's stream has reached this call, i.e. nothing reads its field any more -- it may be written.  The
+	// all-gather of the cuts' hash IS that barrier (nobody gets the result before everybody has contributed), and it is the check
+	// that the ranks cut the lattice the same way.
 	if (N > 1)
 	{
 		if (ext)
 		{
 			comm_trace(comm, "barrier 1: stream sync");
 			DG_HIP(hipStreamSynchronize(st));
-			comm_trace(comm, "barrier 1: enter");
-			if (comm->ext_barrier(comm->ext_user) != 0)
-				return fail(DG_ERR_HIP, "the caller's barrier failed");
-			comm_trace(comm, "barrier 1: left");
 		}
 		else
 		{
 			DG_HIP(hipEventRecord(comm->entered, st));
 			DG_HIP(hipStreamWaitEvent(comm->gather, comm->entered, 0));
-			s = rccl_stream_barrier(comm);
-			if (s != DG_OK)
-				return s;
-			DG_HIP(hipEventRecord(comm->started, comm->gather));
-			for (int d = 0; d < N; ++d)
-				if (d != comm->rank)
-					DG_HIP(hipStreamWaitEvent(comm->copy_streams[(size_t)d], comm->started, 0));
 		}
+		comm_trace(comm, "barrier 1: hash all-gather");
+		s = agree_on_cuts(comm, cuts, V);
+		if (s != DG_OK)
+			return s;
+		comm_trace(comm, "barrier 1: left");
 	}
 	for (int p = 0; p < pieces; ++p)
 	{
@@ -812,24 +952,10 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	uint32_t cuts[4][dg::kMaxRanks + 1];
 	dg::chunk_planes(grid->resolution, V, plane_cost, cuts);
-	// every rank derives the cuts from its own copy of plane_cost; ranks that disagree would post transfers that do not match
-	// (a hang or a corrupted field): whenever the cuts change, their hash goes round once and a mismatch fails the call
-	if (N > 1 && plane_cost != nullptr)
 	{
-		const uint64_t h = hash_cuts(cuts, V);
-		if (!comm->cuts_checked || h != comm->cuts_hash)
-		{
-			std::vector<uint64_t> all((size_t)N);
-			const dg_status hs = ctrl_allgather(comm, &h, all.data(), sizeof(h));
-			if (hs != DG_OK)
-				return hs;
-			for (int r = 0; r < N; ++r)
-				if (all[(size_t)r] != h)
-					return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank %d: plane_cost must hold the same values on every rank", r,
-								comm->rank);
-			comm->cuts_hash = h;
-			comm->cuts_checked = true;
-		}
+		const dg_status hs = agree_on_cuts(comm, cuts, V);
+		if (hs != DG_OK)
+			return hs;
 	}
 	dg::ClassGeom cg[4];
 	dg::class_geometry(grid->resolution, cg);
@@ -887,6 +1013,47 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
 	DG_HIP(hipEventRecord(comm->t_complete, st));
 	comm->wait_timed = true;
 	comm->last_pieces = pieces;
+	return DG_OK;
+}
+
+dg_status dg_comm_field_alloc(dg_comm* comm, uint64_t n_doubles, double** d_field)
+{
+	if (!comm || !d_field)
+		return fail(DG_ERR_INVALID, "null argument");
+	*d_field = nullptr;
+	if (n_doubles == 0)
+		return fail(DG_ERR_INVALID, "empty field");
+	DG_ON_DEVICE_OF(comm);
+	dgvmm::Array a;
+	const hipError_t e = dgvmm::create(a, (size_t)n_doubles * sizeof(double), comm->device);
+	if (e != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return fail(e == hipErrorOutOfMemory ? DG_ERR_ALLOC : DG_ERR_HIP, "dg_comm_field_alloc: %.2f GB as chunks of %zu MiB: %s", (double)n_doubles * 8e-9,
+					dgvmm::kVmmChunkBytes >> 20, hipGetErrorString(e));
+	}
+	*d_field = reinterpret_cast<double*>(a.base);
+	char* key = a.base;
+	comm->vmm_owned.emplace(key, std::move(a));
+	return DG_OK;
+}
+
+dg_status dg_comm_field_free(dg_comm* comm, double* d_field)
+{
+	if (!comm)
+		return fail(DG_ERR_INVALID, "null argument");
+	if (!d_field)
+		return DG_OK;
+	auto it = comm->vmm_owned.find(reinterpret_cast<char*>(d_field));
+	if (it == comm->vmm_owned.end())
+		return fail(DG_ERR_INVALID, "not an array of dg_comm_field_alloc on this communicator");
+	if (comm->peer_fields.count(d_field) != 0 && comm->nranks > 1)
+		return fail(DG_ERR_INVALID, "the array is registered with the peers (they hold mappings of it): it lives until dg_comm_destroy");
+	DG_ON_DEVICE_OF(comm);
+	DG_HIP(hipDeviceSynchronize());
+	dgvmm::destroy(it->second);
+	comm->vmm_owned.erase(it);
+	comm->peer_fields.erase(d_field);
 	return DG_OK;
 }
 

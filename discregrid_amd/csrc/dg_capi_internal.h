@@ -188,8 +188,8 @@ struct DeviceGuard
 };
 #define DG_ON_DEVICE_OF(handle)                                                                       \
 	if ((handle)->device < 0)                                                                         \
-		return fail(DG_ERR_NO_DEVICE, "host-only mesh handle (created without a HIP device or under DG_FORCE_CPU=1): " \
-									  "only dg_signed_distance_point works on it; this library has no CPU path for batches"); \
+		return fail(DG_ERR_NO_DEVICE, "the handle has no HIP device (a host-only mesh handle -- created without a device or under " \
+									  "DG_FORCE_CPU=1 -- answers dg_signed_distance_point only; there is no CPU path for batches)"); \
 	DeviceGuard device_guard_((handle)->device);                                                      \
 	if (device_guard_.err != hipSuccess)                                                              \
 		return fail(DG_ERR_HIP, "cannot switch to device %d: %s", (handle)->device, hipGetErrorString(device_guard_.err))

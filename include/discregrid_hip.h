@@ -231,12 +231,22 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
  * allocated until dg_comm_destroy); every call brackets the pushes with two barriers ("every rank's stream has reached
  * this call: its field may be written", "every rank's pushes have landed") -- one-word all-reduces on the communicator's
  * stream with RCCL, host-blocking calls of the caller's barrier with an external control plane (below).  plane_cost must
- * be the SAME array on every rank (true for all in-place forms: the cuts decide who sends what; this form checks a hash
- * of the cuts across the ranks whenever they change and fails on a mismatch).  Limit found on the development platform
+ * be the SAME array on every rank (true for all in-place forms: the cuts decide who sends what; every in-place form
+ * all-gathers a hash of the cuts on EVERY call -- host-blocking until every rank has entered the call -- and all ranks fail
+ * with DG_ERR_INVALID on a mismatch).  Limit found on the development platform
  * (ROCm 7.2, dmabuf IPC): hipIpcOpenMemHandle does not return for allocations above 2 GiB, so fields living in larger
- * allocations are REFUSED (every rank gets DG_ERR_INVALID; DG_IPC_MAX_MB overrides) -- 256 x 256 x 512 is the largest
- * lattice of the bench that passes.  UNVERIFIED on more than one device. */
+ * hipMalloc allocations are REFUSED (every rank gets DG_ERR_INVALID; DG_IPC_MAX_MB overrides): allocate such fields with
+ * dg_comm_field_alloc below.  A rank that cannot export or map a field makes EVERY rank fail (the statuses are gathered).
+ * UNVERIFIED on more than one device. */
 #define DG_EXCHANGE_COPY 8
+/* Device arrays for DG_EXCHANGE_COPY beyond that limit: n_doubles of device memory on the communicator's device as
+ * hipMemCreate chunks of 512 MiB behind ONE contiguous address range.  When such an array is registered (first exchange call
+ * with it) every chunk is exported as a POSIX descriptor (hipMemExportToShareableHandle), the descriptors travel to the peers
+ * over a unix-domain socket (SCM_RIGHTS) and each peer maps them side by side -- no allocation above 2 GiB is ever opened as a
+ * whole.  To kernels and copies the array is ordinary device memory.  dg_comm_field_free releases an array no peer maps;
+ * a registered one lives until dg_comm_destroy.  No reference counterpart (single process). */
+dg_status dg_comm_field_alloc(dg_comm* comm, uint64_t n_doubles, double** d_field);
+dg_status dg_comm_field_free(dg_comm* comm, double* d_field);
 /* cuts[c * (nchunks + 1) + v], v = 0..nchunks: first plane of chunk v of class c (class order V, X, Y, Z); host only */
 dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts);
 /* planes [plane_begin[c], plane_end[c]) of every class, sampled into their places in d_field (the WHOLE vector) */
@@ -266,6 +276,37 @@ dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces);
 /* how long the caller's stream had to wait, after this rank's last sampling launch of the most recent exchange call, until
  * the field was complete (the part of the exchange the sampling did not hide); waits for that call */
 dg_status dg_comm_last_exchange_wait_ms(dg_comm* comm, float* ms);
+
+/* The exchange step WITHOUT collective kernels and WITHOUT device IPC: the coefficient vector is assembled in a POSIX
+ * shared-memory segment that every rank (one process per GPU, one node) maps; a rank samples its chunks (the contiguous
+ * cost-weighted chunks of dg_chunk_layout, as the in-place forms) into their places in its own d_field and copies them into
+ * the shared vector with its own copy engine over its own PCIe link while it samples the next piece; a barrier that lives in
+ * the segment says when the vector is whole.  What results is what the reference's addFunction leaves behind -- the HOST
+ * vector m_nodes[field] (cubic_lagrange_discrete_grid.cpp:806-831), here shared by all ranks -- not a device-resident field
+ * on every GPU: use the dg_comm forms for that.  Neither RCCL, HIP IPC nor the virtual-memory API is touched.
+ *   dg_host_field_open: collective over the ranks of the node (rank 0 creates the segment, the others wait for it up to
+ *   DG_COMM_TIMEOUT_S seconds; the name is unlinked once everybody has mapped it); with a HIP device current the mapping is
+ *   registered as a DMA target.  `name` must be unique to the job (e.g. contain the launcher's pid).
+ *   dg_sdf_sample_to_host_field: collective and HOST-BLOCKING; on return the shared vector holds every node, bit for bit
+ *   what dg_sdf_sample_nodes writes on one GPU; d_field (dg_grid_n_nodes doubles, this rank's device memory) holds this
+ *   rank's chunks only.  plane_cost as for dg_sdf_sample_exchange_device: the ranks compare a hash of their cuts behind
+ *   the barrier and all fail with DG_ERR_INVALID when they differ.
+ * No reference counterpart (single process). */
+typedef struct dg_host_field dg_host_field;
+typedef struct dg_host_field_info {
+	int32_t rank, nranks, device;
+	int32_t registered; /* 1: hipHostRegister took the mapping (direct DMA); 0: pageable copies */
+	uint64_t n_doubles;
+} dg_host_field_info;
+dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int nranks, dg_host_field** out);
+double* dg_host_field_data(dg_host_field* hf);
+dg_status dg_host_field_barrier(dg_host_field* hf); /* every rank; fails after DG_COMM_TIMEOUT_S seconds instead of hanging */
+dg_status dg_host_field_get_info(dg_host_field* hf, dg_host_field_info* info);
+void dg_host_field_close(dg_host_field* hf);
+dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_host_field* hf, int pieces,
+									  const float* const plane_cost[4], double* d_field, void* stream);
+/* device time of this rank's sampling launches of the most recent dg_sdf_sample_to_host_field call, one value per piece */
+dg_status dg_host_field_last_chunk_ms(dg_host_field* hf, float* ms, int* n_pieces);
 
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both

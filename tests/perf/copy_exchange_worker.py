@@ -23,6 +23,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     res = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "61 47 53").split()]
     pieces = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    vmm = len(sys.argv) > 3 and sys.argv[3] == "vmm"   # the field comes from dg_comm_field_alloc (hipMemCreate chunks, no size limit)
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     torch.cuda.set_device(0)
     dg.load_library()
     dg.set_device(0)
@@ -43,12 +45,18 @@ def main():
     s = torch.cuda.current_stream().cuda_stream
     want = torch.empty(n, dtype=torch.float64, device="cuda")
     mesh.sample_nodes_device(grid, 0, n, want.data_ptr(), stream=s)
-    field = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    if vmm:
+        arr = comm.field_alloc(n)
+        field = torch.as_tensor(arr, device="cuda")
+        assert field.data_ptr() == arr.ptr and field.numel() == n
+        field.fill_(float("nan"))
+    else:
+        field = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
     flags = dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY
     D2 = [res[2] + 1, res[2] + 1, res[0] + 1, res[1] + 1]
     rng = np.random.default_rng(5)           # the same "measured" costs on every rank
     ok = True
-    for step in range(4):
+    for step in range(steps):
         cost = None if step == 0 else [rng.uniform(0.5, 3.0, d).astype(np.float32) for d in D2]
         field.fill_(float("nan"))
         torch.cuda.synchronize()
@@ -67,7 +75,7 @@ def main():
         except dg.DiscregridError as e:
             mismatch_caught = "plane_cost must hold the same values" in str(e)
     info = comm.info()
-    print(json.dumps({"rank": rank, "world": world, "ok": ok, "mismatch_caught": mismatch_caught, "registered_fields": info["registered_fields"],
+    print(json.dumps({"rank": rank, "world": world, "ok": ok, "vmm": vmm, "field_gb": n * 8e-9, "mismatch_caught": mismatch_caught, "registered_fields": info["registered_fields"],
                       "rccl_nranks": info["rccl_nranks"], "wait_ms": comm.last_exchange_wait_ms()}), flush=True)
     comm.close()
     dist.barrier()

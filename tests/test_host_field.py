@@ -1,0 +1,76 @@
+"""The shared-memory coefficient vector of the exchange form that needs neither RCCL nor device IPC (dg_host_field_*,
+discregrid_amd/csrc/dg_capi_hostfield.cpp), without a GPU: several PROCESSES map one POSIX segment through the C ABI, write
+disjoint ranges, meet at the barrier that lives in the segment and read each other's data; a rank that never arrives makes the
+others FAIL after DG_COMM_TIMEOUT_S instead of hanging.  (The sampling step dg_sdf_sample_to_host_field needs a device:
+tests/test_gpu_multirank.py.)"""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+
+import dgtest as T  # noqa: F401  (puts the repo on sys.path)
+
+
+def _rank(rank, world, name, n, rounds, q):
+    try:
+        import discregrid_amd as dg
+        hf = dg.HostField(name, n, rank, world)
+        info = hf.info()
+        ok = info["nranks"] == world and info["rank"] == rank and info["n_doubles"] == n
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        for r in range(rounds):
+            hf.data[lo:hi] = np.arange(lo, hi) * (r + 1.0) + rank      # my range of round r
+            hf.barrier()                                               # everybody has written
+            for o in range(world):
+                a, b = o * n // world, (o + 1) * n // world
+                ok = ok and bool(np.array_equal(hf.data[a:b], np.arange(a, b) * (r + 1.0) + o))
+            hf.barrier()                                               # everybody has read
+        hf.close()
+        q.put((rank, ok, None))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, False, "%s: %s" % (type(e).__name__, e)))
+
+
+def _run(world, n, rounds=25, missing=(), env=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "dg_test_%d_%d" % (os.getpid(), int(time.time() * 1e6) % 1000000007)
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        procs = [ctx.Process(target=_rank, args=(r, world, name, n, rounds, q)) for r in range(world) if r not in missing]
+        for p in procs:
+            p.start()
+        out = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(30)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return sorted(out)
+
+
+def test_ranks_share_one_vector_and_meet_at_its_barrier():
+    out = _run(3, 100003)
+    assert [(r, ok) for r, ok, _ in out] == [(0, True), (1, True), (2, True)], out
+
+
+def test_single_rank_needs_no_peer():
+    out = _run(1, 4097, rounds=2)
+    assert out == [(0, True, None)], out
+
+
+def test_a_missing_rank_fails_the_others_instead_of_hanging():
+    t0 = time.time()
+    out = _run(3, 1000, missing=(2,), env={"DG_COMM_TIMEOUT_S": "2"})
+    assert time.time() - t0 < 60
+    assert len(out) == 2 and all(not ok and err and "did not arrive" in err for _, ok, err in out), out
+
+
+def test_a_missing_creator_fails_the_others():
+    out = _run(2, 1000, missing=(0,), env={"DG_COMM_TIMEOUT_S": "2"})
+    assert len(out) == 1 and not out[0][1] and "did not appear" in out[0][2], out

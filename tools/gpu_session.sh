@@ -35,6 +35,10 @@ PY
       timeout 600 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu -k "cpp_multi_gpu_tool" > $OUT/tool.log 2>&1; tail -2 $OUT/tool.log ;;
     gputests)
       timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/gputests.log 2>&1; tail -5 $OUT/gputests.log ;;
+    gputests_all)   # every GPU test, no stop at the first failure
+      timeout 2400 python -m pytest tests -q -m gpu --timeout 900 > $OUT/gputests.log 2>&1; tail -30 $OUT/gputests.log ;;
+    multirank)
+      timeout 1800 python -m pytest tests/test_gpu_multirank.py -q -m gpu --timeout 600 > $OUT/multirank.log 2>&1; tail -40 $OUT/multirank.log ;;
     bench)
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json ;;
     collect)
