@@ -4,6 +4,7 @@
 // host-pointer entry points in dg_capi_host.cpp.  No CPU compute path exists anywhere: without a
 // gfx950 device every compute entry point fails with DG_ERR_NO_DEVICE.
 #include "dg_capi_internal.h"
+#include "dg_host_query.h"
 
 #include <dlfcn.h>
 
@@ -318,6 +319,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	m->info.device_bytes = host_only ? 0 : nb + tb + pb + sb + ab;
 	m->info.build_seconds = std::chrono::duration<double>(t1 - t0).count();
 	m->host = std::move(B);
+	dg::host::mesh_view(m->host, m->host_view);
 	*out = m;
 	return DG_OK;
 }

@@ -118,6 +118,7 @@ struct dg_mesh
 	mutable uint32_t* bin_flag_host = nullptr; // pinned: was the previous batch unordered? (prediction, starts at 1)
 	double bbox_lo[3], bbox_hi[3];       // of the vertices
 	dg::MeshBuild host;                  // the arrays that were uploaded, kept for dg_signed_distance_point (immutable)
+	dg::MeshDev host_view;               // ... as the kernels' MeshDev (host pointers): what the one-lane traversal walks
 };
 
 struct HostCopyJob; // dg_capi_host.cpp: the asynchronous copy of a device-resident field into the caller's host array

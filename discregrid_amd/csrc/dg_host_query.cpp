@@ -3,9 +3,9 @@
 // thread safe at :188,199 and called per node or per particle from user code such as the lambda of
 // cmd/generate_sdf/main.cpp:97-101).  A kernel launch per point costs 100 us; this evaluates the point
 // where the caller is: the same BVH (the sibling-pair records and triangle packets dg_mesh_create
-// uploaded, kept in host memory as well), the same conservative float bounds (dg_geom.h: pair_lb2), the
-// same double-precision triangle test and epilogue (tri_closest, finish_query) -- so the distance has
-// the bits K1 / K1p produce.  Read-only on immutable data: no locks, any number of concurrent callers.
+// uploaded, kept in host memory as well) walked by the SAME traversal template the kernels instantiate
+// (dg_traverse.h: packet_walk + ExactWalk, here with a wave of one lane), the same conservative float bounds,
+// the same double-precision triangle test and epilogue -- so the distance has the bits K1 / K1p produce.  Read-only on immutable data: no locks, any number of concurrent callers.
 //
 // This is the per-point evaluator of the host API (like the scalar interpolate of dg_lattice.h), not a
 // substitute for the kernels: batches go to dg_signed_distance / dg_sdf_sample_nodes.  It is also all a HOST-ONLY mesh
@@ -21,7 +21,7 @@ extern "C" dg_status dg_signed_distance_point(const dg_mesh* mesh, const double 
 	if (!mesh || !xyz || !dist)
 		return fail(DG_ERR_INVALID, "null argument");
 	dg::LaneResult r;
-	if (!dg::host::signed_distance_point(mesh->host, xyz[0], xyz[1], xyz[2], r))
+	if (!dg::host::signed_distance_point(mesh->host_view, xyz[0], xyz[1], xyz[2], r))
 	{
 		*dist = DG_NO_VALUE;
 		if (tri) *tri = -1;

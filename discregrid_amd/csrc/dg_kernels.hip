@@ -41,6 +41,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include "dg_kernels.h"
+#include "dg_traverse.h"
 
 namespace dg
 {
@@ -74,190 +75,132 @@ __device__ __forceinline__ double pack_double(int lo, int hi)
 	return __hiloint2double(hi, lo);
 }
 
-// a pair record in SGPRs: the interleaved bound floats + the two info words
-struct SPair
+// ---- the device's wave context of the packet traversal (dg_traverse.h) -------------------------------------------------------
+// One lane per thread; everything wave-uniform goes through the SCALAR unit: a bound record (two siblings, 128 B), a
+// triangle packet (128 B) or a filter record (192 B) is fetched ONCE per wave with s_load_dwordx16 into SGPRs and is an
+// operand of every lane's vector instruction for free.  The shared stack: the info word of entry i lives in lane i of one
+// VGPR (pushed with a lane select, popped with v_readlane under the wave-uniform stack pointer), the lanes' bounds for the
+// entry are parked in LDS -- as floats or, in the filtered kernel, whose LDS also holds the candidate lists, as the upper
+// 16 bits of the float (truncation = a lower bound of a non-negative value, relative loss < 2^-7): LDS per wave decides
+// how many waves a CU holds.
+struct SPair // a pair record in SGPRs: the interleaved bound floats + the two info words
 {
 	float r[kPairFloats];
 	int info0, info1;
 };
-__device__ __forceinline__ SPair load_pair(const PairRec* base, int idx)
+struct SApprox // a filter record in SGPRs
 {
-	const char* p = (const char*)(base + idx);
-	SPair s;
-#if DG_OBB
-	const v16i a = sload16(p);
-	const v16i b = sload16(p + 64);
-#pragma unroll
-	for (int i = 0; i < 16; ++i)
-		s.r[i] = __int_as_float(a[i]);
-#pragma unroll
-	for (int i = 0; i < 14; ++i)
-		s.r[16 + i] = __int_as_float(b[i]);
-	s.info0 = b[14];
-	s.info1 = b[15];
-#else
-	const v16i a = sload16(p);
-	const v8i b = sload8(p + 64);
-#pragma unroll
-	for (int i = 0; i < 16; ++i)
-		s.r[i] = __int_as_float(a[i]);
-#pragma unroll
-	for (int i = 0; i < 6; ++i)
-		s.r[16 + i] = __int_as_float(b[i]);
-	s.info0 = b[6];
-	s.info1 = b[7];
-#endif
-	return s;
-}
-
-// Leaf: `cnt` triangle positions (even, <= 16) starting at the even position `first`
-// (wave-uniform arguments), handled pair by pair.  A triangle gets the full double-precision
-// test only if some lane's float lower bound -- the larger of the leaf's bound and the
-// triangle's own box+slab bound -- is below that lane's running best.
-__device__ __forceinline__ int test_leaf(const MeshDev& M, int first, int cnt, float leaf_lb2, LaneQuery& q)
-{
-	int tests = 0; // wave-uniform
-	for (int g = 0; g < cnt; g += 2)
-	{
-		const SPair pr = load_pair(M.tri_pairs, (first + g) >> 1);
-		const f2 lb = pair_lb2(pr.r, q.fp);
-		const bool w0 = __ballot(fmax2(lb.x, leaf_lb2) < q.bestf) != 0ull;
-		const bool w1 = __ballot(fmax2(lb.y, leaf_lb2) < q.bestf) != 0ull;
-#pragma unroll
-		for (int side = 0; side < 2; ++side)
-		{
-			if (!(side == 0 ? w0 : w1))
-				continue;
-			++tests;
-			const int t = first + g + side;
-			const char* base = (const char*)(M.tris + t);
-			const v16i a = sload16(base);
-			const v16i b = sload16(base + 64);
-			const double v0x = pack_double(a[0], a[1]), v0y = pack_double(a[2], a[3]), v0z = pack_double(a[4], a[5]);
-			const double e0x = pack_double(a[6], a[7]), e0y = pack_double(a[8], a[9]), e0z = pack_double(a[10], a[11]);
-			const double e1x = pack_double(a[12], a[13]), e1y = pack_double(a[14], a[15]),
-						 e1z = pack_double(b[0], b[1]);
-			const double a00 = pack_double(b[2], b[3]), a01 = pack_double(b[4], b[5]), a11 = pack_double(b[6], b[7]);
-			const double det = pack_double(b[8], b[9]), inv_det = pack_double(b[10], b[11]);
-			const double denom = pack_double(b[12], b[13]);
-			const Hit h = tri_closest<false>(v0x, v0y, v0z, e0x, e0y, e0z, e1x, e1y, e1z, a00, a01, a11, det, inv_det,
-											 denom, q.px, q.py, q.pz);
-			offer(q, h.d2, t);
-		}
-	}
-	return tests;
-}
-
-// Packet traversal, near-first.  On return every active lane holds the minimum squared distance
-// over all triangles (q.best_d2) and the position attaining it.
-//
-// The wave walks the tree with ONE shared stack: the info word of a postponed subtree lives in
-// one VGPR (entry i in lane i, pushed with a lane select, popped with v_readlane under a
-// wave-uniform stack pointer); each lane's own lower bound for that subtree is parked in LDS
-// (one float per lane and level), so a popped entry is re-tested against the by then tighter
-// running bests with one compare -- no reload, no recomputation.  At an inner node ONE scalar
-// load fetches the bounds of both children, which are evaluated with packed two-wide float
-// math; a child is entered if ANY lane may still improve there, the child most lanes are
-// closer to first, the other one is pushed.
-//
-// `start` is the info word of the subtree to search.  With `ovf_count` set the wave counts its work
-// (node steps + exact triangle tests); when the count passes heavy_work it claims an
-// overflow slot and returns the slot number at once -- the caller parks the lanes' running
-// bests there (dg_kernels.h, "Heavy bricks").  If all slots are taken the wave simply carries on.
-// Returns -1 when the subtree was searched to the end.
-// The parked bounds live in LDS either as floats or -- in the filtered kernel, whose LDS also holds the
-// candidate lists -- as the upper 16 bits of the float (truncation = a lower bound of a non-negative value,
-// relative loss < 2^-7): LDS per wave decides how many waves a CU holds.
+	float r[kApproxFloats];
+	int valid0, valid1;
+};
 __device__ __forceinline__ void park_bound(float* p, int i, float lb) { p[i] = lb; }
 __device__ __forceinline__ float parked_bound(const float* p, int i) { return p[i]; }
 __device__ __forceinline__ void park_bound(uint16_t* p, int i, float lb) { p[i] = (uint16_t)(__float_as_uint(lb) >> 16); }
 __device__ __forceinline__ float parked_bound(const uint16_t* p, int i) { return __uint_as_float((uint32_t)p[i] << 16); }
+typedef __attribute__((address_space(3))) int lds_int_t;
 
 template <class StackT>
-__device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* lds_lb /* [M.stack_levels][64] of this wave */,
-										int start, uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
+struct DevWave
 {
-	const int lane_id = (int)__lane_id();
+	static constexpr int kLanes = 1;
+	typedef SPair Pair;
+	typedef SApprox Approx;
+	StackT* lds_lb; // [M.stack_levels][64] of this wave
+	int lane_id;
 	int stackv = 0; // info words: lane i holds entry i
-	int sp = 0;     // wave-uniform
-	int cur = start;
-	float lbcur = 0.0f; // this lane's lower bound for `cur`
-	int work = 0;       // wave-uniform
-	int budget = ovf_count ? heavy_work : 0x7fffffff;
-	int parked = -1;
-	// (Shape of the loop: an inner loop for the way down and the budget test after a pop keep every wave-uniform
-	// variable defined on every path -- with one loop and a `continue` the compiler carries undefined values
-	// for cur/sp/work across the leaf branch and materialises them with VALU moves on every step.)
-	while (true)
+	__device__ __forceinline__ DevWave(StackT* lds, int lane) : lds_lb(lds), lane_id(lane) {}
+	template <class F>
+	__device__ __forceinline__ void lanes(F f) const { f(0); }
+	template <class P>
+	__device__ __forceinline__ unsigned long long ballot(P p) const { return __ballot(p(0)); }
+	__device__ __forceinline__ SPair load_pair(const PairRec* base, int idx) const
 	{
-		// down the tree while some lane needs a child; `dead`: the node's children are out of every lane's reach
-		bool dead = false;
-		while (cur >= 0)
-		{
-			++work;
-			const SPair pr = load_pair(M.pairs, cur);
-			f2 cd;
-			const f2 lb = pair_lb2(pr.r, q.fp, &cd);
-			const bool hl = lb.x < q.bestf, hr = lb.y < q.bestf;
-			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
-			if ((bl | br) == 0ull)
-			{
-				dead = true;
-				break;
-			}
-			bool left = bl != 0ull;
-			if (bl != 0ull && br != 0ull)
-			{
-				// both children are needed: the one most lanes are closer to first, the other is
-				// postponed (its info word to the VGPR stack, every lane's bound for it to LDS)
-				const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br); // (by the distance to the box centres)
-				left = 2 * __popcll(pref) >= __popcll(bl | br);
-				if (sp < M.stack_levels) // always true: one push per tree level at most
-				{
-					stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-					park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
-					++sp;
-				}
-			}
-			cur = left ? pr.info0 : pr.info1;
-			lbcur = left ? lb.x : lb.y;
-		}
-		if (!dead)
-		{
-			const unsigned code = ~(unsigned)cur;
-			work += 1 + test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, q);
-		}
-		// pop the next postponed subtree that some lane still needs
-		bool found = false;
-		while (sp > 0)
-		{
-			--sp;
-			lbcur = parked_bound(lds_lb, sp * 64 + lane_id);
-			if (__ballot(lbcur < q.bestf) != 0ull)
-			{
-				cur = __builtin_amdgcn_readlane(stackv, sp);
-				found = true;
-				break;
-			}
-		}
-		if (!found)
-			break;
-		// the work budget is looked at when a subtree is finished, not on every step
-		if (work > budget)
-		{
-			int slot = 0;
-			if (lane_id == 0)
-				slot = (int)atomicAdd(ovf_count, 1u);
-			slot = uniform(slot);
-			if ((unsigned)slot < ovf_slots)
-			{
-				parked = slot;
-				break;
-			}
-			budget = 0x7fffffff;
-		}
+		const char* p = (const char*)(base + idx);
+		SPair s;
+		const v16i a = sload16(p);
+		const v16i b = sload16(p + 64);
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			s.r[i] = __int_as_float(a[i]);
+#pragma unroll
+		for (int i = 0; i < 14; ++i)
+			s.r[16 + i] = __int_as_float(b[i]);
+		s.info0 = b[14];
+		s.info1 = b[15];
+		return s;
 	}
-	return parked;
+	__device__ __forceinline__ TriRegs load_tri(const TriPacket* tris, int t) const
+	{
+		const char* base = (const char*)(tris + t);
+		const v16i a = sload16(base);
+		const v16i b = sload16(base + 64);
+		TriRegs T;
+		T.v0x = pack_double(a[0], a[1]), T.v0y = pack_double(a[2], a[3]), T.v0z = pack_double(a[4], a[5]);
+		T.e0x = pack_double(a[6], a[7]), T.e0y = pack_double(a[8], a[9]), T.e0z = pack_double(a[10], a[11]);
+		T.e1x = pack_double(a[12], a[13]), T.e1y = pack_double(a[14], a[15]), T.e1z = pack_double(b[0], b[1]);
+		T.a00 = pack_double(b[2], b[3]), T.a01 = pack_double(b[4], b[5]), T.a11 = pack_double(b[6], b[7]);
+		T.det = pack_double(b[8], b[9]), T.inv_det = pack_double(b[10], b[11]);
+		T.denom = pack_double(b[12], b[13]);
+		return T;
+	}
+	__device__ __forceinline__ SApprox load_approx(const TriApproxPair* recs, int idx) const
+	{
+		const char* base = (const char*)(recs + idx);
+		const v16i a = sload16(base);
+		const v16i b = sload16(base + 64);
+		const v16i c = sload16(base + 128);
+		SApprox s;
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+		{
+			s.r[i] = __int_as_float(a[i]);
+			s.r[16 + i] = __int_as_float(b[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < kApproxFloats - 32; ++i)
+			s.r[32 + i] = __int_as_float(c[i]);
+		s.valid0 = c[14];
+		s.valid1 = c[15];
+		return s;
+	}
+	template <class B>
+	__device__ __forceinline__ void push(int sp, int info, B lb)
+	{
+		stackv = (lane_id == sp) ? info : stackv;
+		park_bound(lds_lb, sp * 64 + lane_id, lb(0));
+	}
+	__device__ __forceinline__ float parked(int sp, int) const { return parked_bound(lds_lb, sp * 64 + lane_id); }
+	__device__ __forceinline__ int info(int sp) const { return __builtin_amdgcn_readlane(stackv, sp); }
+	__device__ __forceinline__ uint32_t claim(uint32_t* counter) const
+	{
+		int slot = 0;
+		if (lane_id == 0)
+			slot = (int)atomicAdd(counter, 1u);
+		return (uint32_t)uniform(slot);
+	}
+	__device__ __forceinline__ void list_store(uint32_t slot, int v) const { *(lds_int_t*)(uintptr_t)slot = v; }
+	// (the emulator's counters)
+	__device__ __forceinline__ void note_pair_step(const MeshDev&, int) const {}
+	__device__ __forceinline__ void note_leaf(int, int) const {}
+	__device__ __forceinline__ void note_leaf_pair() const {}
+	__device__ __forceinline__ void note_tri_test(int, bool) const {}
+	__device__ __forceinline__ void note_pop() const {}
+	__device__ __forceinline__ void note_stale_pop() const {}
+	__device__ __forceinline__ void note_filter_pair() const {}
+	__device__ __forceinline__ void note_filter_rest() const {}
+	__device__ __forceinline__ void note_append(bool) const {}
+};
+
+// the exact traversal of the subtree `start` by this wave (dg_traverse.h: packet_walk + ExactWalk); returns the heavy slot
+// the wave claimed, or -1 when the subtree was searched to the end
+template <class StackT>
+__device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* lds_lb, int start, uint32_t* ovf_count, uint32_t ovf_slots,
+										int heavy_work)
+{
+	DevWave<StackT> w(lds_lb, (int)__lane_id());
+	auto lane_query = [&](int) -> LaneQuery& { return q; };
+	ExactWalk<DevWave<StackT>, decltype(lane_query)> pol(lane_query);
+	return packet_walk(w, pol, M, start, ovf_count, ovf_slots, heavy_work);
 }
 
 struct DeviceSqrt
@@ -417,162 +360,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DG_K1_MIN_WAVES) void k_sample
 // met) get the exact traversal in the same wave, pruned from the start by their upper bounds; a brick whose
 // work budget runs out is parked as a heavy brick with the upper bounds as seeds.
 // ------------------------------------------------------------------------------------------------
-struct FastLane
-{
-	ApproxLane a;
-	float U;      // upper bound of the lane's minimum d^2; -inf: lane inactive
-	float Uprune; // what bound tests compare with: U (1 + theta) + kappa
-	float Lmin;   // smallest lower value among the listed candidates
-	uint32_t slot; // LDS byte address of the lane's next list entry: base + 256 * listed candidates, capped at
-	               // base + 256 * kFastListCap (a list that reaches the cap may have overflowed)
-};
 // returns -1 (searched to the end), -2 (searched to the end, but a degenerate triangle was met: the lists are
 // incomplete) or the heavy slot the wave claimed
-typedef __attribute__((address_space(3))) int lds_int_t;
 __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint16_t* lds_lb, uint32_t list_base /* f.slot of an empty list */,
 											 uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
 {
-	const int lane_id = (int)__lane_id();
-	const uint32_t list_limit = list_base + 256u * (uint32_t)kFastListCap;
-	int stackv = 0;
-	int sp = 0;
-	int cur = M.root_info;
-	float lbcur = 0.0f;
-	int work = 0;
-	int budget = ovf_count ? kFastWorkFactor * heavy_work : 0x7fffffff;
-	bool degenerate = false; // wave-uniform: a degenerate triangle was met
-	int parked = -1;
-	while (true)
-	{
-		// down the tree while some lane needs a child; `dead`: the node's children are out of every lane's reach
-		bool dead = false;
-		while (cur >= 0)
-		{
-			++work;
-			const SPair pr = load_pair(M.pairs, cur);
-			f2 cd;
-			const f2 lb = pair_lb2_fast(pr.r, f.a.x, &cd);
-			const bool hl = lb.x <= f.Uprune, hr = lb.y <= f.Uprune;
-			const unsigned long long bl = __ballot(hl), br = __ballot(hr);
-			if ((bl | br) == 0ull)
-			{
-				dead = true;
-				break;
-			}
-			bool left = bl != 0ull;
-			if (bl != 0ull && br != 0ull)
-			{
-				// both children are needed: the one most lanes are closer to -- by the distance to the box
-				// CENTRE -- first, the other is postponed
-				const unsigned long long pref = __ballot(cd.x <= cd.y) & (bl | br);
-				left = 2 * __popcll(pref) >= __popcll(bl | br);
-				if (sp < M.stack_levels)
-				{
-					stackv = (lane_id == sp) ? (left ? pr.info1 : pr.info0) : stackv;
-					park_bound(lds_lb, sp * 64 + lane_id, left ? lb.y : lb.x);
-					++sp;
-				}
-			}
-			cur = left ? pr.info0 : pr.info1;
-			lbcur = left ? lb.x : lb.y;
-		}
-		if (!dead)
-		{
-			++work;
-			const unsigned code = ~(unsigned)cur;
-			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
-			// error terms for this leaf's triangles around the lane's current distance estimate (its upper
-			// bound, or the leaf's own bound while no triangle has been seen); they are valid for any estimate
-			float theta, kappa;
-			approx_err_terms(f.a.E, f.U < __builtin_inff() ? f.U : lbcur, &theta, &kappa);
-			for (int g = 0; g < cnt; g += 2)
-			{
-				const char* base = (const char*)(M.tri_approx + ((first + g) >> 1));
-				const v16i a = sload16(base);
-				const v16i b = sload16(base + 64);
-				const v16i c = sload16(base + 128);
-				float r[kApproxFloats];
-#pragma unroll
-				for (int i = 0; i < 16; ++i)
-				{
-					r[i] = __int_as_float(a[i]);
-					r[16 + i] = __int_as_float(b[i]);
-				}
-#pragma unroll
-				for (int i = 0; i < kApproxFloats - 32; ++i)
-					r[32 + i] = __int_as_float(c[i]);
-				const int valid0 = c[14], valid1 = c[15]; // 1: triangle, 0: padding slot of an odd leaf, 2: degenerate triangle
-				degenerate = degenerate || valid0 == 2 || valid1 == 2;
-				// step 1: frame coordinates + rectangle bound; most pairs of a visited leaf end here
-				TriFrame fr;
-				const f2 qlb = tri_approx_frame(r, f.a, &fr);
-				const f2 lo_lb = qlb - f2_fma(qlb, f2_splat(theta), f2_splat(kappa));
-#ifndef DG_TRI_PREFILTER
-#define DG_TRI_PREFILTER 1 // 0: A/B variant without the early-out
-#endif
-				if (DG_TRI_PREFILTER && __ballot((valid0 == 1 && lo_lb.x <= f.U) || (valid1 == 1 && lo_lb.y <= f.U)) == 0ull)
-				{
-					++work;
-					continue;
-				}
-				const f2 q = tri_approx_rest(r, f.a, fr);
-				const f2 err = f2_fma(q, f2_splat(theta), f2_splat(kappa));
-				const f2 up = q + err, lo = q - err;
-				++work;
-#pragma unroll
-				for (int side = 0; side < 2; ++side)
-				{
-					if ((side == 0 ? valid0 : valid1) != 1) // wave-uniform
-						continue;
-					const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
-					if (lo_s <= f.U)
-					{
-						// a candidate; if even its upper value is below every listed lower value, the list is obsolete
-						const bool reset = up_s < f.Lmin;
-						f.slot = reset ? list_base : f.slot;
-						*(lds_int_t*)(uintptr_t)f.slot = first + g + side;
-						f.slot = min(f.slot + 256u, list_limit);
-						f.Lmin = fmin_sel(reset ? __builtin_inff() : f.Lmin, lo_s);
-					}
-					f.U = fmin_sel(f.U, up_s);
-				}
-			}
-			// the threshold the bound tests compare with (dg_geom.h: approx_err_terms)
-			f.Uprune = __builtin_fmaf(f.U, 1.0f + theta, kappa);
-		}
-		bool found = false;
-		while (sp > 0)
-		{
-			--sp;
-			lbcur = parked_bound(lds_lb, sp * 64 + lane_id);
-			if (__ballot(lbcur <= f.Uprune) != 0ull)
-			{
-				cur = __builtin_amdgcn_readlane(stackv, sp);
-				found = true;
-				break;
-			}
-		}
-		if (!found)
-			break;
-		// the work budget is looked at when a subtree is finished (not on every step: the traversal is
-		// the same either way, only the moment a brick is declared heavy moves by a few steps)
-		if (work > budget)
-		{
-			int slot = 0;
-			if (lane_id == 0)
-				slot = (int)atomicAdd(ovf_count, 1u);
-			slot = uniform(slot);
-			if ((unsigned)slot < ovf_slots)
-			{
-				parked = slot;
-				break;
-			}
-			budget = 0x7fffffff;
-		}
-	}
+	DevWave<uint16_t> w(lds_lb, (int)__lane_id());
+	auto lane_state = [&](int) -> FastLane& { return f; };
+	auto lane_list = [&](int) { return list_base; };
+	FastWalk<DevWave<uint16_t>, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
+	const int parked = packet_walk(w, pol, M, M.root_info, ovf_count, ovf_slots, kFastWorkFactor * heavy_work);
 	if (parked >= 0)
 		return parked;
-	return degenerate ? -2 : -1;
+	return pol.degenerate ? -2 : -1;
 }
 
 template <bool POINTS>
@@ -601,11 +401,8 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	// `exact`: lanes the filter cannot serve -- outside its range (or NaN) from the start, later those
 	// whose list filled up -- get the exact traversal below, in this wave, with only them active
 	bool exact = sample && !(f.a.E < __builtin_inff());
-	f.U = (sample && !exact) ? __builtin_inff() : -__builtin_inff();
-	f.Uprune = f.U;
-	f.Lmin = __builtin_inff();
 	const uint32_t list_base = (uint32_t)(uintptr_t)(lds_int_t*)(lds_list + lane); // LDS byte address of the lane's entry 0
-	f.slot = list_base;
+	init_fast_lane(f, sample && !exact, list_base);
 	if (__ballot(sample && !exact) != 0ull)
 	{
 		const int slot = traverse_fast(P.mesh, f, lds_lb16, list_base, P.ovf.count, P.ovf.slots, P.ovf.heavy_work);

@@ -45,159 +45,41 @@ struct Wave
 	LaneQuery q[64];
 };
 
-int test_leaf(const MeshDev& M, int first, int cnt, const float* leaf_lb2 /*per lane*/, Wave& w, Stats& st)
+// ---- the traversals: the PRODUCT's template (dg_traverse.h: packet_walk + ExactWalk / FastWalk) instantiated with the host
+// wave context of dg_host_query.h carrying 64 lanes; what is written here is only where the counters of the design studies go
+struct FastStats;
+struct EmuCounters
 {
-	int tests = 0;
-	for (int g = 0; g < cnt; g += 2)
-	{
-		const PairRec& pr = M.tri_pairs[(first + g) >> 1];
-		st.leaf_groups++;
-		bool want[2] = {false, false};
-		int n_int[2] = {0, 0};
-		for (int l = 0; l < 64; ++l)
-		{
-			const f2 lb = pair_lb2(&pr.f[0][0], w.q[l].fp);
-			const bool h0 = fmax2(lb.x, leaf_lb2[l]) < w.q[l].bestf;
-			const bool h1 = fmax2(lb.y, leaf_lb2[l]) < w.q[l].bestf;
-			want[0] = want[0] || h0;
-			want[1] = want[1] || h1;
-			n_int[0] += h0;
-			n_int[1] += h1;
-		}
-		for (int side = 0; side < 2; ++side)
-		{
-			st.slab_tests++;
-			if (!want[side])
-				continue;
-			st.tri_tests++;
-			++tests;
-			st.lane_interest += n_int[side];
-			const int t = first + g + side;
-			const TriPacket& T = M.tris[t];
-			bool useful = false;
-			for (int l = 0; l < 64; ++l)
-			{
-				const Hit h = tri_closest<false>(T, w.q[l].px, w.q[l].py, w.q[l].pz);
-				useful = useful || (h.d2 < w.q[l].best_d2);
-				offer(w.q[l], h.d2, t);
-			}
-			st.useful_tests += useful;
-		}
-	}
-	return tests;
-}
+	Stats* st = nullptr;     // the exact traversal counts into this ...
+	FastStats* fs = nullptr; // ... the filtered one into this
+	void pair_step(const MeshDev& M, int cur);
+	void leaf(int first, int cnt);
+	void leaf_pair();
+	void tri_test(int interested, bool useful);
+	void pop();
+	void stale_pop();
+	void filter_pair();
+	void filter_rest();
+	void append(bool reset);
+};
+typedef dg::host::HostWave<64, EmuCounters> EmuWave;
 
-// mirrors traverse() of dg_kernels.hip: near-first packet traversal, wave-shared stack of info
-// words, per-lane bounds of postponed subtrees parked per level
-// (including the work budget / overflow-slot claim of the heavy-brick path)
-float truncate16(float v) // park_bound / parked_bound of the 16-bit stack
+// the exact traversal of subtree `start` by the 64 lanes of w (k_sample_nodes / k_heavy_subtrees; stack16: as the second pass
+// of k_sample_fast runs it, bounds parked in 16 bits); returns the heavy slot claimed or -1
+int walk_exact(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf, bool stack16 = false)
 {
-	uint32_t bits;
-	std::memcpy(&bits, &v, 4);
-	bits &= 0xffff0000u;
-	std::memcpy(&v, &bits, 4);
-	return v;
-}
-int traverse(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf, bool stack16 = false)
-{
-	int stack_info[kStackDepth];
-	static thread_local float stack_lb[kStackDepth][64];
-	int sp = 0;
-	int cur = start;
-	float lbcur[64];
-	for (int k = 0; k < 64; ++k)
-		lbcur[k] = 0.0f;
-	int work = 0;
-	int budget = ovf ? ovf->heavy_work : 0x7fffffff;
-	while (true)
-	{
-		++work;
-		bool descended = false;
-		if (cur < 0)
-		{
-			st.leaf_visits++;
-			const unsigned code = ~(unsigned)cur;
-			work += test_leaf(M, (int)(code >> kLeafBits), (int)(code & (unsigned)(kMaxLeaf - 1)) + 1, lbcur, w, st);
-		}
-		else
-		{
-			const PairRec& pr = M.pairs[cur];
-			st.node_visits += 2;
-			float lbl[64], lbr[64];
-			bool anyl = false, anyr = false;
-			int pref = 0, act = 0;
-			for (int k = 0; k < 64; ++k)
-			{
-				f2 cd;
-				const f2 lb = pair_lb2(&pr.f[0][0], w.q[k].fp, &cd);
-				lbl[k] = lb.x;
-				lbr[k] = lb.y;
-				const bool hl = lb.x < w.q[k].bestf, hr = lb.y < w.q[k].bestf;
-				anyl = anyl || hl;
-				anyr = anyr || hr;
-				if (hl || hr)
-				{
-					act++;
-					pref += (cd.x <= cd.y);
-				}
-			}
-			if (anyl || anyr)
-			{
-				bool left = anyl;
-				if (anyl && anyr)
-				{
-					left = 2 * pref >= act;
-					if (sp < M.stack_levels)
-					{
-						stack_info[sp] = left ? pr.info[1] : pr.info[0];
-						for (int k = 0; k < 64; ++k)
-							stack_lb[sp][k] = stack16 ? truncate16(left ? lbr[k] : lbl[k]) : (left ? lbr[k] : lbl[k]);
-						++sp;
-					}
-				}
-				cur = left ? pr.info[0] : pr.info[1];
-				for (int k = 0; k < 64; ++k)
-					lbcur[k] = left ? lbl[k] : lbr[k];
-				descended = true;
-			}
-		}
-		if (descended)
-			continue;
-		bool found = false;
-		while (sp > 0)
-		{
-			--sp;
-			st.pops++;
-			bool any = false;
-			for (int k = 0; k < 64; ++k)
-			{
-				lbcur[k] = stack_lb[sp][k];
-				any = any || (lbcur[k] < w.q[k].bestf);
-			}
-			if (any)
-			{
-				cur = stack_info[sp];
-				found = true;
-				break;
-			}
-			st.stale_pops++;
-		}
-		if (!found)
-			break;
-		// the work budget is looked at when a subtree is finished (as the kernels do)
-		if (work > budget)
-		{
-			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
-			if (slot < ovf->slots)
-				return (int)slot;
-			budget = 0x7fffffff;
-		}
-	}
-	return -1;
+	EmuCounters c;
+	c.st = &st;
+	EmuWave ew;
+	ew.stats = &c;
+	ew.stack16 = stack16;
+	auto lane_query = [&](int l) -> LaneQuery& { return w.q[l]; };
+	ExactWalk<EmuWave, decltype(lane_query)> pol(lane_query);
+	return packet_walk(ew, pol, M, start, ovf ? ovf->count : nullptr, ovf ? ovf->slots : 0u, ovf ? ovf->heavy_work : 0);
 }
 
 
-// ---- filtered traversal: mirrors traverse_fast() / k_sample_fast of dg_kernels.hip ----------------------
+// ---- filtered kernel: the wave-level bookkeeping of k_sample_fast around the product's traversal ----------------------
 static unsigned long long g_need_sum = 0, g_need_max = 0;
 extern "C" void emu_need(unsigned long long* o) { o[0] = g_need_sum; o[1] = g_need_max; }
 struct FastStats
@@ -216,12 +98,13 @@ int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_K1_FA
 int g_brick_blocking = 0; // 1: the blocked brick order K3 launches use (dg_kernels.h: map_lane)
 FastStats g_fs;
 
-struct FastLane
+// the candidate lists of one wave with the kernel's LDS layout: entry k of lane l at byte 256 k + 4 l (dg::FastLane::slot)
+struct FastLists
 {
-	ApproxLane a;
-	float U, Uprune, Lmin;
-	int cnt;
-	int list[kFastListCap + 1];
+	int v[(kFastListCap + 1) * 64];
+	static uint32_t base(int l) { return 4u * (uint32_t)l; }
+	static int count(const FastLane& f, int l) { return (int)((f.slot - base(l)) >> 8); }
+	int at(int l, int k) const { return v[k * 64 + l]; }
 };
 // design study (EMU_DEPTH_HIST=1): pair steps of the filtered traversal by depth of the node in the tree
 int g_depth_hist_on = getenv("EMU_DEPTH_HIST") != nullptr;
@@ -253,168 +136,73 @@ static void depth_hist_note(const MeshDev& M, int cur)
 }
 extern "C" void emu_depth_hist(uint64_t* out /*64*/) { for (int i = 0; i < 64; ++i) out[i] = g_depth_hist[i]; }
 thread_local std::vector<std::pair<int,int>> g_leaf_log; // (first, cnt) of the leaves a traversal visited (design studies)
-int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowBuf* ovf)
+// the filtered traversal (k_sample_fast's first pass); returns -1, -2 (a degenerate triangle was met) or the heavy slot claimed
+int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
 {
 	g_leaf_log.clear();
-	int stack_info[kStackDepth];
-	static thread_local float stack_lb[kStackDepth][64];
-	int sp = 0;
-	int cur = M.root_info;
-	float lbcur[64];
-	for (int k = 0; k < 64; ++k)
-		lbcur[k] = 0.0f;
-	int work = 0;
-	int budget = (ovf && ovf->count) ? kFastWorkFactor * ovf->heavy_work : 0x7fffffff;
-	bool degenerate = false;
-	while (true)
+	EmuCounters c;
+	c.fs = &st;
+	EmuWave ew;
+	ew.stats = &c;
+	ew.stack16 = true;
+	ew.lists = lists.v;
+	auto lane_state = [&](int l) -> FastLane& { return fl[l]; };
+	auto lane_list = [](int l) { return FastLists::base(l); };
+	FastWalk<EmuWave, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
+	const bool budgeted = ovf && ovf->count;
+	const int parked = packet_walk(ew, pol, M, M.root_info, budgeted ? ovf->count : nullptr, budgeted ? ovf->slots : 0u,
+								   budgeted ? kFastWorkFactor * ovf->heavy_work : 0);
+	if (parked >= 0)
+		return parked;
+	return pol.degenerate ? -2 : -1;
+}
+void EmuCounters::pair_step(const MeshDev& M, int cur)
+{
+	if (st) st->node_visits += 2;
+	if (fs)
 	{
-		++work;
-		bool descended = false;
-		if (cur < 0)
-		{
-			st.leaf_visits++;
-			const unsigned code = ~(unsigned)cur;
-			const int first = (int)(code >> kLeafBits), cnt = (int)(code & (unsigned)(kMaxLeaf - 1)) + 1;
-			g_leaf_log.push_back(std::make_pair(first, cnt));
-			if (getenv("EMU_LEAF_TRACE"))
-			{
-				int acc = 0; float best_margin = 1e30f, umin = 1e30f, umax = -1e30f;
-				for (int l = 0; l < 64; ++l)
-				{
-					if (!(fl[l].U > -1e30f)) continue;
-					if (lbcur[l] <= fl[l].Uprune) acc++;
-					best_margin = std::min(best_margin, (lbcur[l] - fl[l].Uprune) / std::max(fl[l].Uprune, 1e-30f));
-					umin = std::min(umin, fl[l].U); umax = std::max(umax, fl[l].U);
-				}
-				fprintf(stderr, "  visit leaf first=%d cnt=%d lanes_accepting=%d min_rel_margin=%.3g U range [%.5g, %.5g]\n", first, cnt, acc, best_margin, umin, umax);
-			}
-			float theta[64], kappa[64];
-			for (int l = 0; l < 64; ++l)
-			{
-				approx_err_terms(fl[l].a.E, fl[l].U < __builtin_inff() ? fl[l].U : lbcur[l], &theta[l], &kappa[l]);
-			}
-			for (int g = 0; g < cnt; g += 2)
-			{
-				const TriApproxPair& rec = M.tri_approx[(first + g) >> 1];
-				const float* r = &rec.f[0][0];
-				degenerate = degenerate || rec.valid[0] == 2 || rec.valid[1] == 2;
-				++work;
-				// step 1 for the whole wave: does any lane's rectangle bound reach below its upper bound?
-				TriFrame frs[64];
-				bool any = false;
-				for (int l = 0; l < 64; ++l)
-				{
-					const f2 qlb = tri_approx_frame(r, fl[l].a, &frs[l]);
-					const f2 lo_lb = qlb - f2_fma(qlb, f2_splat(theta[l]), f2_splat(kappa[l]));
-					any = any || (rec.valid[0] == 1 && lo_lb.x <= fl[l].U) || (rec.valid[1] == 1 && lo_lb.y <= fl[l].U);
-				}
-				st.hist[16] += 1; // (pairs that reached step 1)
-				if (!any)
-					continue;
-				st.tri_pairs++;
-				for (int l = 0; l < 64; ++l)
-				{
-					FastLane& f = fl[l];
-					const f2 q = tri_approx_rest(r, f.a, frs[l]);
-					const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l]));
-					const f2 up = q + err, lo = q - err;
-					for (int side = 0; side < 2; ++side)
-					{
-						if (rec.valid[side] != 1)
-							continue;
-						const float lo_s = side == 0 ? lo.x : lo.y, up_s = side == 0 ? up.x : up.y;
-						if (lo_s <= f.U)
-						{
-							const bool reset = up_s < f.Lmin;
-							st.resets += reset && f.cnt > 0;
-							f.cnt = reset ? 0 : f.cnt;
-							f.list[f.cnt] = first + g + side;
-							f.cnt = f.cnt + 1 < kFastListCap ? f.cnt + 1 : kFastListCap;
-							f.Lmin = fmin_sel(reset ? __builtin_inff() : f.Lmin, lo_s);
-							st.appends++;
-						}
-						f.U = fmin_sel(f.U, up_s);
-					}
-				}
-			}
-			for (int l = 0; l < 64; ++l)
-				fl[l].Uprune = __builtin_fmaf(fl[l].U, 1.0f + theta[l], kappa[l]);
-		}
-		else
-		{
-			const PairRec& pr = M.pairs[cur];
-			st.pair_steps++;
-			if (g_depth_hist_on)
-				depth_hist_note(M, cur);
-			float lbl[64], lbr[64];
-			bool anyl = false, anyr = false;
-			int pref = 0, act = 0;
-			for (int k = 0; k < 64; ++k)
-			{
-				f2 cd;
-				const f2 lb = pair_lb2_fast(&pr.f[0][0], fl[k].a.x, &cd);
-				lbl[k] = lb.x;
-				lbr[k] = lb.y;
-				const bool hl = lb.x <= fl[k].Uprune, hr = lb.y <= fl[k].Uprune;
-				anyl = anyl || hl;
-				anyr = anyr || hr;
-				if (hl || hr)
-				{
-					act++;
-					pref += (cd.x <= cd.y);
-				}
-			}
-			if (anyl || anyr)
-			{
-				bool left = anyl;
-				if (anyl && anyr)
-				{
-					left = 2 * pref >= act;
-					if (sp < M.stack_levels)
-					{
-						stack_info[sp] = left ? pr.info[1] : pr.info[0];
-						for (int k = 0; k < 64; ++k)
-							stack_lb[sp][k] = truncate16(left ? lbr[k] : lbl[k]);
-						++sp;
-					}
-				}
-				cur = left ? pr.info[0] : pr.info[1];
-				for (int k = 0; k < 64; ++k)
-					lbcur[k] = left ? lbl[k] : lbr[k];
-				descended = true;
-			}
-		}
-		if (descended)
-			continue;
-		bool found = false;
-		while (sp > 0)
-		{
-			--sp;
-			bool any = false;
-			for (int k = 0; k < 64; ++k)
-			{
-				lbcur[k] = stack_lb[sp][k];
-				any = any || (lbcur[k] <= fl[k].Uprune);
-			}
-			if (any)
-			{
-				cur = stack_info[sp];
-				found = true;
-				break;
-			}
-		}
-		if (!found)
-			break;
-		// the work budget is looked at when a subtree is finished (as the kernels do)
-		if (work > budget)
-		{
-			const uint32_t slot = __atomic_fetch_add(ovf->count, 1u, __ATOMIC_RELAXED);
-			if (slot < ovf->slots)
-				return (int)slot;
-			budget = 0x7fffffff;
-		}
+		fs->pair_steps++;
+		if (g_depth_hist_on)
+			depth_hist_note(M, cur);
 	}
-	return degenerate ? -2 : -1;
+}
+void EmuCounters::leaf(int first, int cnt)
+{
+	if (st) st->leaf_visits++;
+	if (fs)
+	{
+		fs->leaf_visits++;
+		g_leaf_log.push_back(std::make_pair(first, cnt));
+	}
+}
+void EmuCounters::leaf_pair()
+{
+	if (st)
+	{
+		st->leaf_groups++;
+		st->slab_tests += 2;
+	}
+}
+void EmuCounters::tri_test(int interested, bool useful)
+{
+	if (st)
+	{
+		st->tri_tests++;
+		st->lane_interest += (uint64_t)interested;
+		st->useful_tests += useful;
+	}
+}
+void EmuCounters::pop() { if (st) st->pops++; }
+void EmuCounters::stale_pop() { if (st) st->stale_pops++; }
+void EmuCounters::filter_pair() { if (fs) fs->hist[16] += 1; } // (pairs that reached step 1)
+void EmuCounters::filter_rest() { if (fs) fs->tri_pairs++; }
+void EmuCounters::append(bool reset)
+{
+	if (fs)
+	{
+		fs->appends++;
+		fs->resets += reset;
+	}
 }
 
 
@@ -423,24 +211,22 @@ int traverse_fast(const MeshDev& M, FastLane* fl, FastStats& st, const OverflowB
 void fast_wave_unparked(const MeshDev& M, Wave& w, const bool* sample, FastStats& fs, Stats& ls)
 {
 	FastLane fl[64];
+	FastLists lists;
 	bool exact[64];
 	bool any_fast = false, any_exact = false;
 	for (int l = 0; l < 64; ++l)
 	{
 		fl[l].a = make_approx_lane(w.q[l].px - M.origin[0], w.q[l].py - M.origin[1], w.q[l].pz - M.origin[2], M.mesh_l1);
 		exact[l] = sample[l] && !(fl[l].a.E < __builtin_inff());
-		fl[l].U = (sample[l] && !exact[l]) ? __builtin_inff() : -__builtin_inff();
-		fl[l].Uprune = fl[l].U;
-		fl[l].Lmin = __builtin_inff();
-		fl[l].cnt = 0;
+		init_fast_lane(fl[l], sample[l] && !exact[l], FastLists::base(l));
 		any_fast = any_fast || (sample[l] && !exact[l]);
 	}
 	fs.bricks++;
 	if (any_fast)
 	{
-		const int r = traverse_fast(M, fl, fs, nullptr);
+		const int r = walk_fast(M, fl, lists, fs, nullptr);
 		for (int l = 0; l < 64; ++l)
-			exact[l] = exact[l] || (sample[l] && (r == -2 || fl[l].cnt >= kFastListCap));
+			exact[l] = exact[l] || (sample[l] && (r == -2 || FastLists::count(fl[l], l) >= kFastListCap));
 	}
 	for (int l = 0; l < 64; ++l)
 		any_exact = any_exact || exact[l];
@@ -454,7 +240,7 @@ void fast_wave_unparked(const MeshDev& M, Wave& w, const bool* sample, FastStats
 			if (exact[l] && fl[l].U > 0.0f)
 				wx.q[l].bestf = best_as_float((double)fl[l].U);
 		}
-		traverse(M, wx, ls, M.root_info, nullptr, true);
+		walk_exact(M, wx, ls, M.root_info, nullptr, true);
 	}
 	for (int l = 0; l < 64; ++l)
 	{
@@ -466,9 +252,9 @@ void fast_wave_unparked(const MeshDev& M, Wave& w, const bool* sample, FastStats
 			w.q[l].best_tri = wx.q[l].best_tri;
 			continue;
 		}
-		for (int k = 0; k < fl[l].cnt; ++k)
+		for (int k = 0; k < FastLists::count(fl[l], l); ++k)
 		{
-			const int t = fl[l].list[k];
+			const int t = lists.at(l, k);
 			const Hit h = tri_closest<false>(M.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
 			offer(w.q[l], h.d2, t);
 		}
@@ -499,20 +285,7 @@ void* emu_mesh_create(const double* verts, size_t nv, const uint32_t* tris, size
 		delete m;
 		return nullptr;
 	}
-	m->dev.pairs = m->B.pairs.data();
-	m->dev.tri_pairs = m->B.tri_pairs.data();
-	m->dev.tris = m->B.tris.data();
-	m->dev.tri_approx = m->B.tri_approx.data();
-	m->dev.pn = m->B.pn.data();
-	m->dev.mesh_l1 = m->B.mesh_l1;
-	m->dev.root_info = m->B.root_info;
-	m->dev.n_positions = (int32_t)m->B.tris.size();
-	m->dev.stack_levels = (int32_t)std::min<uint32_t>(m->B.depth + 1, kStackDepth);
-	for (int d = 0; d < 3; ++d)
-		m->dev.origin[d] = m->B.origin[d];
-	m->dev.n_sub = (int32_t)m->B.sub_roots.size();
-	for (size_t i = 0; i < (size_t)kSubtrees; ++i)
-		m->dev.sub_roots[i] = i < m->B.sub_roots.size() ? m->B.sub_roots[i] : m->B.root_info;
+	dg::host::mesh_view(m->B, m->dev);
 	return m;
 }
 void emu_mesh_free(void* h) { delete static_cast<HostMesh*>(h); }
@@ -804,6 +577,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 			{
 				// k_sample_fast
 				FastLane fl[64];
+				FastLists lists;
 				FastStats fs;
 				fs.bricks = 1;
 				bool exact[64];
@@ -813,15 +587,12 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 					fl[l].a = make_approx_lane(w.q[l].px - P.mesh.origin[0], w.q[l].py - P.mesh.origin[1],
 											   w.q[l].pz - P.mesh.origin[2], P.mesh.mesh_l1);
 					exact[l] = sample[l] && !(fl[l].a.E < __builtin_inff());
-					fl[l].U = (sample[l] && !exact[l]) ? __builtin_inff() : -__builtin_inff();
-					fl[l].Uprune = fl[l].U;
-					fl[l].Lmin = __builtin_inff();
-					fl[l].cnt = 0;
+					init_fast_lane(fl[l], sample[l] && !exact[l], FastLists::base(l));
 					any_fast = any_fast || (sample[l] && !exact[l]);
 				}
 				if (any_fast)
 				{
-					slot = traverse_fast(P.mesh, fl, fs, &P.ovf);
+					slot = walk_fast(P.mesh, fl, lists, fs, &P.ovf);
 					if (slot >= 0) // parked as a heavy brick with the upper bounds as seeds
 					{
 						fs.parked = 1;
@@ -834,7 +605,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 					}
 					else
 						for (int l = 0; l < 64; ++l)
-							exact[l] = exact[l] || (sample[l] && (slot == -2 || fl[l].cnt >= kFastListCap));
+							exact[l] = exact[l] || (sample[l] && (slot == -2 || FastLists::count(fl[l], l) >= kFastListCap));
 				}
 				if (slot < 0)
 				{
@@ -851,7 +622,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 							if (exact[l] && fl[l].U > 0.0f)
 								wx.q[l].bestf = best_as_float((double)fl[l].U);
 						}
-						slot2 = traverse(P.mesh, wx, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr, true);
+						slot2 = walk_exact(P.mesh, wx, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr, true);
 					}
 					if (slot2 >= 0)
 					{
@@ -878,13 +649,14 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 								continue;
 							}
 							fs.lanes++;
-							fs.sum_list += fl[l].cnt;
-							fs.hist[fl[l].cnt]++;
-							mx = fl[l].cnt > mx ? fl[l].cnt : mx;
+							const int n_cand = FastLists::count(fl[l], l);
+							fs.sum_list += n_cand;
+							fs.hist[n_cand]++;
+							mx = n_cand > mx ? n_cand : mx;
 							int need = 0;
-							for (int k = 0; k < fl[l].cnt; ++k)
+							for (int k = 0; k < n_cand; ++k)
 							{
-								const int t = fl[l].list[k];
+								const int t = lists.at(l, k);
 								const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
 								offer(w.q[l], h.d2, t);
 								need += h.d2 <= (double)fl[l].U * 1.00001;
@@ -906,8 +678,8 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 						for (int l = 0; l < 64 && !win; ++l)
 						{
 							if (!sample[l]) continue;
-							for (int k = 0; k < fl[l].cnt; ++k)
-								if (fl[l].list[k] >= lf.first && fl[l].list[k] < lf.first + lf.second)
+							for (int k = 0; k < FastLists::count(fl[l], l); ++k)
+								if (lists.at(l, k) >= lf.first && lists.at(l, k) < lf.first + lf.second)
 									cand = true;
 							if (w.q[l].best_tri >= lf.first && w.q[l].best_tri < lf.first + lf.second)
 								win = true;
@@ -930,7 +702,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 				continue;
 			}
 			if (any)
-				slot = traverse(P.mesh, w, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
+				slot = walk_exact(P.mesh, w, ls, P.mesh.root_info, P.ovf.count ? &P.ovf : nullptr);
 			if (slot >= 0) // k_sample_nodes parks the wave
 			{
 				P.ovf.brick[slot] = (uint32_t)brick;
@@ -976,7 +748,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 				else if (sample[l] && P.ovf.saved_tri[slot * 64 + l] == kSeedOnly)
 					w.q[l].bestf = fmin2(w.q[l].bestf, best_as_float(P.ovf.saved_d2[slot * 64 + l]));
 			}
-			traverse(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
+			walk_exact(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
 			for (int l = 0; l < 64; ++l)
 			{
 				const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)l;
@@ -1023,7 +795,7 @@ void emu_host_signed_distance(void* h, const double* xyz, uint64_t n, int thread
 	for (long long i = 0; i < (long long)n; ++i)
 	{
 		LaneResult r;
-		if (!dg::host::signed_distance_point(m->B, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], r))
+		if (!dg::host::signed_distance_point(m->dev, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], r))
 		{
 			dist[i] = 1.7976931348623157e308;
 			if (tri) tri[i] = -1;
@@ -1066,7 +838,7 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 			g_fs.add(fs);
 		}
 		else
-			traverse(m->dev, w, st, m->dev.root_info, nullptr);
+			walk_exact(m->dev, w, st, m->dev.root_info, nullptr);
 		for (int l = 0; l < 64; ++l)
 		{
 			const uint64_t gid = (uint64_t)wv * 64 + l;
@@ -1108,7 +880,7 @@ void emu_points_work(void* h, const double* xyz, uint64_t n, uint64_t* stats /*4
 			const uint64_t g = gid < n ? gid : n - 1;
 			init_query(m->dev.origin, m->dev.mesh_l1, gid < n, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
 		}
-		traverse(m->dev, w, st, m->dev.root_info, nullptr);
+		walk_exact(m->dev, w, st, m->dev.root_info, nullptr);
 		nv += st.node_visits;
 		tt += st.tri_tests;
 		lg += st.leaf_groups;
