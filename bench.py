@@ -852,10 +852,10 @@ def main():
                 "unit": "fraction of the VALU issue cycles of the %d SIMDs" % N_SIMDS,
                 "frac": k1["valu_busy"] if k1 else None,
                 "traffic": k1["hbm_bytes_per_launch"] if k1 else None,
-                # one dg_sdf_sample_*_device call = k_sample_fast (the filtered K1 kernel; k_sample_nodes with DG_K1_FAST=0)
+                # one dg_sdf_sample_*_device call = k_sample_fast (the filtered K1 kernel; k_sample_nodes with DG_FORCE=k1_fast=0)
                 # + the two heavy-brick kernels (4 % of it); kernel_ms: HIP events around the call, in the timed region
                 "kernel": "%s (+ k_heavy_subtrees, k_heavy_finish)" % ((k1 or {}).get("kernel") or
-                          ("k_sample_nodes" if os.environ.get("DG_K1_FAST") == "0" else "k_sample_fast")),
+                          ("k_sample_nodes" if "k1_fast=0" in os.environ.get("DG_FORCE", "") else "k_sample_fast")),
                 "kernel_ms": kernel_ms,
                 "hbm": {
                     "bound_by_hbm": False,

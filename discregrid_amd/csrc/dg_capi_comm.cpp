@@ -661,10 +661,10 @@ static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, Pee
 				if (all[(size_t)q].pid == rec.pid)
 					return fail(DG_ERR_INVALID, "ranks %d and %d live in one process: DG_EXCHANGE_COPY is one process per rank", q, r);
 		}
-		// -- step 4: the ranks map each other's fields ONE RANK AT A TIME (DG_IPC_STAGGER=0: all at once): four processes that
+		// -- step 4: the ranks map each other's fields ONE RANK AT A TIME (DG_FORCE=ipc_stagger=0: all at once): four processes that
 		// opened each other's handles simultaneously never returned from hipIpcOpenMemHandle on the box this was developed
 		// on (two did), and the set-up happens once per field.  A rank whose open fails keeps taking part in the barriers.
-		const bool stagger = env_int("DG_IPC_STAGGER", 1, 0, 1) != 0;
+		const bool stagger = force_int("ipc_stagger", 1, 0, 1) != 0;
 		uint64_t my_open_status = 0; // 0: every peer mapped; else 1 + the rank whose field could not be mapped
 		std::string my_open_error;
 		dg_status barrier_failure = DG_OK;

@@ -599,12 +599,13 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	dg::layout_range(L, sdf->grid.resolution, node_begin, node_end);
 	L.mask = d_pred_mask;
 	L.out = d_out;
-	L.brick_blocking = env_int("DG_K3_BLOCKED", 1, 0, 1);
-	P.lds_waves = env_int("DG_K3_LDS", 0, 0, 3); // experiment: coefficients staged through LDS (measured slower)
+	L.brick_blocking = force_int("k3_blocked", 1, 0, 1);
 	const bool unreduced_field = dev.cells == nullptr && dev.cell_map == nullptr;
-	// An eighth of the lattice or more of an unreduced field: row-block waves on the x-major copy (k_density_rows; DG_K3_ROWS=0: the cube-shaped
-	// waves of k_density_pairs on the tile-major copy, 1..5: lane shapes, dg_layout.h row_shape_lanes()).  The copy (Y and Z
-	// classes with x fastest, 0.57 x the field) and the per-cell "no value" bits are stream-ordered scratch of this launch.
+	// An eighth of the lattice or more of an unreduced field: k_density_cells -- one lane per lattice POINT with its seven nodes
+	// (dg_density_cells.h: 3 cell fetches per 7 nodes and quadrature point, one sweep of the field for all node classes) on the
+	// x-major copy of the Y / Z classes (x fastest, 0.57 x the field).  The copy and the per-cell "no value" bits are
+	// stream-ordered scratch of this launch.  Everything else (reduced fields, short node ranges, classes beyond 32-bit
+	// offsets; DG_FORCE=k3_cells=0) is the brick kernel.
 	// (scratch slots go back to their pools on EVERY way out of this function: a slot left busy is never handed out again)
 	struct SlotGuard
 	{
@@ -615,10 +616,7 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	};
 	int rows_idx = -1;
 	SlotGuard rows_guard{sdf->tile_scratch, rows_idx, st};
-	int rows_shape = env_int("DG_K3_ROWS", 1, 0, 4);
-	if (rows_shape == 2 || rows_shape == 3)
-		rows_shape = 1; // (lane shapes measured slower are not instantiated)
-	if (unreduced_field && rows_shape != 0 && (node_end - node_begin) * 8 >= total && P.lds_waves == 0 && env_int("DG_K3_PAIRS", 2, 0, 3) != 0)
+	if (unreduced_field && (node_end - node_begin) * 8 >= total && dg::k3c_geometry_fits(dev.res) && force_int("k3_cells", 1, 0, 1) != 0)
 	{
 		const size_t copy_bytes = ((size_t)dg::xmajor_doubles(dev.res) * sizeof(double) + 255) & ~(size_t)255;
 		const size_t flag_bytes = (size_t)dev.res[2] * dev.res[1] * dg::xmajor_flag_words(dev.res) * sizeof(uint64_t);
@@ -632,19 +630,11 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 			// kernel ms / L2 hit rate): 1 x 16 x 8 472 / 0.890, 1 x 12 x 8 466 / 0.894, 1 x 8 x 8 468 / 0.853, 1 x 6 x 22 462 / 0.899,
 			// 1 x 3 x 43 467 / 0.864, 1 x 2 x 64 465 / 0.816, 1 x 8 x 16 489 / 0.911 -- moderately tall in z: the quadrature's
 			// innermost loop sweeps z, so the waves of a block read what their z-neighbours read a step ago
-			const bool cells_kernel = env_int("DG_K3_CELLS", 1, 0, 1) != 0 && dg::k3c_geometry_fits(dev.res);
-			const uint32_t block[3] = {(uint32_t)env_int("DG_K3_RB0", 1, 1, 256), (uint32_t)env_int("DG_K3_RB1", cells_kernel ? 6 : 16, 1, 256),
-									   (uint32_t)env_int("DG_K3_RB2", cells_kernel ? 22 : 8, 1, 256)};
-			// round 4: one lane per lattice POINT with its seven nodes (k_density_cells, dg_density_cells.h: 3 cell fetches per 7
-			// nodes and quadrature point instead of 5, one sweep of the field instead of one per node class); DG_K3_CELLS=0: the
-			// row-block kernel with one node / edge per lane
-			if (cells_kernel)
-				dg::layout_density_cells(P, L, sdf->grid.resolution, block);
-			else
-				dg::layout_density_rows(P, L, sdf->grid.resolution, rows_shape, block);
+			const uint32_t block[3] = {(uint32_t)force_int("k3_rb0", 1, 1, 256), (uint32_t)force_int("k3_rb1", 6, 1, 256),
+									   (uint32_t)force_int("k3_rb2", 22, 1, 256)};
+			dg::layout_density_cells(P, L, sdf->grid.resolution, block);
 			P.row_node_begin = node_begin;
 			P.row_node_end = node_end;
-			P.row_waves3 = env_int("DG_K3_WAVES3", 1, 0, 1); // (3 waves per SIMD: 256^3 0.666 -> 0.618 s; the spilled registers belong to the prefilter)
 		}
 		else
 		{
@@ -653,18 +643,11 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 			rows_idx = -1;
 		}
 	}
-	if (rows_idx >= 0)
-		;
-	else if (unreduced_field && env_int("DG_K3_PAIRS", 2, 0, 3) != 0 && P.lds_waves == 0)
-	{
-		dg::pair_bricks(L); // two edge nodes per lane: the pair shares its cell's coefficients two times out of three
-		L.pair_nodes = env_int("DG_K3_PAIRS", 2, 0, 3); // (2 / 3: waves per SIMD asked of the register allocator)
-	}
 	// zero-weight quadrature points are skipped unless the field holds non-finite / huge values (checked
-	// on the device before every launch: an attached device array may have changed); DG_K3_SKIP=0: never
+	// on the device before every launch: an attached device array may have changed); DG_FORCE=k3_skip=0: never
 	int flag_idx = -1; // the flag k_field_check writes belongs to this launch (stream-ordered scratch)
 	SlotGuard flag_guard{sdf->flag_scratch, flag_idx, st};
-	const bool skip_points = env_int("DG_K3_SKIP", 1, 0, 1) != 0 && support_radius >= 1.0e-12;
+	const bool skip_points = force_int("k3_skip", 1, 0, 1) != 0 && support_radius >= 1.0e-12;
 	// (always: besides the values that forbid the skip, k_field_check reports whether the field holds "no value" coefficients at all)
 	{
 		void* d_flag = nullptr;
@@ -677,11 +660,11 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
 	// Unreduced field without a tile-major copy: build one for this launch (stream-ordered scratch, built from
 	// the coefficients as they are NOW -- an attached device array may have changed since the last call).  One
 	// pass over the field against 1 + 4096 interpolations per integrated node: 128^3 161 -> 135 ms
-	// (DG_K3_TILES=0: off).  Launches over a small part of the lattice are not worth the pass.
+	// (DG_FORCE=k3_tiles=0: off).  Launches over a small part of the lattice are not worth the pass.
 	int tile_idx = -1;
 	SlotGuard tile_guard{sdf->tile_scratch, tile_idx, st};
 	if (rows_idx < 0 && dev.tile_major == nullptr && dev.cell_major == nullptr && dev.cells == nullptr && dev.cell_map == nullptr &&
-		env_int("DG_K3_TILES", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
+		force_int("k3_tiles", 1, 0, 1) != 0 && (node_end - node_begin) * 8 >= total)
 	{
 		const uint64_t n_tiles = (uint64_t)dev.ntile[0] * dev.ntile[1] * dev.ntile[2];
 		void* d_tiles = nullptr;
@@ -745,15 +728,15 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	if (copy_ready) // the copy may still be being built on another stream
 		DG_HIP(hipStreamWaitEvent(st, copy_ready, 0));
 	// A field with a cell-major copy: one contiguous row per query, fetched cooperatively -- the order of the queries
-	// does not matter, nothing is sorted (DG_K2_ROWS=0: the binned / per-lane kernels on the copy, as in round 1).
-	if (dev.cell_major != nullptr && dev.tile_major == nullptr && env_int("DG_K2_ROWS", 1, 0, 1) != 0)
+	// does not matter, nothing is sorted (DG_FORCE=k2_rows=0: the binned / per-lane kernels on the copy, as in round 1).
+	if (dev.cell_major != nullptr && dev.tile_major == nullptr && force_int("k2_rows", 1, 0, 1) != 0)
 	{
 		DG_HIP(dg::launch_interpolate_rows(dev, d_xyz, n, d_phi, d_grad, st));
 		return DG_OK;
 	}
 	// A field with a band-limited cell-major copy (and no full one): rows for the queries inside the band, the plain gather
-	// for the others, in one launch, queries in any order (DG_K2_BAND=0: ignore the copy)
-	if (dev.band_rows != nullptr && dev.cell_major == nullptr && dev.tile_major == nullptr && env_int("DG_K2_BAND", 1, 0, 1) != 0)
+	// for the others, in one launch, queries in any order (DG_FORCE=k2_band=0: ignore the copy)
+	if (dev.band_rows != nullptr && dev.cell_major == nullptr && dev.tile_major == nullptr && force_int("k2_band", 1, 0, 1) != 0)
 	{
 		if (band_ready)
 			DG_HIP(hipStreamWaitEvent(st, band_ready, 0));
@@ -762,8 +745,8 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	}
 	// Large batches against a field that does not fit the L2s go through the binned path (queries in
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and
-	// run as they are).  DG_K2_BINNING=0 switches it off, =2 forces it for any size.
-	const int binning = env_int("DG_K2_BINNING", 1, 0, 2);
+	// run as they are).  DG_FORCE=k2_binning=0 switches it off, =2 forces it for any size.
+	const int binning = force_int("k2_binning", 1, 0, 2);
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
 		dg::BinScratch S;

@@ -241,11 +241,11 @@ struct HostTarget // RAII: the registrations end with the call
 };
 // May [out, out + bytes) -- an array this call overwrites completely -- become a DMA target?  Returns false if
 // the staged form should run instead (array already resident in pages of unknown size, or switched off with
-// DG_HOST_DIRECT=0; =2 takes the direct form whatever the state of the pages).  Nothing is touched or pinned yet:
+// DG_FORCE=host_direct=0; =2 takes the direct form whatever the state of the pages).  Nothing is touched or pinned yet:
 // prepare_host_piece() does that range by range, so that the first copies run while the rest is prepared.
 bool begin_host_target(void* out, size_t bytes, HostTarget& T)
 {
-	const int mode = env_int("DG_HOST_DIRECT", 1, 0, 2);
+	const int mode = force_int("host_direct", 1, 0, 2);
 	if (mode == 0 || (mode != 2 && bytes < (1u << 22)))
 		return false;
 	T.out = static_cast<char*>(out);
@@ -394,11 +394,13 @@ void schedule_cuts(const uint32_t res[3], uint64_t node_begin, uint64_t node_end
 	}
 	cuts.push_back(node_end);
 }
-// chunk sizes of the direct form as fractions of the range (DG_HOST_DIRECT_FRACTIONS="0.1,0.2,...": experiments)
-std::vector<double> parse_fractions(std::vector<double> f, const char* env_name)
+// chunk sizes of the direct form as fractions of the range (DG_FORCE=host_direct_fractions=0.1,0.2,...: experiments)
+std::vector<double> parse_fractions(std::vector<double> f, const char* force_key)
 {
-	if (const char* e = std::getenv(env_name))
+	std::string forced;
+	if (dg::force_lookup(force_key, forced))
 	{
+		const char* e = forced.c_str();
 		std::vector<double> g;
 		double sum = 0;
 		for (const char* p = e; *p;)
@@ -423,13 +425,13 @@ std::vector<double> parse_fractions(std::vector<double> f, const char* env_name)
 	}
 	return f;
 }
-std::vector<double> direct_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "DG_HOST_DIRECT_FRACTIONS"); }
+std::vector<double> direct_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "host_direct_fractions"); }
 // dg_sdf_sample_field: ONE profile for callers that read the field on the device next and for callers that wait for the
 // host vector (round 4).  The copy engine moves 57 GB/s, K1 produces 64 GB/s: the copy must start early and never run
 // dry, so the chunks are fine and shrink towards the end (the last copy is what the host waits for after the last kernel).
 // Measured at 256^3 on one stream (ms until the field is complete on the device / in the host vector; one launch then
 // eight copy pieces: 16.4 / 34.7): 3 chunks 17.2 / 27.2, 4 chunks 19.0 / 25.3, 5 chunks 18.1 / 23.1, these seven 18.3 / 21.6.
-std::vector<double> field_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "DG_FIELD_FRACTIONS"); }
+std::vector<double> field_fractions() { return parse_fractions({0.22, 0.22, 0.20, 0.16, 0.11, 0.06, 0.03}, "field_fractions"); }
 } // namespace
 
 // One array of a pipelined host-pointer call: read from the host (`in`) or written back to it (`out`),
@@ -557,9 +559,9 @@ static dg_status run_k1_chunks(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 // of the bytes chunk i ends in), one piece ahead of the copy that needs it: preparing the whole array first took 6 ms
 // of a 23 ms call at 256^3 during which no copy ran; piece by piece the preparation costs more in total (~1.4 ms per
 // registration) but hides behind the sampling, and the call ends one kernel tail after the last chunk: 23.0 -> 21.9 ms
-// on the same box (DG_HOST_PIECES=0: the whole array at once, as before).  Measured and not kept: the chunks alternating
+// on the same box (DG_FORCE=host_pieces=0: the whole array at once, as before).  Measured and not kept: the chunks alternating
 // between two compute streams so that a chunk's tail runs under the next chunk's bulk (25.0 ms: the two launches slow
-// each other down by more than the tails they hide), other chunk size profiles (DG_HOST_DIRECT_FRACTIONS).
+// each other down by more than the tails they hide), other chunk size profiles (DG_FORCE=host_direct_fractions=...).
 // `begin` (cheap: mode, size, page state) runs before anything is enqueued: may the direct form run at all?  If it
 // says no the caller runs the staged form and nothing was sampled twice; only if a PIECE cannot be prepared later
 // (registration fails) are the chunks in flight given up and the staged form run over the whole range.
@@ -590,7 +592,7 @@ static dg_status run_k1_direct(HostPipe& pipe, const dg_mesh* mesh, const dg_gri
 	dg_status st = DG_OK;
 	// piece i = bytes [bound[i], bound[i + 1]) of the array: chunk i's bytes end in it.  Interior bounds are the chunk
 	// starts rounded up to 2 MiB (of the address), so a chunk may begin in the last 2 MiB of the piece before.
-	const bool by_piece = env_int("DG_HOST_PIECES", 1, 0, 1) != 0;
+	const bool by_piece = force_int("host_pieces", 1, 0, 1) != 0;
 	const bool pieces = (bool)host.piece && stride == 1 && first == 0 && by_piece;
 	const size_t total_bytes = (size_t)(cuts[n_chunks] - cuts[0]) * sizeof(double);
 	std::vector<size_t> bound(mine.size() + 1, 0);
@@ -793,7 +795,7 @@ struct HostCopyJob
 			bound[i] = std::max(bound[i - 1], std::min<size_t>(total, (size_t)(up - (uintptr_t)h_dst)));
 		}
 		size_t next = 0; // first segment that has not been enqueued / copied
-		const bool debug = std::getenv("DG_HOST_DEBUG") != nullptr;
+		const bool debug = dg::force_set("host_debug");
 		if (debug)
 			std::fprintf(stderr, "  host copy job: started after %.2f ms, %s\n",
 						 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3, direct ? "direct" : "blocking copies");
@@ -870,7 +872,7 @@ dg_status finish_host_job(dg_field* field)
 		return DG_OK;
 	const dg_status st = job->status;
 	const std::string msg = job->message;
-	if (std::getenv("DG_HOST_DEBUG"))
+	if (dg::force_set("host_debug"))
 		std::fprintf(stderr, "host copy job: %s, %zu segments, %.1f ms\n", job->direct ? "direct" : "blocking copies", job->ev.size(),
 					 job->seconds * 1e3);
 	{
@@ -994,7 +996,7 @@ static dg_status upload_producer_mask(dg_field* f, const uint8_t* pred_mask, uin
 // items [0, n) in uniform chunks (K1p, K2): big enough to amortise the launches, small enough to overlap
 static void uniform_cuts(uint64_t n, int default_chunk, std::vector<uint64_t>& cuts)
 {
-	const uint64_t chunk = (uint64_t)env_int("DG_HOST_CHUNK_ITEMS", default_chunk, 1 << 8, 1 << 28);
+	const uint64_t chunk = (uint64_t)force_int("host_chunk_items", default_chunk, 1 << 8, 1 << 28);
 	cuts.clear();
 	for (uint64_t at = 0; at < n; at += chunk)
 		cuts.push_back(at);
@@ -1032,12 +1034,12 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		return s;
 	// ~10 chunks per call (every chunk costs a kernel tail, ~0.4 ms), 32..256 MiB of results each
 	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
-	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
+	const uint64_t target = (uint64_t)force_int("host_chunk_nodes", (int)auto_target, 1 << 10, 1 << 28);
 	std::vector<uint64_t> cuts, direct_cuts;
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
 	// direct form: seven chunks, the last one small -- its copy is the only one nothing overlaps
-	// (DG_HOST_CHUNK_NODES set: the uniform chunks above, as in the staged form)
-	if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
+	// (DG_FORCE=host_chunk_nodes set: the uniform chunks above, as in the staged form)
+	if (dg::force_set("host_chunk_nodes") || n < (1u << 24))
 		direct_cuts = cuts;
 	else
 		schedule_cuts(grid->resolution, node_begin, node_end, direct_fractions(), direct_cuts);
@@ -1054,7 +1056,7 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		const auto t0 = std::chrono::steady_clock::now();
 		const bool ok = prepare_host_piece(host_target, lo, hi);
 		const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-		if (std::getenv("DG_HOST_DEBUG"))
+		if (dg::force_set("host_debug"))
 			std::fprintf(stderr, "  piece [%zu, %zu) MiB prepared in %.2f ms\n", lo >> 20, hi >> 20, dt * 1e3);
 		t_prepare += dt;
 		return ok;
@@ -1069,7 +1071,7 @@ dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		return s;
 	progress.report(n);
 	g_last_ms = kernel_ms;
-	if (std::getenv("DG_HOST_DEBUG"))
+	if (dg::force_set("host_debug"))
 		std::fprintf(stderr, "dg_sdf_sample_nodes: %s, %zu chunks, kernels %.1f ms, host prepared the array in %.1f ms, waited %.1f ms, copied %.1f ms\n",
 					 direct ? "direct" : "staged", (direct ? direct_cuts : cuts).size() - 1, kernel_ms, t_prepare * 1e3, t_wait * 1e3, t_copy * 1e3);
 	return DG_OK;
@@ -1090,7 +1092,7 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		return s;
 	const uint64_t n = dg_grid_n_nodes(grid);
 	DG_ON_DEVICE_OF(mesh);
-	const bool debug = std::getenv("DG_HOST_DEBUG") != nullptr;
+	const bool debug = dg::force_set("host_debug");
 	const auto t_begin = std::chrono::steady_clock::now();
 	dg_field* f = nullptr;
 	s = new_produced_field(grid, n, &f);
@@ -1117,10 +1119,10 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		for (uint64_t i = 0; i <= pieces; ++i)
 			copy_cuts.push_back(i == pieces ? n : ((n / pieces * i) & ~(uint64_t)511));
 	}
-	else if (std::getenv("DG_HOST_CHUNK_NODES") || n < (1u << 24))
+	else if (dg::force_set("host_chunk_nodes") || n < (1u << 24))
 	{
 		const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / 10, 1u << 22), 1u << 25);
-		chunk_cuts(grid->resolution, 0, n, (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28), cuts);
+		chunk_cuts(grid->resolution, 0, n, (uint64_t)force_int("host_chunk_nodes", (int)auto_target, 1 << 10, 1 << 28), cuts);
 	}
 	else
 	{
@@ -1150,13 +1152,13 @@ dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int
 		job->after_kernel = !copy_cuts.empty();
 	}
 	hipError_t e = hipSuccess;
-	// DG_FIELD_STREAMS=2: the chunks alternate between the field's stream and a second one, so that a chunk's last waves
+	// DG_FORCE=field_streams=2: the chunks alternate between the field's stream and a second one, so that a chunk's last waves
 	// (and its two small heavy-brick kernels) do not run alone.  Measured at 256^3: 18.5 / 21.7 ms (device / host complete)
 	// against 18.6 / 21.8 on one stream -- nothing: the 2.2 ms the chunks cost a consumer on the device against one launch
 	// (16.3 ms) are not tails.  Off by default.
 	hipStream_t second = nullptr;
 	hipEvent_t second_done = nullptr;
-	if (cuts.size() > 2 && env_int("DG_FIELD_STREAMS", 1, 1, 2) == 2)
+	if (cuts.size() > 2 && force_int("field_streams", 1, 1, 2) == 2)
 	{
 		if (g_streams.take(mesh->device, 0, &second) != hipSuccess)
 			second = nullptr;
@@ -1334,7 +1336,7 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
 			return fail(DG_ERR_NO_DEVICE, "meshes[%d] is a host-only handle (dg_mesh_device() < 0)", i);
 	// chunks are dealt round-robin: thin interleaved pieces equalise the very uneven cost per node
 	const uint64_t auto_target = std::min<uint64_t>(std::max<uint64_t>(n / (10ull * (uint64_t)n_meshes), 1u << 21), 1u << 25);
-	const uint64_t target = (uint64_t)env_int("DG_HOST_CHUNK_NODES", (int)auto_target, 1 << 10, 1 << 28);
+	const uint64_t target = (uint64_t)force_int("host_chunk_nodes", (int)auto_target, 1 << 10, 1 << 28);
 	std::vector<uint64_t> cuts;
 	chunk_cuts(grid->resolution, node_begin, node_end, target, cuts);
 	std::vector<dg_status> status((size_t)n_meshes, DG_OK);

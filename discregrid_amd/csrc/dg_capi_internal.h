@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "dg_build.h"
+#include "dg_force.h"
 #include "dg_kernels.h"
 #include "dg_layout.h"
 
@@ -225,7 +226,8 @@ extern thread_local double g_last_ms;     // dg_last_kernel_ms()
 dg_status fail(dg_status s, const char* fmt, ...);
 dg_status require_device();
 bool valid_grid(const dg_grid_desc* g);
-int env_int(const char* name, int fallback, int lo, int hi);
+int env_int(const char* name, int fallback, int lo, int hi); // a DOCUMENTED variable; test hooks / tuning: force_int (dg_force.h)
+using dg::force_int;
 uint32_t env_xcd_chunk();
 // binning scratch of a K1p / K2 batch (dg_kernels.h: BinScratch): fills S from `pool`; *flag_host is the
 // handle's pinned prediction word (allocated on first use).  Returns the pool index or -1 (no binning).

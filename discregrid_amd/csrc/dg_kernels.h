@@ -24,10 +24,10 @@ static const int kWavesPerBlock = DG_WAVES_PER_BLOCK; // K1: one brick per wave
 // BVH for every parked brick in its own wave (starting from the parked bests), and a third kernel
 // takes the per-lane minimum over the subtrees and writes the node values.  min is exact, so the
 // result is the one the single wave would have produced.
-#ifndef DG_HEAVY_SLOTS
-#define DG_HEAVY_SLOTS 2048
+#ifndef DG_OVERFLOW_SLOTS
+#define DG_OVERFLOW_SLOTS 2048
 #endif
-static const int kOverflowSlots = DG_HEAVY_SLOTS; // most bricks one launch can park (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
+static const int kOverflowSlots = DG_OVERFLOW_SLOTS; // most bricks one launch can park (12 B x 64 lanes x kSubtrees of scratch each); further heavy bricks simply run on
 static const int kHeavyWork = 1600;     // traversal steps + exact triangle tests before a brick counts as heavy (~0.7 ms of one wave)
 // Budget of a brick for a mesh of n_positions triangle slots.  Cutting a brick's search over the
 // top-level subtrees pays only when it needs a sizeable part of the WHOLE tree; a brick whose 64
@@ -473,6 +473,10 @@ hipError_t reduce_field_device(const uint32_t res[3], const double dmin[3], cons
 							   const double* d_coeffs, uint64_t n, const ReducePredicate& pred, ReduceResult& out, hipStream_t stream);
 
 size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles); // rocPRIM's requirement for n pairs
+// the binning passes shared by K2 and K1p (dg_kernels_k2.hip): probe (always) and -- if the host predicts an unordered batch
+// (S.sort_launched) -- tile keys + radix sort, which leaves the processing order in S.perm
+hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in,
+						  hipStream_t stream);
 inline size_t bin_scratch_bytes(uint32_t n_tiles, uint64_t n, size_t off[6])
 {
 	size_t o = 0;

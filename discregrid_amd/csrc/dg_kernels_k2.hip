@@ -1,0 +1,567 @@
+// dg_kernels_k2.hip -- K2: batched CubicLagrangeDiscreteGrid::interpolate (cubic_lagrange_discrete_grid.cpp:977-1063): k_interpolate*,
+// the device-side binning of unordered query batches (also used by K1p) and the optional copies of a field (cell-major, band-limited,
+// tile-major).
+// Compile with -ffp-contract=off (parity) -- see discregrid_amd/build.py.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <stdint.h>
+#include <algorithm>
+#include "dg_kernels.h"
+#include "dg_device.h"
+
+namespace dg
+{
+namespace
+{
+
+// ------------------------------------------------------------------------------------------------
+// K2: one thread per query point.  The 32-term sum must run in j order for parity, so the
+// evaluation is per-lane; the 32 coefficients are fetched as 16 x 16-byte pairs (closed-form
+// rows) with all loads issued before the first use.
+// ------------------------------------------------------------------------------------------------
+// XCD-aware block order for K2: the hardware deals consecutive workgroups to the 8 XCDs in turn, so eight
+// neighbouring blocks of queries -- which, in tile order, gather from the same coefficient lines -- would
+// each pull those lines into a different L2.  Chunks of kK2XcdChunk consecutive LOGICAL blocks (one
+// chunk = what an XCD holds in flight) go to one XCD instead.  Returns false for padding blocks.
+#ifndef DG_K2_XCD_CHUNK
+#define DG_K2_XCD_CHUNK 256
+#endif
+static const uint32_t kK2XcdChunk = DG_K2_XCD_CHUNK;
+__device__ __forceinline__ bool k2_logical_block(uint32_t block_idx, uint32_t n_blocks, uint32_t* blk)
+{
+	if (kK2XcdChunk == 0)
+	{
+		*blk = block_idx;
+		return block_idx < n_blocks;
+	}
+	const uint32_t xcd = block_idx & 7u, within = block_idx >> 3;
+	const uint32_t b = ((within / kK2XcdChunk) * 8u + xcd) * kK2XcdChunk + within % kK2XcdChunk;
+	*blk = b;
+	return b < n_blocks;
+}
+static uint32_t k2_grid(uint64_t n)
+{
+	const uint32_t blocks = (uint32_t)((n + 255) / 256);
+	if (kK2XcdChunk == 0)
+		return blocks;
+	const uint32_t round = 8u * kK2XcdChunk;
+	return (blocks + round - 1) / round * round;
+}
+
+// Occupancy matters more than anything else for this gather-latency bound kernel: left alone the compiler keeps all
+// 32 coefficients AND all 32 shape functions in registers (132 / 154 VGPRs, 3 waves per SIMD); asked for more
+// waves it forms the shape functions where they are consumed.
+#ifndef DG_K2_WAVES
+#define DG_K2_WAVES 3
+#endif
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+													  double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	uint32_t blk;
+	if (!k2_logical_block(blockIdx.x, (uint32_t)((n + 255) / 256), &blk))
+		return;
+	const uint64_t gid = (uint64_t)blk * blockDim.x + threadIdx.x;
+	if (gid >= n)
+		return;
+	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
+	double g[3];
+	phi_out[gid] = interpolate_point_mode<GRAD, MODE>(F, x, g);
+	if (GRAD)
+	{
+		grad_out[3 * gid] = g[0];
+		grad_out[3 * gid + 1] = g[1];
+		grad_out[3 * gid + 2] = g[2];
+	}
+}
+
+// ---- K2 query binning (dg_kernels.h: BinScratch) ---------------------------------------------------------
+__device__ __forceinline__ uint32_t tile_of(const TileGrid& G, const double* __restrict__ xyz, uint64_t i)
+{
+	uint32_t t[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d)
+	{
+		const double u = (xyz[3 * i + d] - G.origin[d]) * G.inv_size[d];
+		uint32_t c = u > 0.0 ? (uint32_t)(u < 4.0e9 ? u : 4.0e9) : 0u; // NaN -> 0
+		t[d] = c < G.dims[d] ? c : G.dims[d] - 1;
+	}
+	return tile_key(G.dims, t);
+}
+// one block: how often do consecutive queries (among the first 4096) change tile?
+__global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S, uint32_t one_in)
+{
+	__shared__ uint32_t changes;
+	if (threadIdx.x == 0)
+		changes = 0;
+	__syncthreads();
+	const uint64_t m = n < 4096 ? n : 4096;
+	uint32_t mine = 0;
+	for (uint64_t i = threadIdx.x; i + 1 < m; i += blockDim.x)
+		mine += tile_of(F, xyz, i) != tile_of(F, xyz, i + 1);
+	atomicAdd(&changes, mine);
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const uint32_t unordered = ((uint64_t)one_in * changes > m) ? 1u : 0u; // more than one change of tile in `one_in` steps
+		S.flag[0] = unordered;
+		*(volatile uint32_t*)S.flag_host = unordered; // prediction for the handle's next batch
+	}
+}
+// sort keys: tile of every point, values: the point indices
+__global__ __launch_bounds__(256) void k_bin_keys(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+	{
+		S.keys[i] = tile_of(F, xyz, i);
+		S.vals[i] = (uint32_t)i;
+	}
+}
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate_binned(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+															 double* __restrict__ phi_out, double* __restrict__ grad_out, BinScratch S)
+{
+	uint32_t blk;
+	if (!k2_logical_block(blockIdx.x, (uint32_t)((n + 255) / 256), &blk))
+		return;
+	uint64_t gid = (uint64_t)blk * blockDim.x + threadIdx.x;
+	if (gid >= n)
+		return;
+	if (S.sort_launched != 0 && S.flag[0] != 0)
+		gid = S.perm[gid];
+	const double x[3] = {xyz[3 * gid], xyz[3 * gid + 1], xyz[3 * gid + 2]};
+	double g[3];
+	phi_out[gid] = interpolate_point_mode<GRAD, MODE>(F, x, g);
+	if (GRAD)
+	{
+		grad_out[3 * gid] = g[0];
+		grad_out[3 * gid + 1] = g[1];
+		grad_out[3 * gid + 2] = g[2];
+	}
+}
+
+// K2 over a field with a CELL-MAJOR copy, queries in ANY order, no binning: one wave = 64 queries.  A query's 32
+// coefficients are one contiguous 256-byte row of the copy; left to itself every lane would read its own row with
+// sixteen 16-byte loads, 64 different lines per instruction.  Here the wave fetches the 64 rows TOGETHER -- sixteen
+// loads, each covering four whole rows (lane = (row in the group, 16-byte piece)), i.e. four fully used 256-byte
+// segments per instruction --, hands them to their owners through LDS (rows padded to 33 doubles: the owners' reads are
+// conflict-free) and every lane then evaluates its own query exactly as interpolate_point_mode does (locate_query /
+// evaluate_cell: the same statements).  HBM moves 256 B + 24 B + 8 B per query whatever the order of the queries.
+static const int kRowStride = 33; // doubles per staged row
+template <bool GRAD>
+__global__ __launch_bounds__(64) void k_interpolate_rows(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+														   double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	__shared__ double rows[64 * kRowStride];
+	const int lane = (int)threadIdx.x;
+	const int sub = lane & 15, grp = lane >> 4;
+	for (uint64_t base = (uint64_t)blockIdx.x * 64u; base < n; base += (uint64_t)gridDim.x * 64u)
+	{
+		const uint64_t gid = base + (uint64_t)lane;
+		const bool have = gid < n;
+		double x[3] = {0.0, 0.0, 0.0};
+		if (have)
+		{
+			x[0] = xyz[3 * gid];
+			x[1] = xyz[3 * gid + 1];
+			x[2] = xyz[3 * gid + 2];
+		}
+		CellQuery q = locate_query(F, x);
+		q.valid = q.valid && have;
+		const uint32_t my_row = q.valid ? q.row : 0u; // (row 0 exists: a field has at least one cell row)
+		__syncthreads(); // the previous round's rows have been read
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const int owner = 4 * k + grp;
+			const uint32_t r = (uint32_t)__shfl((int)my_row, owner);
+			const double2 v = *reinterpret_cast<const double2*>(F.cell_major + 32 * (size_t)r + 2 * sub);
+			rows[owner * kRowStride + 2 * sub] = v.x;
+			rows[owner * kRowStride + 2 * sub + 1] = v.y;
+		}
+		__syncthreads();
+		double cf[32];
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			cf[j] = rows[lane * kRowStride + j];
+		double g[3] = {0.0, 0.0, 0.0};
+		double phi = 1.7976931348623157e308;
+		if (q.valid)
+			phi = evaluate_cell<GRAD>(cf, q.xi, q.c0, g);
+		if (have)
+		{
+			phi_out[gid] = phi;
+			if (GRAD)
+			{
+				grad_out[3 * gid] = g[0];
+				grad_out[3 * gid + 1] = g[1];
+				grad_out[3 * gid + 2] = g[2];
+			}
+		}
+	}
+}
+
+// K2 over a field with a BAND-LIMITED cell-major copy (FieldDev::band_rows / band_map): k_interpolate_rows for the queries
+// whose cell has a row in the copy -- the wave fetches those rows together, four whole rows per load instruction, owners
+// read them from LDS --, and in the same launch the plain gather (closed-form indices or the cell table) for the lanes
+// whose cell has none.  A load group whose owner has no row (or no query) is switched off, so a batch that lives in the
+// band moves 256 B per query and a batch far from it moves what the plain kernel moves plus 4 B of map.  Same
+// locate_query / evaluate_cell statements as every other K2 path: same bits.
+// (one lane's query of a round: located, and looked up in the band copy)
+struct BandQuery
+{
+	CellQuery q;
+	uint32_t row; // in the band copy, 0xffffffff: none (or no query)
+	bool have;
+};
+__device__ __forceinline__ BandQuery band_locate(const FieldDev& F, const double* __restrict__ xyz, uint64_t gid, uint64_t n)
+{
+	BandQuery b;
+	b.have = gid < n;
+	double x[3] = {0.0, 0.0, 0.0};
+	if (b.have)
+	{
+		x[0] = xyz[3 * gid];
+		x[1] = xyz[3 * gid + 1];
+		x[2] = xyz[3 * gid + 2];
+	}
+	b.q = locate_query(F, x);
+	b.q.valid = b.q.valid && b.have;
+	b.row = b.q.valid ? band_row_of(F, b.q.row) : 0xffffffffu;
+	return b;
+}
+template <bool GRAD, int MODE>
+__global__ __launch_bounds__(64) void k_interpolate_band(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
+														   double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	__shared__ double rows[64 * kRowStride];
+	const int lane = (int)threadIdx.x;
+	const int sub = lane & 15, grp = lane >> 4;
+	const uint64_t stride = (uint64_t)gridDim.x * 64u;
+	uint64_t base = (uint64_t)blockIdx.x * 64u;
+	if (base >= n)
+		return;
+	// The look-up (query -> cell -> bit / rank words -> row) is a chain of two dependent memory round trips in front of the
+	// row fetch; the wave therefore locates the queries of its NEXT round while the rows of the current one are in flight.
+	BandQuery cur = band_locate(F, xyz, base + (uint64_t)lane, n);
+	for (; base < n; base += stride)
+	{
+		const uint64_t gid = base + (uint64_t)lane;
+		const bool mapped = cur.row != 0xffffffffu;
+		__syncthreads(); // the previous round's rows have been read
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const int owner = 4 * k + grp;
+			// (owners without a row read row 0 -- it exists, and it is the same cached line for all of them --: unconditional
+			// loads let the sixteen fetches be in flight together; behind a branch each they ran one after the other, 11 instead
+			// of 18 Gq/s on a batch that lives in the band)
+			uint32_t r = (uint32_t)__shfl((int)cur.row, owner);
+			r = r != 0xffffffffu ? r : 0u;
+			const double2 v = *reinterpret_cast<const double2*>(F.band_rows + 32 * (size_t)r + 2 * sub);
+			rows[owner * kRowStride + 2 * sub] = v.x;
+			rows[owner * kRowStride + 2 * sub + 1] = v.y;
+		}
+		BandQuery nxt;
+		nxt.have = false;
+		nxt.row = 0xffffffffu;
+		nxt.q.valid = false;
+		if (base + stride < n) // (wave-uniform)
+			nxt = band_locate(F, xyz, base + stride + (uint64_t)lane, n);
+		__syncthreads();
+		double cf[32];
+		if (mapped)
+		{
+#pragma unroll
+			for (int j = 0; j < 32; ++j)
+				cf[j] = rows[lane * kRowStride + j];
+		}
+		else if (cur.q.valid)
+			fetch_cell<MODE>(F, cur.q.mi[0], cur.q.mi[1], cur.q.mi[2], cur.q.row, cf);
+		double g[3] = {0.0, 0.0, 0.0};
+		double phi = 1.7976931348623157e308;
+		if (cur.q.valid)
+			phi = evaluate_cell<GRAD>(cf, cur.q.xi, cur.q.c0, g);
+		if (cur.have)
+		{
+			phi_out[gid] = phi;
+			if (GRAD)
+			{
+				grad_out[3 * gid] = g[0];
+				grad_out[3 * gid + 1] = g[1];
+				grad_out[3 * gid + 2] = g[2];
+			}
+		}
+		cur = nxt;
+	}
+}
+// the band copy's builders: (1) per cell row, does any value the cell's 32 coefficients span reach into [lo, hi]?
+// (min <= hi and max >= lo: a cell that straddles a thin band counts); (2) after a scan of the flags: rows and map
+__device__ __forceinline__ void band_cell_indices(const FieldDev& F, uint64_t row, uint32_t idx[32])
+{
+	if (F.cells)
+	{
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			idx[j] = F.cells[32 * row + j];
+	}
+	else
+	{
+		const uint32_t n01 = F.res[0] * F.res[1];
+		const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+		cell_node_indices(r % F.res[0], r / F.res[0], k, F.res, idx);
+	}
+}
+__global__ __launch_bounds__(256) void k_band_flags(const FieldDev F, uint64_t n_rows, double lo, double hi, uint32_t* __restrict__ flag)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= n_rows)
+		return;
+	uint32_t idx[32];
+	band_cell_indices(F, row, idx);
+	double mn = F.coeffs[idx[0]], mx = mn;
+#pragma unroll
+	for (int j = 1; j < 32; ++j)
+	{
+		const double v = F.coeffs[idx[j]];
+		mn = v < mn ? v : mn;
+		mx = v > mx ? v : mx;
+	}
+	flag[row] = (mn <= hi && mx >= lo) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_band_expand(const FieldDev F, uint64_t n_rows, const uint32_t* __restrict__ flag,
+													   const uint32_t* __restrict__ pos, uint64_t* __restrict__ bits, uint32_t* __restrict__ rank,
+													   double* __restrict__ out)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // (64 consecutive rows per wave: one word of bits)
+	const bool keep = row < n_rows && flag[row] != 0u;
+	const unsigned long long word = __ballot(keep);
+	if ((threadIdx.x & 63u) == 0u && row < n_rows)
+	{
+		bits[row >> 6] = word;
+		rank[row >> 6] = pos[row]; // rows of the copy before this word (exclusive scan of the flags)
+	}
+	if (!keep)
+		return;
+	const uint32_t r = pos[row];
+	uint32_t idx[32];
+	band_cell_indices(F, row, idx);
+	double* o = out + 32 * (size_t)r;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		o[j] = F.coeffs[idx[j]];
+}
+
+// Builds the cell-major copy of a field (FieldDev::cell_major): one thread per cell row.
+__global__ __launch_bounds__(256) void k_expand_cells(const FieldDev F, uint64_t n_rows, double* __restrict__ out)
+{
+	const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= n_rows)
+		return;
+	uint32_t idx[32];
+	if (F.cells)
+	{
+#pragma unroll
+		for (int j = 0; j < 32; ++j)
+			idx[j] = F.cells[32 * row + j];
+	}
+	else
+	{
+		const uint32_t n01 = F.res[0] * F.res[1];
+		const uint32_t k = (uint32_t)(row / n01), r = (uint32_t)(row % n01);
+		cell_node_indices(r % F.res[0], r / F.res[0], k, F.res, idx);
+	}
+	double* o = out + 32 * row;
+#pragma unroll
+	for (int j = 0; j < 32; ++j)
+		o[j] = F.coeffs[idx[j]];
+}
+
+// Builds the tile-major copy of an unreduced field (dg_lattice.h): one thread per slot, one block row per tile;
+// reads are gathers from the reference layout (each node is read by at most 8 tiles), writes are contiguous.
+__global__ __launch_bounds__(256) void k_expand_tiles(const FieldDev F, uint64_t n_tiles, double* __restrict__ out)
+{
+	const uint64_t total = n_tiles * kTmNodes;
+	for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (uint64_t)gridDim.x * blockDim.x)
+	{
+		const uint64_t tile = e / kTmNodes;
+		const uint32_t slot = (uint32_t)(e - tile * kTmNodes);
+		const uint32_t ti = (uint32_t)(tile % F.ntile[0]);
+		const uint32_t tj = (uint32_t)((tile / F.ntile[0]) % F.ntile[1]);
+		const uint32_t tk = (uint32_t)(tile / ((uint64_t)F.ntile[0] * F.ntile[1]));
+		const uint32_t node = tile_slot_node(slot, ti, tj, tk, F.res);
+		out[e] = node == 0xffffffffu ? 0.0 : F.coeffs[node];
+	}
+}
+// second pass: the "no value" flags of the 64 cells of every tile (dg_lattice.h: kTmFlags); one wave per tile
+__global__ __launch_bounds__(256) void k_tile_flags(uint64_t n_tiles, double* __restrict__ tiles)
+{
+	const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (tile >= n_tiles)
+		return;
+	const uint32_t c = threadIdx.x & 63u;
+	uint32_t slots[32];
+	tile_node_slots(c & 3u, (c >> 2) & 3u, c >> 4, slots);
+	const double* t = tiles + tile * kTmNodes;
+	bool nov = false;
+#pragma unroll
+	for (int q = 0; q < 32; ++q)
+		nov = nov || (t[slots[q]] == 1.7976931348623157e308);
+	const unsigned long long flags = __ballot(nov);
+	if (c == 0)
+		*(unsigned long long*)(tiles + tile * kTmNodes + kTmFlags) = flags;
+}
+
+} // namespace
+
+hipError_t launch_expand_tiles(const FieldDev& f, uint64_t n_tiles, double* d_out, hipStream_t stream)
+{
+	if (n_tiles == 0)
+		return hipSuccess;
+	const uint64_t total = n_tiles * kTmNodes;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_expand_tiles, dim3(blocks), dim3(256), 0, stream, f, n_tiles, d_out);
+	hipLaunchKernelGGL(k_tile_flags, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, stream, n_tiles, d_out);
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 63) / 64, 256ull * 64ull);
+	const bool table = f.cells != nullptr;
+#define DG_K2_BAND(G, M) hipLaunchKernelGGL((k_interpolate_band<G, M>), dim3(blocks), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad)
+	if (d_grad && table) DG_K2_BAND(true, kFieldTable);
+	else if (d_grad) DG_K2_BAND(true, kFieldClosed);
+	else if (table) DG_K2_BAND(false, kFieldTable);
+	else DG_K2_BAND(false, kFieldClosed);
+#undef DG_K2_BAND
+	return hipGetLastError();
+}
+hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_band_flags, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, lo, hi, d_flag);
+	return hipGetLastError();
+}
+// exclusive scan of the flags (rocPRIM); tmp: scratch of *tmp_bytes (query with d_tmp == nullptr)
+hipError_t band_scan(const uint32_t* d_flag, uint32_t* d_pos, uint64_t n_rows, void* d_tmp, size_t* tmp_bytes, hipStream_t stream)
+{
+	return rocprim::exclusive_scan(d_tmp, *tmp_bytes, d_flag, d_pos, 0u, (size_t)n_rows, rocprim::plus<uint32_t>(), stream);
+}
+hipError_t launch_band_expand(const FieldDev& f, uint64_t n_rows, const uint32_t* d_flag, const uint32_t* d_pos, uint64_t* d_bits, uint32_t* d_rank,
+							  double* d_rows, hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_band_expand, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, d_flag, d_pos, d_bits, d_rank, d_rows);
+	return hipGetLastError();
+}
+
+hipError_t launch_expand_cells(const FieldDev& f, uint64_t n_rows, double* d_out, hipStream_t stream)
+{
+	if (n_rows == 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_expand_cells, dim3((uint32_t)((n_rows + 255) / 256)), dim3(256), 0, stream, f, n_rows, d_out);
+	return hipGetLastError();
+}
+
+// the binning passes shared by K2 and K1p: S.flag / S.perm describe the order to process the points in
+static uint32_t key_bits(uint32_t n_tiles)
+{
+	uint32_t bits = 1;
+	while (bits < 32 && (1u << bits) < n_tiles)
+		++bits;
+	return bits;
+}
+size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles)
+{
+	size_t bytes = 0;
+	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+									(uint32_t*)nullptr, (size_t)n, 0u, 32u, (hipStream_t) nullptr); // (all 32 bits: an upper bound for any key width)
+	return bytes;
+}
+// the binning passes shared by K2 and K1p: probe (always), and -- if the host predicts an unordered batch
+// (S.sort_launched) -- tile keys + radix sort, which leaves the processing order in S.perm
+hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, probe_tiles, d_xyz, n, S, one_in);
+	if (S.sort_launched == 0)
+		return hipGetLastError();
+	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
+	hipLaunchKernelGGL(k_bin_keys, dim3(wide), dim3(256), 0, stream, tiles, d_xyz, n, S);
+	size_t bytes = S.sort_tmp_bytes;
+	const hipError_t e = rocprim::radix_sort_pairs(S.sort_tmp, bytes, (const uint32_t*)S.keys, S.keys_out, (const uint32_t*)S.vals, S.perm,
+												  (size_t)n, 0u, tile_key_bits(tiles), stream);
+	return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+							  hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const uint32_t grid = k2_grid(n);
+#define DG_K2_LAUNCH(MODE)                                                                                                  \
+	if (d_grad)                                                                                                             \
+		hipLaunchKernelGGL((k_interpolate<true, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);      \
+	else                                                                                                                    \
+		hipLaunchKernelGGL((k_interpolate<false, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	switch (field_mode(f))
+	{
+	case kFieldTileMajor: DG_K2_LAUNCH(kFieldTileMajor) break;
+	case kFieldCellMajor: DG_K2_LAUNCH(kFieldCellMajor) break;
+	case kFieldTable: DG_K2_LAUNCH(kFieldTable) break;
+	default: DG_K2_LAUNCH(kFieldClosed)
+	}
+#undef DG_K2_LAUNCH
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_rows(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	if (f.cell_major == nullptr)
+		return hipErrorInvalidValue;
+	const uint64_t waves = (n + 63) / 64;
+	const uint32_t grid = (uint32_t)std::min<uint64_t>(waves, 256ull * 64ull); // grid-stride beyond 64 waves per CU
+	if (d_grad)
+		hipLaunchKernelGGL((k_interpolate_rows<true>), dim3(grid), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	else
+		hipLaunchKernelGGL((k_interpolate_rows<false>), dim3(grid), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad);
+	return hipGetLastError();
+}
+
+hipError_t launch_interpolate_binned(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,
+									 const BinScratch& S, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	// K2: row-ordered queries are coherent enough; bin only if more than a quarter of the steps change tile
+	const hipError_t e = launch_binning(field_tiles(f), field_tiles(f, kSortCells), d_xyz, n, S, 4u, stream);
+	if (e != hipSuccess)
+		return e;
+	const uint32_t grid = k2_grid(n);
+#define DG_K2_LAUNCH(MODE)                                                                                                        \
+	if (d_grad)                                                                                                                   \
+		hipLaunchKernelGGL((k_interpolate_binned<true, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);  \
+	else                                                                                                                          \
+		hipLaunchKernelGGL((k_interpolate_binned<false, MODE>), dim3(grid), dim3(256), 0, stream, f, d_xyz, n, d_phi, d_grad, S);
+	switch (field_mode(f))
+	{
+	case kFieldTileMajor: DG_K2_LAUNCH(kFieldTileMajor) break;
+	case kFieldCellMajor: DG_K2_LAUNCH(kFieldCellMajor) break;
+	case kFieldTable: DG_K2_LAUNCH(kFieldTable) break;
+	default: DG_K2_LAUNCH(kFieldClosed)
+	}
+#undef DG_K2_LAUNCH
+	return hipGetLastError();
+}
+
+} // namespace dg

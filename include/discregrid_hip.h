@@ -352,8 +352,8 @@ dg_status dg_field_set_immutable(dg_field* field, int immutable);
  * works as in dg_sdf_sample_nodes.  host_first is a hint without effect since round 4: ONE chunk profile serves callers
  * that read on the device next and callers that wait for the host vector -- seven chunks that shrink towards the end
  * [MI355X, 256^3: field complete on the device after 18.5 ms, in the host vector after 21.7 ms; one launch followed by
- * the copy: 16.3 / 34.6 ms]; DG_FIELD_FRACTIONS="f0,f1,..." overrides, DG_FIELD_ONE_LAUNCH=1 with host_first == 0 is
- * round 3's single launch, DG_FIELD_STREAMS=2 alternates the chunks between two streams (measured: no gain). */
+ * the copy: 16.3 / 34.6 ms]; DG_FORCE="field_fractions=f0,f1,..." overrides, DG_FIELD_ONE_LAUNCH=1 with host_first == 0 is
+ * round 3's single launch, DG_FORCE=field_streams=2 alternates the chunks between two streams (measured: no gain). */
 dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
 							  double* host_out, int host_first, dg_field** out);
 /* K3 over the whole lattice of `sdf` into a NEW device-resident field on the same grid (the density map the

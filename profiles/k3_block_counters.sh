@@ -9,7 +9,7 @@ echo "# k_density_cells, icosphere SDF 256^3, h = 0.1: per launch (mean of 2)"
 echo "# block(x y z)   kernel_ms   HBM_fetch_GB   HBM_write_GB   L2_hit"
 for shape in "1 16 8" "1 12 8" "1 8 8" "1 6 22" "1 3 43" "1 2 64" "1 8 16" "2 8 8"; do
   set -- $shape
-  export DG_K3_RB0=$1 DG_K3_RB1=$2 DG_K3_RB2=$3
+  export DG_FORCE="k3_rb0=$1;k3_rb1=$2;k3_rb2=$3"
   tag=b$1_$2_$3
   timeout 120 rocprofv3 --kernel-trace --stats -d $OUT -o ${tag}_kt -- python profiles/pmc_workloads.py k3 > $OUT/${tag}_kt.log 2>&1
   # (FETCH_SIZE and WRITE_SIZE in ONE pass never finished on the box of round 4 -- every run sat out its timeout and returned

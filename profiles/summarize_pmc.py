@@ -155,7 +155,7 @@ def main():
             derived.setdefault(w, {})[k] = e
     k1 = None
     if "k1" in derived:
-        # the dominant kernel of a K1 launch: the filtered kernel by default, the exact one with DG_K1_FAST=0
+        # the dominant kernel of a K1 launch: the filtered kernel by default, the exact one with DG_FORCE=k1_fast=0
         for want in ("k_sample_fast", "k_sample_nodes"):
             for k, e in derived["k1"].items():
                 if k1 is None and k.startswith(want):

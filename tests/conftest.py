@@ -29,12 +29,13 @@ def golden():
 
 def k1_variant_fixture():
     """Autouse fixture factory for the GPU modules that exercise K1 / K1p on SMALL meshes: every test runs
-    with the exact kernel only (DG_K1_FAST=0) and with the filtered kernel forced (DG_K1_FAST=1; by default
+    with the exact kernel only (DG_FORCE=k1_fast=0) and with the filtered kernel forced (k1_fast=1; by default
     meshes below dg::kFastMinTriangles triangles keep the exact kernel, so without this the filtered path
     -- in-wave exact fallback, seed parking, degenerate triangles, out-of-range points -- would only be
     covered by the large digest configs)."""
     @pytest.fixture(autouse=True, params=["exact", "filtered"])
     def k1_variant(request, monkeypatch):
-        monkeypatch.setenv("DG_K1_FAST", "1" if request.param == "filtered" else "0")
+        import dgtest as T
+        T.force(monkeypatch, k1_fast="1" if request.param == "filtered" else "0")
         return request.param
     return k1_variant

@@ -161,7 +161,7 @@ int main(int argc, char** argv)
 		CubicLagrangeDiscreteGrid g{std::string(argv[2])};
 		const double lo = std::stod(argv[3]), hi = std::stod(argv[4]);
 		if (std::string(argv[6]) == "host")
-			setenv("DG_REDUCE_ON_HOST", "1", 1);
+			setenv("DG_FORCE", "reduce_on_host=1", 1);
 		g.reduceField(0u, ValuePredicate::band(lo, hi, 0.0));
 		std::printf("%s\n", g.lastReduceFieldUsedGpu() ? "gpu" : "host");
 		g.save(argv[5]);

@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE -- nothing here is imported by the product package.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 import numpy as np
 
@@ -602,3 +603,44 @@ class RefGrid:
         ch = np.empty((nn.value, 2), dtype=np.int32)
         self.L.ref_md_get(self.h, dp(pt), dp(pe), dp(pv), dp(sp), ip(ch))
         return dict(pn_tri=pt, pn_edge=pe, pn_vert=pv, spheres=sp, children=ch)
+
+
+# ---- DG_FORCE: the library's test hooks and tuning knobs live behind ONE variable (discregrid_amd/csrc/dg_force.h) ----------
+def _force_parse(txt):
+    out = {}
+    for item in re.split(r"[; \t]+", txt or ""):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k] = v
+    return out
+
+
+def force_string(base=None, **kv):
+    """DG_FORCE value: `base` (an existing DG_FORCE string) updated with key=value pairs; a value of None removes the key"""
+    d = _force_parse(base)
+    for k, v in kv.items():
+        if v is None:
+            d.pop(k, None)
+        else:
+            d[k] = str(v)
+    return ";".join("%s=%s" % (k, v) for k, v in d.items())
+
+
+def force(monkeypatch, **kv):
+    """sets / removes keys of DG_FORCE in this process through pytest's monkeypatch (undone at teardown)"""
+    v = force_string(os.environ.get("DG_FORCE"), **kv)
+    if v:
+        monkeypatch.setenv("DG_FORCE", v)
+    else:
+        monkeypatch.delenv("DG_FORCE", raising=False)
+
+
+def force_env(env=None, **kv):
+    """a copy of `env` (default: os.environ) with the given keys of DG_FORCE set, for subprocesses"""
+    e = dict(os.environ if env is None else env)
+    v = force_string(e.get("DG_FORCE"), **kv)
+    if v:
+        e["DG_FORCE"] = v
+    else:
+        e.pop("DG_FORCE", None)
+    return e

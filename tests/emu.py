@@ -218,7 +218,7 @@ def interpolate_rows(domain, res, coeffs, P, grad=False, cells=None, cell_map=No
 
 def set_fast(on=1):
     """Filtered K1 kernel (float filter + per-lane candidate lists) in the emulated launches; 0 = exact kernel
-    only (DG_K1_FAST=0).  Resets the counters of fast_stats()."""
+    only (DG_FORCE=k1_fast=0).  Resets the counters of fast_stats()."""
     lib().emu_set_fast(int(on))
 
 

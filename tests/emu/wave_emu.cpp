@@ -94,7 +94,7 @@ struct FastStats
 		for (int k = 0; k < 17; ++k) hist[k] += o.hist[k];
 	}
 };
-int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_K1_FAST=0)
+int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_FORCE=k1_fast=0)
 int g_brick_blocking = 0; // 1: the blocked brick order K3 launches use (dg_kernels.h: map_lane)
 FastStats g_fs;
 

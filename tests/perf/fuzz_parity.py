@@ -103,17 +103,13 @@ def main():
             k3 = fk.density_map_nodes(len(sdf), h, 1000.0, band, b, e)
             w3 = T.oracle_density_map(dom, res, sdf, h, 1000.0, band, b, e)
             ok = ok and np.array_equal(k3, w3, equal_nan=True)
-            # the whole lattice goes through the point-lane kernel (k_density_cells, round 4), a small slice through the pair kernel:
-            # the slice of the one == the oracle, and the whole == the row-block kernel's and the pair kernel's whole
+            # the whole lattice goes through the point-lane kernel (k_density_cells), a small slice through the brick kernel:
+            # the slice of the one == the oracle, and the whole == the brick kernel's whole
             full = fk.density_map_nodes(len(sdf), h, 1000.0, band)
-            os.environ["DG_K3_CELLS"] = "0"
-            full_rows = fk.density_map_nodes(len(sdf), h, 1000.0, band)
-            del os.environ["DG_K3_CELLS"]
-            os.environ["DG_K3_ROWS"] = "0"
-            full_pairs = fk.density_map_nodes(len(sdf), h, 1000.0, band)
-            del os.environ["DG_K3_ROWS"]
-            ok = ok and np.array_equal(full[b:e], w3, equal_nan=True) and np.array_equal(full, full_pairs, equal_nan=True) and \
-                np.array_equal(full, full_rows, equal_nan=True)
+            os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), k3_cells=0)
+            full_bricks = fk.density_map_nodes(len(sdf), h, 1000.0, band)
+            os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), k3_cells=None)
+            ok = ok and np.array_equal(full[b:e], w3, equal_nan=True) and np.array_equal(full, full_bricks, equal_nan=True)
             k3_rounds[0] += 1
         rounds += 1
         nodes += len(got)

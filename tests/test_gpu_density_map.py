@@ -49,13 +49,12 @@ def test_density_map_vs_reference_golden(dg, golden, monkeypatch, name, res, h, 
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 777, 2500), want[777:2500])
     f.drop_tile_major()
-    monkeypatch.setenv("DG_K3_TILES", "0")   # and without any copy
+    T.force(monkeypatch, k3_tiles=0)   # and without any copy
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
-    monkeypatch.delenv("DG_K3_TILES")
-    monkeypatch.setenv("DG_K3_BLOCKED", "0")   # bricks in row-major instead of blocked order
+    T.force(monkeypatch, k3_tiles=None, k3_blocked=0)   # bricks in row-major instead of blocked order
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True), want)
     np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, 777, 2500), want[777:2500])
-    monkeypatch.delenv("DG_K3_BLOCKED")
+    T.force(monkeypatch, k3_blocked=None)
     if key == "torus_density_h015":
         np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False), golden["torus_density_h015_nopred"])
 
@@ -98,11 +97,11 @@ def test_density_map_without_predicate_on_a_bigger_grid(dg):
     np.testing.assert_array_equal(f.density_map_nodes(n, 0.2, 1000.0, False), got)
 
 
-def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatch):
-    """Whole-lattice launches over an unreduced field take k_density_cells (round 4: a lane owns a lattice point with its seven
-    nodes, waves of 16 x 2 x 2 points on the x-major copy of the Y / Z classes); DG_K3_CELLS=0 is k_density_rows (one node or
-    edge per lane), DG_K3_ROWS=0 k_density_pairs on the tile-major copy.  Same bits from all of them, from both register
-    budgets, other block shapes and lane shapes, on resolutions that are no multiples of the lane shape, with a node mask, and
+def test_point_lane_kernel_equals_the_brick_kernel_and_the_emulator(dg, monkeypatch):
+    """Whole-lattice launches over an unreduced field take k_density_cells (a lane owns a lattice point with its seven
+    nodes, waves of 16 x 2 x 2 points on the x-major copy of the Y / Z classes); DG_FORCE=k3_cells=0 is the brick kernel
+    k_density_bricks (one node per lane; what reduced fields and short node ranges take), with and without its tile-major copy.
+    Same bits from all of them, from other block shapes, on resolutions that are no multiples of the lane shape, with a node mask, and
     on fields spoilt with "no value" (answered by the copy's one bit per cell), NaN and Inf coefficients (no skipping of
     zero-weight points) -- checked against the host emulation of the product's arithmetic."""
     import emu
@@ -122,25 +121,20 @@ def test_row_block_kernel_equals_the_pair_kernel_and_the_emulator(dg, monkeypatc
         for name, coeffs in (("clean", sdf), ("no value", spoilt), ("nan / inf", worse)):
             f = dg.Field(grid, coeffs)
             got = {}
-            for tag, env in (("cells", {}), ("cells, 2 waves", {"DG_K3_WAVES3": "0"}),
-                             ("cells, other blocks", {"DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}),
-                             ("rows", {"DG_K3_CELLS": "0"}), ("rows 8x4x2", {"DG_K3_CELLS": "0", "DG_K3_ROWS": "4"}),
-                             ("rows, 2 waves", {"DG_K3_CELLS": "0", "DG_K3_WAVES3": "0"}),
-                             ("rows, other blocks", {"DG_K3_CELLS": "0", "DG_K3_RB0": "3", "DG_K3_RB1": "2", "DG_K3_RB2": "5"}),
-                             ("pairs", {"DG_K3_ROWS": "0"})):
-                for k_, v_ in env.items():
-                    monkeypatch.setenv(k_, v_)
+            for tag, env in (("cells", {}), ("cells, other blocks", {"k3_rb0": 3, "k3_rb1": 2, "k3_rb2": 5}),
+                             ("cells, row-major", {"k3_blocked": 0}),
+                             ("bricks", {"k3_cells": 0}), ("bricks, no copy", {"k3_cells": 0, "k3_tiles": 0})):
+                T.force(monkeypatch, **env)
                 got[tag] = (f.density_map_nodes(n, h, 1000.0, True), f.density_map_nodes(n, h, 1000.0, False, mask=mask))
-                for k_ in env:
-                    monkeypatch.delenv(k_)
+                T.force(monkeypatch, **{k_: None for k_ in env})
             for tag in got:
-                np.testing.assert_array_equal(got[tag][0], got["pairs"][0], err_msg="%s %s %s" % (res, name, tag))
-                np.testing.assert_array_equal(got[tag][1], got["pairs"][1], err_msg="%s %s %s (mask)" % (res, name, tag))
+                np.testing.assert_array_equal(got[tag][0], got["bricks"][0], err_msg="%s %s %s" % (res, name, tag))
+                np.testing.assert_array_equal(got[tag][1], got["bricks"][1], err_msg="%s %s %s (mask)" % (res, name, tag))
             assert (got["cells"][1][mask == 0] == DBL_MAX).all()
-            # node ranges: an eighth of the lattice or more stays with the point kernel (lanes outside the range idle), less goes to the pair kernel
+            # node ranges: an eighth of the lattice or more stays with the point kernel (lanes outside the range idle), less goes to the brick kernel
             for b, e in ((n // 3, n - 5), (n // 2, n // 2 + n // 7), (17, 17 + n // 20)):
-                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, b, e), got["pairs"][0][b:e], err_msg="%s %s [%d, %d)" % (res, name, b, e))
-                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False, b, e, mask=mask[b:e]), got["pairs"][1][b:e])
+                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, True, b, e), got["bricks"][0][b:e], err_msg="%s %s [%d, %d)" % (res, name, b, e))
+                np.testing.assert_array_equal(f.density_map_nodes(n, h, 1000.0, False, b, e, mask=mask[b:e]), got["bricks"][1][b:e])
             if res[0] != 40:   # (the emulator walks every quadrature point of every node on the host)
                 want = emu.density_map(dom, res, coeffs, h, 1000.0, band=True)
                 np.testing.assert_array_equal(got["cells"][0], want, err_msg="%s %s" % (res, name))
@@ -193,7 +187,7 @@ def test_density_map_bigger_lattice_vs_oracle(dg):
 def test_point_lane_kernel_beyond_two_gigabytes_of_offsets(dg, monkeypatch):
     """k_density_cells addresses a cell by 32-bit byte offsets on scalar row bases.  At 512^3 the X class alone is 2.16 GB and the
     x-major copy of the Y / Z classes 2 x 2.15 GB: offsets beyond 2^31 must be taken as UNSIGNED by the load.  Node ranges at
-    the far end of every class (where the offsets are largest), point-lane kernel == row-block kernel, bit for bit."""
+    the far end of every class (where the offsets are largest), point-lane kernel == brick kernel, bit for bit."""
     import torch
     V, F = T.icosphere(24)
     dom = T.oracle_default_domain(V)
@@ -209,14 +203,14 @@ def test_point_lane_kernel_beyond_two_gigabytes_of_offsets(dg, monkeypatch):
     m = n // 8 + 1000                      # (an eighth of the lattice or more: the whole-lattice kernels)
     outs = {}
     for begin in (nv + ne2 - m, nv + 2 * ne2 - m, n - m):      # the ends of the X, Y and Z classes
-        for tag, cells in (("cells", "1"), ("rows", "0")):
-            monkeypatch.setenv("DG_K3_CELLS", cells)
+        for tag, cells in (("cells", "1"), ("bricks", "0")):
+            T.force(monkeypatch, k3_cells=cells)
             out = torch.full((m,), -1.0, dtype=torch.float64, device="cuda")
             fld.density_map_nodes_device(0.05, 1000.0, True, begin, begin + m, out.data_ptr(), stream=s)
             torch.cuda.synchronize()
             outs[tag] = out
-        monkeypatch.delenv("DG_K3_CELLS")
-        assert torch.equal(outs["cells"], outs["rows"]), begin
+        T.force(monkeypatch, k3_cells=None)
+        assert torch.equal(outs["cells"], outs["bricks"]), begin
         got = outs["cells"]
         assert int(((got != DBL_MAX) & (got != 0.0)).sum().item()) > 100000      # (the band is there: real quadratures ran)
     fld.close()

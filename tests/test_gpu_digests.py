@@ -196,13 +196,13 @@ def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, pat
     if path in ("cell_major_rows", "cell_major_per_lane", "cell_sorted_input_cell_major"):
         fld.build_cell_major(stream=torch.cuda.current_stream().cuda_stream)
     if path == "cell_major_per_lane":
-        monkeypatch.setenv("DG_K2_ROWS", "0")
+        T.force(monkeypatch, k2_rows=0)
     if path == "tile_major":
         fld.build_tile_major(stream=torch.cuda.current_stream().cuda_stream)
     if path.startswith("cell_sorted_input"):
         order = cell_order(dom, [256] * 3)
     if path == "no_binning":
-        monkeypatch.setenv("DG_K2_BINNING", "0")
+        T.force(monkeypatch, k2_binning=0)
     if path.startswith("band_copy"):
         n_cells = 256 ** 3
         diag = float(np.linalg.norm((np.asarray(dom[3:]) - np.asarray(dom[:3])) / 256.0))

@@ -142,10 +142,10 @@ def test_sliver_band_around_the_filter_threshold(dg, monkeypatch):
     want = np.abs(T.OracleMesh(V, F).signed_distance(P))
     got = {}
     for fast in ("0", "1"):
-        monkeypatch.setenv("DG_K1_FAST", fast)
+        T.force(monkeypatch, k1_fast=fast)
         m = dg.Mesh(V, F)
         for binning in ("1", "0"):
-            monkeypatch.setenv("DG_K1P_BINNING", binning)
+            T.force(monkeypatch, k1p_binning=binning)
             d = np.abs(m.signed_distance(P))     # (a soup has no inside: only the magnitude is defined by the reference)
             np.testing.assert_array_equal(d, want)
         dom = np.array([-1.2, -1.2, -1.2, 1.2, 1.2, 1.2])

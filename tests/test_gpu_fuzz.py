@@ -17,6 +17,6 @@ def test_fuzz_parity_short(seed, k1_fast):
     """(k1_fast: the exact K1 kernel only / the filtered kernel forced also for the small random meshes)"""
     script = os.path.join(T.ROOT, "tests", "perf", "fuzz_parity.py")
     out = subprocess.run([sys.executable, script, "6", str(seed)], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, DG_K1_FAST=k1_fast))
+                         env=T.force_env(k1_fast=k1_fast))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "fuzz ok" in out.stdout

@@ -51,7 +51,7 @@ def test_generate_sdf_cli_on_several_devices(tmp_path):
     V, F = T.box_mesh()
     T.write_obj(obj, V, F)
     out = str(tmp_path / "box.cdf")
-    env = dict(os.environ, DG_DEVICES="0,0,0", DG_HOST_CHUNK_NODES="1024")
+    env = T.force_env(dict(os.environ, DG_DEVICES="0,0,0"), host_chunk_nodes=1024)
     subprocess.check_call([exe, "-r", "5 5 5", "-o", out, obj], stdout=subprocess.DEVNULL, env=env)
     assert open(out, "rb").read() == open(os.path.join(T.GOLDEN, "box.cdf"), "rb").read()
     tor = str(tmp_path / "torus.obj")

@@ -94,7 +94,7 @@ def test_ranges_masks_invert(dg, name):
 @pytest.mark.parametrize("name", list(MESHES))
 def test_heavy_brick_split_is_bit_exact(dg, golden, monkeypatch, name):
     """Bricks that exhaust their work budget are parked and finished by k_heavy_subtrees /
-    k_heavy_finish.  Forced here with a tiny budget (DG_HEAVY_WORK) so that (almost) every brick
+    k_heavy_finish.  Forced here with a tiny budget (DG_FORCE=heavy_work=...) so that (almost) every brick
     takes that path, with only 3 slots (all other heavy bricks carry on unsplit), and switched
     off: always the bits of the golden vectors; masks, inversion and shards included."""
     V, F = MESHES[name]()
@@ -103,8 +103,7 @@ def test_heavy_brick_split_is_bit_exact(dg, golden, monkeypatch, name):
     g = grid_of(dg, dom, res)
     m = dg.Mesh(V, F)
     for slots, work in (("256", "4"), ("3", "1"), ("256", "60"), ("0", "4")):
-        monkeypatch.setenv("DG_HEAVY_SLOTS", slots)
-        monkeypatch.setenv("DG_HEAVY_WORK", work)
+        T.force(monkeypatch, heavy_slots=slots, heavy_work=work)
         for _ in range(2):   # the second launch reuses the scratch of the first
             assert assert_parity(m.sample_nodes(g), want, name) == 0
         heavy, split = m.last_heavy_bricks()
@@ -112,8 +111,7 @@ def test_heavy_brick_split_is_bit_exact(dg, golden, monkeypatch, name):
             assert (heavy, split) == (0, 0)
         elif work != "60":
             assert heavy >= split == min(int(slots), heavy) > 0, (heavy, split)   # the path really ran
-    monkeypatch.setenv("DG_HEAVY_SLOTS", "256")
-    monkeypatch.setenv("DG_HEAVY_WORK", "4")
+    T.force(monkeypatch, heavy_slots=256, heavy_work=4)
     rng = np.random.default_rng(5)
     mask = rng.integers(0, 2, size=len(want)).astype(np.uint8)
     got = m.sample_nodes(g, mask=mask, invert=True)
@@ -160,9 +158,9 @@ def test_signed_distance_binned_launch(dg, monkeypatch):
     P[3000:4000] = P[3000]                                                              # duplicates
     line = np.linspace(lo - 0.1, hi + 0.1, 20000)                                       # one long line
     for Q in (P, line, P[np.argsort(P[:, 0])]):
-        monkeypatch.setenv("DG_K1P_BINNING", "0")
+        T.force(monkeypatch, k1p_binning=0)
         d0, t0, e0, n0 = m.signed_distance(Q, full=True)
-        monkeypatch.setenv("DG_K1P_BINNING", "1")
+        T.force(monkeypatch, k1p_binning=1)
         d1, t1, e1, n1 = m.signed_distance(Q, full=True)
         np.testing.assert_array_equal(d1, d0)
         # exact ties (nearest point on a shared edge or vertex: identical d^2 from several triangles)
@@ -206,17 +204,17 @@ def test_interpolate_vs_golden(dg, golden, name, monkeypatch):
     assert (grad[~inside] == 0).all()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     # cell-major device copy: bit-identical results -- through the cooperative row kernel (default: no binning, any
-    # query order, batch sizes that are no multiples of a wave) and through the per-lane kernels (DG_K2_ROWS=0)
+    # query order, batch sizes that are no multiples of a wave) and through the per-lane kernels (DG_FORCE=k2_rows=0)
     f.build_cell_major()
     for rows in ("1", "0"):
-        monkeypatch.setenv("DG_K2_ROWS", rows)
+        T.force(monkeypatch, k2_rows=rows)
         phi2, grad2 = f.interpolate(P, grad=True)
         np.testing.assert_array_equal(phi2, phi)
         np.testing.assert_array_equal(grad2, grad)
         np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
         for m in (1, 63, 65, 1000):
             np.testing.assert_array_equal(f.interpolate(P[:m]), golden[name + "_phi"][:m])
-    monkeypatch.delenv("DG_K2_ROWS")
+    T.force(monkeypatch, k2_rows=None)
     f.drop_cell_major()
     np.testing.assert_array_equal(f.interpolate(P), golden[name + "_phi"])
     # tile-major device copy (4^3-cell tiles of 736 doubles): bit-identical results, takes precedence over cell-major
@@ -282,8 +280,7 @@ def test_multi_device_host_path(dg, golden, monkeypatch, n_meshes):
     g = grid_of(dg, dom, res)
     meshes = [dg.Mesh(V, F) for _ in range(n_meshes)]
     for chunk, direct in (("2000", "2"), ("2000", "0"), ("100000000", "2")):
-        monkeypatch.setenv("DG_HOST_CHUNK_NODES", chunk)
-        monkeypatch.setenv("DG_HOST_DIRECT", direct)   # 2: results DMA'd straight into the array, 0: staged
+        T.force(monkeypatch, host_chunk_nodes=chunk, host_direct=direct)   # 2: results DMA'd straight into the array, 0: staged
         np.testing.assert_array_equal(dg.sample_nodes_multi(meshes, g), want)
         rng = np.random.default_rng(8)
         mask = rng.integers(0, 2, size=len(want)).astype(np.uint8)
@@ -313,10 +310,10 @@ def test_interpolate_binned_path(dg, golden, monkeypatch, name):
     P[1000:2000] = P[1000]                                                            # duplicates
     cell = np.floor((np.clip(P, lo, hi) - lo) / (hi - lo) * res).astype(np.int64)
     order = np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))
-    monkeypatch.setenv("DG_K2_BINNING", "0")
+    T.force(monkeypatch, k2_binning=0)
     want = {k: f.interpolate(Q, grad=True) for k, Q in (("random", P), ("sorted", P[order]))}
     np.testing.assert_array_equal(want["random"][0], T.oracle_interpolate(dom, res, coeffs, P))
-    monkeypatch.setenv("DG_K2_BINNING", "2")
+    T.force(monkeypatch, k2_binning=2)
     for k, Q in (("random", P), ("sorted", P[order]), ("random", P)):
         phi, grad = f.interpolate(Q, grad=True)
         np.testing.assert_array_equal(phi, want[k][0])
@@ -338,7 +335,7 @@ def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks, monkeypatch):
     n = dg.n_nodes(g)
     ref = m.sample_nodes(g)
     if nranks == 3:
-        monkeypatch.setenv("DG_HEAVY_WORK", "8")   # shards through the heavy-brick path as well
+        T.force(monkeypatch, heavy_work=8)   # shards through the heavy-brick path as well
     stride = dg.shard_layout(g, 0, nranks)[1]
     gathered = torch.full((nranks * stride,), float("nan"), dtype=torch.float64, device="cuda")
     total = 0

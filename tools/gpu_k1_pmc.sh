@@ -4,14 +4,14 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 mkdir -p gpurun_out
 TAG=${1:-ab}
 for fast in 0 1; do
-  DG_K1_FAST=$fast timeout 300 python bench.py --steps 20 --warmup 5 --no-extras > gpurun_out/${TAG}_bench_fast$fast.json 2> gpurun_out/${TAG}_bench_fast$fast.err
+  DG_FORCE="k1_fast=$fast" timeout 300 python bench.py --steps 20 --warmup 5 --no-extras > gpurun_out/${TAG}_bench_fast$fast.json 2> gpurun_out/${TAG}_bench_fast$fast.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/${TAG}_bench_fast$fast.json"))
-print("DG_K1_FAST=$fast", d["value"], "Mnodes/s", d["ms_per_step"], "ms")
+print("k1_fast=$fast", d["value"], "Mnodes/s", d["ms_per_step"], "ms")
 PY
 done
-export DG_K1_FAST=1
+export DG_FORCE="k1_fast=1"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-extras > /tmp/prof_kt.log 2>&1
 i=0
@@ -26,7 +26,7 @@ python - <<PY > gpurun_out/${TAG}_pmc.txt
 import sqlite3, glob
 db = glob.glob("/tmp/prof_$TAG/**/kt_results.db", recursive=True)[0]
 c = sqlite3.connect(db)
-print("# kernel durations (rocprofv3 --kernel-trace --stats), DG_K1_FAST=1")
+print("# kernel durations (rocprofv3 --kernel-trace --stats), k1_fast=1")
 for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     if "dg::" in name: print("%-70s calls %3d avg %.3f ms" % (name[:70], calls, avg / 1e3))
 for r in c.execute("select name,duration,grid_x,workgroup_x,vgpr_count,sgpr_count,lds_size,scratch_size from kernels where name like '%k_sample_fast%' limit 1"):

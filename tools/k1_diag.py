@@ -20,5 +20,5 @@ for it in range(3):
     mesh.sample_nodes_device(grid, 0, n, out.data_ptr())
     torch.cuda.synchronize(); dt = time.time() - t
 print("leaf=%s fast=%s: %.3f ms, heavy (asked, split) = %s, info %s" % (
-    os.environ.get("DG_MAX_LEAF", "-"), os.environ.get("DG_K1_FAST", "-"), dt * 1e3, mesh.last_heavy_bricks(),
+    os.environ.get("DG_FORCE", "-"), "-", dt * 1e3, mesh.last_heavy_bricks(),
     {k: v for k, v in mesh.info().items() if k in ("bvh_depth", "n_bvh_nodes")}))

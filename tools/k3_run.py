@@ -40,10 +40,10 @@ def main():
     key = "density%d_digest" % a.res
     for setting in (a.sweep.split(";") if a.sweep else [""]):
         names = []
-        for kv in filter(None, setting.split(",")):
+        for kv in filter(None, setting.split(",")):      # keys of DG_FORCE (k3_rb1=6, k3_cells=0, ...: discregrid_amd/csrc/dg_force.h)
             name, v = kv.split("=")
-            os.environ[name] = v
             names.append(name)
+        os.environ["DG_FORCE"] = ";".join(filter(None, setting.split(",")))
         out.fill_(-1.0)
         ms = []
         for _ in range(a.steps):
@@ -61,8 +61,7 @@ def main():
             else:
                 res["mismatching_blocks"] = None
         print(json.dumps(res), flush=True)
-        for name in names:
-            del os.environ[name]
+        os.environ.pop("DG_FORCE", None)
 
 if __name__ == "__main__":
     main()
