@@ -137,6 +137,7 @@ struct dg_field
 	void* d_band_map = nullptr;
 	uint64_t band_rows = 0;
 	hipEvent_t band_ready = nullptr;
+	mutable uint32_t* band_probe_host = nullptr; // pinned, 2 words: of the previous large batch's sampled queries, how many had a cell / a row in the band copy
 	hipEvent_t cell_major_ready = nullptr; // recorded behind k_expand_cells: launches on other streams wait for it
 	hipEvent_t tile_major_ready = nullptr; // the same for k_expand_tiles (one event per copy: they may be built on different streams)
 	// A field whose coefficients a kernel of this library produces (dg_sdf_sample_field, dg_density_map_field): the

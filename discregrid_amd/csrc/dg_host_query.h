@@ -104,12 +104,14 @@ struct HostWave
 		std::memcpy(&v, &bits, 4);
 		return v;
 	}
-	template <class B>
-	void push(int sp, int info, B lb)
+	void push(int sp, int info, const LaneVar<f2, N>& lb, bool second)
 	{
 		infos[sp] = info;
 		for (int l = 0; l < N; ++l)
-			bounds[sp][l] = stack16 ? truncate16(lb(l)) : lb(l);
+		{
+			const float v = second ? lb[l].y : lb[l].x;
+			bounds[sp][l] = stack16 ? truncate16(v) : v;
+		}
 	}
 	float parked(int sp, int l) const { return bounds[sp][l]; }
 	int info(int sp) const { return infos[sp]; }

@@ -503,6 +503,8 @@ inline void bin_scratch_assign(BinScratch& S, void* mem, const size_t off[6], ui
 }
 // K2 through the band-limited cell-major copy (FieldDev::band_rows / band_map) and the copy's builders
 hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream);
+// host_counts (pinned, 2 words): sampled queries with a cell / of those with a row in the band copy -- the routing prediction
+hipError_t launch_band_probe(const FieldDev& f, const double* d_xyz, uint64_t n, uint32_t* host_counts, hipStream_t stream);
 hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream);
 hipError_t band_scan(const uint32_t* d_flag, uint32_t* d_pos, uint64_t n_rows, void* d_tmp, size_t* tmp_bytes, hipStream_t stream);
 hipError_t launch_band_expand(const FieldDev& f, uint64_t n_rows, const uint32_t* d_flag, const uint32_t* d_pos, uint64_t* d_bits, uint32_t* d_rank,

@@ -130,11 +130,10 @@ struct DevWave
 		s.valid1 = c[15];
 		return s;
 	}
-	template <class B>
-	__device__ __forceinline__ void push(int sp, int info, B lb)
+	__device__ __forceinline__ void push(int sp, int info, const LaneVar<f2, 1>& lb, bool second)
 	{
 		stackv = (lane_id == sp) ? info : stackv;
-		park_bound(lds_lb, sp * 64 + lane_id, lb(0));
+		park_bound(lds_lb, sp * 64 + lane_id, second ? lb[0].y : lb[0].x);
 	}
 	__device__ __forceinline__ float parked(int sp, int) const { return parked_bound(lds_lb, sp * 64 + lane_id); }
 	__device__ __forceinline__ int info(int sp) const { return __builtin_amdgcn_readlane(stackv, sp); }

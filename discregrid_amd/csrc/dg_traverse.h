@@ -14,7 +14,7 @@
 //   Pair   load_pair(const PairRec*, int)           .r -> kPairFloats floats, .info0, .info1   (device: SGPRs)
 //   Tri    load_tri(const TriPacket*, int)          the 15 doubles of a packet                  (device: SGPRs)
 //   Approx load_approx(const TriApproxPair*, int)   .r -> kApproxFloats floats, .valid0, .valid1 (device: SGPRs)
-//   void push(int sp, int info, B lb)               stack entry sp: the info word, and lb(l) parked per lane
+//   void push(int sp, int info, lb, bool second)    stack entry sp: the info word, and per lane lb[l].y (second) or lb[l].x parked
 //   float parked(int sp, int l); int info(int sp)   ... and back
 //   uint32_t claim(uint32_t* counter)               atomic fetch-add 1 (heavy-brick slots)
 //   void list_store(uint32_t slot, int v)           a word of the lanes' candidate lists (LDS on the device)
@@ -90,7 +90,8 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 				left = 2 * __builtin_popcountll(pref) >= __builtin_popcountll(bl | br);
 				if (sp < M.stack_levels) // always true: one push per tree level at most
 				{
-					w.push(sp, left ? pr.info1 : pr.info0, [&](int l) { return left ? lb[l].y : lb[l].x; });
+					// (the flag goes in as an argument: captured in a callable it takes a detour through a vector register on the device)
+					w.push(sp, left ? pr.info1 : pr.info0, lb, left);
 					++sp;
 				}
 			}
@@ -243,7 +244,11 @@ struct FastWalk
 			});
 			++work;
 			w.note_filter_pair();
-			if (DG_TRI_PREFILTER && w.ballot([&](int l) { return (valid0 == 1 && lo_lb[l].x <= f(l).U) || (valid1 == 1 && lo_lb[l].y <= f(l).U); }) == 0ull)
+			// (two ballots combined with the wave-uniform validity on the scalar side: written as ONE per-lane predicate the
+			// uniform flags take a detour through vector registers on the device)
+			const unsigned long long reach0 = w.ballot([&](int l) { return lo_lb[l].x <= f(l).U; });
+			const unsigned long long reach1 = w.ballot([&](int l) { return lo_lb[l].y <= f(l).U; });
+			if (DG_TRI_PREFILTER && ((valid0 == 1 ? reach0 : 0ull) | (valid1 == 1 ? reach1 : 0ull)) == 0ull)
 				continue;
 			w.note_filter_rest();
 			w.lanes([&](int l) {

@@ -128,6 +128,13 @@ def bunny_mesh():
     return z["V"].astype(np.float64), z["F"].astype(np.uint32)
 
 
+def dragon_mesh():
+    """The reference's third sample mesh, cmd/generate_sdf/resources/dragon.obj (79 988 triangles), staged as
+    tests/golden/dragon.npz by tests/golden/make_digests.py dragon128 (the OBJ itself only exists under /root/reference)."""
+    z = np.load(os.path.join(GOLDEN, "dragon.npz"))
+    return z["V"].astype(np.float64), z["F"].astype(np.uint32)
+
+
 def write_obj(path, V, F):
     with open(path, "w") as f:
         for v in V:

@@ -95,6 +95,7 @@ struct FastStats
 	}
 };
 int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_FORCE=k1_fast=0)
+int g_seed_study = 0; // 1: the filtered traversal starts from an oracle-tight upper bound per lane (design study)
 int g_brick_blocking = 0; // 1: the blocked brick order K3 launches use (dg_kernels.h: map_lane)
 FastStats g_fs;
 
@@ -308,6 +309,7 @@ void emu_fast_stats(uint64_t* out /*28*/)
 	for (int k = 0; k < 17; ++k) out[11 + k] = g_fs.hist[k];
 }
 void emu_set_brick_blocking(int on) { g_brick_blocking = on; }
+void emu_set_seed_study(int on) { g_seed_study = on; }
 // udiv_by / udiv_magic of dg_kernels.h against the host's division; returns the number of mismatches
 uint64_t emu_udiv_check(const uint32_t* n, const uint32_t* d, uint64_t count)
 {
@@ -589,6 +591,25 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 					exact[l] = sample[l] && !(fl[l].a.E < __builtin_inff());
 					init_fast_lane(fl[l], sample[l] && !exact[l], FastLists::base(l));
 					any_fast = any_fast || (sample[l] && !exact[l]);
+				}
+				if (any_fast && g_seed_study)
+				{
+					// design study: what would an ORACLE-TIGHT initial upper bound save?  A first traversal (not counted) gives every
+					// lane's final upper bound; the counted traversal starts from it
+					FastStats discard;
+					FastLists scratch_lists;
+					FastLane pre[64];
+					for (int l = 0; l < 64; ++l)
+						pre[l] = fl[l];
+					(void)walk_fast(P.mesh, pre, scratch_lists, discard, nullptr);
+					for (int l = 0; l < 64; ++l)
+						if (sample[l] && !exact[l] && pre[l].U < __builtin_inff())
+						{
+							float theta, kappa;
+							fl[l].U = pre[l].U * (1.0f + 1.0e-5f);
+							approx_err_terms(fl[l].a.E, fl[l].U, &theta, &kappa);
+							fl[l].Uprune = __builtin_fmaf(fl[l].U, 1.0f + theta, kappa);
+						}
 				}
 				if (any_fast)
 				{

@@ -9,6 +9,10 @@ nodes: the first 16 bytes of SHA-256 over the raw little-endian doubles.  The GP
 (tests/test_gpu_digests.py) reduce the device field the same way and compare every block.
 
   bunny128    BASELINE configs[1]: bunny (69 630 tris), 128^3, 14 926 977 nodes      (~1 min on 8 cores)
+  dragon128   the reference's third sample mesh, cmd/generate_sdf/resources/dragon.obj (79 988 tris), 128^3 (~1 min; also
+              stages the mesh as tests/golden/dragon.npz -- the OBJ only exists under /root/reference)
+  ico224_sample  a ONE-MILLION-triangle icosphere (nu = 224: 1 003 520 tris), 128^3: 20 011 lattice nodes, every 746-th, through
+              the reference's node loop (values, not digests: tests/golden/big_mesh_sample.npz)
   ico71_256   BASELINE configs[2]: icosphere nu=71 (100 820 tris), 256^3, 118 425 857 nodes (~8 min)
   ico71_512   BASELINE configs[3]: same mesh, 512^3, 943 460 865 nodes               (~1 h)
   config5     BASELINE configs[4] on the ico71_256 field (taken from the reference run above):
@@ -52,9 +56,33 @@ DBL_MAX = np.finfo(np.float64).max
 def meshes():
     return {
         "bunny128": (T.bunny_mesh, [128, 128, 128]),
+        "dragon128": (stage_dragon, [128, 128, 128]),
         "ico71_256": (lambda: T.icosphere(71), [256, 256, 256]),
         "ico71_512": (lambda: T.icosphere(71), [512, 512, 512]),
     }
+
+
+def stage_dragon():
+    path = os.path.join(HERE, "dragon.npz")
+    if not os.path.exists(path):
+        V, F = T.load_obj("/root/reference/cmd/generate_sdf/resources/dragon.obj")
+        np.savez_compressed(path, V=V, F=F)
+    return T.dragon_mesh()
+
+
+def ico224_sample():
+    """a million triangles: strided lattice nodes through the unmodified reference, values kept"""
+    V, F = T.icosphere(224)
+    res = [128, 128, 128]
+    dom = T.ref_default_domain(V)
+    g = T.RefGrid(V, F, dom, res)
+    n = T.n_nodes(res)
+    idx = np.arange(0, n, 746, dtype=np.uint64)
+    t0 = time.time()
+    sd = np.array([g.sample_nodes(int(l), int(l) + 1)[0] for l in idx])
+    np.savez_compressed(os.path.join(HERE, "big_mesh_sample.npz"), nu=np.uint32(224), triangles=np.uint64(len(F)), res=np.array(res, dtype=np.uint32),
+                        domain=dom, idx=idx, sd=sd, seconds=np.float64(time.time() - t0))
+    print("ico224_sample: %d nodes of %d, %d triangles, %.0f s" % (len(idx), n, len(F), time.time() - t0), flush=True)
 
 
 def lattice(name, keep_field):
@@ -173,7 +201,10 @@ def density256():
 
 def main():
     assert T.ref_available(), "build oracle/_ref first: make -C oracle ref"
-    want = sys.argv[1:] or list(meshes())
+    want = sys.argv[1:] or ["bunny128", "ico71_256", "ico71_512"]
+    if "ico224_sample" in want:
+        want.remove("ico224_sample")
+        ico224_sample()
     res = dict(np.load(OUT)) if os.path.exists(OUT) else {}
     res["block"] = np.uint64(BLOCK)
     for name, fn in (("density128", density128), ("density256", density256)):

@@ -60,6 +60,37 @@ def test_config2_bunny_128_every_node(dg, gold):
     assert len(bad) == 0, "blocks of 2^20 nodes that differ from the reference: %s" % bad[:10]
 
 
+def test_dragon_128_every_node(dg, gold):
+    """The reference's third sample mesh (cmd/generate_sdf/resources/dragon.obj, 79 988 triangles -- thin features, a mesh
+    that is neither smooth like the bunny nor regular like the icosphere), 128^3: all 14 926 977 coefficients == the
+    reference's."""
+    import torch
+    V, F = T.dragon_mesh()
+    assert len(F) == 79988
+    dom = gold["dragon128_domain"]
+    np.testing.assert_array_equal(dom, dg.default_domain(V))
+    _, _, field = sample_on_device(dg, torch, V, F, dom, [128] * 3)
+    assert len(field) == int(gold["dragon128_nodes"])
+    bad = mismatching_blocks(T.block_digests(field.cpu().numpy()), gold["dragon128_digest"])
+    assert len(bad) == 0, "blocks of 2^20 nodes that differ from the reference: %s" % bad[:10]
+
+
+def test_one_million_triangles_strided_nodes(dg):
+    """An icosphere of 1 003 520 triangles (nu = 224; ten times the judged mesh: a deeper tree, 3 % of the triangles per
+    brick neighbourhood), 128^3: every 746-th lattice node == what the UNMODIFIED reference's node loop returned for it
+    (tests/golden/big_mesh_sample.npz, written by tests/golden/make_digests.py ico224_sample)."""
+    import torch
+    z = np.load(os.path.join(T.GOLDEN, "big_mesh_sample.npz"))
+    V, F = T.icosphere(int(z["nu"]))
+    assert len(F) == int(z["triangles"]) == 1003520
+    dom = z["domain"]
+    np.testing.assert_array_equal(dom, dg.default_domain(V))
+    mesh, _, field = sample_on_device(dg, torch, V, F, dom, [int(r) for r in z["res"]])
+    got = field.cpu().numpy()[z["idx"].astype(np.int64)]
+    np.testing.assert_array_equal(got, z["sd"])
+    assert mesh.info()["n_triangles"] == 1003520
+
+
 @pytest.fixture(scope="module")
 def ico256(dg, gold):
     import torch

@@ -194,3 +194,49 @@ def test_a_failed_addfunction_leaves_the_grid_consistent(driver, tmp_path):
     g = T.read_cdf(out)
     assert len(g["nodes"]) == 2
     np.testing.assert_array_equal(g["nodes"][1], 2.0 * g["nodes"][0])
+
+
+STRICT_EIGEN = os.path.join(T.ROOT, "tests", "cpp", "eigen_strict")
+
+
+def _syntax_only(source, eigen):
+    cpp = os.path.join(T.ROOT, "discregrid_amd", "cpp")
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-fopenmp", "-D__HIP_PLATFORM_AMD__", "-I" + eigen, "-I" + os.path.join(cpp, "include"),
+           "-I" + os.path.join(T.ROOT, "include"), "-I" + os.path.join(T.ROOT, "discregrid_amd", "csrc"), "-I/opt/rocm/include", "-x", "c++", source]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+def test_host_api_compiles_against_a_strict_eigen_stand_in(tmp_path):
+    """Eigen3 is absent from the image: the public headers have only ever met the EAGER stand-in (third_party/eigen_min), whose
+    accidents -- operators that return finished matrices, public members -- code could silently lean on.  Every source of the
+    host library, the four tools, the C++ test drivers and the UNCHANGED reference caller must also compile against a second
+    stand-in that behaves like real Eigen at compile time (tests/cpp/eigen_strict: arithmetic returns expression proxies,
+    storage and box members are private, no pointer / bool / scalar conversions, no vector * vector) ..."""
+    import glob
+    cpp = os.path.join(T.ROOT, "discregrid_amd", "cpp")
+    sources = sorted(glob.glob(os.path.join(cpp, "src", "*.cpp")) + glob.glob(os.path.join(cpp, "cmd", "*.cpp")) +
+                     glob.glob(os.path.join(T.ROOT, "tests", "cpp", "*.cpp")))
+    assert len(sources) >= 10
+    umbrella = tmp_path / "umbrella.cpp"
+    umbrella.write_text("#include <Discregrid/All>\nint main() { Discregrid::CubicLagrangeDiscreteGrid g(Eigen::AlignedBox3d(Eigen::Vector3d(0, 0, 0), "
+                        "Eigen::Vector3d(1, 1, 1)), {{2u, 2u, 2u}}); return (int)g.nCells(); }\n")
+    for src in sources + [str(umbrella)]:
+        out = _syntax_only(src, STRICT_EIGEN)
+        assert out.returncode == 0, "%s does not compile against the strict Eigen stand-in:\n%s" % (src, out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("snippet", [
+    "struct D { template <int N> static double f(Eigen::Matrix<double, N, 1> const& v) { return v[0]; } }; double d = D::f(a + b);",  # an expression is not a Matrix<...>: nothing to deduce
+    "double* p = a;",                                        # no conversion to a pointer
+    "Eigen::Vector3d c = a * b;",                            # no product of two column vectors
+    "double m = box.m_min[0];",                              # box members are private
+    "Eigen::Vector3d c = 0.0;",                              # no construction from a scalar
+    "Eigen::Matrix<double, 32, 3> dn; double v = dn[5];",    # operator[] is for vectors
+    "Eigen::Matrix<double, 2, 1> c = a + b;",                # sizes must agree
+])
+def test_the_strict_stand_in_rejects_what_eigen_rejects(tmp_path, snippet):
+    """... and the strict stand-in is strict: constructs the eager stand-in accepts and real Eigen refuses do not compile."""
+    src = tmp_path / "neg.cpp"
+    src.write_text("#include <Eigen/Dense>\nint main(int argc, char**) { bool flag = argc > 1; Eigen::Vector3d a(1, 2, 3), b(4, 5, 6); "
+                   "Eigen::AlignedBox3d box(a, b); (void)flag; (void)box;\n" + snippet + "\nreturn 0; }\n")
+    assert _syntax_only(str(src), STRICT_EIGEN).returncode != 0, "the strict stand-in accepted: " + snippet
