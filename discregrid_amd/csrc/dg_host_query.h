@@ -80,6 +80,12 @@ struct HostWave
 		for (int l = 0; l < N; ++l)
 			f(l);
 	}
+	int uniform(int v) const { return v; }
+	void pick(LaneVar<float, N>& out, const LaneVar<f2, N>& lb, bool first) const
+	{
+		for (int l = 0; l < N; ++l)
+			out[l] = first ? lb[l].x : lb[l].y;
+	}
 	template <class P>
 	unsigned long long ballot(P p) const
 	{

@@ -78,6 +78,8 @@ struct DevWave
 	__device__ __forceinline__ DevWave(StackT* lds, int lane) : lds_lb(lds), lane_id(lane) {}
 	template <class F>
 	__device__ __forceinline__ void lanes(F f) const { f(0); }
+	__device__ __forceinline__ int uniform(int v) const { return dg::uniform(v); }
+	__device__ __forceinline__ void pick(LaneVar<float, 1>& out, const LaneVar<f2, 1>& lb, bool first) const { out[0] = first ? lb[0].x : lb[0].y; }
 	template <class P>
 	__device__ __forceinline__ unsigned long long ballot(P p) const { return __ballot(p(0)); }
 	__device__ __forceinline__ SPair load_pair(const PairRec* base, int idx) const
@@ -164,7 +166,7 @@ __device__ __forceinline__ int traverse(const MeshDev& M, LaneQuery& q, StackT* 
 										int heavy_work)
 {
 	DevWave<StackT> w(lds_lb, (int)__lane_id());
-	auto lane_query = [&](int) -> LaneQuery& { return q; };
+	auto lane_query = [&](int) DG_LANE -> LaneQuery& { return q; };
 	ExactWalk<DevWave<StackT>, decltype(lane_query)> pol(lane_query);
 	return packet_walk(w, pol, M, start, ovf_count, ovf_slots, heavy_work);
 }
@@ -332,8 +334,8 @@ __device__ __forceinline__ int traverse_fast(const MeshDev& M, FastLane& f, uint
 											 uint32_t* ovf_count, uint32_t ovf_slots, int heavy_work)
 {
 	DevWave<uint16_t> w(lds_lb, (int)__lane_id());
-	auto lane_state = [&](int) -> FastLane& { return f; };
-	auto lane_list = [&](int) { return list_base; };
+	auto lane_state = [&](int) DG_LANE -> FastLane& { return f; };
+	auto lane_list = [&](int) DG_LANE { return list_base; };
 	FastWalk<DevWave<uint16_t>, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
 	const int parked = packet_walk(w, pol, M, M.root_info, ovf_count, ovf_slots, kFastWorkFactor * heavy_work);
 	if (parked >= 0)

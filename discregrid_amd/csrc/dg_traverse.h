@@ -10,12 +10,16 @@
 // A wave context W provides
 //   static constexpr int kLanes                     lanes one thread of this instantiation carries (device 1, emulator 64)
 //   void lanes(F f)                                 f(l) for each of them
+//   void pick(out, lb, bool first)                  out[l] = first ? lb[l].x : lb[l].y  (a wave-uniform flag the lanes select by goes
+//                                                   in as an ARGUMENT of a context member: captured in a callable it takes a detour
+//                                                   through a vector register on the device)
 //   unsigned long long ballot(P p)                  bit l = p(l) over the lanes of the WAVE
 //   Pair   load_pair(const PairRec*, int)           .r -> kPairFloats floats, .info0, .info1   (device: SGPRs)
 //   Tri    load_tri(const TriPacket*, int)          the 15 doubles of a packet                  (device: SGPRs)
 //   Approx load_approx(const TriApproxPair*, int)   .r -> kApproxFloats floats, .valid0, .valid1 (device: SGPRs)
 //   void push(int sp, int info, lb, bool second)    stack entry sp: the info word, and per lane lb[l].y (second) or lb[l].x parked
 //   float parked(int sp, int l); int info(int sp)   ... and back
+//   int uniform(int v)                              v, known to be the same in every lane (device: v_readfirstlane)
 //   uint32_t claim(uint32_t* counter)               atomic fetch-add 1 (heavy-brick slots)
 //   void list_store(uint32_t slot, int v)           a word of the lanes' candidate lists (LDS on the device)
 //   note_pair_step / note_leaf / note_*             counters of the emulator's design studies; empty on the device
@@ -33,6 +37,12 @@
 #pragma once
 #include "dg_geom.h"
 #include "dg_kernels.h"
+
+// Per-lane callables are always inlined.  Device lore learnt the hard way (same-box A/B, +3.7 %): a wave-uniform variable that a
+// per-lane callable captures BY REFERENCE and that changes in a loop (a counter, a flag) is kept in a vector register by the
+// device compiler -- loop counters become v_add + vcc, selects by a flag become v_cndmask 0/1 + v_cmp.  Such values go in by
+// value (ints) or as arguments of a context member (flags: W::pick, W::push).
+#define DG_LANE __attribute__((always_inline))
 
 namespace dg
 {
@@ -56,7 +66,7 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 	int sp = 0; // wave-uniform
 	int cur = start;
 	LaneVar<float, W::kLanes> lbcur; // every lane's lower bound for `cur`
-	w.lanes([&](int l) { lbcur[l] = 0.0f; });
+	w.lanes([&](int l) DG_LANE { lbcur[l] = 0.0f; });
 	int work = 0; // wave-uniform
 	int budget = ovf_count ? budget0 : 0x7fffffff;
 	int parked = -1;
@@ -73,9 +83,9 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 			w.note_pair_step(M, cur);
 			const typename W::Pair pr = w.load_pair(M.pairs, cur);
 			LaneVar<f2, W::kLanes> lb, cd;
-			w.lanes([&](int l) { lb[l] = pol.bounds(l, pr.r, &cd[l]); });
-			const unsigned long long bl = w.ballot([&](int l) { return pol.reach(l, lb[l].x); });
-			const unsigned long long br = w.ballot([&](int l) { return pol.reach(l, lb[l].y); });
+			w.lanes([&](int l) DG_LANE { lb[l] = pol.bounds(l, pr.r, &cd[l]); });
+			const unsigned long long bl = w.ballot([&](int l) DG_LANE { return pol.reach(l, lb[l].x); });
+			const unsigned long long br = w.ballot([&](int l) DG_LANE { return pol.reach(l, lb[l].y); });
 			if ((bl | br) == 0ull)
 			{
 				dead = true;
@@ -86,7 +96,7 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 			{
 				// both children are needed: the one most lanes are closer to -- by the distance to the box CENTRE --
 				// first, the other is postponed (its info word and every lane's bound for it go on the stack)
-				const unsigned long long pref = w.ballot([&](int l) { return cd[l].x <= cd[l].y; }) & (bl | br);
+				const unsigned long long pref = w.ballot([&](int l) DG_LANE { return cd[l].x <= cd[l].y; }) & (bl | br);
 				left = 2 * __builtin_popcountll(pref) >= __builtin_popcountll(bl | br);
 				if (sp < M.stack_levels) // always true: one push per tree level at most
 				{
@@ -96,7 +106,7 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 				}
 			}
 			cur = left ? pr.info0 : pr.info1;
-			w.lanes([&](int l) { lbcur[l] = left ? lb[l].x : lb[l].y; });
+			w.pick(lbcur, lb, left);
 		}
 		if (!dead)
 		{
@@ -108,9 +118,9 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 		while (sp > 0)
 		{
 			--sp;
-			w.lanes([&](int l) { lbcur[l] = w.parked(sp, l); });
+			w.lanes([&](int l) DG_LANE { lbcur[l] = w.parked(sp, l); });
 			w.note_pop();
-			if (w.ballot([&](int l) { return pol.reach(l, lbcur[l]); }) != 0ull)
+			if (w.ballot([&](int l) DG_LANE { return pol.reach(l, lbcur[l]); }) != 0ull)
 			{
 				cur = w.info(sp);
 				found = true;
@@ -157,9 +167,9 @@ struct ExactWalk
 		{
 			const typename W::Pair pr = w.load_pair(M.tri_pairs, (first + g) >> 1);
 			LaneVar<f2, W::kLanes> lb;
-			w.lanes([&](int l) { lb[l] = pair_lb2(pr.r, q(l).fp); });
-			const unsigned long long m0 = w.ballot([&](int l) { return fmax2(lb[l].x, leaf_lb2[l]) < q(l).bestf; });
-			const unsigned long long m1 = w.ballot([&](int l) { return fmax2(lb[l].y, leaf_lb2[l]) < q(l).bestf; });
+			w.lanes([&](int l) DG_LANE { lb[l] = pair_lb2(pr.r, q(l).fp); });
+			const unsigned long long m0 = w.ballot([&](int l) DG_LANE { return fmax2(lb[l].x, leaf_lb2[l]) < q(l).bestf; });
+			const unsigned long long m1 = w.ballot([&](int l) DG_LANE { return fmax2(lb[l].y, leaf_lb2[l]) < q(l).bestf; });
 			w.note_leaf_pair();
 #pragma unroll
 			for (int side = 0; side < 2; ++side)
@@ -171,7 +181,7 @@ struct ExactWalk
 				const int t = first + g + side;
 				const TriRegs T = w.load_tri(M.tris, t);
 				bool useful = false; // (emulator statistics; dead code on the device)
-				w.lanes([&](int l) {
+				w.lanes([&](int l) DG_LANE {
 					const Hit h = tri_closest<false>(T.v0x, T.v0y, T.v0z, T.e0x, T.e0y, T.e0z, T.e1x, T.e1y, T.e1z, T.a00, T.a01, T.a11, T.det,
 													 T.inv_det, T.denom, q(l).px, q(l).py, q(l).pz);
 					useful = useful || h.d2 < q(l).best_d2;
@@ -225,11 +235,12 @@ struct FastWalk
 	DG_HD int leaf(W& w, const MeshDev& M, int first, int cnt, const LaneVar<float, W::kLanes>& lbcur)
 	{
 		int work = 1;
+		cnt = w.uniform(cnt); // (the loop below is a scalar loop: tell the device compiler so)
 		w.note_leaf(first, cnt);
 		// error terms for this leaf's triangles around the lane's current distance estimate (its upper bound, or the
 		// leaf's own bound while no triangle has been seen); they are valid for any estimate
 		LaneVar<float, W::kLanes> theta, kappa;
-		w.lanes([&](int l) { approx_err_terms(f(l).a.E, f(l).U < __builtin_inff() ? f(l).U : lbcur[l], &theta[l], &kappa[l]); });
+		w.lanes([&](int l) DG_LANE { approx_err_terms(f(l).a.E, f(l).U < __builtin_inff() ? f(l).U : lbcur[l], &theta[l], &kappa[l]); });
 		for (int g = 0; g < cnt; g += 2)
 		{
 			const typename W::Approx rec = w.load_approx(M.tri_approx, (first + g) >> 1);
@@ -238,7 +249,7 @@ struct FastWalk
 			// step 1: frame coordinates + rectangle bound; most pairs of a visited leaf end here
 			LaneVar<TriFrame, W::kLanes> fr;
 			LaneVar<f2, W::kLanes> lo_lb;
-			w.lanes([&](int l) {
+			w.lanes([&](int l) DG_LANE {
 				const f2 qlb = tri_approx_frame(rec.r, f(l).a, &fr[l]);
 				lo_lb[l] = qlb - f2_fma(qlb, f2_splat(theta[l]), f2_splat(kappa[l]));
 			});
@@ -246,12 +257,13 @@ struct FastWalk
 			w.note_filter_pair();
 			// (two ballots combined with the wave-uniform validity on the scalar side: written as ONE per-lane predicate the
 			// uniform flags take a detour through vector registers on the device)
-			const unsigned long long reach0 = w.ballot([&](int l) { return lo_lb[l].x <= f(l).U; });
-			const unsigned long long reach1 = w.ballot([&](int l) { return lo_lb[l].y <= f(l).U; });
+			const unsigned long long reach0 = w.ballot([&](int l) DG_LANE { return lo_lb[l].x <= f(l).U; });
+			const unsigned long long reach1 = w.ballot([&](int l) DG_LANE { return lo_lb[l].y <= f(l).U; });
 			if (DG_TRI_PREFILTER && ((valid0 == 1 ? reach0 : 0ull) | (valid1 == 1 ? reach1 : 0ull)) == 0ull)
 				continue;
 			w.note_filter_rest();
-			w.lanes([&](int l) {
+			const int position = first + g; // (loop-varying wave-uniform scalars go into the per-lane code BY VALUE: see DG_LANE)
+			w.lanes([&, valid0, valid1, position](int l) DG_LANE {
 				FastLane& fl = f(l);
 				const f2 q = tri_approx_rest(rec.r, fl.a, fr[l]);
 				const f2 err = f2_fma(q, f2_splat(theta[l]), f2_splat(kappa[l]));
@@ -269,7 +281,7 @@ struct FastWalk
 						const bool reset = up_s < fl.Lmin;
 						w.note_append(reset && fl.slot != base);
 						fl.slot = reset ? base : fl.slot;
-						w.list_store(fl.slot, first + g + side);
+						w.list_store(fl.slot, position + side);
 						fl.slot = fl.slot + 256u < limit ? fl.slot + 256u : limit;
 						fl.Lmin = fmin_sel(reset ? __builtin_inff() : fl.Lmin, lo_s);
 					}
@@ -278,7 +290,7 @@ struct FastWalk
 			});
 		}
 		// the threshold the bound tests compare with (dg_geom.h: approx_err_terms)
-		w.lanes([&](int l) { f(l).Uprune = __builtin_fmaf(f(l).U, 1.0f + theta[l], kappa[l]); });
+		w.lanes([&](int l) DG_LANE { f(l).Uprune = __builtin_fmaf(f(l).U, 1.0f + theta[l], kappa[l]); });
 		return work;
 	}
 };
