@@ -737,7 +737,7 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	}
 	// A field with a band-limited cell-major copy (and no full one): rows for the queries inside the band, the plain gather
 	// for the others, in one launch, queries in any order (DG_FORCE=k2_band=0: ignore the copy)
-	// Routed by measurement: every large batch is probed (4096 of its queries: how many have a row in the copy?), and the verdict
+	// Routed by measurement: every large batch is probed (1024 of its queries: how many have a row in the copy?), and the verdict
 	// of the field's PREVIOUS large batch decides -- a batch of which less than three quarters map into the band is faster through
 	// the sorted gather of the binned path below (uniform queries over a shell copy, 57 % mapped: 8.3 against 5.5 Gq/s; the band
 	// kernel wins from ~78 % mapped on: 0.055 ns per mapped query, 0.35 ns per unmapped one, against 0.12 ns binned).

@@ -104,9 +104,12 @@ dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int
 	{
 		(void)shm_unlink(hf->name.c_str()); // (a segment a crashed job left behind)
 		hf->fd = shm_open(hf->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-		if (hf->fd < 0 || ftruncate(hf->fd, (off_t)hf->map_bytes) != 0)
+		// (posix_fallocate: the pages are claimed NOW -- a tmpfs that is too small answers ENOSPC here instead of SIGBUS at the
+		// first touch of a page it cannot back)
+		int falloc = 0;
+		if (hf->fd < 0 || ftruncate(hf->fd, (off_t)hf->map_bytes) != 0 || (falloc = posix_fallocate(hf->fd, 0, (off_t)hf->map_bytes)) != 0)
 		{
-			const int err = errno;
+			const int err = falloc != 0 ? falloc : errno;
 			if (hf->fd >= 0)
 			{
 				(void)close(hf->fd);

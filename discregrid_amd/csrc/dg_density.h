@@ -31,17 +31,14 @@ struct DensityParams
 	// kmask[i*16 + j] has bit k set where W(xi_i, xi_j, xi_k) != 0.
 	// skip_mode 0: evaluate every point; 1: skip the zero-weight points; 2 (device): skip them unless
 	// bit 0 of *unsafe is set (by k_field_check when the field holds NaN / Inf / huge values; bit 1 of the same
-	// word: the field holds "no value" coefficients -- the LDS kernel then consults the tile copy's flag bits).
+	// word: the field holds "no value" coefficients).
 	uint16_t kmask[256];
 	int32_t skip_mode;
-	int32_t lds_waves; // device, tile-major copy: > 0: the kernel that stages the coefficients through LDS (waves per SIMD to aim for)
-	// device, x-major copy (k_density_rows): lane shape of a wave's row block (1: 16 x 2 x 2 cells, 4: 8 x 4 x 2 -- measured
-	// slower: 2: 32 x 2 x 1, 3: 16 x 4 x 1, 5: 64 x 1 x 1, kept for the partition test --; 0: not this kernel), waves along x / y / z of the blocks consecutive wave ids fill, and per
-	// class the wave counts along the three axes with the first wave id of the class
-	// 6 (kRowShapeCells): k_density_cells -- a lane owns a lattice POINT with its seven nodes, waves of 16 x 2 x 2 points (dg_density_cells.h)
+	// device, x-major copy: kRowShapeCells = k_density_cells (a lane owns a lattice POINT with its seven nodes, waves of 16 x 2 x 2
+	// points, dg_density_cells.h), 0: the brick kernel; waves along x / y / z of the blocks consecutive wave ids fill, and the wave
+	// counts along the three axes with the first wave id
 	int32_t row_shape;
-	uint64_t row_node_begin, row_node_end; // k_density_rows: the launch's node range (out[l - row_node_begin]); lanes outside idle
-	int32_t row_waves3; // k_density_rows: 1: the instantiation whose register budget allows three waves per SIMD
+	uint64_t row_node_begin, row_node_end; // k_density_cells: the launch's node range (out[l - row_node_begin]); lanes outside idle
 	uint32_t row_block[3];
 	uint32_t row_waves[4][3];
 	uint32_t row_prefix[5];
@@ -49,7 +46,7 @@ struct DensityParams
 };
 
 static const int kRowShapeCells = 6;
-// k_density_rows: wave id -> (class, wave coordinates along x, y, z).  The waves of a class fill blocks of
+// k_density_cells: wave id -> (class, wave coordinates along x, y, z).  The waves of a class fill blocks of
 // row_block[0] x [1] x [2] waves (truncated at the upper faces), blocks in row-major order: the waves an XCD has in
 // flight -- consecutive ids -- integrate over (nearly) the same part of the field at the same time.  A bijection of
 // [row_prefix[c], row_prefix[c + 1]) onto the class's waves, all in wave-uniform integers.
@@ -82,52 +79,6 @@ DG_HD RowWave row_wave_map(const DensityParams& P, uint32_t id)
 	m.w[1] = i1 * B1 + (r3 / s0) % s1;
 	m.w[2] = i2 * B2 + r3 / (s0 * s1);
 	return m;
-}
-
-// the item of `lane` in wave m of lane shape (lx, ly, lz): the vertex (class 0) or cell edge (classes 1..3) that starts at
-// cell-lattice point (i, j, k) -- node A = class coordinates (a, b, s), node B = (a + 1, b, s) for the edge classes --
-// clamped to the lattice (valid = false for the lanes that hang over), and node A's index in the coefficient vector
-struct RowItem
-{
-	bool valid;
-	uint32_t a, b, s;
-	uint64_t node;
-};
-DG_HD RowItem row_lane_item(const RowWave& m, int lane, uint32_t lx, uint32_t ly, uint32_t lz, const uint32_t res[3])
-{
-	const int cls = m.cls;
-	const uint32_t nx = res[0], ny = res[1], nz = res[2];
-	uint32_t i = m.w[0] * lx + (uint32_t)lane % lx, j = m.w[1] * ly + ((uint32_t)lane / lx) % ly, k = m.w[2] * lz + (uint32_t)lane / (lx * ly);
-	const uint32_t ix = nx + (cls == 1 ? 0u : 1u), iy = ny + (cls == 2 ? 0u : 1u), iz = nz + (cls == 3 ? 0u : 1u);
-	RowItem it;
-	it.valid = i < ix && j < iy && k < iz;
-	i = i < ix ? i : ix - 1u;
-	j = j < iy ? j : iy - 1u;
-	k = k < iz ? k : iz - 1u;
-	it.a = i;
-	it.b = j;
-	it.s = k;
-	if (cls == 1)
-		it.a = 2u * i;
-	else if (cls == 2)
-	{
-		it.a = 2u * j;
-		it.b = k;
-		it.s = i;
-	}
-	else if (cls == 3)
-	{
-		it.a = 2u * k;
-		it.b = i;
-		it.s = j;
-	}
-	uint32_t D[3];
-	class_dims(cls, res, D);
-	const uint64_t nv = (uint64_t)(nx + 1) * (ny + 1) * (nz + 1);
-	const uint64_t nex = 2ull * nx * (ny + 1) * (nz + 1), ney = 2ull * (nx + 1) * ny * (nz + 1);
-	const uint64_t off = cls == 0 ? 0ull : (cls == 1 ? nv : (cls == 2 ? nv + nex : nv + nex + ney));
-	it.node = off + ((uint64_t)it.s * D[1] + it.b) * D[0] + it.a;
-	return it;
 }
 
 // CubicKernel::setRadius / W (sph_kernel.hpp:11-42); r.norm() as Eigen evaluates it for a 3-vector

@@ -44,6 +44,8 @@ struct NoStats // the product's instantiation counts nothing
 	void leaf(int, int) {}
 	void leaf_pair() {}
 	void tri_test(int, bool) {}
+	void dead() {}
+	void push() {}
 	void pop() {}
 	void stale_pop() {}
 	void filter_pair() {}
@@ -127,6 +129,8 @@ struct HostWave
 	void note_leaf(int first, int cnt) const { if (stats) stats->leaf(first, cnt); }
 	void note_leaf_pair() const { if (stats) stats->leaf_pair(); }
 	void note_tri_test(int interested, bool useful) const { if (stats) stats->tri_test(interested, useful); }
+	void note_dead() const { if (stats) stats->dead(); }
+	void note_push() const { if (stats) stats->push(); }
 	void note_pop() const { if (stats) stats->pop(); }
 	void note_stale_pop() const { if (stats) stats->stale_pop(); }
 	void note_filter_pair() const { if (stats) stats->filter_pair(); }

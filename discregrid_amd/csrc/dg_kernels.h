@@ -181,7 +181,6 @@ struct SampleParams
 	OverflowBuf ovf;
 	int32_t filtered;        // K1 / K1p: 1 = the filtered kernel (k_sample_fast), 0 = the exact kernel only
 	int32_t brick_blocking;  // 0: bricks of a class in row-major order; 1: in blocks of kBlk0 x kBlk1 x kBlkQ bricks (K3)
-	int32_t pair_nodes;      // K3: the edge classes count DOUBLE bricks (8 x 4 x 4 nodes) along a: a lane owns the two nodes of a cell edge
 	PointsDesc pts;          // K1p: "brick" b = the 64 points (in processing order) b*64 .. b*64+63
 };
 

@@ -152,6 +152,8 @@ struct DevWave
 	__device__ __forceinline__ void note_leaf(int, int) const {}
 	__device__ __forceinline__ void note_leaf_pair() const {}
 	__device__ __forceinline__ void note_tri_test(int, bool) const {}
+	__device__ __forceinline__ void note_dead() const {}
+	__device__ __forceinline__ void note_push() const {}
 	__device__ __forceinline__ void note_pop() const {}
 	__device__ __forceinline__ void note_stale_pop() const {}
 	__device__ __forceinline__ void note_filter_pair() const {}

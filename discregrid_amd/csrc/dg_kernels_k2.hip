@@ -298,27 +298,30 @@ __global__ __launch_bounds__(64) void k_interpolate_band(const FieldDev F, const
 		cur = nxt;
 	}
 }
-// Routing probe of the band path: of (up to) 4096 queries spread evenly over the batch, how many have a cell and how many of
+// Routing probe of the band path: of (up to) 1024 queries spread evenly over the batch, how many have a cell and how many of
 // those have a row in the band copy?  One block; the two counts go to pinned host words -- the prediction the HOST routes the
 // field's NEXT large batch with (a batch that mostly misses the band is faster through the sorted gather of the binned path
 // than through this kernel's unsorted one: 8.3 against 5.5 Gq/s with 57 % of the queries mapped).
-__global__ __launch_bounds__(256) void k_band_probe(const FieldDev F, const double* __restrict__ xyz, uint64_t n, uint32_t* host_counts)
+__global__ __launch_bounds__(1024) void k_band_probe(const FieldDev F, const double* __restrict__ xyz, uint64_t n, uint32_t* host_counts)
 {
+	// ONE sample per thread (1024 of them): the look-up is a chain of dependent loads, and a thread that walked several chains one
+	// after the other made the probe cost 80 us in front of a 550 us launch
 	__shared__ uint32_t valid, mapped;
 	if (threadIdx.x == 0)
 		valid = mapped = 0;
 	__syncthreads();
-	const uint64_t m = n < 4096 ? n : 4096;
+	const uint64_t m = n < 1024 ? n : 1024;
 	const uint64_t step = n / m;
-	uint32_t v = 0, h = 0;
-	for (uint64_t i = threadIdx.x; i < m; i += blockDim.x)
+	if (threadIdx.x < m)
 	{
-		const BandQuery b = band_locate(F, xyz, i * step, n);
-		v += b.q.valid;
-		h += b.row != 0xffffffffu;
+		const BandQuery b = band_locate(F, xyz, (uint64_t)threadIdx.x * step, n);
+		const unsigned long long v = __ballot(b.q.valid), h = __ballot(b.row != 0xffffffffu);
+		if ((threadIdx.x & 63u) == 0)
+		{
+			atomicAdd(&valid, (uint32_t)__popcll(v));
+			atomicAdd(&mapped, (uint32_t)__popcll(h));
+		}
 	}
-	atomicAdd(&valid, v);
-	atomicAdd(&mapped, h);
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
@@ -474,7 +477,7 @@ hipError_t launch_band_probe(const FieldDev& f, const double* d_xyz, uint64_t n,
 {
 	if (n == 0 || !host_counts)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_band_probe, dim3(1), dim3(256), 0, stream, f, d_xyz, n, host_counts);
+	hipLaunchKernelGGL(k_band_probe, dim3(1), dim3(1024), 0, stream, f, d_xyz, n, host_counts);
 	return hipGetLastError();
 }
 hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream)

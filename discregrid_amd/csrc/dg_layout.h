@@ -90,27 +90,8 @@ inline void finish_bricks(SampleParams& P)
 	finish_blocks(P);
 }
 
-// K3's two-nodes-per-lane form: the edge classes are cut into double bricks of 8 x 4 x 4 nodes along a (the axis their
+
 // two nodes per cell edge run along); the vertex class keeps its 4 x 4 x 4 bricks.  Call after layout_range().
-inline void pair_bricks(SampleParams& P)
-{
-	uint64_t prefix = 0;
-	for (int c = 0; c < 4; ++c)
-	{
-		ClassDesc& C = P.cls[c];
-		if (c != 0)
-			C.nb0 = (C.nb0 + 1) / 2;
-		C.rcp_nb0 = udiv_magic(C.nb0);
-		C.rcp_nb01 = udiv_magic(C.nb0 * C.nb1);
-		C.brick_prefix = prefix;
-		prefix += (uint64_t)C.nb0 * C.nb1 * C.nbq;
-	}
-	P.total_bricks = prefix;
-	P.n_blocks = (uint32_t)((prefix + kWavesPerBlock - 1) / kWavesPerBlock);
-	P.pair_nodes = 1;
-	P.xcd_chunk = 0;
-	finish_blocks(P);
-}
 
 inline void init_params(SampleParams& P, const MeshDev& mesh, const double dmin[3], const double cell[3], int invert)
 {
@@ -329,52 +310,11 @@ inline void init_density_params(DensityParams& P, double h, double rho0, const d
 		P.fast_div = (h >= 1.0e-12 && h <= 1.0e12 && (bits & 0xfffffffffffffull) != 0xfffffffffffffull) ? 1 : 0;
 	}
 	P.skip_mode = 0;
-	P.lds_waves = 0;
 	P.row_shape = 0;
-	P.row_waves3 = 0;
 	P.unsafe = nullptr;
 }
-// lanes of a wave of k_density_rows along x, y, z (DensityParams::row_shape)
-inline void row_shape_lanes(int shape, uint32_t l[3])
-{
-	l[0] = shape == 2 ? 32u : (shape == 4 ? 8u : (shape == 5 ? 64u : 16u));
-	l[1] = shape == 3 || shape == 4 ? 4u : (shape == 5 ? 1u : 2u);
-	l[2] = shape == 1 || shape == 4 ? 2u : 1u;
-}
-// K3 in row blocks over the WHOLE lattice: waves per class and their first ids; returns the number of waves
-// (block: waves along x / y / z of the blocks consecutive ids fill)
-inline uint64_t layout_density_rows(DensityParams& P, SampleParams& L, const uint32_t res[3], int shape, const uint32_t block[3])
-{
-	uint32_t l[3];
-	row_shape_lanes(shape, l);
-	P.row_shape = shape;
-	uint64_t prefix = 0;
-	for (int c = 0; c < 4; ++c)
-	{
-		const uint32_t items[3] = {res[0] + (c == 1 ? 0u : 1u), res[1] + (c == 2 ? 0u : 1u), res[2] + (c == 3 ? 0u : 1u)};
-		P.row_prefix[c] = (uint32_t)prefix;
-		uint64_t n = 1;
-		for (int d = 0; d < 3; ++d)
-		{
-			P.row_waves[c][d] = (items[d] + l[d] - 1) / l[d];
-			n *= P.row_waves[c][d];
-		}
-		prefix += n;
-	}
-	P.row_prefix[4] = (uint32_t)prefix;
-	P.row_node_begin = 0;
-	P.row_node_end = ~0ull;
-	for (int d = 0; d < 3; ++d)
-		P.row_block[d] = std::max(1u, block[d]);
-	L.total_bricks = prefix;
-	L.n_blocks = (uint32_t)prefix;
-	L.pair_nodes = 0;
-	L.xcd_chunk = 0;
-	finish_blocks(L);
-	return prefix;
-}
 // K3 with one lane per lattice point (k_density_cells): waves of 16 x 2 x 2 points over the (n + 1)^3 point lattice, ids in
-// blocks of `block` waves like layout_density_rows() (one "class" holds every wave); returns the number of waves
+// blocks of `block` waves along x / y / z (one "class" holds every wave; DensityParams::row_block); returns the number of waves
 inline uint64_t layout_density_cells(DensityParams& P, SampleParams& L, const uint32_t res[3], const uint32_t block[3])
 {
 	const uint32_t l[3] = {(uint32_t)kK3cLx, (uint32_t)kK3cLy, (uint32_t)kK3cLz};
@@ -396,7 +336,6 @@ inline uint64_t layout_density_cells(DensityParams& P, SampleParams& L, const ui
 		P.row_block[d] = std::max(1u, block[d]);
 	L.total_bricks = n;
 	L.n_blocks = (uint32_t)n;
-	L.pair_nodes = 0;
 	L.xcd_chunk = 0;
 	finish_blocks(L);
 	return n;

@@ -88,6 +88,7 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 			const unsigned long long br = w.ballot([&](int l) DG_LANE { return pol.reach(l, lb[l].y); });
 			if ((bl | br) == 0ull)
 			{
+				w.note_dead();
 				dead = true;
 				break;
 			}
@@ -102,6 +103,7 @@ DG_HD int packet_walk(W& w, P& pol, const MeshDev& M, int start, uint32_t* ovf_c
 				{
 					// (the flag goes in as an argument: captured in a callable it takes a detour through a vector register on the device)
 					w.push(sp, left ? pr.info1 : pr.info0, lb, left);
+					w.note_push();
 					++sp;
 				}
 			}

@@ -289,18 +289,6 @@ def set_tile_major(on=1):
     lib().emu_set_tile_major(int(on))
 
 
-def density_rows_cover(res, shape, block):
-    """hits per node of one emulated k_density_rows launch over the whole lattice, and its wave count."""
-    res = np.ascontiguousarray(res, dtype=np.uint32)
-    block = np.ascontiguousarray(block, dtype=np.uint32)
-    hits = np.zeros(T.n_nodes(res), dtype=np.uint32)
-    L = lib()
-    L.emu_density_rows_cover.restype = C.c_uint64
-    L.emu_density_rows_cover.argtypes = [T.c_up, C.c_int, T.c_up, C.c_void_p]
-    waves = int(L.emu_density_rows_cover(T.up(res), int(shape), T.up(block), hits.ctypes.data_as(C.c_void_p)))
-    return hits, waves
-
-
 def density_cells(domain, res, coeffs, h, rho0, band=True, begin=0, end=None, mask=None, block=(1, 16, 8)):
     """One emulated k_density_cells launch (a lane owns a lattice point with its seven nodes, dg_density_cells.h) over the
     node range: the values and, per node, how many lanes wrote it."""

@@ -56,6 +56,8 @@ struct EmuCounters
 	void leaf(int first, int cnt);
 	void leaf_pair();
 	void tri_test(int interested, bool useful);
+	void dead();
+	void push();
 	void pop();
 	void stale_pop();
 	void filter_pair();
@@ -193,8 +195,27 @@ void EmuCounters::tri_test(int interested, bool useful)
 		st->useful_tests += useful;
 	}
 }
-void EmuCounters::pop() { if (st) st->pops++; }
-void EmuCounters::stale_pop() { if (st) st->stale_pops++; }
+static uint64_t g_fast_events[4]; // filtered traversal: dead steps, pushes, pops, stale pops (design studies)
+extern "C" void emu_fast_events(uint64_t* out, int reset)
+{
+	for (int i = 0; i < 4; ++i)
+	{
+		out[i] = g_fast_events[i];
+		if (reset) g_fast_events[i] = 0;
+	}
+}
+void EmuCounters::dead() { if (fs) __atomic_fetch_add(&g_fast_events[0], 1, __ATOMIC_RELAXED); }
+void EmuCounters::push() { if (fs) __atomic_fetch_add(&g_fast_events[1], 1, __ATOMIC_RELAXED); }
+void EmuCounters::pop()
+{
+	if (st) st->pops++;
+	if (fs) __atomic_fetch_add(&g_fast_events[2], 1, __ATOMIC_RELAXED);
+}
+void EmuCounters::stale_pop()
+{
+	if (st) st->stale_pops++;
+	if (fs) __atomic_fetch_add(&g_fast_events[3], 1, __ATOMIC_RELAXED);
+}
 void EmuCounters::filter_pair() { if (fs) fs->hist[16] += 1; } // (pairs that reached step 1)
 void EmuCounters::filter_rest() { if (fs) fs->tri_pairs++; }
 void EmuCounters::append(bool reset)
@@ -1079,35 +1100,6 @@ static void build_xmajor(FieldDev& F, XMajorCopy& X)
 					X.flags[((size_t)k * F.res[1] + j) * words + (i >> 6)] |= 1ull << (i & 63u);
 			}
 	F.xmajor_flags = X.flags.data();
-}
-// every wave and lane of a k_density_rows launch (dg_layout.h layout_density_rows(), logical_block(), row_wave_map(),
-// row_lane_item()): hits[node] += 1 for every node a valid lane owns; returns the number of waves
-uint64_t emu_density_rows_cover(const uint32_t res[3], int shape, const uint32_t block[3], uint32_t* hits)
-{
-	DensityParams P;
-	SampleParams L;
-	std::memset(&L, 0, sizeof(L));
-	std::memset(&P, 0, sizeof(P));
-	const uint64_t waves = layout_density_rows(P, L, res, shape, block);
-	uint32_t l[3];
-	row_shape_lanes(shape, l);
-	for (uint32_t b = 0; b < L.blocks_per_xcd * 8u; ++b)
-	{
-		uint32_t blk;
-		if (!logical_block(L, b, &blk) || blk >= P.row_prefix[4])
-			continue;
-		const RowWave m = row_wave_map(P, blk);
-		for (int lane = 0; lane < 64; ++lane)
-		{
-			const RowItem it = row_lane_item(m, lane, l[0], l[1], l[2], res);
-			if (!it.valid)
-				continue;
-			hits[it.node] += 1;
-			if (m.cls != 0)
-				hits[it.node + 1] += 1;
-		}
-	}
-	return waves;
 }
 extern int g_density_skip;
 // K3 with one lane per lattice point (dg_density_cells.h) on the host: every wave and lane of a k_density_cells launch over

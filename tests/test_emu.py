@@ -449,17 +449,6 @@ def test_xmajor_copy_is_the_same_field(golden):
         emu.set_tile_major(0)
 
 
-@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5])
-def test_row_block_waves_own_every_node_once(shape):
-    """k_density_rows: wave ids -> row blocks (blocked order, XCD chunks) -> lanes -> nodes is a partition of the lattice for
-    every lane shape, block shape and resolution (no multiples of anything included)."""
-    for res, block in (([8, 8, 8], [2, 8, 8]), ([5, 7, 3], [2, 8, 8]), ([33, 3, 5], [1, 2, 3]), ([1, 1, 1], [4, 4, 4]),
-                       ([17, 9, 20], [3, 1, 64]), ([70, 4, 2], [2, 2, 2])):
-        hits, waves = emu.density_rows_cover(res, shape, block)
-        assert waves > 0
-        assert (hits == 1).all(), (res, block, np.unique(hits))
-
-
 def test_point_lanes_with_seven_nodes_equal_the_per_node_body(golden):
     """k_density_cells (dg_density_cells.h): a lane owns a lattice point with its seven nodes, evaluates the points that share a
     cell from one fetch and takes the axis states of the shifted coordinates from tables.  Every node of the lattice is written
