@@ -53,10 +53,10 @@ struct NoStats // the product's instantiation counts nothing
 	void append(bool) {}
 };
 
-// N lanes carried by one host thread.  The shared stack is two arrays; `stack16` parks the bounds as the filtered kernel
+// N lanes carried by one host thread.  The shared stack is two arrays; STACK16 parks the bounds as the filtered kernel
 // does (upper 16 bits of the float); the candidate lists of the filtered traversal live in `lists` with the kernel's
 // layout (entry k of lane l at byte 256 k + 4 l, i.e. lists[64 k + l] for a full wave).
-template <int N, class S = NoStats>
+template <int N, class S = NoStats, bool STACK16 = false>
 struct HostWave
 {
 	static constexpr int kLanes = N;
@@ -71,7 +71,6 @@ struct HostWave
 		int valid0, valid1;
 	};
 	S* stats = nullptr;
-	bool stack16 = false;
 	int* lists = nullptr;
 	int infos[kStackDepth];
 	float bounds[kStackDepth][N];
@@ -118,7 +117,7 @@ struct HostWave
 		for (int l = 0; l < N; ++l)
 		{
 			const float v = second ? lb[l].y : lb[l].x;
-			bounds[sp][l] = stack16 ? truncate16(v) : v;
+			bounds[sp][l] = STACK16 ? truncate16(v) : v;
 		}
 	}
 	float parked(int sp, int l) const { return bounds[sp][l]; }

@@ -64,20 +64,25 @@ struct EmuCounters
 	void filter_rest();
 	void append(bool reset);
 };
-typedef dg::host::HostWave<64, EmuCounters> EmuWave;
+typedef dg::host::HostWave<64, EmuCounters, false> EmuWave;   // bounds parked as floats (k_sample_nodes, k_heavy_subtrees)
+typedef dg::host::HostWave<64, EmuCounters, true> EmuWave16;  // ... in 16 bits (k_sample_fast: both of its traversals)
 
 // the exact traversal of subtree `start` by the 64 lanes of w (k_sample_nodes / k_heavy_subtrees; stack16: as the second pass
 // of k_sample_fast runs it, bounds parked in 16 bits); returns the heavy slot claimed or -1
-int walk_exact(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf, bool stack16 = false)
+template <class EW>
+int walk_exact_with(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf)
 {
 	EmuCounters c;
 	c.st = &st;
-	EmuWave ew;
+	EW ew;
 	ew.stats = &c;
-	ew.stack16 = stack16;
 	auto lane_query = [&](int l) -> LaneQuery& { return w.q[l]; };
-	ExactWalk<EmuWave, decltype(lane_query)> pol(lane_query);
+	ExactWalk<EW, decltype(lane_query)> pol(lane_query);
 	return packet_walk(ew, pol, M, start, ovf ? ovf->count : nullptr, ovf ? ovf->slots : 0u, ovf ? ovf->heavy_work : 0);
+}
+int walk_exact(const MeshDev& M, Wave& w, Stats& st, int start, const OverflowBuf* ovf, bool stack16 = false)
+{
+	return stack16 ? walk_exact_with<EmuWave16>(M, w, st, start, ovf) : walk_exact_with<EmuWave>(M, w, st, start, ovf);
 }
 
 
@@ -140,24 +145,29 @@ static void depth_hist_note(const MeshDev& M, int cur)
 extern "C" void emu_depth_hist(uint64_t* out /*64*/) { for (int i = 0; i < 64; ++i) out[i] = g_depth_hist[i]; }
 thread_local std::vector<std::pair<int,int>> g_leaf_log; // (first, cnt) of the leaves a traversal visited (design studies)
 // the filtered traversal (k_sample_fast's first pass); returns -1, -2 (a degenerate triangle was met) or the heavy slot claimed
-int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
+template <class EW>
+int walk_fast_with(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
 {
 	g_leaf_log.clear();
 	EmuCounters c;
 	c.fs = &st;
-	EmuWave ew;
+	EW ew;
 	ew.stats = &c;
-	ew.stack16 = true;
 	ew.lists = lists.v;
 	auto lane_state = [&](int l) -> FastLane& { return fl[l]; };
 	auto lane_list = [](int l) { return FastLists::base(l); };
-	FastWalk<EmuWave, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
+	FastWalk<EW, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
 	const bool budgeted = ovf && ovf->count;
 	const int parked = packet_walk(ew, pol, M, M.root_info, budgeted ? ovf->count : nullptr, budgeted ? ovf->slots : 0u,
 								   budgeted ? kFastWorkFactor * ovf->heavy_work : 0);
 	if (parked >= 0)
 		return parked;
 	return pol.degenerate ? -2 : -1;
+}
+int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
+{
+	static const bool stack32 = getenv("EMU_STACK32") != nullptr; // (design study: bounds parked as full floats)
+	return stack32 ? walk_fast_with<EmuWave>(M, fl, lists, st, ovf) : walk_fast_with<EmuWave16>(M, fl, lists, st, ovf);
 }
 void EmuCounters::pair_step(const MeshDev& M, int cur)
 {
@@ -628,6 +638,12 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 						{
 							float theta, kappa;
 							fl[l].U = pre[l].U * (1.0f + 1.0e-5f);
+							if (g_seed_study == 2) // what a coarse pre-pass could hand down: the distance at the brick's centre + the brick's radius
+							{
+								const float radius = 1.5f * sqrtf((float)(P.cell[0] * P.cell[0] + P.cell[1] * P.cell[1] + P.cell[2] * P.cell[2]));
+								const float d = sqrtf(pre[l].U) + 2.0f * radius; // (centre value <= own + radius; own <= centre + radius)
+								fl[l].U = d * d;
+							}
 							approx_err_terms(fl[l].a.E, fl[l].U, &theta, &kappa);
 							fl[l].Uprune = __builtin_fmaf(fl[l].U, 1.0f + theta, kappa);
 						}
