@@ -11,11 +11,11 @@ cubic_lagrange_discrete_grid.cpp:806-831), with the mesh/BVH already resident in
 left in HBM.  Workload (BASELINE.json configs[2], the one the metric is quoted on): synthetic class-I
 geodesic icosphere, nu = 71 -> 100 820 triangles, unit radius; grid 256^3 over the reference's default
 domain -> 118 425 857 nodes per GPU.  For N > 1 (weak scaling, BASELINE configs[3]) the grid grows with
-N -- (256a, 256b, 256c), abc = N, i.e. 512^3 at N = 8 -- and one step is the library's
-dg_sdf_sample_allgather_device: the lattice is dealt to the ranks in 4-plane slabs, every rank samples
-its shards in --pieces C pieces, RCCL (inside libdiscregrid_hip.so, its own communicator) all-gathers
-piece p over xGMI while piece p+1 is sampled and piece p-1 is unpacked into reference node order.
-value = total nodes / time, max over ranks.
+N -- (256a, 256b, 256c), abc = N, i.e. 512^3 at N = 8 -- and one step is ONE call of the library's exchange step: every rank
+samples its part of the lattice in --pieces C pieces and the parts are exchanged while the next piece is sampled.  Five forms
+exist (host vector, slabs, in place, p2p, copy); by default EVERY form is measured -- its own warm-up and
+--steps timed steps between barriers, max over ranks, each form under a watchdog -- and `value` is the fastest
+(config.exchange lists them all).  value = total nodes / time.
 
 On the JSON line besides the contract's keys:
   roofline      K1 is bound by VALU issue, not by HBM: `frac` = fraction of the VALU issue cycles of the
@@ -25,6 +25,8 @@ On the JSON line besides the contract's keys:
                 profiles/collect.sh writes together with a hash of discregrid_amd/csrc: if the sources
                 changed since, they are null ("stale").  `algorithmic_gbs` (the reference traversal's
                 bytes, SURVEY.md 8(d), / kernel time) is informational and is NOT a fraction of anything.
+                The figures an API user sees are repeated INSIDE roofline as plain scalars (d2h_mnodes_s, host_ready_ms,
+                k2_*_frac, k3_seconds, k1_*_ms ...): the driver's record keeps roofline and drops the nested objects below.
   value_with_d2h   Mnodes/s of dg_sdf_sample_nodes: kernels + D2H into the caller's host array.
   addfunction_e2e  the C++ CubicLagrangeDiscreteGrid::addFunction(MeshSDF) call, wall time.
   secondary     K2 (10 M queries, uniform and SPH-like shell, value / value+gradient) and K3 (density
@@ -110,14 +112,23 @@ def cpu_baseline(V, F, dom, res, budget_s):
             om.sample_nodes(dom, res, b, e)
             return om.last_seconds
     n_chunks = 32
-    # calibrate on a small spread sample, then size the sample for ~budget_s seconds
-    probe = 4096
     starts = [int((i + 0.5) * n / n_chunks) for i in range(n_chunks)]
+    # sized in two stages (a small probe underestimates the rate -- thread start-up -- by a factor that varies from run to run:
+    # 14 % ... 44 % of the lattice for the same budget): probe, then a quarter of the budget by the probe's rate, then the rest of
+    # the budget by the rate MEASURED on that quarter; the quarter and the rest are both part of the sample
+    probe = 4096
     t = sum(run(s, s + probe) for s in starts)
     rate = n_chunks * probe / max(t, 1e-9)
-    per_chunk = int(min(max(rate * budget_s / n_chunks, probe), n // n_chunks))
-    t = sum(run(s, min(n, s + per_chunk)) for s in starts)
-    nodes = sum(min(n, s + per_chunk) - s for s in starts)
+    cap = n // n_chunks // 2        # (a run starts in the middle of its slot of n / 32 nodes and stays inside it)
+    first = int(min(max(rate * 0.25 * budget_s / n_chunks, probe), cap))
+    t = sum(run(s, min(n, s + first)) for s in starts)
+    nodes = sum(min(n, s + first) - s for s in starts)
+    rate = nodes / max(t, 1e-9)
+    second = int(min(max(rate * max(budget_s - t, 0.0) / n_chunks, 0), cap - first))
+    if second > 0:
+        t += sum(run(s + first, min(n, s + first + second)) for s in starts)
+        nodes += sum(min(n, s + first + second) - min(n, s + first) for s in starts)
+    per_chunk = first + second
     return {
         "value": nodes / t / 1e6, "unit": "Mnodes/s", "cores": os.cpu_count(), "kind": kind,
         "sample_nodes": nodes, "sample_fraction": nodes / n, "sample_seconds": t,
