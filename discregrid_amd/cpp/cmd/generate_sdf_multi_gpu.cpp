@@ -49,6 +49,7 @@ struct Options
 	bool invert = false;
 	int gpus = 1, pieces = 4, steps = 1;
 	int exchange = 0; // flags of dg_sdf_sample_exchange_device (--inplace, --p2p, --copy)
+	bool host_vector = false; // --host: dg_sdf_sample_to_host_field (a shared-memory host vector; no RCCL, no device IPC)
 	std::string output, input;
 };
 
@@ -101,6 +102,42 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 	}
 	const uint64_t n_nodes = dg_grid_n_nodes(&grid);
 
+	hipStream_t stream = nullptr;
+	check_hip(rank, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+	const dg_mesh* dmesh = static_cast<const dg_mesh*>(md.deviceMesh());
+	if (opt.host_vector)
+	{
+		// the form that needs neither RCCL nor device IPC: every rank copies its chunks into ONE shared-memory vector (the
+		// segment's name is derived from the id file's, which is unique to this run); rank 0 saves from it
+		std::string name = "dg_sdfmulti_" + id_file.substr(id_file.find_last_of('/') + 1);
+		dg_host_field* hf = nullptr;
+		check(rank, dg_host_field_open(name.c_str(), n_nodes, rank, opt.gpus, &hf), "dg_host_field_open");
+		double* d_mine = nullptr;
+		check_hip(rank, hipMalloc(reinterpret_cast<void**>(&d_mine), n_nodes * sizeof(double)), "hipMalloc");
+		check(rank, dg_sdf_sample_to_host_field(dmesh, &grid, opt.invert ? 1 : 0, hf, opt.pieces, nullptr, d_mine, stream), "sample to the host vector");
+		double seconds = 0.0;
+		if (opt.steps > 1 || !time_file.empty())
+		{
+			const double t0 = now();
+			for (int k = 0; k < opt.steps; ++k)
+				check(rank, dg_sdf_sample_to_host_field(dmesh, &grid, opt.invert ? 1 : 0, hf, opt.pieces, nullptr, d_mine, stream), "sample to the host vector");
+			seconds = now() - t0;
+		}
+		if (!time_file.empty())
+			std::ofstream(time_file) << seconds << "\n";
+		if (rank == 0 && !opt.output.empty())
+		{
+			const double* v = dg_host_field_data(hf);
+			sdf.addNodeData(Discregrid::FieldVector(v, v + n_nodes));
+			sdf.save(opt.output);
+		}
+		check(rank, dg_host_field_barrier(hf), "barrier"); // (rank 0 has read the vector)
+		dg_host_field_close(hf);
+		(void)hipFree(d_mine);
+		(void)hipStreamDestroy(stream);
+		return 0;
+	}
+
 	// communicator: rank 0 publishes the RCCL unique id through a file (written whole, then renamed)
 	uint8_t id[DG_UNIQUE_ID_BYTES];
 	if (rank == 0)
@@ -127,11 +164,14 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 	dg_comm* comm = nullptr;
 	check(rank, dg_comm_create(id, rank, opt.gpus, &comm), "dg_comm_create");
 
+	// the copy form's field comes from the communicator (chunks the peers can map whatever the field's size); the RCCL forms
+	// take any device array
+	const bool from_comm = (opt.exchange & DG_EXCHANGE_COPY) != 0;
 	double* d_field = nullptr;
-	check_hip(rank, hipMalloc(reinterpret_cast<void**>(&d_field), n_nodes * sizeof(double)), "hipMalloc");
-	hipStream_t stream = nullptr;
-	check_hip(rank, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
-	const dg_mesh* dmesh = static_cast<const dg_mesh*>(md.deviceMesh());
+	if (from_comm)
+		check(rank, dg_comm_field_alloc(comm, n_nodes, &d_field), "dg_comm_field_alloc");
+	else
+		check_hip(rank, hipMalloc(reinterpret_cast<void**>(&d_field), n_nodes * sizeof(double)), "hipMalloc");
 
 	// one untimed step (first-use allocations, RCCL channel set-up), then the timed ones
 	check(rank, dg_sdf_sample_exchange_device(dmesh, &grid, opt.invert ? 1 : 0, comm, opt.pieces, opt.exchange, 0, nullptr, d_field, stream), "sample + exchange");
@@ -155,8 +195,9 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 		sdf.addNodeData(std::move(coeffs));
 		sdf.save(opt.output);
 	}
-	dg_comm_destroy(comm);
-	(void)hipFree(d_field);
+	dg_comm_destroy(comm); // (releases a field of dg_comm_field_alloc as well)
+	if (!from_comm)
+		(void)hipFree(d_field);
 	(void)hipStreamDestroy(stream);
 	return 0;
 }
@@ -181,7 +222,7 @@ int main(int argc, char* argv[])
 		if (a == "-h" || a == "--help")
 		{
 			std::cout << "Usage: " << argv[0]
-					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p | --copy] [--steps k] [-o out.cdf] mesh.obj"
+					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p | --copy | --host] [--steps k] [-o out.cdf] mesh.obj"
 					  << std::endl;
 			return 0;
 		}
@@ -206,7 +247,9 @@ int main(int argc, char* argv[])
 			opt.exchange |= DG_EXCHANGE_INPLACE;
 		else if (a == "--p2p") // ... exchanged with send / recv pairs instead
 			opt.exchange |= DG_EXCHANGE_INPLACE | DG_EXCHANGE_P2P;
-		else if (a == "--copy") // ... pushed into the peers' fields by the copy engines (HIP IPC), no collective kernel
+		else if (a == "--host") // every rank copies its chunks into a shared-memory host vector: no RCCL, no device IPC
+			opt.host_vector = true;
+		else if (a == "--copy") // ... pushed into the peers' fields by the copy engines (fields of dg_comm_field_alloc), no collective kernel
 			opt.exchange = DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY;
 		else if (a == "--steps")
 		{

@@ -62,7 +62,9 @@ def test_cpp_multi_gpu_tool_one_rank(tmp_path):
     subprocess.check_call([os.path.join(build, "GenerateSDF"), "-r", "24 20 22", "-o", ref, obj], stdout=subprocess.DEVNULL)
     dg.load_library()
     for gpus in sorted({1, min(dg.device_count(), 8)}):
-        for extra in ([], ["--inplace"], ["--p2p"], ["--copy"]):      # interleaved slabs + unpack / contiguous chunks exchanged in place / pushed by peer copies
+        # interleaved slabs + unpack / contiguous chunks exchanged in place / pushed by peer copies into a field of
+        # dg_comm_field_alloc / copied into the shared-memory host vector (no communicator at all)
+        for extra in ([], ["--inplace"], ["--p2p"], ["--copy"], ["--host"]):
             out = str(tmp_path / ("multi%d%s.cdf" % (gpus, "".join(extra))))
             txt = subprocess.check_output([os.path.join(build, "GenerateSDFMultiGPU"), "-g", str(gpus), "-r", "24 20 22", "--steps", "3",
                                            "--pieces", "2", "-o", out, obj] + extra, timeout=600).decode()
