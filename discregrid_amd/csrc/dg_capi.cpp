@@ -401,7 +401,7 @@ extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, co
 extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
-	// Which K1 kernel: the filtered one (dg_kernels.hip: k_sample_fast) or the exact one only.  By default: from dg::kFastMinTriangles triangles up, and for lattices only where a brick (3 cells) is not much
+	// Which K1 kernel: the filtered one (dg_kernels_k1.hip: k_sample_fast) or the exact one only.  By default: from dg::kFastMinTriangles triangles up, and for lattices only where a brick (3 cells) is not much
 	// smaller than a triangle -- the filter pays through the exact tests it saves, and a brick smaller than the
 	// triangles around it needs few (icosphere 100 820 triangles: 128^3 -21 %, 256^3 -9.5 %, 512^3 +2.8 %; brick /
 	// mean triangle edge = 2.8, 1.4, 0.7).  DG_FORCE=k1_fast=0 / 1 force the exact / the filtered kernel.

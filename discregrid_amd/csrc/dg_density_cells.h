@@ -2,10 +2,10 @@
 // emulator of the CPU tests.  Same rules as dg_geom.h / dg_density.h: the reference's operations in the reference's
 // order (cmd/generate_density_map/main.cpp:86-133, gauss_quadrature.cpp:5927-5960), -ffp-contract=off.
 //
-// Why another K3.  k_density_rows (one node or one edge's node pair per lane) sits on the texture-data path: every lane
-// pulls the 256 bytes of its cell through L1 at every quadrature point, 0.71 fetches per node and point once a pair
-// shares a fetch two times out of three (profiles/r03_pmc_summary.txt: TD busy 0.98, VALU 0.81, and it sweeps the field
-// four times, once per node class).  Here a lane owns ALL SEVEN nodes that hang on lattice point (i, j, k): the vertex
+// Why this shape.  A kernel with one node (or one edge's node pair) per lane -- round 3's row-block kernel, removed in round 5 --
+// sits on the texture-data path: every lane pulls the 256 bytes of its cell through L1 at every quadrature point, 0.71 fetches
+// per node and point once a pair shares a fetch two times out of three (profiles/r03_pmc_summary.txt: TD busy 0.98, VALU 0.81,
+// and it sweeps the field four times, once per node class).  Here a lane owns ALL SEVEN nodes that hang on lattice point (i, j, k): the vertex
 // and the two nodes of each of the three cell edges that start there, at 1/3 and 2/3 of the edge.  Shifted by the same
 // quadrature offset the seven evaluation points lie within 2/3 of a cell of each other along one axis each, so they
 // fall into the vertex point's cell c0 or into c0 + ex / c0 + ey / c0 + ez: 3.0 fetches per 7 nodes and point on average
@@ -16,7 +16,7 @@
 // the same operations on the same values, so the bits do not change (tests/test_emu.py, tests/test_gpu_density_map.py,
 // the reference digests of tests/test_gpu_digests.py).
 //
-// A wave is a row block of 16 x 2 x 2 lattice points (lanes side by side along x as in k_density_rows: the sixteen
+// A wave is a row block of 16 x 2 x 2 lattice points (lanes side by side along x: the sixteen
 // coefficient pairs of a cell are 256-byte runs along x in the field's V / X classes and in the x-major copy of the
 // Y / Z classes, dg_lattice.h).
 #pragma once

@@ -445,7 +445,7 @@ DG_HD float best_as_float(double d2)
 // the point/triangle distance in float whose error is bounded rigorously: the exact double test with
 // the reference's operation order (tri_closest) then runs only on each lane's own short list of
 // candidates, once, after the traversal -- instead of on every triangle any lane of the wave is
-// interested in (dg_kernels.hip: k_sample_fast).
+// interested in (dg_kernels_k1.hip: k_sample_fast).
 //
 // Formulation (chosen for its error analysis, not for minimal arithmetic): the triangle carries an
 // orthonormal frame (u along v0->v1, w in the plane towards v2, n the normal).  With d = p - v0:

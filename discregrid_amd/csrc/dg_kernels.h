@@ -1,5 +1,5 @@
 // dg_kernels.h -- launch interface between the C ABI (dg_capi*.cpp) and the gfx950 kernels
-// (dg_kernels.hip).  Plain C++ structs, no HIP types in the signatures except the stream.
+// (dg_kernels_k1.hip / _k2.hip / _k3.hip / _aux.hip).  Plain C++ structs, no HIP types in the signatures except the stream.
 #pragma once
 #include <cstdint>
 #include <hip/hip_runtime_api.h>

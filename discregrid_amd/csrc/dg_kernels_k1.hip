@@ -134,7 +134,9 @@ struct DevWave
 	}
 	__device__ __forceinline__ void push(int sp, int info, const LaneVar<f2, 1>& lb, bool second)
 	{
-		stackv = (lane_id == sp) ? info : stackv;
+		// entry sp lives in lane sp: ONE v_writelane_b32 (a lane select costs a compare, a move of the info word and the select);
+		// the lane index goes through M0 (two different SGPR operands would exceed the constant-bus limit of the encoding)
+		__asm__("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stackv) : "s"(info), "s"(sp) : "m0");
 		park_bound(lds_lb, sp * 64 + lane_id, second ? lb[0].y : lb[0].x);
 	}
 	__device__ __forceinline__ float parked(int sp, int) const { return parked_bound(lds_lb, sp * 64 + lane_id); }

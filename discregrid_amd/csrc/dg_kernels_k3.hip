@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_xmajor_copy(const FieldDev F, uint32_t 
 	}
 }
 // the "no value" bit of every cell, one wave per 64 cells of a row; only if k_field_check found such a value at all
-// (flag bit 1) -- k_density_rows does not read the bits otherwise
+// (flag bit 1) -- the kernel does not read the bits otherwise
 __global__ __launch_bounds__(256) void k_xmajor_flags(const FieldDev F, const uint32_t* __restrict__ field_flags, uint64_t* __restrict__ out)
 {
 	if ((field_flags[0] & 2u) == 0u)

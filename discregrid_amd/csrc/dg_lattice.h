@@ -379,8 +379,8 @@ DG_HD int field_mode(const FieldDev& F)
 
 // ---- x-major copy of the Y and Z edge classes (K3) -------------------------------------------------------------
 // The reference numbers the Y edges y-fastest ((2j+h, k, i)) and the Z edges z-fastest ((2k+h, i, j)): lanes that sit
-// side by side along x read them a plane apart.  K3's lanes do sit side by side along x (k_density_rows: a wave is a
-// row block of 16 x 2 x 2 cells), so that the vertex and X-edge pairs of a wave -- x-fastest in the reference layout
+// side by side along x read them a plane apart.  K3's lanes do sit side by side along x (k_density_cells: a wave is a
+// row block of 16 x 2 x 2 lattice points), so that the vertex and X-edge pairs of a wave -- x-fastest in the reference layout
 // already -- come in 256-byte runs; the x-major copy gives the other two classes the same property at 1.0 x their
 // memory: Y'[k][j][i][h] (k <= nz, j < ny, i <= nx) followed by Z'[k][j][i][h] (k < nz, j <= ny, i <= nx).
 // Same values, same arithmetic: bit-identical results.

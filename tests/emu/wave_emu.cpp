@@ -1,7 +1,7 @@
 // tests/emu/wave_emu.cpp -- TEST INFRASTRUCTURE ONLY.
 //
 // Host-side lock-step emulation of the K1 / K1p / K2 / unpack kernels of
-// discregrid_amd/csrc/dg_kernels.hip.  It runs the PRODUCT's own data structures (dg_build:
+// discregrid_amd/csrc/dg_kernels_k*.hip.  It runs the PRODUCT's own data structures (dg_build:
 // flattened BVH, triangle packets, pseudonormals), the product's own lattice decomposition
 // (dg_layout.h, map_lane) and the product's own per-lane arithmetic (dg_geom.h) -- only the
 // wave-level control flow (ballots over 64 lanes) is re-expressed as loops over lane arrays.
