@@ -24,10 +24,8 @@ namespace
 #ifndef DG_FLAT_PATCH
 #define DG_FLAT_PATCH 0.8
 #endif
-#if DG_OBB
 const double kFlatPatch = DG_FLAT_PATCH; // |mean normal| / area above which a patch gets an oriented box
 const int kMinRectPrims = 24;            // patches of at most this many triangles: minimum-area rectangle instead of principal axes
-#endif
 
 struct D3
 {
@@ -128,7 +126,6 @@ struct Prim
 inline float down(double v) { return std::nextafterf(round_down(v), -std::numeric_limits<float>::infinity()); }
 inline float up(double v) { return std::nextafterf(round_up(v), std::numeric_limits<float>::infinity()); }
 
-#if DG_OBB
 // oriented box of a set of primitives (dg_geom.h: PairRec), float, relative to origin, rounded outward
 struct Bounds
 {
@@ -277,83 +274,6 @@ void put_empty(PairRec& r, int side)
 	for (int a = 0; a < 3; ++a)
 		r.f[12 + a][side] = -std::numeric_limits<float>::max();
 }
-#else
-// box + slab of a set of primitives, float, relative to origin, rounded outward
-struct Bounds
-{
-	float lo[3], hi[3], u[3], slo, shi;
-};
-
-
-Bounds bounds_of(const Prim* p, size_t n, const double origin[3])
-{
-	Bounds B;
-	double lo[3], hi[3], m[3] = {0, 0, 0};
-	for (int d = 0; d < 3; ++d)
-	{
-		lo[d] = std::numeric_limits<double>::max();
-		hi[d] = std::numeric_limits<double>::lowest();
-	}
-	for (size_t i = 0; i < n; ++i)
-		for (int d = 0; d < 3; ++d)
-		{
-			lo[d] = std::min(lo[d], p[i].lo[d]);
-			hi[d] = std::max(hi[d], p[i].hi[d]);
-			m[d] += p[i].an[d];
-		}
-	for (int d = 0; d < 3; ++d)
-	{
-		// two ulps outward: the subtraction of the origin rounds as well
-		B.lo[d] = down(lo[d] - origin[d]);
-		B.hi[d] = up(hi[d] - origin[d]);
-	}
-	// slab along the area-weighted mean normal, shrunk by 1e-6 so that |u| <= 1 after rounding
-	const double len = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-	B.u[0] = B.u[1] = B.u[2] = 0.0f; // u = 0: lower bound 0, never prunes (degenerate / cancelling normals)
-	B.slo = B.shi = 0.0f;
-	if (len > 0 && std::isfinite(len))
-	{
-		const double sc = (1.0 - 1.0e-6) / len;
-		for (int d = 0; d < 3; ++d)
-			B.u[d] = (float)(m[d] * sc);
-		double plo = std::numeric_limits<double>::max(), phi = std::numeric_limits<double>::lowest();
-		for (size_t i = 0; i < n; ++i)
-			for (int k = 0; k < 3; ++k)
-			{
-				const double pr = (double)B.u[0] * (p[i].v[k][0] - origin[0]) + (double)B.u[1] * (p[i].v[k][1] - origin[1]) +
-								  (double)B.u[2] * (p[i].v[k][2] - origin[2]);
-				plo = std::min(plo, pr);
-				phi = std::max(phi, pr);
-			}
-		B.slo = down(plo);
-		B.shi = up(phi);
-	}
-	return B;
-}
-
-void put_side(PairRec& r, int side, const Bounds& B)
-{
-	for (int d = 0; d < 3; ++d)
-	{
-		r.f[d][side] = B.lo[d];
-		r.f[3 + d][side] = B.hi[d];
-		r.f[6 + d][side] = B.u[d];
-	}
-	r.f[9][side] = B.slo;
-	r.f[10][side] = B.shi;
-}
-// a side that can never be hit: empty box (distance = inf)
-void put_empty(PairRec& r, int side)
-{
-	for (int d = 0; d < 3; ++d)
-	{
-		r.f[d][side] = std::numeric_limits<float>::max();
-		r.f[3 + d][side] = -std::numeric_limits<float>::max();
-		r.f[6 + d][side] = 0.0f;
-	}
-	r.f[9][side] = r.f[10][side] = 0.0f;
-}
-#endif
 void clear_rec(PairRec& r)
 {
 	std::memset(&r, 0, sizeof(r));

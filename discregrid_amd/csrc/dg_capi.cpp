@@ -412,7 +412,7 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 		if (!(brick >= dg::kFastMinBrickRatio * mesh->host.mean_edge))
 			fast_default = 0;
 	}
-	P.filtered = (force_int("k1_fast", fast_default, 0, 1) != 0 && DG_OBB != 0 && mesh->dev.n_positions < (1 << 26)) ? 1 : 0;
+	P.filtered = (force_int("k1_fast", fast_default, 0, 1) != 0 && mesh->dev.n_positions < (1 << 26)) ? 1 : 0;
 	const uint32_t slots = (uint32_t)force_int("heavy_slots", (int)dg::overflow_slots_for(P.total_bricks), 0, dg::kOverflowSlots);
 	if (slots == 0 || mesh->dev.n_sub < 2)
 	{

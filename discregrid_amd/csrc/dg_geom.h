@@ -30,14 +30,9 @@ namespace dg
 // fetches both and (b) the wave tests both with packed two-wide float instructions
 // (v_pk_add/mul/fma_f32) -- the kernel is VALU-issue bound, every packed instruction saved is
 // time saved.  All bounds are float, relative to the mesh origin, rounded OUTWARD: they are only
-// ever used to prune, so their arithmetic is free.  DG_OBB=0 selects the first design, kept for
-// A/B measurements: an axis-aligned box AND one slab along the mean normal, which is tight on the
-// concave side of a curved surface but cannot separate neighbouring facets seen from far away
-// (their boxes are fat along a tilted normal): 45 ms against 22 ms per 256^3 launch.
-#ifndef DG_OBB
-#define DG_OBB 1
-#endif
-#if DG_OBB
+// ever used to prune, so their arithmetic is free.  (The first design -- an axis-aligned box AND one slab along the
+// mean normal, tight on the concave side of a curved surface but unable to separate neighbouring facets seen from far
+// away -- took 45 ms against 22 ms per 256^3 launch; docs/DESIGN_history_r1_r3.md.)
 // Bounds of an item (subtree or triangle) = an oriented box: centre c, directions u_a, half widths
 //     |u_a . (y - c)| <= half_a   for every point y of the item,  a = 0, 1, 2,
 // with (nearly) orthonormal directions u_a whose Gram matrix has no eigenvalue above 1, so that
@@ -50,15 +45,6 @@ struct alignas(128) PairRec
 	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
 };
 static const int kPairFloats = 30;
-#else
-struct alignas(128) PairRec
-{
-	float f[11][2];  // [k][side], k: 0..2 box lo xyz, 3..5 box hi xyz, 6..8 slab direction, 9 slab lo, 10 slab hi
-	int32_t info[2]; // node pairs: what is below each side (see below); triangle pairs: unused
-	float pad_[8];
-};
-static const int kPairFloats = 22;
-#endif
 static_assert(sizeof(PairRec) == 128, "PairRec must be 128 bytes");
 // info word of a subtree:  >= 0: index of the PairRec holding its two children;
 //                          <  0: leaf, ~info = (first_position << kLeafBits) | (positions - 1),
@@ -369,7 +355,6 @@ DG_HD f2 f2_splat(float a) { return f2_make(a, a); }
 DG_HD float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 DG_HD float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-#if DG_OBB
 // Squared lower bounds of BOTH items of a pair record for one query: distance to the oriented box,
 // r = the record's 30 interleaved floats (PairRec::f).  d = p - centre, then per axis
 // excess = |u.d| - (half + es), clamped at 0 and squared: 30 VALU instructions for the two items
@@ -396,42 +381,6 @@ DG_HD f2 pair_lb2(const float* r, const FPoint& p, f2* centre2 = nullptr)
 	}
 	return acc;
 }
-#else
-// Squared lower bounds (box and slab combined) of BOTH items of a pair record for one query.
-// r = the record's 22 interleaved floats (PairRec::f).
-DG_HD f2 pair_lb2(const float* r, const FPoint& p, f2* centre2 = nullptr)
-{
-	if (centre2) // box centres: (lo + hi) / 2
-	{
-		f2 c2 = f2_splat(0.0f);
-		for (int d = 0; d < 3; ++d)
-		{
-			const f2 m = f2_splat(p.x[d]) - (f2_make(r[2 * d], r[2 * d + 1]) + f2_make(r[6 + 2 * d], r[6 + 2 * d + 1])) * f2_splat(0.5f);
-			c2 = f2_fma(m, m, c2);
-		}
-		*centre2 = c2;
-	}
-	f2 acc = f2_splat(0.0f);
-	for (int d = 0; d < 3; ++d)
-	{
-		const f2 lo = f2_make(r[2 * d], r[2 * d + 1]);
-		const f2 hi = f2_make(r[6 + 2 * d], r[6 + 2 * d + 1]);
-		const f2 a = lo - f2_splat(p.hi[d]);
-		const f2 b = f2_splat(p.lo[d]) - hi;
-		const f2 m = f2_make(fmax3(a.x, b.x, 0.0f), fmax3(a.y, b.y, 0.0f));
-		acc = f2_fma(m, m, acc);
-	}
-	f2 t = f2_make(r[16], r[17]) * f2_splat(p.x[2]);
-	t = f2_fma(f2_make(r[14], r[15]), f2_splat(p.x[1]), t);
-	t = f2_fma(f2_make(r[12], r[13]), f2_splat(p.x[0]), t);
-	const f2 es = f2_splat(p.es);
-	const f2 q1 = t - es - f2_make(r[20], r[21]);
-	const f2 q2 = f2_make(r[18], r[19]) - t - es;
-	const f2 ds = f2_make(fmax3(q1.x, q2.x, 0.0f), fmax3(q1.y, q2.y, 0.0f));
-	const f2 s2 = ds * ds;
-	return f2_make(fmax2(acc.x, s2.x), fmax2(acc.y, s2.y));
-}
-#endif
 // float upper bound of the running best d^2 (strictly above it unless it is 0 or inf)
 DG_HD float best_as_float(double d2)
 {
@@ -709,7 +658,6 @@ DG_HD f2 tri_approx_pair(const float* r, const ApproxLane& p) // both steps (int
 	return tri_approx_rest(r, p, fr);
 }
 
-#if DG_OBB
 // The bound test of the filtered traversal: pair_lb2 without the per-slab error term (the caller's
 // threshold carries it, approx_err_terms) and with the slab excess as t - median(t, -half, half).
 // Node pairs only (no empty sides: an inner node has two children).
@@ -736,7 +684,6 @@ DG_HD f2 pair_lb2_fast(const float* r, const float* x, f2* centre2)
 	}
 	return acc;
 }
-#endif
 
 // ---- per-lane query state and epilogue ------------------------------------------------------------------
 struct LaneQuery

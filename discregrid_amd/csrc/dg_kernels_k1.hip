@@ -416,66 +416,15 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
 	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
-	// wave totals: T candidates in all, the longest list; `before` = candidates of the lanes below this one
-	uint32_t before = 0, T = 0;
-	int longest = 0;
-	unsigned long long holders = ~0ull; // lanes whose count agrees with `longest` in the bits seen so far
-#pragma unroll
-	for (int b = 3; b >= 0; --b) // n_cand <= kFastListCap < 16
+	// (A transposed form -- the (lane, triangle) pairs laid out contiguously, 64 pairs tested per round with the owners' points
+	// fetched by ds_bpermute -- was measured 1.1 % SLOWER on the judged workload and is gone: docs/DESIGN_history_r1_r3.md.)
+	for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
 	{
-		const unsigned long long m = __ballot(((n_cand >> b) & 1) != 0);
-		before += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
-		T += (uint32_t)__popcll(m) << b;
-		if ((m & holders) != 0ull)
+		if (k < n_cand)
 		{
-			longest |= 1 << b;
-			holders &= m;
-		}
-	}
-	const uint32_t item_cap = (uint32_t)P.mesh.stack_levels * 32u, res_cap = (uint32_t)(kFastListCap + 1) * 32u;
-	const uint32_t rounds = (T + 63u) >> 6;
-#ifndef DG_EPILOGUE_COMPACT
-#define DG_EPILOGUE_COMPACT 0 // measured 1.1 % SLOWER than the lane-by-lane loop on the judged workload (same box A/B): kept as a variant
-#endif
-	if (DG_EPILOGUE_COMPACT && rounds + 1u < (uint32_t)longest && T <= item_cap && T <= res_cap)
-	{
-		// Transposed form.  Per-lane lists are short but uneven (a lane next to a mesh vertex holds six candidates,
-		// its neighbours one or two): lane by lane the wave would run `longest` rounds of the double test, most of
-		// them for a handful of lanes.  Instead the (lane, triangle) pairs are laid out contiguously (the bound stack's
-		// LDS is free by now), the 64 lanes test 64 pairs per round -- every lane fetches the point of the pair's
-		// owner with ds_bpermute --, the values go back through LDS (over the lists, which are no longer needed)
-		// and every owner takes the minimum of its own pairs in list order: the same values, the same winner.
-		uint32_t* items = (uint32_t*)lds_lb16;
-		double* res = (double*)lds_list;
-		for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
-			if (k < n_cand)
-				items[before + (uint32_t)k] = ((uint32_t)lane << 26) | (uint32_t)lds_list[k * 64 + lane];
-		__syncthreads();
-		for (uint32_t base = 0; base < T; base += 64u)
-		{
-			const uint32_t i = base + (uint32_t)lane;
-			const bool active = i < T;
-			const uint32_t item = items[active ? i : 0u];
-			const int owner = (int)(item >> 26);
-			const double opx = __shfl(q.px, owner), opy = __shfl(q.py, owner), opz = __shfl(q.pz, owner);
-			if (active)
-				res[i] = tri_closest<false>(P.mesh.tris[item & 0x3ffffffu], opx, opy, opz).d2;
-		}
-		__syncthreads();
-		for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
-			if (k < n_cand)
-				offer(q, res[before + (uint32_t)k], (int)(items[before + (uint32_t)k] & 0x3ffffffu));
-	}
-	else
-	{
-		for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
-		{
-			if (k < n_cand)
-			{
-				const int tri = lds_list[k * 64 + lane];
-				const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
-				offer(q, h.d2, tri);
-			}
+			const int tri = lds_list[k * 64 + lane];
+			const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
+			offer(q, h.d2, tri);
 		}
 	}
 	if (exact)

@@ -419,13 +419,8 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 			const PairRec& tp = m->B.tri_pairs[t >> 1];
 			if (id < 0)
 			{
-#if DG_OBB
 				if (!(tp.f[12][t & 1] < 0.0f)) // padding must have empty slabs
 					return 10;
-#else
-				if (!(tp.f[0][t & 1] > tp.f[3][t & 1])) // padding must have an empty box
-					return 10;
-#endif
 				continue;
 			}
 			seen[id]++;
@@ -437,7 +432,6 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 			{
 				const float* r = all[a];
 				const int sd = sides[a];
-#if DG_OBB
 				// every vertex inside the three slabs; Gram matrix of the directions: no eigenvalue above 1
 				double U[3][3];
 				for (int x = 0; x < 3; ++x)
@@ -460,25 +454,6 @@ static int check_subtree(const HostMesh* m, int32_t info, const double* verts, c
 						if (!(std::fabs(pr) <= (double)r[2 * (12 + x) + sd]))
 							return 12;
 					}
-#else
-				for (int k = 0; k < 3; ++k)
-				{
-					double pr = 0;
-					for (int d = 0; d < 3; ++d)
-					{
-						const double v = verts[3 * tris[3 * id + k] + d] - m->B.origin[d];
-						if (!((double)r[2 * d + sd] <= v && v <= (double)r[6 + 2 * d + sd]))
-							return 6;
-						pr += (double)r[12 + 2 * d + sd] * v;
-					}
-					const double ulen = std::sqrt((double)r[12 + sd] * r[12 + sd] + (double)r[14 + sd] * r[14 + sd] +
-												  (double)r[16 + sd] * r[16 + sd]);
-					if (ulen > 1.0)
-						return 11;
-					if (ulen > 0 && !((double)r[18 + sd] <= pr + 1e-12 && pr - 1e-12 <= (double)r[20 + sd]))
-						return 12;
-				}
-#endif
 			}
 		}
 		return 0;
@@ -553,7 +528,7 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 		P.ovf.slots = slots;
 		P.ovf.heavy_work = g_heavy_work > 0 ? g_heavy_work : heavy_work_for(P.mesh.n_positions);
 	}
-	P.filtered = (g_fast && DG_OBB) ? 1 : 0;
+	P.filtered = g_fast ? 1 : 0;
 	auto write_nodes = [&](const LaneNode* ln, const bool* sample, const Wave& w) {
 		for (int l = 0; l < 64; ++l)
 		{
@@ -888,7 +863,7 @@ void emu_signed_distance(void* h, const double* xyz, uint64_t n, double* dist, i
 			init_query(m->dev.origin, m->dev.mesh_l1, valid, xyz[3 * g], xyz[3 * g + 1], xyz[3 * g + 2], w.q[l]);
 			act[l] = valid;
 		}
-		if (g_fast && DG_OBB)
+		if (g_fast)
 		{
 			FastStats fs;
 			fast_wave_unparked(m->dev, w, act, fs, st);
