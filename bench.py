@@ -113,18 +113,20 @@ def cpu_baseline(V, F, dom, res, budget_s):
             return om.last_seconds
     n_chunks = 32
     starts = [int((i + 0.5) * n / n_chunks) for i in range(n_chunks)]
-    # sized in two stages (a small probe underestimates the rate -- thread start-up -- by a factor that varies from run to run:
-    # 14 % ... 44 % of the lattice for the same budget): probe, then a quarter of the budget by the probe's rate, then the rest of
-    # the budget by the rate MEASURED on that quarter; the quarter and the rest are both part of the sample
+    # Sized in two stages towards 40 % of the lattice within budget_s seconds (a small probe underestimates the rate -- thread
+    # start-up -- by a factor that varied between 1 and 2.6 from run to run: 14 % ... 44 % of the lattice for the same budget):
+    # probe; a tenth of the lattice (less if the probe says that alone would take a third of the budget); then the rest of the
+    # 40 %, scaled down only if the rate MEASURED on the first stage says the budget would be exceeded.  Both stages count.
     probe = 4096
     t = sum(run(s, s + probe) for s in starts)
     rate = n_chunks * probe / max(t, 1e-9)
     cap = n // n_chunks // 2        # (a run starts in the middle of its slot of n / 32 nodes and stays inside it)
-    first = int(min(max(rate * 0.25 * budget_s / n_chunks, probe), cap))
+    first = int(min(max(min(0.10 * n, rate * budget_s / 3.0) / n_chunks, probe), cap))
     t = sum(run(s, min(n, s + first)) for s in starts)
     nodes = sum(min(n, s + first) - s for s in starts)
     rate = nodes / max(t, 1e-9)
-    second = int(min(max(rate * max(budget_s - t, 0.0) / n_chunks, 0), cap - first))
+    want = 0.40 * n - nodes
+    second = int(min(max(min(want, rate * max(budget_s - t, 0.0)) / n_chunks, 0), cap - first))
     if second > 0:
         t += sum(run(s + first, min(n, s + first + second)) for s in starts)
         nodes += sum(min(n, s + first + second) - min(n, s + first) for s in starts)
@@ -488,7 +490,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=28.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="ceiling of the cpu_baseline leg, which samples 40 %% of the lattice (about 30 s on 256 cores; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed K1 steps (profiling runs)")
     ap.add_argument("--pieces", type=int, default=4,
                     help="N > 1: issue the exchange in this many pieces, overlapped with the sampling kernel")
