@@ -340,9 +340,13 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
     k3k = k3c.get(k3name) if k3name else None
     out_secondary["k3_density_map"]["roofline"] = None if k3k is None else {
         "kernel": k3name,
-        "bound": "f64 VALU issue and the vector memory pipeline together (round 4, k_density_cells: a lane owns a lattice point with its seven "
+        "bound": "f64 VALU issue and the vector memory pipeline together (k_density_cells: a lane owns a lattice point with its seven "
                  "nodes -- 3 cell fetches of 256 B per 7 nodes and quadrature point instead of 5, one sweep of the field for all node "
-                 "classes; both units near 0.85-0.9 busy at the 3 waves per SIMD the registers allow)",
+                 "classes; both units near 0.87-0.9 busy at the 3 waves per SIMD the registers allow).  The floor of this formulation: TD "
+                 "needs 22 cycles per load instruction where 16 would do (the 256-byte runs of a wave start at arbitrary 16-byte offsets "
+                 "and straddle an extra 128-byte line two times out of three: 38 of 64 B/clk/CU delivered); with VALU at 0.87 removing "
+                 "that entirely is worth <= 13 %; traffic is 197 x the compulsory bytes because every quadrature point re-fetches its "
+                 "cell through L2 (hit rate 0.90), not because HBM binds (0.16 of its peak)",
         # what the launch has to move at least (field read once + x-major copy of the Y / Z classes written and read + result written)
         # against what the HBM counters saw
         "compulsory_bytes": int(8 * n_nodes * (1 + 2 * 0.57 + 1)), "traffic": k3k.get("hbm_bytes_per_launch"),
@@ -359,7 +363,10 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
     k2["roofline_band_kernel"] = None if k2bk is None else {
         "bound": "hbm", "achieved": k2bk["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2bk["hbm_frac"],
         "traffic": k2bk["hbm_bytes_per_launch"], "algorithmic_bytes": 288 * nq, "replayed": True,
-        "what": "k_interpolate_band, 10 M shell queries (value), through the band-limited cell-major copy"}
+        "what": "k_interpolate_band, 10 M shell queries (value), through the band-limited cell-major copy.  traffic / algorithmic_bytes = 1.36: "
+                "256 B of row + 24 B of point + 8 B of result are the algorithmic 288 B; on top come the look-up's bit and rank words (two "
+                "loads per query from 3 MB of tables that do not all stay in L2 beside 2.9 GB of streaming rows: ~64 B of sector traffic per "
+                "query) and the sectors of rows that straddle two 128-byte lines as seen by their four 64-byte quarter fetches"}
     k2c = ((counters or {}).get("workloads", {}).get("k2r") or {})
     k2k = next((v for k, v in k2c.items() if k.startswith("k_interpolate_rows<false")), None)
     k2["roofline_rows_kernel"] = None if k2k is None else {
