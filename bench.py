@@ -71,7 +71,7 @@ def csrc_hash():
     d = os.path.join(ROOT, "discregrid_amd", "csrc")
     for f in sorted(os.listdir(d)):
         # (not the host-only sources: the copy pipeline, the CPU point query and the exchange glue do not change what the kernels do)
-        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_capi_vmm.h"):
+        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_capi_vmm.h", "dg_capi_shm.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
@@ -503,10 +503,11 @@ def main():
                     help="N > 1: issue the exchange in this many pieces, overlapped with the sampling kernel")
     ap.add_argument("--force-shard-path", action="store_true",
                     help="run the N > 1 protocol (communicator, shards, all-gather, unpack) even at N = 1 (self-test)")
-    ap.add_argument("--exchange", choices=["auto", "host", "slabs", "inplace", "inplace-p2p", "copy", "to-root"], default="auto",
+    ap.add_argument("--exchange", choices=["auto", "host", "copy-shm", "slabs", "inplace", "inplace-p2p", "copy", "to-root"], default="auto",
                     help="N > 1: auto (default) = run --warmup + --steps steps of EVERY form, each under --form-timeout, and report the "
                          "fastest (the others' times are on the line).  host = every rank copies its chunks into a shared-memory host "
-                         "vector (no RCCL, no device IPC: cannot fail for lack of either; measured first); slabs = interleaved 4-plane "
+                         "vector (no RCCL, no device IPC: cannot fail for lack of either; measured first); copy-shm = the copy form with "
+                         "its control plane in shared memory (dg_comm_create_shm: the whole field on every GPU without RCCL); slabs = interleaved 4-plane "
                          "slabs, packed buffers, all-gather, unpack; inplace = contiguous chunks cut by measured cost, sampled into "
                          "place and exchanged with grouped broadcasts (no unpack pass, no scratch); inplace-p2p: the same with "
                          "send / recv pairs; copy: the same chunks pushed into the peers' fields by the copy engines (fields from "
@@ -567,8 +568,10 @@ def main():
     field = torch.empty(n_nodes, dtype=torch.float64, device="cuda")
     comm = None          # the library's RCCL communicator
     comm_ext = None      # one-GPU self-test: the library's communicator with gloo as its control plane (copy form only)
+    comm_shm = [None]    # the library's communicator with its control plane in shared memory (dg_comm_create_shm; copy form only)
     hostf = [None]       # the shared-memory host vector of the "host" form (opened on first use)
     copy_field = [None]  # the field of the "copy" form: an array of dg_comm_field_alloc (mappable by the peers whatever its size)
+    copy_shm_field = [None]
     pieces = 1
     comm_note = None
     launch_nodes = n_nodes
@@ -633,7 +636,8 @@ def main():
 
     plane_cost = [None]            # chunked forms: relative cost per plane of every class (None: uniform), refined from measured times
     FLAGS = {"inplace": dg.EXCHANGE_INPLACE, "inplace-p2p": dg.EXCHANGE_INPLACE | dg.EXCHANGE_P2P,
-             "to-root": dg.EXCHANGE_INPLACE | dg.EXCHANGE_TO_ROOT, "copy": dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY}
+             "to-root": dg.EXCHANGE_INPLACE | dg.EXCHANGE_TO_ROOT, "copy": dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY,
+             "copy-shm": dg.EXCHANGE_INPLACE | dg.EXCHANGE_COPY}
     CHUNKED = set(FLAGS) | {"host"}
     last_python_ms = [None]
 
@@ -676,9 +680,13 @@ def main():
         last_python_ms[0] = [a.elapsed_time(b) for a, b in times]
 
     def comm_of(form):
+        if form == "copy-shm":
+            return comm_shm[0]
         return comm if comm is not None else (comm_ext if form == "copy" else None)
 
     def field_of(form):
+        if form == "copy-shm":
+            return copy_shm_field[0]
         return copy_field[0] if (form == "copy" and copy_field[0] is not None) else field
 
     def prepare(form):
@@ -691,6 +699,17 @@ def main():
                 if world > 1:
                     dist.broadcast_object_list(name, src=0)
                 hostf[0] = dg.HostField(name[0], n_nodes, rank, world)
+            return
+        if form == "copy-shm":
+            if comm_shm[0] is None:
+                name = [None]
+                if rank == 0:
+                    name[0] = "dg_benchctl_%d_%d" % (os.getpid(), int(time.time()))
+                if world > 1:
+                    dist.broadcast_object_list(name, src=0)
+                comm_shm[0] = dg.Comm.shared_memory(name[0], rank, world)
+                copy_shm_field[0] = torch.as_tensor(comm_shm[0].field_alloc(n_nodes), device="cuda")
+                copy_shm_field[0].fill_(float("nan"))
             return
         make_comm()
         if form == "copy" and copy_field[0] is None and comm_of("copy") is not None:
@@ -835,8 +854,10 @@ def main():
                     % (pieces, ("torch.distributed (python)" + ("; " + comm_note if comm_note else "")) if comm is None
                        else "dg_sdf_sample_allgather_device (RCCL inside the library)"))
         return ("contiguous chunks cut by measured cost, sampled in place, %s in %d piece(s) by %s"
-                % (form, pieces, "torch.distributed broadcasts (python)" if (comm is None and not (form == "copy" and comm_ext))
-                   else ("dg_sdf_sample_exchange_device (%s)" % (("peer copies on the copy engines, fields of dg_comm_field_alloc mapped chunk by chunk"
+                % (form, pieces, "torch.distributed broadcasts (python)" if comm_of(form) is None
+                   else ("dg_sdf_sample_exchange_device (%s)" % ("peer copies on the copy engines, fields of dg_comm_field_alloc mapped chunk by chunk, control plane in shared memory: no RCCL"
+                                                                 if form == "copy-shm" else
+                                                                 ("peer copies on the copy engines, fields of dg_comm_field_alloc mapped chunk by chunk"
                                                                   if copy_field[0] is not None else "peer copies on the copy engines, HIP IPC")
                                                                  if form == "copy" else "RCCL inside the library"))))
 
@@ -846,7 +867,7 @@ def main():
         balg = load_balg()
         counters, counters_note = load_counters()
         k1 = (counters or {}).get("k1") if world == 1 else None
-        rccl_nranks = comm.info()["rccl_nranks"] if (comm is not None and form not in (None, "host")) else None
+        rccl_nranks = comm.info()["rccl_nranks"] if (comm is not None and form not in (None, "host", "copy-shm")) else None
         return {
             "metric": "Mnodes/s SDF sampling (256³ grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
             "value": n_nodes * args.steps / elapsed / 1e6,
@@ -916,7 +937,8 @@ def main():
     else:
         # Measure, do not guess: none of these has ever run on more than one GPU where this was developed.  "host" first: it needs
         # nothing but shared memory and each GPU's own copy engine, so a number exists before RCCL or device IPC are touched.
-        candidates = ["host", "slabs", "inplace", "inplace-p2p", "copy"]
+        # "copy-shm" second: the whole field on every GPU, still without RCCL.
+        candidates = ["host", "copy-shm", "slabs", "inplace", "inplace-p2p", "copy"]
     results, errors = {}, {}
     best = None
     for cand in candidates:
@@ -966,6 +988,8 @@ def main():
         comm.close()
     if comm_ext is not None:
         comm_ext.close()
+    if comm_shm[0] is not None:
+        comm_shm[0].close()
     if sharded:
         ctl_barrier()
         dist.destroy_process_group()

@@ -98,6 +98,7 @@ SYMBOLS = {
     "dg_comm_last_exchange_wait_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "dg_comm_create_external": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dg_comm_get_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dg_comm_create_shm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dg_comm_field_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "dg_comm_field_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dg_host_field_open": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -448,6 +449,18 @@ class Comm:
         h = C.c_void_p()
         _check(self._lib.dg_comm_create_external(rank, nranks, C.cast(self._callbacks[0], C.c_void_p), C.cast(self._callbacks[1], C.c_void_p),
                                                  None, C.byref(h)))
+        self.handle = h
+        self.rank, self.nranks = rank, nranks
+        return self
+
+    @classmethod
+    def shared_memory(cls, name, rank, nranks):
+        """dg_comm_create_shm: a communicator whose control plane lives in a POSIX shared-memory segment (one node; RCCL-free;
+        runs EXCHANGE_INPLACE | EXCHANGE_COPY only).  Collective; `name` must be unique to the job."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.dg_comm_create_shm(name.encode(), rank, nranks, C.byref(h)))
         self.handle = h
         self.rank, self.nranks = rank, nranks
         return self

@@ -19,7 +19,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 SOURCES_HIP = ["dg_kernels_k1.hip", "dg_kernels_k2.hip", "dg_kernels_k3.hip", "dg_kernels_aux.hip"]
 SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_build.cpp"]
-HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_host_query.h", "dg_traverse.h", "dg_device.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
+HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_capi_shm.h", "dg_host_query.h", "dg_traverse.h", "dg_device.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
 
 
 def _stale():
@@ -50,7 +50,7 @@ DEPS = {
     "dg_build.cpp": ["dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h"],
     "dg_host_query.cpp": ["dg_host_query.h", "dg_traverse.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h",
                           "dg_capi_internal.h", "dg_layout.h", os.path.join("..", "..", "include", "discregrid_hip.h")],
-    "dg_capi_hostfield.cpp": ["dg_capi_internal.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_layout.h", os.path.join("..", "..", "include", "discregrid_hip.h")],
+    "dg_capi_hostfield.cpp": ["dg_capi_internal.h", "dg_capi_shm.h", "dg_build.h", "dg_geom.h", "dg_kernels.h", "dg_layout.h", os.path.join("..", "..", "include", "discregrid_hip.h")],
 }
 
 

@@ -50,6 +50,7 @@ struct Options
 	int gpus = 1, pieces = 4, steps = 1;
 	int exchange = 0; // flags of dg_sdf_sample_exchange_device (--inplace, --p2p, --copy)
 	bool host_vector = false; // --host: dg_sdf_sample_to_host_field (a shared-memory host vector; no RCCL, no device IPC)
+	bool shm_control = false; // --copy-shm: the copy form on dg_comm_create_shm (control plane in shared memory: no RCCL)
 	std::string output, input;
 };
 
@@ -138,31 +139,40 @@ int run_rank(const Options& opt, int rank, const std::string& id_file, const std
 		return 0;
 	}
 
-	// communicator: rank 0 publishes the RCCL unique id through a file (written whole, then renamed)
-	uint8_t id[DG_UNIQUE_ID_BYTES];
-	if (rank == 0)
+	dg_comm* comm = nullptr;
+	if (opt.shm_control)
 	{
-		check(rank, dg_comm_unique_id(id), "dg_comm_unique_id");
-		const std::string tmp = id_file + ".tmp";
-		const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600); // (never through a file somebody else made)
-		if (fd < 0 || write(fd, id, sizeof(id)) != (ssize_t)sizeof(id) || close(fd) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
-			die(rank, "cannot publish the communicator id");
+		// no RCCL at all: the copy form's two small collectives run over a shared-memory segment named after this run's id file
+		const std::string name = "dg_sdfmulti_ctl_" + id_file.substr(id_file.find_last_of('/') + 1);
+		check(rank, dg_comm_create_shm(name.c_str(), rank, opt.gpus, &comm), "dg_comm_create_shm");
 	}
 	else
 	{
-		const double t0 = now();
-		while (true)
+		// communicator: rank 0 publishes the RCCL unique id through a file (written whole, then renamed)
+		uint8_t id[DG_UNIQUE_ID_BYTES];
+		if (rank == 0)
 		{
-			std::ifstream in(id_file, std::ios::binary);
-			if (in.good() && in.read(reinterpret_cast<char*>(id), sizeof(id)))
-				break;
-			if (now() - t0 > 120.0)
-				die(rank, "timed out waiting for the communicator id");
-			std::this_thread::sleep_for(std::chrono::milliseconds(20));
+			check(rank, dg_comm_unique_id(id), "dg_comm_unique_id");
+			const std::string tmp = id_file + ".tmp";
+			const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600); // (never through a file somebody else made)
+			if (fd < 0 || write(fd, id, sizeof(id)) != (ssize_t)sizeof(id) || close(fd) != 0 || std::rename(tmp.c_str(), id_file.c_str()) != 0)
+				die(rank, "cannot publish the communicator id");
 		}
+		else
+		{
+			const double t0 = now();
+			while (true)
+			{
+				std::ifstream in(id_file, std::ios::binary);
+				if (in.good() && in.read(reinterpret_cast<char*>(id), sizeof(id)))
+					break;
+				if (now() - t0 > 120.0)
+					die(rank, "timed out waiting for the communicator id");
+				std::this_thread::sleep_for(std::chrono::milliseconds(20));
+			}
+		}
+		check(rank, dg_comm_create(id, rank, opt.gpus, &comm), "dg_comm_create");
 	}
-	dg_comm* comm = nullptr;
-	check(rank, dg_comm_create(id, rank, opt.gpus, &comm), "dg_comm_create");
 
 	// the copy form's field comes from the communicator (chunks the peers can map whatever the field's size); the RCCL forms
 	// take any device array
@@ -222,7 +232,7 @@ int main(int argc, char* argv[])
 		if (a == "-h" || a == "--help")
 		{
 			std::cout << "Usage: " << argv[0]
-					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p | --copy | --host] [--steps k] [-o out.cdf] mesh.obj"
+					  << " [-r \"x y z\"] [-d \"minX minY minZ maxX maxY maxZ\"] [-i] [-g gpus] [--pieces c] [--inplace | --p2p | --copy | --copy-shm | --host] [--steps k] [-o out.cdf] mesh.obj"
 					  << std::endl;
 			return 0;
 		}
@@ -247,6 +257,11 @@ int main(int argc, char* argv[])
 			opt.exchange |= DG_EXCHANGE_INPLACE;
 		else if (a == "--p2p") // ... exchanged with send / recv pairs instead
 			opt.exchange |= DG_EXCHANGE_INPLACE | DG_EXCHANGE_P2P;
+		else if (a == "--copy-shm") // the copy form with its control plane in shared memory: the whole field on every GPU, no RCCL
+		{
+			opt.exchange = DG_EXCHANGE_INPLACE | DG_EXCHANGE_COPY;
+			opt.shm_control = true;
+		}
 		else if (a == "--host") // every rank copies its chunks into a shared-memory host vector: no RCCL, no device IPC
 			opt.host_vector = true;
 		else if (a == "--copy") // ... pushed into the peers' fields by the copy engines (fields of dg_comm_field_alloc), no collective kernel

@@ -7,6 +7,7 @@
 // this library never load it, and a process that already carries an RCCL (PyTorch ships one) keeps
 // exactly that one.
 #include "dg_capi_internal.h"
+#include "dg_capi_shm.h"
 #include "dg_capi_vmm.h"
 
 #include <chrono>
@@ -115,6 +116,7 @@ struct dg_comm
 	dg_comm_allgather_fn ext_allgather = nullptr;
 	dg_comm_barrier_fn ext_barrier = nullptr;
 	void* ext_user = nullptr;
+	dgshm::Segment* shm = nullptr; // dg_comm_create_shm: the control plane lives in a shared-memory segment (ext_* point at it)
 	// DG_EXCHANGE_COPY: one copy stream per peer (the chunks are pushed by the copy engines), the fields whose peers
 	// are known, a device word for the stream-ordered barriers of the RCCL control plane
 	std::vector<hipStream_t> copy_streams;
@@ -313,6 +315,56 @@ dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn all
 	return DG_OK;
 }
 
+// ---- a control plane in shared memory: the copy form without RCCL and without callbacks -------------------------------------
+namespace
+{
+constexpr uint32_t kKindCtrl = 2;
+constexpr size_t kCtrlSlot = 256; // bytes per rank and message (the registration record is the largest: 136 bytes)
+int shm_ctrl_allgather(const void* mine, void* all, size_t bytes, void* user)
+{
+	dgshm::Segment* seg = static_cast<dgshm::Segment*>(user);
+	if (bytes > kCtrlSlot)
+		return 1;
+	std::memcpy(seg->payload + (size_t)seg->rank * kCtrlSlot, mine, bytes);
+	if (dgshm::barrier(*seg) != DG_OK) // everybody has written
+		return 1;
+	for (int r = 0; r < seg->nranks; ++r)
+		std::memcpy(static_cast<char*>(all) + (size_t)r * bytes, seg->payload + (size_t)r * kCtrlSlot, bytes);
+	return dgshm::barrier(*seg) == DG_OK ? 0 : 1; // everybody has read: the slots may be written again
+}
+int shm_ctrl_barrier(void* user) { return dgshm::barrier(*static_cast<dgshm::Segment*>(user)) == DG_OK ? 0 : 1; }
+} // namespace
+
+dg_status dg_comm_create_shm(const char* name, int rank, int nranks, dg_comm** out)
+{
+	if (!out)
+		return fail(DG_ERR_INVALID, "out is null");
+	*out = nullptr;
+	if (!name || !*name || nranks < 1 || nranks > dg::kMaxRanks || rank < 0 || rank >= nranks)
+		return fail(DG_ERR_INVALID, "bad name, or rank %d / nranks %d out of range (max %d ranks)", rank, nranks, dg::kMaxRanks);
+	dg_status s = require_device();
+	if (s != DG_OK)
+		return s;
+	dgshm::Segment* seg = new (std::nothrow) dgshm::Segment;
+	if (!seg)
+		return fail(DG_ERR_ALLOC, "host allocation failed");
+	s = dgshm::open(*seg, name, (size_t)dg::kMaxRanks * kCtrlSlot, kKindCtrl, rank, nranks);
+	if (s != DG_OK)
+	{
+		delete seg;
+		return s;
+	}
+	s = dg_comm_create_external(rank, nranks, shm_ctrl_allgather, shm_ctrl_barrier, seg, out);
+	if (s != DG_OK)
+	{
+		dgshm::close(*seg);
+		delete seg;
+		return s;
+	}
+	(*out)->shm = seg;
+	return DG_OK;
+}
+
 dg_status dg_comm_get_info(dg_comm* comm, dg_comm_info* info)
 {
 	if (!comm || !info)
@@ -357,6 +409,11 @@ void dg_comm_destroy(dg_comm* c)
 		if (e) (void)hipEventDestroy(e);
 	for (auto& kv : c->opened_handles)
 		(void)hipIpcCloseMemHandle(kv.second);
+	if (c->shm)
+	{
+		dgshm::close(*c->shm);
+		delete c->shm;
+	}
 	for (dgvmm::Array& a : c->vmm_imported)
 		dgvmm::destroy(a);
 	for (auto& kv : c->vmm_owned)

@@ -6,42 +6,19 @@
 // addFunction leaves behind is exactly that host vector (cubic_lagrange_discrete_grid.cpp:806-831).  Nothing here touches
 // RCCL, HIP IPC or the virtual-memory API, so it is the form that still works when those do not.
 // No reference counterpart (the reference is one process).
-#include "dg_capi_internal.h"
-
-#include <atomic>
-#include <fcntl.h>
-#include <sched.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
+#include "dg_capi_shm.h"
 
 namespace
 {
-constexpr uint64_t kMagic = 0x64675f686f737466ull; // "dg_hostf"
-constexpr size_t kHeaderBytes = 4096;
-struct ShmHeader // lives at the start of the segment; every member is address-free
-{
-	std::atomic<uint64_t> magic;     // set last by the creating rank
-	uint64_t n_doubles;
-	uint32_t nranks;
-	uint32_t pad;
-	std::atomic<uint32_t> arrived;    // barrier: ranks that have arrived in the current generation
-	std::atomic<uint32_t> generation; // barrier: bumped by the last arrival
-	std::atomic<uint32_t> attached;   // ranks that mapped the segment
-	uint32_t pad2;
-	uint64_t cuts_hash[2][dg::kMaxRanks]; // [call parity][rank]: the cuts every rank derived for the call (a rank is at most one call ahead)
-};
-static_assert(sizeof(ShmHeader) <= kHeaderBytes, "header page");
-static_assert(std::atomic<uint32_t>::is_always_lock_free && std::atomic<uint64_t>::is_always_lock_free, "shared-memory atomics");
+constexpr uint32_t kKindHostField = 1;
+// the owner's words of the segment header: [call parity][rank] the cuts every rank derived for the call (a rank is at most one call ahead)
+inline uint64_t& cuts_hash(dgshm::Segment& seg, int parity, int rank) { return seg.hdr->user[(size_t)parity * dg::kMaxRanks + (size_t)rank]; }
+static_assert(2 * dg::kMaxRanks <= 496, "header words");
 } // namespace
 
 struct dg_host_field
 {
-	std::string name;
-	int fd = -1;
-	void* map = nullptr;
-	size_t map_bytes = 0;
-	ShmHeader* hdr = nullptr;
+	dgshm::Segment seg;
 	double* data = nullptr;
 	uint64_t n_doubles = 0;
 	int rank = 0, nranks = 1, device = -1;
@@ -50,34 +27,9 @@ struct dg_host_field
 	hipStream_t copy = nullptr;
 	std::vector<hipEvent_t> sampled, t_begin, t_end;
 	int last_pieces = 0;
-	double timeout_s = 180.0;
 };
 
-static dg_status shm_barrier(dg_host_field* hf)
-{
-	if (hf->nranks <= 1)
-		return DG_OK;
-	ShmHeader* h = hf->hdr;
-	const uint32_t gen = h->generation.load(std::memory_order_acquire);
-	if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)hf->nranks)
-	{
-		h->arrived.store(0, std::memory_order_relaxed);
-		h->generation.store(gen + 1, std::memory_order_release);
-		return DG_OK;
-	}
-	const auto t0 = std::chrono::steady_clock::now();
-	for (uint64_t spins = 0; h->generation.load(std::memory_order_acquire) == gen; ++spins)
-	{
-		if (spins < 2000)
-			continue;
-		(void)sched_yield();
-		if ((spins & 1023) == 0 && hf->timeout_s > 0 &&
-			std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > hf->timeout_s)
-			return fail(DG_ERR_HIP, "shared-memory barrier: the other ranks did not arrive within %.0f s (rank %d of %d): is every rank running?",
-						hf->timeout_s, hf->rank, hf->nranks);
-	}
-	return DG_OK;
-}
+static dg_status shm_barrier(dg_host_field* hf) { return dgshm::barrier(hf->seg); }
 
 extern "C"
 {
@@ -92,90 +44,16 @@ dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int
 	dg_host_field* hf = new (std::nothrow) dg_host_field;
 	if (!hf)
 		return fail(DG_ERR_ALLOC, "host allocation failed");
-	hf->name = name[0] == '/' ? std::string(name) : "/" + std::string(name);
 	hf->rank = rank;
 	hf->nranks = nranks;
 	hf->n_doubles = n_doubles;
-	hf->timeout_s = (double)env_int("DG_COMM_TIMEOUT_S", 180, 0, 86400);
-	hf->map_bytes = kHeaderBytes + (size_t)n_doubles * sizeof(double);
-	const auto t0 = std::chrono::steady_clock::now();
-	auto expired = [&]() { return hf->timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > hf->timeout_s; };
-	if (rank == 0)
+	const dg_status os = dgshm::open(hf->seg, name, (size_t)n_doubles * sizeof(double), kKindHostField, rank, nranks);
+	if (os != DG_OK)
 	{
-		(void)shm_unlink(hf->name.c_str()); // (a segment a crashed job left behind)
-		hf->fd = shm_open(hf->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-		// (posix_fallocate: the pages are claimed NOW -- a tmpfs that is too small answers ENOSPC here instead of SIGBUS at the
-		// first touch of a page it cannot back)
-		int falloc = 0;
-		if (hf->fd < 0 || ftruncate(hf->fd, (off_t)hf->map_bytes) != 0 || (falloc = posix_fallocate(hf->fd, 0, (off_t)hf->map_bytes)) != 0)
-		{
-			const int err = falloc != 0 ? falloc : errno;
-			if (hf->fd >= 0)
-			{
-				(void)close(hf->fd);
-				(void)shm_unlink(hf->name.c_str());
-			}
-			delete hf;
-			return fail(DG_ERR_ALLOC, "shared-memory segment %s of %.2f GB: %s", name, (double)n_doubles * 8e-9, std::strerror(err));
-		}
-	}
-	else
-	{
-		// the creating rank may be later than this one: wait for the segment to exist at its full size
-		while (true)
-		{
-			hf->fd = shm_open(hf->name.c_str(), O_RDWR, 0600);
-			struct stat st;
-			if (hf->fd >= 0 && fstat(hf->fd, &st) == 0 && (size_t)st.st_size == hf->map_bytes)
-				break;
-			if (hf->fd >= 0)
-				(void)close(hf->fd);
-			hf->fd = -1;
-			if (expired())
-			{
-				delete hf;
-				return fail(DG_ERR_HIP, "shared-memory segment %s did not appear within the deadline (rank %d of %d): is rank 0 running?", name, rank, nranks);
-			}
-			(void)usleep(2000);
-		}
-	}
-	hf->map = mmap(nullptr, hf->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, hf->fd, 0);
-	if (hf->map == MAP_FAILED)
-	{
-		const int err = errno;
-		hf->map = nullptr;
-		(void)close(hf->fd);
-		if (rank == 0)
-			(void)shm_unlink(hf->name.c_str());
 		delete hf;
-		return fail(DG_ERR_ALLOC, "mapping the shared-memory segment %s: %s", name, std::strerror(err));
+		return os;
 	}
-	hf->hdr = static_cast<ShmHeader*>(hf->map);
-	hf->data = reinterpret_cast<double*>(static_cast<char*>(hf->map) + kHeaderBytes);
-	if (rank == 0)
-	{
-		hf->hdr->n_doubles = n_doubles; // (fresh pages are zero: counters and hashes start at 0)
-		hf->hdr->nranks = (uint32_t)nranks;
-		hf->hdr->magic.store(kMagic, std::memory_order_release);
-	}
-	else
-	{
-		while (hf->hdr->magic.load(std::memory_order_acquire) != kMagic)
-		{
-			if (expired())
-			{
-				dg_host_field_close(hf);
-				return fail(DG_ERR_HIP, "shared-memory segment %s was never initialised by rank 0", name);
-			}
-			(void)usleep(1000);
-		}
-		if (hf->hdr->n_doubles != n_doubles || hf->hdr->nranks != (uint32_t)nranks)
-		{
-			dg_host_field_close(hf);
-			return fail(DG_ERR_INVALID, "shared-memory segment %s was created for another size or rank count", name);
-		}
-	}
-	hf->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+	hf->data = reinterpret_cast<double*>(hf->seg.payload);
 	// with a device: the mapping becomes a DMA target (without one -- CPU-only tests of the barrier -- it stays plain memory)
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&hf->device) == hipSuccess)
@@ -194,15 +72,6 @@ dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int
 	{
 		(void)hipGetLastError();
 		hf->device = -1;
-	}
-	// everybody has mapped the segment: its name can go (the memory lives until the last rank unmaps it)
-	const dg_status s = shm_barrier(hf);
-	if (rank == 0)
-		(void)shm_unlink(hf->name.c_str());
-	if (s != DG_OK)
-	{
-		dg_host_field_close(hf);
-		return s;
 	}
 	*out = hf;
 	return DG_OK;
@@ -234,10 +103,7 @@ void dg_host_field_close(dg_host_field* hf)
 		if (hf->registered)
 			(void)hipHostUnregister(hf->data);
 	}
-	if (hf->map)
-		(void)munmap(hf->map, hf->map_bytes);
-	if (hf->fd >= 0)
-		(void)close(hf->fd);
+	dgshm::close(hf->seg);
 	delete hf;
 }
 
@@ -282,7 +148,7 @@ dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* g
 		}
 	const int parity = (int)(hf->calls & 1u);
 	++hf->calls;
-	hf->hdr->cuts_hash[parity][hf->rank] = h;
+	cuts_hash(hf->seg, parity, hf->rank) = h;
 	dg::ClassGeom cg[4];
 	dg::class_geometry(grid->resolution, cg);
 	while ((int)hf->sampled.size() < pieces)
@@ -326,7 +192,7 @@ dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* g
 	if (bs != DG_OK)
 		return bs;
 	for (int r = 0; r < N; ++r)
-		if (hf->hdr->cuts_hash[parity][r] != hf->hdr->cuts_hash[parity][0])
+		if (cuts_hash(hf->seg, parity, r) != cuts_hash(hf->seg, parity, 0))
 			return fail(DG_ERR_INVALID, "rank %d cut the lattice differently from rank 0: plane_cost must hold the same values on every rank (this is rank %d)",
 						r, hf->rank);
 	return DG_OK;

@@ -264,6 +264,11 @@ typedef int (*dg_comm_allgather_fn)(const void* mine, void* all, size_t bytes, v
 typedef int (*dg_comm_barrier_fn)(void* user);
 dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn allgather, dg_comm_barrier_fn barrier, void* user,
 								  dg_comm** out);
+/* The same without callbacks: the control plane lives in a POSIX shared-memory segment the ranks of ONE node map (rank 0
+ * creates "/name", the others wait for it up to DG_COMM_TIMEOUT_S seconds; `name` must be unique to the job).  With fields from
+ * dg_comm_field_alloc this is the exchange that leaves the whole field on every GPU with NO collective library at all: copy
+ * engines for the data, two barriers in shared memory per step.  Collective; no reference counterpart. */
+dg_status dg_comm_create_shm(const char* name, int rank, int nranks, dg_comm** out);
 typedef struct dg_comm_info {
 	int32_t rank, nranks, device;
 	int32_t rccl_nranks; /* ncclCommCount() of the wrapped communicator; -1: external control plane */

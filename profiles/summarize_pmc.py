@@ -39,7 +39,7 @@ def csrc_hash():
     d = os.path.join(ROOT, "discregrid_amd", "csrc")
     for f in sorted(os.listdir(d)):
         # (not the host-only sources: the copy pipeline, the CPU point query and the exchange glue do not change what the kernels do)
-        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_capi_vmm.h"):
+        if f.endswith((".hip", ".h", ".cpp")) and f not in ("dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_capi_vmm.h", "dg_capi_shm.h"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

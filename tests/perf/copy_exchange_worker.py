@@ -23,7 +23,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     res = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "61 47 53").split()]
     pieces = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    vmm = len(sys.argv) > 3 and sys.argv[3] == "vmm"   # the field comes from dg_comm_field_alloc (hipMemCreate chunks, no size limit)
+    vmm = len(sys.argv) > 3 and sys.argv[3] in ("vmm", "shm")   # the field comes from dg_comm_field_alloc (hipMemCreate chunks, no size limit)
+    shm = len(sys.argv) > 3 and sys.argv[3] == "shm"            # ... and the control plane lives in shared memory (dg_comm_create_shm)
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     torch.cuda.set_device(0)
     dg.load_library()
@@ -36,7 +37,14 @@ def main():
         dist.all_gather(outs, t)
         return [bytes(o.numpy().tobytes()) for o in outs]
 
-    comm = dg.Comm.external(rank, world, allgather, dist.barrier)
+    if shm:
+        names = [None]
+        if rank == 0:
+            names[0] = "dg_ctltest_%d" % os.getpid()
+        dist.broadcast_object_list(names, src=0)      # (gloo hands the segment's name round; the exchange itself never uses it)
+        comm = dg.Comm.shared_memory(names[0], rank, world)
+    else:
+        comm = dg.Comm.external(rank, world, allgather, dist.barrier)
     V, F = T.torus()
     dom = T.oracle_default_domain(V)
     grid = dg.grid_desc(dom[:3], dom[3:], res)
@@ -75,7 +83,7 @@ def main():
         except dg.DiscregridError as e:
             mismatch_caught = "plane_cost must hold the same values" in str(e)
     info = comm.info()
-    print(json.dumps({"rank": rank, "world": world, "ok": ok, "vmm": vmm, "field_gb": n * 8e-9, "mismatch_caught": mismatch_caught, "registered_fields": info["registered_fields"],
+    print(json.dumps({"rank": rank, "world": world, "ok": ok, "vmm": vmm, "shm": shm, "field_gb": n * 8e-9, "mismatch_caught": mismatch_caught, "registered_fields": info["registered_fields"],
                       "rccl_nranks": info["rccl_nranks"], "wait_ms": comm.last_exchange_wait_ms()}), flush=True)
     comm.close()
     dist.barrier()

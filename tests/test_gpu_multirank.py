@@ -64,7 +64,7 @@ def test_cpp_multi_gpu_tool_one_rank(tmp_path):
     for gpus in sorted({1, min(dg.device_count(), 8)}):
         # interleaved slabs + unpack / contiguous chunks exchanged in place / pushed by peer copies into a field of
         # dg_comm_field_alloc / copied into the shared-memory host vector (no communicator at all)
-        for extra in ([], ["--inplace"], ["--p2p"], ["--copy"], ["--host"]):
+        for extra in ([], ["--inplace"], ["--p2p"], ["--copy"], ["--copy-shm"], ["--host"]):
             out = str(tmp_path / ("multi%d%s.cdf" % (gpus, "".join(extra))))
             txt = subprocess.check_output([os.path.join(build, "GenerateSDFMultiGPU"), "-g", str(gpus), "-r", "24 20 22", "--steps", "3",
                                            "--pieces", "2", "-o", out, obj] + extra, timeout=600).decode()
@@ -162,6 +162,19 @@ def test_copy_exchange_through_vmm_chunks_with_several_ranks_on_one_gpu(world, r
         assert all(r["field_gb"] > 2.147 for r in recs)
 
 
+@pytest.mark.parametrize("world,res,pieces,steps", [(2, "61 47 53", 3, 4), (3, "40 36 33", 2, 4), (4, "256 256 600", 2, 2)])
+def test_copy_exchange_without_any_collective_library(world, res, pieces, steps):
+    """DG_EXCHANGE_COPY on a communicator whose control plane lives in shared memory (dg_comm_create_shm) with fields of
+    dg_comm_field_alloc: copy engines for the data, descriptors over a unix socket for the set-up, two barriers in a shared-memory
+    segment per step -- the whole field on every rank's device without RCCL and without caller-supplied collectives.  Several
+    processes on the one GPU, the last case with a field of 2.2 GB; every rank asserts field == direct launch, bit for bit, and
+    ranks with different plane costs are all told so."""
+    out = _torchrun(world, os.path.join(T.ROOT, "tests", "perf", "copy_exchange_worker.py"), res, pieces, "shm", steps, timeout=420)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    recs = [json.loads(l) for l in out.stdout.replace("}{", "}\n{").splitlines() if l.startswith("{")]
+    assert len(recs) == world and all(r["ok"] and r["shm"] and r["mismatch_caught"] and r["registered_fields"] == 1 and r["rccl_nranks"] == -1 for r in recs), recs
+
+
 @pytest.mark.parametrize("world,res,pieces,steps", [(2, "61 47 53", 3, 4), (3, "40 36 33", 2, 4), (4, "61 47 53", 2, 4), (4, "256 256 600", 2, 2)])
 def test_host_vector_exchange_with_several_ranks_on_one_gpu(world, res, pieces, steps):
     """dg_sdf_sample_to_host_field (the form that needs neither collective kernels nor device IPC): every rank copies the chunks
@@ -205,15 +218,15 @@ def test_host_vector_form_in_bench_one_rank():
 
 
 def test_bench_watchdog_reports_the_forms_measured_before_a_hang():
-    """A form that never completes must not take the scaling number with it: two ranks on the one GPU, the third form (inplace)
-    made to hang on every rank, 25 s per form -- rank 0 prints the line of the best form measured before it (host, slabs), the
-    line says which form was cut off, and every rank leaves."""
+    """A form that never completes must not take the scaling number with it: two ranks on the one GPU, the fourth form (inplace)
+    made to hang on every rank, 25 s per form -- rank 0 prints the line of the best form measured before it (host, copy-shm,
+    slabs), the line says which form was cut off, and every rank leaves."""
     env = dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1", DG_BENCH_HANG_FORM="inplace")
     out = _torchrun(2, os.path.join(T.ROOT, "bench.py"), "--gpus", 2, "--steps", 2, "--warmup", 1, "--pieces", 2, "--form-timeout", 25, env=env, timeout=300)
     assert "watchdog: exchange form inplace did not complete" in out.stderr, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     ex = rec["config"]["exchange"]
-    assert rec["value"] > 0 and set(ex["ms_by_form"]) == {"host", "slabs"} and ex["chosen"] in ("host", "slabs")
+    assert rec["value"] > 0 and set(ex["ms_by_form"]) == {"host", "copy-shm", "slabs"} and ex["chosen"] in ("host", "copy-shm", "slabs")
     assert "inplace did not complete within 25 s" in ex["watchdog"]
 
 
@@ -229,7 +242,7 @@ def test_exchange_auto_times_every_form_and_explains_itself():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     ex = rec["config"]["exchange"]
-    assert set(ex["ms_by_form"]) == {"host", "slabs", "inplace", "inplace-p2p", "copy"} and not ex["errors"], ex
+    assert set(ex["ms_by_form"]) == {"host", "copy-shm", "slabs", "inplace", "inplace-p2p", "copy"} and not ex["errors"], ex
     assert ex["chosen"] == min(ex["ms_by_form"], key=ex["ms_by_form"].get)
     assert len(ex["per_rank"]["sample_ms"]) == 2
 
