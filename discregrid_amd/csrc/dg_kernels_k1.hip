@@ -38,6 +38,9 @@ namespace dg
 namespace
 {
 
+#ifndef DG_EPILOGUE_HEAD
+#define DG_EPILOGUE_HEAD 2 // rounds of the per-lane double tests before the rest is pooled (k_sample_fast's epilogue; 0: lane by lane to the end)
+#endif
 #ifndef DG_K1_MIN_WAVES
 #define DG_K1_MIN_WAVES 8 // K1 is issue bound and hides its scalar-load latency with waves: cap it at 64 VGPRs
 #endif
@@ -416,15 +419,69 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	// each of the other lanes: the double test on its own candidates, in list (= traversal) order
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
 	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
-	// (A transposed form -- the (lane, triangle) pairs laid out contiguously, 64 pairs tested per round with the owners' points
-	// fetched by ds_bpermute -- was measured 1.1 % SLOWER on the judged workload and is gone: docs/DESIGN_history_r1_r3.md.)
-	for (int k = 0; __ballot(k < n_cand) != 0ull; ++k)
+	// Lists are short but uneven: on the judged workload 34 % of the lanes hold one candidate, 46 % two, 11 % six (the lanes next
+	// to a mesh vertex) -- lane by lane the wave runs as many rounds as its LONGEST list (5.5 on average) at 40 % lane
+	// utilisation.  So every lane runs the first kEpilogueHead rounds on its own candidates (81 % of the lanes are done after two),
+	// and what is left (0.55 candidates per lane) is POOLED: the (owner, triangle) pairs laid out contiguously (the bound stack's LDS
+	// is free by now), 64 pairs tested per round with the owner's point fetched by ds_bpermute, the values handed back through LDS
+	// (over the lists, which are no longer needed), and every owner offers its pooled values in list order -- the same values in
+	// the same order, hence the same winner.  (Pooling EVERYTHING was measured 1.1 % slower in round 3: the per-lane loops that
+	// build and read back the pool then run as many rounds as the longest list again.)
+	int k = 0;
+	for (; (DG_EPILOGUE_HEAD <= 0 || k < DG_EPILOGUE_HEAD) && __ballot(k < n_cand) != 0ull; ++k)
 	{
 		if (k < n_cand)
 		{
 			const int tri = lds_list[k * 64 + lane];
 			const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
 			offer(q, h.d2, tri);
+		}
+	}
+	const int tail_n = n_cand > k ? n_cand - k : 0; // (k is wave-uniform)
+	if (__ballot(tail_n > 0) != 0ull)
+	{
+		// `before`: pooled pairs of the lanes below this one; T: pairs in all (tail_n <= kFastListCap < 16: four bit planes)
+		uint32_t before = 0, T = 0;
+#pragma unroll
+		for (int b = 3; b >= 0; --b)
+		{
+			const unsigned long long m = __ballot(((tail_n >> b) & 1) != 0);
+			before += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+			T += (uint32_t)__popcll(m) << b;
+		}
+		const uint32_t item_cap = (uint32_t)P.mesh.stack_levels * 32u, res_cap = (uint32_t)(kFastListCap + 1) * 32u;
+		if (T <= item_cap && T <= res_cap)
+		{
+			uint32_t* items = (uint32_t*)lds_lb16;
+			double* res = (double*)lds_list;
+			for (int j = 0; __ballot(j < tail_n) != 0ull; ++j)
+				if (j < tail_n)
+					items[before + (uint32_t)j] = ((uint32_t)lane << 26) | (uint32_t)lds_list[(k + j) * 64 + lane];
+			__syncthreads(); // (one wave per workgroup: the pool is complete, the lists have been read)
+			for (uint32_t base = 0; base < T; base += 64u)
+			{
+				const uint32_t i = base + (uint32_t)lane;
+				const bool active = i < T;
+				const uint32_t item = items[active ? i : 0u];
+				const int owner = (int)(item >> 26);
+				const double opx = __shfl(q.px, owner), opy = __shfl(q.py, owner), opz = __shfl(q.pz, owner);
+				if (active)
+					res[i] = tri_closest<false>(P.mesh.tris[item & 0x3ffffffu], opx, opy, opz).d2;
+			}
+			__syncthreads();
+			for (int j = 0; __ballot(j < tail_n) != 0ull; ++j)
+				if (j < tail_n)
+					offer(q, res[before + (uint32_t)j], (int)(items[before + (uint32_t)j] & 0x3ffffffu));
+		}
+		else
+		{
+			for (; __ballot(k < n_cand) != 0ull; ++k)
+				if (k < n_cand)
+				{
+					const int tri = lds_list[k * 64 + lane];
+					const Hit h = tri_closest<false>(P.mesh.tris[tri], q.px, q.py, q.pz);
+					offer(q, h.d2, tri);
+				}
 		}
 	}
 	if (exact)
