@@ -39,7 +39,7 @@ namespace
 {
 
 #ifndef DG_EPILOGUE_HEAD
-#define DG_EPILOGUE_HEAD 2 // rounds of the per-lane double tests before the rest is pooled (k_sample_fast's epilogue; 0: lane by lane to the end)
+#define DG_EPILOGUE_HEAD 1 // rounds of the per-lane double tests before the rest is pooled (k_sample_fast's epilogue; 0: lane by lane to the end)
 #endif
 #ifndef DG_K1_MIN_WAVES
 #define DG_K1_MIN_WAVES 8 // K1 is issue bound and hides its scalar-load latency with waves: cap it at 64 VGPRs
@@ -421,12 +421,14 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 	const int n_cand = (sample && !exact) ? (int)((f.slot - list_base) >> 8) : 0;
 	// Lists are short but uneven: on the judged workload 34 % of the lanes hold one candidate, 46 % two, 11 % six (the lanes next
 	// to a mesh vertex) -- lane by lane the wave runs as many rounds as its LONGEST list (5.5 on average) at 40 % lane
-	// utilisation.  So every lane runs the first kEpilogueHead rounds on its own candidates (81 % of the lanes are done after two),
-	// and what is left (0.55 candidates per lane) is POOLED: the (owner, triangle) pairs laid out contiguously (the bound stack's LDS
-	// is free by now), 64 pairs tested per round with the owner's point fetched by ds_bpermute, the values handed back through LDS
-	// (over the lists, which are no longer needed), and every owner offers its pooled values in list order -- the same values in
-	// the same order, hence the same winner.  (Pooling EVERYTHING was measured 1.1 % slower in round 3: the per-lane loops that
-	// build and read back the pool then run as many rounds as the longest list again.)
+	// utilisation.  So every lane runs the first DG_EPILOGUE_HEAD round(s) on its own candidates, and what is left (1.2 candidates
+	// per lane after one round) is POOLED: the (owner, triangle) pairs laid out contiguously (the bound stack's LDS is free by
+	// now), 64 pairs tested per round with the owner's point fetched by ds_bpermute, the values handed back through LDS (over the
+	// lists, which are no longer needed), and every owner offers its pooled values in list order -- the same values in the same
+	// order, hence the same winner.  Same-box A/B at 256^3 (icosphere / bunny / dragon, ms): lane by lane 14.84 / 17.30 / 16.57,
+	// head 1 14.44 / 17.27 / 16.57, head 2 14.52 / 17.23 / 16.53, head 3 14.67 / 17.28 / 16.56 (profiles/r05_k1_epilogue_ab.txt).
+	// (Pooling EVERYTHING was measured 1.1 % slower in round 3: the per-lane loops that build and read back the pool then run as
+	// many rounds as the longest list again.)
 	int k = 0;
 	for (; (DG_EPILOGUE_HEAD <= 0 || k < DG_EPILOGUE_HEAD) && __ballot(k < n_cand) != 0ull; ++k)
 	{
