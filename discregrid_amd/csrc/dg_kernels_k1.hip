@@ -41,6 +41,10 @@ namespace
 #ifndef DG_EPILOGUE_HEAD
 #define DG_EPILOGUE_HEAD 1 // rounds of the per-lane double tests before the rest is pooled (k_sample_fast's epilogue; 0: lane by lane to the end)
 #endif
+#ifndef DG_HEAVY_WAVES_PER_BLOCK
+#define DG_HEAVY_WAVES_PER_BLOCK 2
+#endif
+static const int kHeavyWavesPerBlock = DG_HEAVY_WAVES_PER_BLOCK; // k_heavy_subtrees: jobs (waves) per block
 #ifndef DG_K1_MIN_WAVES
 #define DG_K1_MIN_WAVES 8 // K1 is issue bound and hides its scalar-load latency with waves: cap it at 64 VGPRs
 #endif
@@ -495,32 +499,39 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 }
 
 // Heavy bricks, step 2: job (slot, s) searches subtree s of the BVH for the brick parked in `slot`,
-// starting from the parked bests.  One wave per block, jobs dealt grid-stride (the number of parked
-// bricks is only known on the device).
+// starting from the parked bests.  ONE job per wave, kHeavyWavesPerBlock waves per block, a block for every job a full
+// set of slots could bring (the number of parked bricks is only known on the device; waves without a job leave at once).
+// Four fifths of the jobs end at their subtree's root pair, a few -- the bricks next to the centre of a sphere-like mesh --
+// test every triangle of the subtree (tests/perf/emu_heavy_study.py): dealt several to a wave (a capped grid, grid-stride)
+// the launch lasts as long as the unluckiest wave's jobs in a row -- icosphere 256^3: 0.58 ms with 32 768 waves, 0.47 with
+// 131 071, 0.41 one job each.  (Drawing the jobs from a counter is no way out: 161 000 atomic adds on one address take 2 ms.)
+// Two waves per block: a launch without a parked brick pays for its empty blocks -- bunny 256^3: 55 us with one wave per
+// block, 28 with two, 15 with four (8 before), against 0.41 / 0.44 / 0.46 ms on the icosphere.
 template <bool POINTS>
-__global__ __launch_bounds__(64) void k_heavy_subtrees(const SampleParams P)
+__global__ __launch_bounds__(64 * kHeavyWavesPerBlock) void k_heavy_subtrees(const SampleParams P)
 {
 	const uint32_t n_sub = (uint32_t)P.mesh.n_sub;
 	const uint32_t parked = min(*P.ovf.count, P.ovf.slots);
-	const int lane = (int)threadIdx.x;
-	extern __shared__ __attribute__((aligned(16))) float lds_lb[];
-	for (uint32_t job = blockIdx.x; job < parked * n_sub; job += gridDim.x)
-	{
-		const uint32_t slot = job / n_sub;
-		const uint32_t s = job - slot * n_sub;
-		const LaneTask t = lane_task<POINTS>(P, (uint64_t)P.ovf.brick[slot], lane);
-		LaneQuery q;
-		init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
-		const int tri = P.ovf.saved_tri[slot * 64 + lane];
-		if (t.sample && tri >= 0)
-			offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
-		else if (t.sample && tri == kSeedOnly) // parked by the filtered kernel: an upper bound, no triangle yet
-			q.bestf = fmin2(q.bestf, best_as_float(P.ovf.saved_d2[slot * 64 + lane]));
-		traverse(P.mesh, q, lds_lb, P.mesh.sub_roots[s], nullptr, 0u, 0);
-		const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
-		P.ovf.cand_d2[at] = q.best_d2;
-		P.ovf.cand_tri[at] = q.best_tri;
-	}
+	const int wave = uniform((int)(threadIdx.x >> 6));
+	const int lane = (int)(threadIdx.x & 63u);
+	extern __shared__ __attribute__((aligned(16))) float lds_lb[]; // [waves][stack_levels][64]
+	const uint32_t job = blockIdx.x * (uint32_t)kHeavyWavesPerBlock + (uint32_t)wave;
+	if (job >= parked * n_sub)
+		return;
+	const uint32_t slot = job / n_sub;
+	const uint32_t s = job - slot * n_sub;
+	const LaneTask t = lane_task<POINTS>(P, (uint64_t)P.ovf.brick[slot], lane);
+	LaneQuery q;
+	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	const int tri = P.ovf.saved_tri[slot * 64 + lane];
+	if (t.sample && tri >= 0)
+		offer(q, P.ovf.saved_d2[slot * 64 + lane], tri);
+	else if (t.sample && tri == kSeedOnly) // parked by the filtered kernel: an upper bound, no triangle yet
+		q.bestf = fmin2(q.bestf, best_as_float(P.ovf.saved_d2[slot * 64 + lane]));
+	traverse(P.mesh, q, lds_lb + wave * (P.mesh.stack_levels * 64), P.mesh.sub_roots[s], nullptr, 0u, 0);
+	const size_t at = ((size_t)slot * kSubtrees + s) * 64 + (size_t)lane;
+	P.ovf.cand_d2[at] = q.best_d2;
+	P.ovf.cand_tri[at] = q.best_tri;
 }
 
 // Heavy bricks, step 3: per lane the minimum over the subtrees (the parked best is part of every
@@ -529,19 +540,31 @@ template <bool POINTS>
 __global__ __launch_bounds__(64) void k_heavy_finish(const SampleParams P)
 {
 	const uint32_t slot = blockIdx.x;
-	if (slot >= min(*P.ovf.count, P.ovf.slots))
+	if (slot >= min(P.ovf.count[0], P.ovf.slots))
 		return;
 	const int lane = (int)threadIdx.x;
 	const LaneTask t = lane_task<POINTS>(P, (uint64_t)P.ovf.brick[slot], lane);
 	LaneQuery q;
 	init_query(P.mesh.origin, P.mesh.mesh_l1, t.sample, t.x0, t.x1, t.x2, q);
+	// (eight subtrees' candidates are fetched before the first is looked at: one subtree at a time the loop is a chain of 256
+	// memory round trips)
 	if (t.sample)
-		for (int s = 0; s < P.mesh.n_sub; ++s)
+		for (int s0 = 0; s0 < P.mesh.n_sub; s0 += 8)
 		{
-			const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)lane;
-			const int tri = P.ovf.cand_tri[at];
-			if (tri >= 0)
-				offer(q, P.ovf.cand_d2[at], tri);
+			int tri[8];
+			double d2[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+			{
+				const int s = s0 + k < P.mesh.n_sub ? s0 + k : P.mesh.n_sub - 1;
+				const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)lane;
+				tri[k] = P.ovf.cand_tri[at];
+				d2[k] = P.ovf.cand_d2[at];
+			}
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				if (s0 + k < P.mesh.n_sub && tri[k] >= 0)
+					offer(q, d2[k], tri[k]);
 		}
 	write_result<POINTS>(P, t, q);
 }
@@ -569,7 +592,8 @@ static hipError_t launch_k1(const SampleParams& p, hipStream_t stream)
 	{
 		const size_t lds1 = (size_t)p.mesh.stack_levels * 64 * sizeof(float);
 		const uint32_t jobs = p.ovf.slots * (uint32_t)p.mesh.n_sub;
-		hipLaunchKernelGGL(k_heavy_subtrees<POINTS>, dim3(jobs < 32768u ? jobs : 32768u), dim3(64), lds1, stream, p);
+		hipLaunchKernelGGL(k_heavy_subtrees<POINTS>, dim3((jobs + kHeavyWavesPerBlock - 1) / kHeavyWavesPerBlock), dim3(64 * kHeavyWavesPerBlock),
+						   lds1 * kHeavyWavesPerBlock, stream, p);
 		hipLaunchKernelGGL(k_heavy_finish<POINTS>, dim3(p.ovf.slots), dim3(64), 0, stream, p);
 	}
 	return hipGetLastError();

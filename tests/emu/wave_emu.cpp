@@ -146,7 +146,7 @@ extern "C" void emu_depth_hist(uint64_t* out /*64*/) { for (int i = 0; i < 64; +
 thread_local std::vector<std::pair<int,int>> g_leaf_log; // (first, cnt) of the leaves a traversal visited (design studies)
 // the filtered traversal (k_sample_fast's first pass); returns -1, -2 (a degenerate triangle was met) or the heavy slot claimed
 template <class EW>
-int walk_fast_with(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
+int walk_fast_with(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf, int start)
 {
 	g_leaf_log.clear();
 	EmuCounters c;
@@ -158,17 +158,28 @@ int walk_fast_with(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& 
 	auto lane_list = [](int l) { return FastLists::base(l); };
 	FastWalk<EW, decltype(lane_state), decltype(lane_list)> pol(lane_state, lane_list);
 	const bool budgeted = ovf && ovf->count;
-	const int parked = packet_walk(ew, pol, M, M.root_info, budgeted ? ovf->count : nullptr, budgeted ? ovf->slots : 0u,
+	const int parked = packet_walk(ew, pol, M, start, budgeted ? ovf->count : nullptr, budgeted ? ovf->slots : 0u,
 								   budgeted ? kFastWorkFactor * ovf->heavy_work : 0);
 	if (parked >= 0)
 		return parked;
 	return pol.degenerate ? -2 : -1;
 }
-int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
+int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf, int start)
 {
 	static const bool stack32 = getenv("EMU_STACK32") != nullptr; // (design study: bounds parked as full floats)
-	return stack32 ? walk_fast_with<EmuWave>(M, fl, lists, st, ovf) : walk_fast_with<EmuWave16>(M, fl, lists, st, ovf);
+	return stack32 ? walk_fast_with<EmuWave>(M, fl, lists, st, ovf, start) : walk_fast_with<EmuWave16>(M, fl, lists, st, ovf, start);
 }
+int walk_fast(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& st, const OverflowBuf* ovf)
+{
+	return walk_fast(M, fl, lists, st, ovf, M.root_info);
+}
+// design study (emu_set_heavy_study): what the jobs of k_heavy_subtrees cost as they are (exact walk) and what they would cost with
+// the filtered walk seeded by the parked upper bounds (exact walk only for the jobs in which some lane's list fills up)
+int g_heavy_study = 0;
+uint64_t g_hs_hist[8], g_hs_brick_max[4];
+uint64_t g_hs[16]; // 0 jobs, 1 exact: pair steps, 2 leaf groups, 3 tri tests; 4 fast: pair steps, 5 leaf visits, 6 step-1 pairs, 7 step-2 pairs,
+                   // 8 candidates, 9 epilogue rounds (pooled: ceil(candidates / 64)), 10 jobs that fall back, 11..13 exact counts of those jobs,
+                   // 14 jobs whose subtree is pruned at its root pair (exact walk: one pair step)
 void EmuCounters::pair_step(const MeshDev& M, int cur)
 {
 	if (st) st->node_visits += 2;
@@ -341,6 +352,13 @@ void emu_fast_stats(uint64_t* out /*28*/)
 }
 void emu_set_brick_blocking(int on) { g_brick_blocking = on; }
 void emu_set_seed_study(int on) { g_seed_study = on; }
+void emu_set_heavy_study(int on)
+{
+	g_heavy_study = on;
+	for (uint64_t& v : g_hs) v = 0;
+}
+void emu_heavy_study(uint64_t* out /*16*/) { for (int i = 0; i < 16; ++i) out[i] = g_hs[i]; }
+void emu_heavy_study_hist(uint64_t* out /*8*/) { for (int i = 0; i < 8; ++i) { out[i] = g_hs_hist[i]; g_hs_hist[i] = 0; } }
 // udiv_by / udiv_magic of dg_kernels.h against the host's division; returns the number of mismatches
 uint64_t emu_udiv_check(const uint32_t* n, const uint32_t* d, uint64_t count)
 {
@@ -781,7 +799,66 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 				else if (sample[l] && P.ovf.saved_tri[slot * 64 + l] == kSeedOnly)
 					w.q[l].bestf = fmin2(w.q[l].bestf, best_as_float(P.ovf.saved_d2[slot * 64 + l]));
 			}
-			walk_exact(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
+			if (g_heavy_study)
+			{
+				// the job as the filtered walk would run it (seeded by the parked upper bounds); counted, results discarded
+				FastLane fl[64];
+				FastLists lists;
+				FastStats fs;
+				bool any = false, all_seeded = true;
+				for (int l = 0; l < 64; ++l)
+				{
+					fl[l].a = make_approx_lane(w.q[l].px - P.mesh.origin[0], w.q[l].py - P.mesh.origin[1], w.q[l].pz - P.mesh.origin[2], P.mesh.mesh_l1);
+					const bool serve = sample[l] && fl[l].a.E < __builtin_inff();
+					all_seeded = all_seeded && (!sample[l] || (serve && P.ovf.saved_tri[slot * 64 + l] == kSeedOnly && P.ovf.saved_d2[slot * 64 + l] < 1.0e300));
+					init_fast_lane(fl[l], serve, FastLists::base(l));
+					if (serve && P.ovf.saved_d2[slot * 64 + l] < 1.0e300)
+					{
+						float theta, kappa;
+						fl[l].U = (float)P.ovf.saved_d2[slot * 64 + l];
+						approx_err_terms(fl[l].a.E, fl[l].U, &theta, &kappa);
+						fl[l].Uprune = __builtin_fmaf(fl[l].U, 1.0f + theta, kappa);
+					}
+					any = any || serve;
+				}
+				Stats before = st;
+				walk_exact(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
+				const uint64_t e_steps = (st.node_visits - before.node_visits) / 2, e_groups = st.leaf_groups - before.leaf_groups, e_tests = st.tri_tests - before.tri_tests;
+				g_hs[0]++;
+				g_hs[1] += e_steps;
+				g_hs[2] += e_groups;
+				g_hs[3] += e_tests;
+				g_hs[14] += e_steps <= 1 && e_tests == 0;
+				g_hs_hist[e_tests == 0 ? 0 : e_tests < 10 ? 1 : e_tests < 50 ? 2 : e_tests < 100 ? 3 : e_tests < 200 ? 4 : e_tests < 300 ? 5 : e_tests < 380 ? 6 : 7]++;
+				bool fallback = !any || !all_seeded;
+				if (!fallback)
+				{
+					const int r = walk_fast(P.mesh, fl, lists, fs, nullptr, P.mesh.sub_roots[s]);
+					uint64_t cand = 0;
+					for (int l = 0; l < 64; ++l)
+					{
+						const int c = sample[l] ? FastLists::count(fl[l], l) : 0;
+						cand += (uint64_t)c;
+						fallback = fallback || c >= kFastListCap;
+					}
+					fallback = fallback || r == -2;
+					g_hs[4] += fs.pair_steps;
+					g_hs[5] += fs.leaf_visits;
+					g_hs[6] += fs.hist[16];
+					g_hs[7] += fs.tri_pairs;
+					g_hs[8] += cand;
+					g_hs[9] += (cand + 63) / 64;
+				}
+				if (fallback)
+				{
+					g_hs[10]++;
+					g_hs[11] += e_steps;
+					g_hs[12] += e_groups;
+					g_hs[13] += e_tests;
+				}
+			}
+			else
+				walk_exact(P.mesh, w, st, P.mesh.sub_roots[s], nullptr);
 			for (int l = 0; l < 64; ++l)
 			{
 				const size_t at = ((size_t)slot * kSubtrees + (size_t)s) * 64 + (size_t)l;
