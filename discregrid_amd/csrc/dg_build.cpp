@@ -14,7 +14,6 @@
 #include <thread>
 #include <limits>
 #include <numeric>
-#include <unordered_map>
 
 namespace dg
 {
@@ -39,38 +38,83 @@ inline D3 over(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 inline D3 times(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
 inline D3 unit3(D3 a) { return over(a, std::sqrt(dot3(a, a))); }
 
+// [k0, k1) in up to `max_threads` contiguous pieces, each on its own thread (one piece: on the caller's)
+template <class F>
+void parallel_ranges(size_t n, size_t min_per_thread, size_t max_threads, F body)
+{
+	const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+	const size_t threads = std::max<size_t>(1, std::min(std::min(max_threads, hw), n / std::max<size_t>(1, min_per_thread)));
+	if (threads <= 1)
+	{
+		body((size_t)0, n);
+		return;
+	}
+	std::vector<std::thread> workers;
+	const size_t per = (n + threads - 1) / threads;
+	for (size_t k0 = 0; k0 < n; k0 += per)
+		workers.emplace_back(body, k0, std::min(n, k0 + per));
+	for (auto& w : workers)
+		w.join();
+}
+
 // Pseudonormals in the caller's triangle order: out[t*8 + slot], slots per dg_geom.h.
-// Accumulation order = triangle index order, as in the reference's single loop.
+// Accumulation order = triangle index order, as in the reference's single loop: the per-triangle terms (face normal, the
+// three angles: square roots and arc cosines) are computed on many threads, the SUMS -- per vertex, per edge -- are formed
+// by one thread in triangle order, the edges in an open-addressing table (a node-based map was 60 % of this function).
 void pseudonormals(const std::vector<D3>& V, const uint32_t* T, size_t nt, std::vector<D3>& out, uint32_t& flags)
 {
 	const uint64_t nv = V.size();
 	std::vector<D3> vsum(V.size(), D3{0, 0, 0});
-	std::unordered_map<uint64_t, std::pair<D3, int>> edges;
-	edges.reserve(nt * 2);
 	auto key = [nv](uint32_t i, uint32_t j) { return (uint64_t)std::min(i, j) * nv + (uint64_t)std::max(i, j); };
+	out.assign(nt * kPnSlots, D3{0, 0, 0});
+	std::vector<double> angle(3 * nt);
+	parallel_ranges(nt, 8192, 64, [&](size_t t0, size_t t1) {
+		for (size_t t = t0; t < t1; ++t)
+		{
+			const D3 a = V[T[3 * t]], b = V[T[3 * t + 1]], c = V[T[3 * t + 2]];
+			out[t * kPnSlots + kFace] = unit3(cross3(sub(b, a), sub(c, a)));
+			angle[3 * t] = std::acos(std::abs(dot3(unit3(sub(b, a)), unit3(sub(c, a)))));
+			angle[3 * t + 1] = std::acos(std::abs(dot3(unit3(sub(a, b)), unit3(sub(c, b)))));
+			angle[3 * t + 2] = std::acos(std::abs(dot3(unit3(sub(b, c)), unit3(sub(a, c)))));
+		}
+	});
+	// edge table: open addressing, linear probing, at most 3 nt entries in >= 4 nt slots
+	size_t cap = 16;
+	while (cap < 4 * nt)
+		cap <<= 1;
+	const uint64_t kEmpty = ~(uint64_t)0; // (no key: min * nv + max < nv^2 <= 2^64 - 2^33)
+	std::vector<uint64_t> ekey(cap, kEmpty);
+	std::vector<D3> esum(cap);
+	std::vector<uint32_t> ecount(cap, 0u);
+	const int shift = 64 - (int)std::lround(std::log2((double)cap));
+	auto slot_of = [&](uint64_t k) {
+		size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> shift);
+		while (ekey[h] != kEmpty && ekey[h] != k)
+			h = (h + 1) & (cap - 1);
+		return h;
+	};
 	auto add_edge = [&](uint32_t i, uint32_t j, D3 n) {
-		auto it = edges.find(key(i, j));
-		if (it == edges.end())
-			edges.emplace(key(i, j), std::make_pair(n, 1));
+		const uint64_t k = key(i, j);
+		const size_t h = slot_of(k);
+		if (ekey[h] == kEmpty)
+		{
+			ekey[h] = k;
+			esum[h] = n;
+			ecount[h] = 1;
+		}
 		else
 		{
-			it->second.first = add(it->second.first, n);
-			it->second.second += 1;
+			esum[h] = add(esum[h], n);
+			ecount[h] += 1;
 		}
 	};
-	out.assign(nt * kPnSlots, D3{0, 0, 0});
 	for (size_t t = 0; t < nt; ++t)
 	{
 		const uint32_t i0 = T[3 * t], i1 = T[3 * t + 1], i2 = T[3 * t + 2];
-		const D3 a = V[i0], b = V[i1], c = V[i2];
-		const D3 n = unit3(cross3(sub(b, a), sub(c, a)));
-		out[t * kPnSlots + kFace] = n;
-		const double al0 = std::acos(std::abs(dot3(unit3(sub(b, a)), unit3(sub(c, a)))));
-		const double al1 = std::acos(std::abs(dot3(unit3(sub(a, b)), unit3(sub(c, b)))));
-		const double al2 = std::acos(std::abs(dot3(unit3(sub(b, c)), unit3(sub(a, c)))));
-		vsum[i0] = add(vsum[i0], times(al0, n));
-		vsum[i1] = add(vsum[i1], times(al1, n));
-		vsum[i2] = add(vsum[i2], times(al2, n));
+		const D3 n = out[t * kPnSlots + kFace];
+		vsum[i0] = add(vsum[i0], times(angle[3 * t], n));
+		vsum[i1] = add(vsum[i1], times(angle[3 * t + 1], n));
+		vsum[i2] = add(vsum[i2], times(angle[3 * t + 2], n));
 		add_edge(i0, i1, n);
 		add_edge(i1, i2, n);
 		add_edge(i0, i2, n);
@@ -81,23 +125,25 @@ void pseudonormals(const std::vector<D3>& V, const uint32_t* T, size_t nt, std::
 		n = {n.x / l, n.y / l, n.z / l};
 	}
 	flags = 0;
-	for (auto const& kv : edges)
+	for (size_t h = 0; h < cap; ++h)
 	{
-		if (kv.second.second == 1)
+		if (ecount[h] == 1)
 			flags |= 1u;
-		else if (kv.second.second > 2)
+		else if (ecount[h] > 2)
 			flags |= 2u;
 	}
-	for (size_t t = 0; t < nt; ++t)
-	{
-		const uint32_t i0 = T[3 * t], i1 = T[3 * t + 1], i2 = T[3 * t + 2];
-		out[t * kPnSlots + kV0] = vsum[i0];
-		out[t * kPnSlots + kV1] = vsum[i1];
-		out[t * kPnSlots + kV2] = vsum[i2];
-		out[t * kPnSlots + kE01] = unit3(edges.find(key(i0, i1))->second.first);
-		out[t * kPnSlots + kE12] = unit3(edges.find(key(i1, i2))->second.first);
-		out[t * kPnSlots + kE02] = unit3(edges.find(key(i0, i2))->second.first);
-	}
+	parallel_ranges(nt, 8192, 64, [&](size_t t0, size_t t1) {
+		for (size_t t = t0; t < t1; ++t)
+		{
+			const uint32_t i0 = T[3 * t], i1 = T[3 * t + 1], i2 = T[3 * t + 2];
+			out[t * kPnSlots + kV0] = vsum[i0];
+			out[t * kPnSlots + kV1] = vsum[i1];
+			out[t * kPnSlots + kV2] = vsum[i2];
+			out[t * kPnSlots + kE01] = unit3(esum[slot_of(key(i0, i1))]);
+			out[t * kPnSlots + kE12] = unit3(esum[slot_of(key(i1, i2))]);
+			out[t * kPnSlots + kE02] = unit3(esum[slot_of(key(i0, i2))]);
+		}
+	});
 }
 
 inline float round_down(double v)
@@ -294,6 +340,9 @@ struct Builder
 	const double* origin;
 	int max_leaf;
 	std::atomic<uint32_t> depth{0};
+	// levels whose left halves get a thread of their own: 2^levels threads at the bottom of the spawning part
+	// (4 on a small host, 6 from 64 hardware threads up: 0.086 -> 0.05 s for 100 820 triangles on 256 cores)
+	uint32_t spawn_levels = std::thread::hardware_concurrency() >= 64 ? 6u : 4u;
 
 	size_t left_count(size_t n) const
 	{
@@ -369,7 +418,7 @@ struct Builder
 		size_t pl, ql;
 		shape(half, pl, ql);
 		int32_t il, ir;
-		if (level < 4 && e - b > 65536) // the top of a big tree: left half on its own thread
+		if (level < spawn_levels && e - b > 8192) // the top of a big tree: left half on its own thread
 		{
 			auto left = std::async(std::launch::async, [&]() { return build(b, mid, level + 1, rec + 1, pos); });
 			ir = build(mid, e, level + 1, rec + 1 + pl, pos + ql);
@@ -533,7 +582,7 @@ bool build_mesh(const double* verts, size_t n_vertices, const uint32_t* tris, si
 			}
 		}
 	};
-	const size_t n_threads = npos >= (1u << 16) ? std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())) : 1;
+	const size_t n_threads = npos >= (1u << 16) ? std::min<size_t>(64, std::max(1u, std::thread::hardware_concurrency())) : 1;
 	if (n_threads <= 1)
 		fill(0, npos);
 	else
