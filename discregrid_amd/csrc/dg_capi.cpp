@@ -403,8 +403,8 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
 	// Which K1 kernel: the filtered one (dg_kernels_k1.hip: k_sample_fast) or the exact one only.  By default: from dg::kFastMinTriangles triangles up, and for lattices only where a brick (3 cells) is not much
 	// smaller than a triangle -- the filter pays through the exact tests it saves, and a brick smaller than the
-	// triangles around it needs few (icosphere 100 820 triangles: 128^3 -21 %, 256^3 -9.5 %, 512^3 +2.8 %; brick /
-	// mean triangle edge = 2.8, 1.4, 0.7).  DG_FORCE=k1_fast=0 / 1 force the exact / the filtered kernel.
+	// triangles around it needs few (icosphere 100 820 triangles: 128^3 -27 %, 256^3 -9.5 %, 512^3 -2.3 %; brick /
+	// mean triangle edge = 2.8, 1.4, 0.7; bunny 512^3, 0.6: +4 %; dg_kernels.h: kFastMinBrickRatio).  DG_FORCE=k1_fast=0 / 1 force the exact / the filtered kernel.
 	int fast_default = mesh->info.n_triangles >= dg::kFastMinTriangles ? 1 : 0;
 	if (fast_default && P.pts.xyz == nullptr && mesh->host.mean_edge > 0.0)
 	{

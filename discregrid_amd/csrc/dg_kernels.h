@@ -67,7 +67,10 @@ static const int kFastWorkFactor = 1;
 // meshes below this triangle count run the exact kernel: with a few hundred triangles a brick's exact tests
 // are fewer than its filter tests + per-lane candidates (box 256^3: 2.6 vs 4.6 ms, 57 600-triangle torus 18.4 vs 17.2)
 static const uint64_t kFastMinTriangles = 8192;
-static const double kFastMinBrickRatio = 0.8; // lattices: filtered kernel if 3 x (geometric mean cell edge) >= this x mean triangle edge
+// lattices: filtered kernel if 3 x (geometric mean cell edge) >= this x mean triangle edge.  Re-measured at 512^3 with the pooled
+// epilogue (round 5; ratio: filtered / exact ms): icosphere 0.693: 87.9 / 90.0, bunny 0.604: 116.2 / 111.5 -- the crossover
+// lies near 0.66 (0.8 until round 4, when the filtered kernel lost by 2.8 % at 0.693)
+static const double kFastMinBrickRatio = 0.66;
 static const int32_t kSeedOnly = -2; // OverflowBuf::saved_tri: saved_d2 is an upper bound of the lane's d^2, no triangle yet
 inline size_t overflow_bytes(uint32_t slots, size_t off[6])
 {
