@@ -30,6 +30,35 @@ def test_bvh_structure_and_pseudonormals(name):
     assert em.info()["flags"] == 0
 
 
+def test_pseudonormals_of_an_open_non_manifold_mesh():
+    """Edges with one and with three or four incident triangles (fins on an icosphere with holes), enough triangles for the
+    threaded parts of the builder: the per-vertex and per-edge SUMS depend on the order of the additions -- triangle order, as
+    the reference's single loop forms them (TriangleMeshDistance.h:336-428) -- and have to come out bit for bit."""
+    V, F = T.icosphere(30)                       # 18 000 triangles
+    rng = np.random.default_rng(3)
+    keep = np.ones(len(F), dtype=bool)
+    keep[rng.choice(len(F), 400, replace=False)] = False          # holes: edges with one triangle
+    fins = []
+    Vx = [V]
+    for t in rng.choice(np.nonzero(keep)[0], 600, replace=False):  # fins: a third (and sometimes fourth) triangle on an edge
+        a, b = F[t, 0], F[t, 1]
+        for _ in range(int(rng.integers(1, 3))):
+            apex = 1.2 * 0.5 * (V[a] + V[b]) + 0.05 * rng.normal(size=3)
+            Vx.append(apex[None, :])
+            fins.append([a, b, sum(len(v) for v in Vx) - 1])
+    V2 = np.concatenate(Vx)
+    F2 = np.concatenate([F[keep], np.asarray(fins, dtype=F.dtype)])
+    F2 = F2[rng.permutation(len(F2))]             # incident triangles far apart in triangle order
+    em = emu.EmuMesh(V2, F2)
+    c = T.OracleMesh(V2, F2).construction()
+    pn = em.pseudonormals()
+    np.testing.assert_array_equal(pn[:, 6], c["pn_tri"])
+    np.testing.assert_array_equal(pn[:, 3:6], c["pn_edge"])
+    for k in range(3):
+        np.testing.assert_array_equal(pn[:, k], c["pn_vert"][F2[:, k]])
+    assert em.info()["flags"] == 3               # open edges AND edges with more than two triangles
+
+
 @pytest.mark.parametrize("name", list(MESHES))
 def test_subtree_cut_covers_the_tree_once(name):
     """The <= 256 subtree roots heavy bricks are split over reach every triangle exactly once."""
