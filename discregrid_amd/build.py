@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, "libdiscregrid_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function"]
 SOURCES_HIP = ["dg_kernels_k1.hip", "dg_kernels_k2.hip", "dg_kernels_k3.hip", "dg_kernels_aux.hip"]
 SOURCES_CXX = ["dg_capi.cpp", "dg_capi_field.cpp", "dg_capi_host.cpp", "dg_host_query.cpp", "dg_capi_comm.cpp", "dg_capi_hostfield.cpp", "dg_build.cpp"]
 HEADERS = ["dg_geom.h", "dg_lattice.h", "dg_density.h", "dg_density_cells.h", "dg_build.h", "dg_kernels.h", "dg_layout.h", "dg_gauss16.h", "dg_capi_internal.h", "dg_capi_vmm.h", "dg_capi_shm.h", "dg_host_query.h", "dg_traverse.h", "dg_device.h", os.path.join("..", "..", "include", "discregrid_hip.h")]
@@ -26,7 +26,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES_HIP + SOURCES_CXX + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES_HIP + SOURCES_CXX + HEADERS + ["exports.map"]] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -99,7 +99,7 @@ def _build(verbose, defines, objdir, target, force=False):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
         list(pool.map(compile_one, jobs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", target]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", target]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -56,6 +56,11 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points below are ALL it exports (tests/test_abi.py checks that
+ * `nm -D --defined-only` lists no other text / data symbol), so a host application's own fail(), TraceRange ... never
+ * interpose its internals. */
+#define DG_API __attribute__((visibility("default")))
+
 #define DG_NO_VALUE 1.7976931348623157e308
 
 typedef enum dg_status {
@@ -96,37 +101,37 @@ typedef struct dg_shard_info {
 } dg_shard_info;
 
 /* ---- runtime ------------------------------------------------------------------------- */
-const char* dg_version(void);
-const char* dg_last_error(void);
-dg_status dg_device_count(int* count);
-dg_status dg_set_device(int device);
-dg_status dg_current_device(int* device); /* the calling thread's current device (hipGetDevice) */
+DG_API const char* dg_version(void);
+DG_API const char* dg_last_error(void);
+DG_API dg_status dg_device_count(int* count);
+DG_API dg_status dg_set_device(int device);
+DG_API dg_status dg_current_device(int* device); /* the calling thread's current device (hipGetDevice) */
 
 /* ---- grid helpers (host arithmetic of discrete_grid.hpp:22-29, no device work) ---------- */
-dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
+DG_API dg_status dg_grid_desc_init(const double domain_min[3], const double domain_max[3], const uint32_t resolution[3],
 							dg_grid_desc* out);
 /* Default sampling domain of the reference's GenerateSDF tool (cmd/generate_sdf/main.cpp:83-91): the
  * bounding box of the vertices, max grown by 1e-3*|diagonal| first, then min by 1e-3*|diagonal of
  * the already grown box| (the asymmetry is the reference's).  out = {min xyz, max xyz}. */
-dg_status dg_default_domain(const double* verts, uint64_t n_vertices, double out_min_max[6]);
-uint64_t dg_grid_n_nodes(const dg_grid_desc* grid); /* (N+1)^3 + 6N(N+1)^2 generalised, :790-796 */
-uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
+DG_API dg_status dg_default_domain(const double* verts, uint64_t n_vertices, double out_min_max[6]);
+DG_API uint64_t dg_grid_n_nodes(const dg_grid_desc* grid); /* (N+1)^3 + 6N(N+1)^2 generalised, :790-796 */
+DG_API uint64_t dg_grid_n_cells(const dg_grid_desc* grid);
 
 /* ---- mesh / BVH handle ----------------------------------------------------------------- */
 /* verts: 3*n_vertices doubles (xyzxyz...), tris: 3*n_triangles vertex indices.  Builds the
  * pseudonormals exactly as the reference does and a flattened BVH of this library's own design
  * (oriented-box bounds, sibling-pair records) on the host, then uploads everything to the
  * current device. */
-dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
+DG_API dg_status dg_mesh_create(const double* verts, size_t n_vertices, const uint32_t* tris, size_t n_triangles,
 						 dg_mesh** out);
-dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info);
+DG_API dg_status dg_mesh_get_info(const dg_mesh* mesh, dg_mesh_info* info);
 /* The device the handle's arrays live on, or -1 for a HOST-ONLY handle: dg_mesh_create on a machine without a HIP device (or
  * under DG_FORCE_CPU=1) still builds the BVH and the pseudonormals and keeps them in host memory, so that
  * dg_signed_distance_point() -- the reference's per-point TriangleMeshDistance::signed_distance,
  * TriangleMeshDistance.h:252-267, 269-328 -- works wherever the reference works; every entry point that would launch a
  * kernel returns DG_ERR_NO_DEVICE for such a handle. */
-int dg_mesh_device(const dg_mesh* mesh);
-void dg_mesh_destroy(dg_mesh* mesh);
+DG_API int dg_mesh_device(const dg_mesh* mesh);
+DG_API void dg_mesh_destroy(dg_mesh* mesh);
 
 /* ---- K1: SDF node sampling --------------------------------------------------------------- */
 /* out[l - node_begin] = (invert ? -1 : 1) * signed_distance(indexToNodePosition(l)) for
@@ -134,16 +139,16 @@ void dg_mesh_destroy(dg_mesh* mesh);
  * is 0 receive DG_NO_VALUE, mirroring the SamplePredicate branch (:814-817). */
 /* (`out` is scratch from the moment of the call: the direct form touches and pins it before the first result arrives,
  * so a call that returns an error may leave it partly overwritten.) */
-dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+DG_API dg_status dg_sdf_sample_nodes(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 							  uint64_t node_end, const uint8_t* pred_mask, double* out);
-dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
+DG_API dg_status dg_sdf_sample_nodes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, uint64_t node_begin,
 									 uint64_t node_end, const uint8_t* d_pred_mask, double* d_out, void* stream);
 /* Several devices, one process (host results): meshes[i] is the same mesh created once per device
  * (dg_set_device + dg_mesh_create; the same device may appear more than once).  The node range is cut
  * into chunks of whole 4-plane slabs that are dealt round-robin to the meshes; every mesh runs its
  * own kernel / copy pipeline from its own host thread straight into `out`, so no collective is
  * needed (the all-gather of the sharded device path exists to leave the field on every GPU). */
-dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, const dg_grid_desc* grid, int invert,
+DG_API dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, const dg_grid_desc* grid, int invert,
 									uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out);
 
 /* Signed distance at arbitrary points (3*n doubles) -> dist[n]; optional nearest triangle id
@@ -152,9 +157,9 @@ dg_status dg_sdf_sample_nodes_multi(const dg_mesh* const* meshes, int n_meshes, 
  * points that arrive in no spatial order are processed tile by tile (decided on the device, the
  * results land at the caller's positions); where several triangles are exactly equidistant the
  * id of any of them may be returned, as in the reference the first one met wins. */
-dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n, double* dist, int32_t* tri,
+DG_API dg_status dg_signed_distance(const dg_mesh* mesh, const double* xyz, uint64_t n, double* dist, int32_t* tri,
 							 int32_t* entity, double* nearest);
-dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
+DG_API dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, uint64_t n, double* d_dist,
 									int32_t* d_tri, int32_t* d_entity, double* d_nearest, void* stream);
 
 /* ONE point, evaluated on the calling thread (no launch): TriangleMeshDistance::signed_distance(point)
@@ -164,7 +169,7 @@ dg_status dg_signed_distance_device(const dg_mesh* mesh, const double* d_xyz, ui
  * the point (of exactly equidistant triangles either may be named).  Const and lock-free: any number of
  * threads may call it on one mesh.  tri / entity / nearest may be NULL.  Batches belong on the GPU
  * (dg_signed_distance, dg_sdf_sample_nodes): this is the per-point evaluator, not a CPU path for them. */
-dg_status dg_signed_distance_point(const dg_mesh* mesh, const double xyz[3], double* dist, int32_t* tri,
+DG_API dg_status dg_signed_distance_point(const dg_mesh* mesh, const double xyz[3], double* dist, int32_t* tri,
 								   int32_t* entity, double* nearest);
 
 /* ---- multi-GPU sharding of the node lattice (one process per GPU) -------------------------- */
@@ -177,14 +182,14 @@ dg_status dg_signed_distance_point(const dg_mesh* mesh, const double xyz[3], dou
  * p*G + g, p = 0..C-1, of a C*G-way deal can all-gather piece p among the G GPUs while it samples
  * piece p+1; the C gathered pieces laid end to end are the buffer a single C*G-rank all-gather
  * would produce, so the same unpack call (nranks = C*G) applies (bench.py --pieces). */
-dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_shard_info* out);
-dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
+DG_API dg_status dg_shard_layout(const dg_grid_desc* grid, int rank, int nranks, dg_shard_info* out);
+DG_API dg_status dg_sdf_sample_shard_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, int rank, int nranks,
 									 double* d_packed, void* stream);
-dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+DG_API dg_status dg_unpack_shards_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 								  double* d_field, void* stream);
 /* Same for the slots [rank_begin, rank_end) of the gathered buffer only (d_gathered is still the
  * base of the whole buffer): lets a pieced gather unpack piece p while piece p+1 is in flight. */
-dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
+DG_API dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, const double* d_gathered, uint64_t stride,
 									   int rank_begin, int rank_end, double* d_field, void* stream);
 
 /* The exchange step behind the ABI.  A dg_comm wraps an RCCL communicator of one-process-per-GPU ranks
@@ -200,11 +205,11 @@ dg_status dg_unpack_shard_range_device(const dg_grid_desc* grid, int nranks, con
  * pieces is clamped to 64 / nranks; 4 is a good value.  No reference counterpart (single process). */
 #define DG_UNIQUE_ID_BYTES 128
 typedef struct dg_comm dg_comm;
-dg_status dg_comm_unique_id(uint8_t id[DG_UNIQUE_ID_BYTES]);
-dg_status dg_comm_create(const uint8_t id[DG_UNIQUE_ID_BYTES], int rank, int nranks, dg_comm** out);
-dg_status dg_comm_adopt(void* nccl_comm, int rank, int nranks, dg_comm** out); /* does not take ownership */
-void dg_comm_destroy(dg_comm* comm);
-dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm,
+DG_API dg_status dg_comm_unique_id(uint8_t id[DG_UNIQUE_ID_BYTES]);
+DG_API dg_status dg_comm_create(const uint8_t id[DG_UNIQUE_ID_BYTES], int rank, int nranks, dg_comm** out);
+DG_API dg_status dg_comm_adopt(void* nccl_comm, int rank, int nranks, dg_comm** out); /* does not take ownership */
+DG_API void dg_comm_destroy(dg_comm* comm);
+DG_API dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm,
 										 int pieces, double* d_field, void* stream);
 
 /* The same step with the lattice cut into CONTIGUOUS chunks, exchanged in place (DG_EXCHANGE_INPLACE): every class's
@@ -245,14 +250,14 @@ dg_status dg_sdf_sample_allgather_device(const dg_mesh* mesh, const dg_grid_desc
  * over a unix-domain socket (SCM_RIGHTS) and each peer maps them side by side -- no allocation above 2 GiB is ever opened as a
  * whole.  To kernels and copies the array is ordinary device memory.  dg_comm_field_free releases an array no peer maps;
  * a registered one lives until dg_comm_destroy.  No reference counterpart (single process). */
-dg_status dg_comm_field_alloc(dg_comm* comm, uint64_t n_doubles, double** d_field);
-dg_status dg_comm_field_free(dg_comm* comm, double* d_field);
+DG_API dg_status dg_comm_field_alloc(dg_comm* comm, uint64_t n_doubles, double** d_field);
+DG_API dg_status dg_comm_field_free(dg_comm* comm, double* d_field);
 /* cuts[c * (nchunks + 1) + v], v = 0..nchunks: first plane of chunk v of class c (class order V, X, Y, Z); host only */
-dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts);
+DG_API dg_status dg_chunk_layout(const dg_grid_desc* grid, int nchunks, const float* const plane_cost[4], uint32_t* cuts);
 /* planes [plane_begin[c], plane_end[c]) of every class, sampled into their places in d_field (the WHOLE vector) */
-dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint32_t plane_begin[4],
+DG_API dg_status dg_sdf_sample_planes_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint32_t plane_begin[4],
 									  const uint32_t plane_end[4], double* d_field, void* stream);
-dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
+DG_API dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_comm* comm, int pieces,
 										int flags, int root, const float* const plane_cost[4], double* d_field, void* stream);
 /* A communicator WITHOUT RCCL for DG_EXCHANGE_COPY (whose data path is peer copies): the two small host-side collectives
  * it needs come from the caller -- MPI, a TCP store, torch.distributed's gloo backend (tests/test_gpu_multirank.py drives
@@ -262,25 +267,25 @@ dg_status dg_sdf_sample_exchange_device(const dg_mesh* mesh, const dg_grid_desc*
  * such a communicator, and the call blocks the host until the exchange is complete. */
 typedef int (*dg_comm_allgather_fn)(const void* mine, void* all, size_t bytes, void* user);
 typedef int (*dg_comm_barrier_fn)(void* user);
-dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn allgather, dg_comm_barrier_fn barrier, void* user,
+DG_API dg_status dg_comm_create_external(int rank, int nranks, dg_comm_allgather_fn allgather, dg_comm_barrier_fn barrier, void* user,
 								  dg_comm** out);
 /* The same without callbacks: the control plane lives in a POSIX shared-memory segment the ranks of ONE node map (rank 0
  * creates "/name", the others wait for it up to DG_COMM_TIMEOUT_S seconds; `name` must be unique to the job).  With fields from
  * dg_comm_field_alloc this is the exchange that leaves the whole field on every GPU with NO collective library at all: copy
  * engines for the data, two barriers in shared memory per step.  Collective; no reference counterpart. */
-dg_status dg_comm_create_shm(const char* name, int rank, int nranks, dg_comm** out);
+DG_API dg_status dg_comm_create_shm(const char* name, int rank, int nranks, dg_comm** out);
 typedef struct dg_comm_info {
 	int32_t rank, nranks, device;
 	int32_t rccl_nranks; /* ncclCommCount() of the wrapped communicator; -1: external control plane */
 	int32_t registered_fields; /* d_field pointers whose peers are mapped (DG_EXCHANGE_COPY) */
 } dg_comm_info;
-dg_status dg_comm_get_info(dg_comm* comm, dg_comm_info* info);
+DG_API dg_status dg_comm_get_info(dg_comm* comm, dg_comm_info* info);
 /* device time of this rank's sampling launches of the most recent dg_sdf_sample_exchange_device / _allgather_device
  * call on `comm`, one value per piece (waits for that call); *n_pieces in: capacity of ms, out: pieces */
-dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces);
+DG_API dg_status dg_comm_last_chunk_ms(dg_comm* comm, float* ms, int* n_pieces);
 /* how long the caller's stream had to wait, after this rank's last sampling launch of the most recent exchange call, until
  * the field was complete (the part of the exchange the sampling did not hide); waits for that call */
-dg_status dg_comm_last_exchange_wait_ms(dg_comm* comm, float* ms);
+DG_API dg_status dg_comm_last_exchange_wait_ms(dg_comm* comm, float* ms);
 
 /* The exchange step WITHOUT collective kernels and WITHOUT device IPC: the coefficient vector is assembled in a POSIX
  * shared-memory segment that every rank (one process per GPU, one node) maps; a rank samples its chunks (the contiguous
@@ -303,27 +308,27 @@ typedef struct dg_host_field_info {
 	int32_t registered; /* 1: hipHostRegister took the mapping (direct DMA); 0: pageable copies */
 	uint64_t n_doubles;
 } dg_host_field_info;
-dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int nranks, dg_host_field** out);
-double* dg_host_field_data(dg_host_field* hf);
-dg_status dg_host_field_barrier(dg_host_field* hf); /* every rank; fails after DG_COMM_TIMEOUT_S seconds instead of hanging */
-dg_status dg_host_field_get_info(dg_host_field* hf, dg_host_field_info* info);
-void dg_host_field_close(dg_host_field* hf);
-dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_host_field* hf, int pieces,
+DG_API dg_status dg_host_field_open(const char* name, uint64_t n_doubles, int rank, int nranks, dg_host_field** out);
+DG_API double* dg_host_field_data(dg_host_field* hf);
+DG_API dg_status dg_host_field_barrier(dg_host_field* hf); /* every rank; fails after DG_COMM_TIMEOUT_S seconds instead of hanging */
+DG_API dg_status dg_host_field_get_info(dg_host_field* hf, dg_host_field_info* info);
+DG_API void dg_host_field_close(dg_host_field* hf);
+DG_API dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, dg_host_field* hf, int pieces,
 									  const float* const plane_cost[4], double* d_field, void* stream);
 /* device time of this rank's sampling launches of the most recent dg_sdf_sample_to_host_field call, one value per piece */
-dg_status dg_host_field_last_chunk_ms(dg_host_field* hf, float* ms, int* n_pieces);
+DG_API dg_status dg_host_field_last_chunk_ms(dg_host_field* hf, float* ms, int* n_pieces);
 
 /* ---- field handle + K2: batched interpolate ------------------------------------------------ */
 /* cells (32 uint32 per row, n_cell_rows rows) and cell_map (one uint32 per grid cell) may both
  * be NULL for an unreduced field: the kernel then uses the closed-form node indices the
  * reference's own table holds right after addFunction (:833-891). */
-dg_status dg_field_create(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, const uint32_t* cells,
+DG_API dg_status dg_field_create(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, const uint32_t* cells,
 						  uint64_t n_cell_rows, const uint32_t* cell_map, dg_field** out);
 /* Non-owning: wraps device arrays that stay valid for the lifetime of the handle. */
-dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeffs, uint64_t n_coeffs,
+DG_API dg_status dg_field_attach_device(const dg_grid_desc* grid, const double* d_coeffs, uint64_t n_coeffs,
 								 const uint32_t* d_cells, uint64_t n_cell_rows, const uint32_t* d_cell_map,
 								 dg_field** out);
-void dg_field_destroy(dg_field* field);
+DG_API void dg_field_destroy(dg_field* field);
 
 typedef struct dg_field_info {
 	uint64_t n_coeffs;
@@ -337,11 +342,11 @@ typedef struct dg_field_info {
 	int32_t host_copy_pending; /* the asynchronous copy into the caller's host array has not been collected yet */
 	uint64_t band_rows;        /* rows of the band-limited cell-major copy (0: none), dg_field_build_cell_major_band */
 } dg_field_info;
-dg_status dg_field_get_info(const dg_field* field, dg_field_info* info);
+DG_API dg_status dg_field_get_info(const dg_field* field, dg_field_info* info);
 /* An ATTACHED device array (dg_field_attach_device) may change between calls, so batched queries never build the
  * cell-major copy for it by themselves.  immutable != 0 promises that it will not change while the handle lives:
  * the handle then behaves like one made by dg_field_create (copy built on the first batch of >= 2^18 queries). */
-dg_status dg_field_set_immutable(dg_field* field, int immutable);
+DG_API dg_status dg_field_set_immutable(dg_field* field, int immutable);
 
 /* ---- fields produced ON the device (one resident copy per field) ------------------------------------------
  * The reference keeps ONE coefficient vector per field (m_nodes, cubic_lagrange_discrete_grid.hpp:69) that
@@ -359,20 +364,20 @@ dg_status dg_field_set_immutable(dg_field* field, int immutable);
  * [MI355X, 256^3: field complete on the device after 18.5 ms, in the host vector after 21.7 ms; one launch followed by
  * the copy: 16.3 / 34.6 ms]; DG_FORCE="field_fractions=f0,f1,..." overrides, DG_FIELD_ONE_LAUNCH=1 with host_first == 0 is
  * round 3's single launch, DG_FORCE=field_streams=2 alternates the chunks between two streams (measured: no gain). */
-dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
+DG_API dg_status dg_sdf_sample_field(const dg_mesh* mesh, const dg_grid_desc* grid, int invert, const uint8_t* pred_mask,
 							  double* host_out, int host_first, dg_field** out);
 /* K3 over the whole lattice of `sdf` into a NEW device-resident field on the same grid (the density map the
  * reference's GenerateDensityMap adds as field 1, cmd/generate_density_map/main.cpp:83-133); arguments as
  * dg_density_map_nodes, host_out / asynchrony as dg_sdf_sample_field. */
-dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+DG_API dg_status dg_density_map_field(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 							   const uint8_t* pred_mask, double* host_out, dg_field** out);
 /* The coefficient arrays of destroyed produced fields are kept for the next field of the same size (a 1 GB
  * hipMalloc costs ~3 ms), up to DG_FIELD_CACHE_MB megabytes per process (default 2048, 0 = keep nothing);
  * this releases them now. */
-void dg_field_cache_trim(void);
+DG_API void dg_field_cache_trim(void);
 /* Blocks until the host copy a producing call started is complete (DG_OK at once if there is none or it was
  * collected before); returns the status of that copy. */
-dg_status dg_field_host_wait(dg_field* field);
+DG_API dg_status dg_field_host_wait(dg_field* field);
 
 /* Optional: builds (once, asynchronously on `stream`) a cell-major device copy of the field --
  * 32 doubles = 256 contiguous bytes per cell row -- that dg_interpolate_batch* then reads
@@ -385,8 +390,8 @@ dg_status dg_field_host_wait(dg_field* field);
  * For a field made by dg_field_create (the library owns the coefficients) dg_interpolate_batch* builds the copy
  * itself on the first batch of >= 2^18 queries, up to DG_K2_AUTO_CELL_MAJOR_MB megabytes (default 16384; 0: never)
  * and a quarter of the free device memory -- unless dg_field_drop_cell_major was called on the field. */
-dg_status dg_field_build_cell_major(dg_field* field, void* stream);
-dg_status dg_field_drop_cell_major(dg_field* field); /* (drops the band-limited copy below as well) */
+DG_API dg_status dg_field_build_cell_major(dg_field* field, void* stream);
+DG_API dg_status dg_field_drop_cell_major(dg_field* field); /* (drops the band-limited copy below as well) */
 /* The same rows for a VALUE BAND only: a cell row gets its 256 contiguous bytes if the values its 32 coefficients span reach
  * into [lo, hi] (min <= hi and max >= lo), every other cell stays where it is; one bit per cell row (+ a running count per 64) tells which.
  * dg_interpolate_batch* then serves queries into mapped cells from their rows (fetched cooperatively like the full copy's)
@@ -395,7 +400,7 @@ dg_status dg_field_drop_cell_major(dg_field* field); /* (drops the band-limited 
  * [-(2h + cell diagonal), 2h + cell diagonal] the copy holds 10-20 % of the cells -- less than 1 x the field instead of 4.6 x.
  * One-off and host-blocking (the row count has to reach the host); *rows (nullable): rows in the copy.  A field that also
  * has the full or the tile-major copy uses that.  The coefficients must not change afterwards.  No reference counterpart. */
-dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, void* stream, uint64_t* rows);
+DG_API dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, void* stream, uint64_t* rows);
 /* Optional, for UNREDUCED fields: builds (once, asynchronously on `stream`) a tile-major device copy --
  * for every tile of 4x4x4 cells all the nodes its cells reference, 736 contiguous doubles -- that
  * dg_interpolate_batch* and dg_density_map_nodes* then read.  The reference layout [V|X|Y|Z] puts a cell's
@@ -404,13 +409,13 @@ dg_status dg_field_build_cell_major_band(dg_field* field, double lo, double hi, 
  * 256^3; the cell-major copy: 4.3 GB) and one pass over the field; results are bit-identical.  Takes
  * precedence over the cell-major copy when both exist.  No reference counterpart.  The coefficient
  * array must not change afterwards (drop and rebuild if it does). */
-dg_status dg_field_build_tile_major(dg_field* field, void* stream);
-dg_status dg_field_drop_tile_major(dg_field* field);
+DG_API dg_status dg_field_build_tile_major(dg_field* field, void* stream);
+DG_API dg_status dg_field_drop_tile_major(dg_field* field);
 
 /* phi[q] = interpolate(field, x_q [, &grad_q]); DG_NO_VALUE outside the domain, in removed
  * cells or when a coefficient is DG_NO_VALUE (grad_q is then zero).  grad may be NULL. */
-dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad);
-dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
+DG_API dg_status dg_interpolate_batch(const dg_field* field, const double* xyz, uint64_t n, double* phi, double* grad);
+DG_API dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz, uint64_t n, double* d_phi,
 									  double* d_grad, void* stream);
 
 /* ---- reduceField (sparsification of a field) on the device ------------------------------------------ */
@@ -426,17 +431,17 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
  * result can be fetched, and the caller must run the host algorithm (the C++ class does).
  * dg_reduction_fetch copies: coeffs[n_coeffs_out], cells[32 * n_cell_rows], cell_map[dg_grid_n_cells]. */
 typedef struct dg_reduction dg_reduction;
-dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, int closed, double lo,
+DG_API dg_status dg_reduce_field(const dg_grid_desc* grid, const double* coeffs, uint64_t n_coeffs, int closed, double lo,
 						  double hi, double offset, dg_reduction** out);
 /* The same on the coefficients a field handle already holds on the device (no upload). */
-dg_status dg_reduce_field_device(const dg_field* field, int closed, double lo, double hi, double offset,
+DG_API dg_status dg_reduce_field_device(const dg_field* field, int closed, double lo, double hi, double offset,
 								 dg_reduction** out);
 /* The reduced field as a handle of its own (table mode): the reduction's device arrays change owner, nothing is
  * copied or uploaded; call dg_reduction_fetch BEFORE this if the host needs the arrays too. */
-dg_status dg_reduction_to_field(dg_reduction* r, dg_field** out);
-dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys);
-dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* cells, uint32_t* cell_map);
-void dg_reduction_destroy(dg_reduction* r);
+DG_API dg_status dg_reduction_to_field(dg_reduction* r, dg_field** out);
+DG_API dg_status dg_reduction_info(const dg_reduction* r, uint64_t* n_coeffs_out, uint64_t* n_cell_rows, int* tied_keys);
+DG_API dg_status dg_reduction_fetch(const dg_reduction* r, double* coeffs, uint32_t* cells, uint32_t* cell_map);
+DG_API void dg_reduction_destroy(dg_reduction* r);
 
 /* ---- K3: SPH boundary density map (next row of the path: GenerateDensityMap) ------------------ */
 /* out[l - node_begin] = density_func(indexToNodePosition(l)) of cmd/generate_density_map/main.cpp:96-112
@@ -446,9 +451,9 @@ void dg_reduction_destroy(dg_reduction* r);
  * node is farther than 2h from the surface.  band_predicate != 0 additionally applies the node
  * predicate of main.cpp:119-133 (DG_NO_VALUE outside the band -6h < phi + cell_diag, phi - cell_diag < 2h);
  * pred_mask (nullable, indexed l - node_begin) works as in dg_sdf_sample_nodes. */
-dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+DG_API dg_status dg_density_map_nodes(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 							   uint64_t node_begin, uint64_t node_end, const uint8_t* pred_mask, double* out);
-dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
+DG_API dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, double rho0, int band_predicate,
 									  uint64_t node_begin, uint64_t node_end, const uint8_t* d_pred_mask,
 									  double* d_out, void* stream);
 
@@ -457,17 +462,17 @@ dg_status dg_density_map_nodes_device(dg_field* sdf, double support_radius, doub
  * arrive in the caller's array, at most once per second and once at the end -- what
  * addFunction(verbose) prints (cubic_lagrange_discrete_grid.cpp:819-829).  NULL switches it off. */
 typedef void (*dg_progress_fn)(uint64_t done, uint64_t total, void* user);
-void dg_set_progress_callback(dg_progress_fn cb, void* user);
+DG_API void dg_set_progress_callback(dg_progress_fn cb, void* user);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* Device time (HIP events on the launch stream) of the most recent K1 / K2 kernel launch issued
  * by this thread through the HOST entry points, in milliseconds; <0 if none. */
-double dg_last_kernel_ms(void);
+DG_API double dg_last_kernel_ms(void);
 /* Number of 4x4x4-node bricks of the most recent node-sampling launch on `mesh` that exhausted
  * their work budget and asked for the split path ("heavy bricks"); at most
  * `*split` of them (the slot count) were actually split, the others ran on in their own wave.
  * Waits for that launch to finish.  Both zero if that launch ran without the split path. */
-dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32_t* split);
+DG_API dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32_t* split);
 
 #ifdef __cplusplus
 }

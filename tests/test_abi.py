@@ -38,6 +38,22 @@ def test_header_symbols_exported(dg):
     assert all(n.startswith("dg_") for n in exported if not n.startswith("_"))
 
 
+def test_library_exports_nothing_but_the_c_abi(dg):
+    """Thin C ABI: the dynamic symbol table of the shipped library defines the entry points of the header and NOTHING else --
+    no internal C++ function (fail, valid_grid, env_int, TraceRange ...), no data, no libstdc++ instantiation a host
+    application of SPlisHSPlasH's size could interpose (-fvisibility=hidden + csrc/exports.map)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dg.LIB_PATH]).decode()
+    rows = [ln.split() for ln in out.splitlines() if ln.strip()]
+    foreign = [r for r in rows if not r[-1].startswith("dg_")]
+    assert not foreign, foreign[:10]
+    assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"][:10]
+    assert sorted(r[-1] for r in rows) == header_symbols()
+    # every prototype of the header carries the export attribute
+    src = open(os.path.join(T.ROOT, "include", "discregrid_hip.h")).read()
+    protos = re.findall(r"^(\S[^\n]*?)\bdg_[a-z0-9_]+\(", src, flags=re.M)
+    assert len(protos) == len(header_symbols()) and all(p.startswith("DG_API ") for p in protos), [p for p in protos if not p.startswith("DG_API ")]
+
+
 def test_library_contains_gfx950_code_object(dg):
     blob = open(dg.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
