@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- SDF node-sampling throughput of the HIP path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Both forms work: started PLAIN with --gpus N > 1 (no WORLD_SIZE / RANK in the environment) the script starts its own N ranks
+under torch.distributed.run (self_launch below), forwards rank 0's JSON line as the only line on stdout, everything else on
+stderr, and returns the ranks' exit code.
 
 A "step" is one pass of the hot path over the whole grid: every lattice node of a
 CubicLagrangeDiscreteGrid gets the signed distance to the mesh (the addFunction node loop,
@@ -53,9 +57,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 N_SIMDS = 1024         # 256 CUs x 4
 
 
-def grid_for(n_gpus):
+def grid_for(n_gpus, scaling="weak"):
+    """weak: the lattice grows with N (256 a x 256 b x 256 c, abc = N: 512^3 at N = 8 = BASELINE configs[3]);
+    strong: the 256^3 lattice the metric is quoted on at every N"""
     dims = [256, 256, 256]
-    k, axis = n_gpus, 2
+    k, axis = (n_gpus if scaling == "weak" else 1), 2
+    if n_gpus < 1 or (n_gpus & (n_gpus - 1)):
+        raise SystemExit("--gpus must be a power of two")
     while k > 1:
         if k % 2:
             raise SystemExit("--gpus must be a power of two")
@@ -458,6 +466,103 @@ def user_facing_scalars(out):
     }
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n_gpus, argv, port):
+    """the command `python bench.py --gpus N ...` re-executes itself as when nobody started ranks for it: the driver's own form"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """--gpus N > 1 without a launcher: start the N ranks here.  stdout of the ranks is filtered -- the LAST line that parses as
+    the bench's JSON record is printed as the only stdout line once the ranks have ended, everything else goes to stderr as it
+    comes -- and the ranks' exit code is returned (3 if they ended well without a line)."""
+    import signal
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launch_command(n_gpus, argv, free_port())
+    print("bench.py: --gpus %d without WORLD_SIZE in the environment: starting the ranks myself:\n  %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+
+    def forward(signum, _frame):       # (a driver that gives up on us must not leave ranks sitting on the GPUs)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        finally:
+            os._exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, forward)
+    line = None
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        rec = None
+        if ln.startswith("{"):
+            try:
+                rec = json.loads(ln)
+            except ValueError:
+                rec = None
+        if isinstance(rec, dict) and "metric" in rec and "value" in rec:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 3
+    return rc
+
+
+def run_preflight(dist, rank, world, timeout_s):
+    """tools/scale_preflight.py in a child process per rank (a step that hangs is killed with the child, not with the bench);
+    returns ({form: reason} for the forms that cannot run on SOME rank, this rank's step results)"""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale_preflight as pf
+    box = [None]
+    if rank == 0:
+        box[0] = (free_port(), "%d_%d" % (os.getpid(), int(time.time())))
+    dist.broadcast_object_list(box, src=0)
+    port, tag = box[0]
+    out = os.path.join(tempfile.gettempdir(), "dg_preflight_%s_%d.json" % (tag, rank))
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    results, note = {}, None
+    try:
+        proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--json-out", out, "--tag", tag],
+                                env=env, stdout=sys.stderr, start_new_session=True)
+        try:
+            proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            note = "killed after %d s" % timeout_s
+        if os.path.exists(out):
+            with open(out) as f:
+                results = json.load(f)
+            os.unlink(out)
+    except Exception as exc:  # noqa: BLE001  (a preflight that cannot run says nothing; the race decides)
+        note = "%s: %s" % (type(exc).__name__, exc)
+    mine = {}
+    for form in pf.forms_removed(results):
+        why = [st for st in pf.STEPS if form in pf.FORMS_NEEDING[st] and (results.get(st) is None or results[st].get("ok") is False)]
+        mine[form] = "preflight step %s on rank %d: %s" % (why[0], rank, (results.get(why[0]) or {}).get("detail") or note or "not reached")
+    if note:
+        print("bench.py rank %d: preflight %s" % (rank, note), file=sys.stderr, flush=True)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    removed = {}
+    for d in everyone:
+        for form, why in (d or {}).items():
+            removed.setdefault(form, why)
+    return removed, results
+
+
 class Watchdog:
     """N > 1: no exchange form has ever run on more than one GPU where this was developed, and a rank that fails inside a
     collective leaves its peers waiting for ever.  Every candidate form therefore runs under a deadline: when it expires, rank 0
@@ -497,6 +602,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default) = 118.4 M nodes per GPU, the lattice grows with N (512^3 at N = 8: BASELINE configs[3]); "
+                         "strong = the metric's own 256^3 lattice at every N (1.8 ms of kernel per GPU at N = 8: launch, barrier and "
+                         "exchange latency decide)")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip tools/scale_preflight.py (run by default before the race, stderr only)")
+    ap.add_argument("--preflight-timeout", type=int, default=90, help="N > 1: seconds the preflight child may take before it is killed")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="ceiling of the cpu_baseline leg, which samples 40 %% of the lattice (about 30 s on 256 cores; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed K1 steps (profiling runs)")
     ap.add_argument("--pieces", type=int, default=4,
@@ -519,9 +630,24 @@ def main():
                          "dg_sdf_sample_allgather_device (A/B, and the one-GPU self-test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        grid_for(args.gpus)                       # (a bad --gpus fails here, not N times)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
     import torch
     import torch.distributed as dist
+    if os.environ.get("DG_BENCH_DRY_RANKS") == "1":
+        # (tests without a GPU: the launcher plumbing only -- ranks meet, chatter on stdout, rank 0 prints a record marked dry_run)
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        print("rank %s chatter on stdout" % os.environ["RANK"], flush=True)
+        if os.environ["RANK"] == "0":
+            print(json.dumps({"metric": "dry run of the launcher, no measurement", "value": 0.0, "dry_run": True, "n_gpus": int(t.item()),
+                              "scaling": args.scaling, "grid": grid_for(args.gpus, args.scaling)}), flush=True)
+        dist.destroy_process_group()
+        sys.exit(int(os.environ.get("DG_BENCH_DRY_RC", "0")))
     import dgtest as T
     import discregrid_amd as dg
 
@@ -558,7 +684,7 @@ def main():
 
     V, F = T.icosphere(71)
     dom = dg.default_domain(V)            # cmd/generate_sdf/main.cpp:83-91
-    res = grid_for(world)
+    res = grid_for(world, args.scaling)
     grid = dg.grid_desc(dom[:3], dom[3:], res)
     n_nodes = dg.n_nodes(grid)
     mesh = dg.Mesh(V, F)
@@ -576,6 +702,7 @@ def main():
     comm_note = None
     launch_nodes = n_nodes
     state = {"line": None}
+    progress = {"first_step_done": False}
     dog = Watchdog(args.form_timeout if world > 1 else 0, rank, state)
     if sharded:
         pieces = max(1, min(args.pieces, 64 // world))    # dg_shard_layout handles up to 64 (virtual) ranks
@@ -811,6 +938,9 @@ def main():
 
         for w in range(max(args.warmup, 2 if chunked else 0)):
             step()
+            if w == 0:
+                torch.cuda.synchronize()
+                progress["first_step_done"] = True     # (a form that fails before this point failed to come up, not to run)
             if chunked:
                 share_and_rebalance(form)
         torch.cuda.synchronize()
@@ -821,6 +951,7 @@ def main():
         for i in range(args.steps):
             step(i)
         torch.cuda.synchronize()
+        progress["first_step_done"] = True
         if sharded:
             ctl_barrier()
         torch.cuda.synchronize()
@@ -861,6 +992,17 @@ def main():
                                                                   if copy_field[0] is not None else "peer copies on the copy engines, HIP IPC")
                                                                  if form == "copy" else "RCCL inside the library"))))
 
+    def flat_exchange(form, exchange_report, rccl_nranks):
+        """N > 1: which form won, every form's ms per step, what failed -- as plain scalars inside `roofline`"""
+        if not sharded:
+            return {}
+        flat = {"rccl_nranks": rccl_nranks, "exchange_chosen": form, "exchange_pieces": pieces}
+        for k, v in ((exchange_report or {}).get("ms_by_form") or {}).items():
+            flat["exchange_ms_" + k.replace("-", "_")] = v
+        for k, v in ((exchange_report or {}).get("errors") or {}).items():
+            flat["exchange_error_" + k.replace("-", "_")] = str(v)[:160]
+        return flat
+
     def build_line(r, exchange_report):
         """the JSON line for the measured form r (no collectives, no GPU work: the watchdog may call for it at any time)"""
         form, elapsed, kernel_ms = r["form"], r["elapsed"], r["kernel_ms"]
@@ -878,15 +1020,17 @@ def main():
                          "(SURVEY 8(d)'s metric: sampling + D2H into m_nodes); no device-resident copy of the whole field"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "icosphere nu=71 (100820 tris) SDF node sampling, grid %s = %d nodes"
-                            % ("x".join(map(str, res)), n_nodes),
+                "workload": "icosphere nu=71 (100820 tris) SDF node sampling, grid %s = %d nodes%s"
+                            % ("x".join(map(str, res)), n_nodes,
+                               "" if world == 1 else ("; weak scaling: 256^3 per GPU, the lattice grows with N" if args.scaling == "weak" else
+                                                      "; STRONG scaling: the metric's own 256^3 lattice shared by the %d GPUs" % world)),
                 "nodes_per_gpu_launch": launch_nodes,
                 "sharding": sharding_text(form),
                 # every multi-rank figure of this path is UNVERIFIED on hardware until a driver-run SCALE file exists
-                "exchange": (dict(exchange_report or {}, chosen=form, per_rank=r["per_rank"], rccl_nranks=rccl_nranks) if sharded else None),
+                "exchange": (dict(exchange_report or {}, chosen=form, per_rank=r["per_rank"], rccl_nranks=rccl_nranks, preflight=preflight_summary[0]) if sharded else None),
                 "mesh_bvh_build_s": round(mesh.info()["build_seconds"], 4),
             },
             "roofline": {
@@ -923,6 +1067,12 @@ def main():
                 # informational only: bytes the REFERENCE's traversal would move for these nodes / this kernel's time
                 "algorithmic_bytes_per_node": balg["bytes_per_node"],
                 "algorithmic_gbs": balg["bytes_per_node"] * launch_nodes / (kernel_ms * 1e-3) / 1e9,
+                # the HBM fractions the metric asks for, as plain scalars (the driver's record drops the nested `hbm` object):
+                # hbm_frac = HBM traffic per launch by the counters / kernel time / 8 TB/s (replayed, N = 1 only);
+                # compulsory_hbm_frac = the 8 B per node this rank's launches have to write / live kernel time / 8 TB/s
+                "hbm_frac": (k1["hbm_bytes_per_launch"] / (k1["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k1 else None,
+                "compulsory_hbm_frac": 8 * launch_nodes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                **flat_exchange(form, exchange_report, rccl_nranks),
             },
             "cpu_baseline": None,
         }
@@ -941,9 +1091,31 @@ def main():
         candidates = ["host", "copy-shm", "slabs", "inplace", "inplace-p2p", "copy"]
     results, errors = {}, {}
     best = None
+    preflight_summary = [None]
+    RCCL_FORMS = ("slabs", "inplace", "inplace-p2p", "copy", "to-root")
+    rccl_out = None               # set by the first RCCL form that fails before its first step completes: the others are not retried
+    removed, preflight = {}, None
+    if sharded and world > 1 and not args.no_preflight:
+        # tools/scale_preflight.py: which building blocks (shared memory, chunk export / import / peer copy, RCCL) work on this box;
+        # a failing step removes only the forms that need it
+        dog.arm("the preflight")
+        removed, preflight = run_preflight(dist, rank, world, args.preflight_timeout)
+        dog.disarm()
+        if len(candidates) > 1 and all(c in removed for c in candidates):
+            removed = {}          # (nothing would be left: the preflight is then the suspect; race them all)
+        preflight_summary[0] = {"rank0_steps": {k: (v.get("ok") if isinstance(v, dict) and "ok" in v else v) for k, v in (preflight or {}).items()},
+                                "forms_removed": removed or None}
+        if rank == 0:
+            print("bench.py preflight: %s" % ("; ".join("%s out (%s)" % kv for kv in sorted(removed.items())) or "every form may run"), file=sys.stderr, flush=True)
     for cand in candidates:
+        if len(candidates) > 1 and (cand in removed or (rccl_out is not None and cand in RCCL_FORMS)):
+            errors[cand] = ("not run: " + removed[cand]) if cand in removed else ("not run: RCCL did not come up for form %s (%s)" % rccl_out)
+            if rank == 0:
+                print("bench.py exchange race: %s -> %s" % (cand, errors[cand]), file=sys.stderr, flush=True)
+            continue
         dog.arm("exchange form %s" % cand)
         r, note, failed = None, None, 0
+        progress["first_step_done"] = False
         try:
             r = measure(cand)
         except Exception as exc:  # noqa: BLE001 (reported on the line; the form is out of the race)
@@ -951,9 +1123,13 @@ def main():
                 raise
             note = "%s: %s" % (type(exc).__name__, str(exc)[:200])
             failed = 1
+        early = 1 if (failed and not progress["first_step_done"]) else 0
         if sharded and world > 1:
             failed = ctl_max(failed)     # (a form that failed on any rank is out on all of them)
+            early = ctl_max(early)
         dog.disarm()
+        if failed and early and cand in RCCL_FORMS and not selftest:
+            rccl_out = (cand, note or "failed on another rank")
         if failed:
             errors[cand] = note or "failed on another rank"
         else:

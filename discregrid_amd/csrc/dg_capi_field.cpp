@@ -779,6 +779,50 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	// arbitrary order are then processed tile by tile; ordered inputs are detected on the device and
 	// run as they are).  DG_FORCE=k2_binning=0 switches it off, =2 forces it for any size.
 	const int binning = force_int("k2_binning", 1, 0, 2);
+	// Unreduced field in the reference layout, no copy of it (the default for every attached device array): counting sort by tile
+	// of 8^3 cells + the gather that stages a tile in LDS once for all its queries (round 6; dg_kernels.h: TileBin).
+	// DG_FORCE=k2_tiles=0: the per-lane gather behind the radix sort of rounds 1-5.
+	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull && dg::field_mode(dev) == dg::kFieldClosed && dev.cell_map == nullptr &&
+		force_int("k2_tiles", 1, 0, 2) != 0)
+	{
+		dg::TileBin B;
+		std::memset(&B, 0, sizeof(B));
+		B.shape = 0;
+		const uint32_t key_bits = dg::stage_key_bits(dev.res, B.shape, B.tdims, B.tlog);
+		// (k2_tiles=2: whatever the batch's size)
+		const bool dense = n >= (uint64_t)dg::kStageMinPerTile * B.tdims[0] * B.tdims[1] * B.tdims[2] || force_int("k2_tiles", 1, 0, 2) == 2;
+		if (dense && key_bits <= dg::kStageMaxBits && B.tdims[0] <= 1024u && B.tdims[1] <= 1024u && B.tdims[2] <= 1024u)
+		{
+			if (field->bin_flag_host == nullptr)
+			{
+				void* p = nullptr;
+				if (hipHostMalloc(&p, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
+				{
+					field->bin_flag_host = static_cast<uint32_t*>(p);
+					*field->bin_flag_host = 1u; // nothing known yet: assume the first batch is unordered
+				}
+				else
+					(void)hipGetLastError();
+			}
+			size_t off[8];
+			void* mem = nullptr;
+			const int idx = field->bin_flag_host ? field->scratch.acquire(dg::tile_bin_bytes(1u << key_bits, n, off), st, &mem) : -1;
+			if (idx >= 0)
+			{
+				const dg::TileBin shape_of = B;
+				dg::tile_bin_assign(B, mem, off, key_bits, n);
+				B.shape = shape_of.shape;
+				B.flag_host = field->bin_flag_host;
+				B.sort_launched = *reinterpret_cast<volatile uint32_t*>(field->bin_flag_host) != 0u ? 1 : 0;
+				hipError_t e = dg::launch_interpolate_tiles(dev, d_xyz, n, d_phi, d_grad, B, (uint32_t)force_int("k2_tile_chunk", 64, 0, 4096), st);
+				if (e == hipSuccess && B.sort_launched == 0) // predicted ordered: the queries as they came
+					e = dg::launch_interpolate(dev, d_xyz, n, d_phi, d_grad, st);
+				field->scratch.release(idx, st);
+				DG_HIP(e);
+				return DG_OK;
+			}
+		}
+	}
 	if (binning != 0 && (big || binning == 2) && n < 0xffffffffull)
 	{
 		dg::BinScratch S;

@@ -414,6 +414,128 @@ struct BinScratch
 	size_t sort_tmp_bytes;
 	int sort_launched;    // host decision for this batch
 };
+// inverse of tile_key(): the tile coordinates of a key
+DG_HD void tile_from_key(const uint32_t dims[3], uint32_t key, uint32_t t[3])
+{
+	t[0] = t[1] = t[2] = 0;
+#if DG_SORT_MORTON
+	uint32_t pos = 0;
+	for (uint32_t b = 0; b < 11; ++b)
+		for (int d = 0; d < 3; ++d)
+			if ((dims[d] - 1u) >> b)
+			{
+				t[d] |= ((key >> (pos & 31u)) & 1u) << b;
+				++pos;
+			}
+#else
+	t[0] = key % dims[0];
+	t[1] = (key / dims[0]) % dims[1];
+	t[2] = key / (dims[0] * dims[1]);
+#endif
+}
+// ---- K2 on the plain layout, staged (round 6): counting sort by tile of 8^3 cells + a gather that serves a tile's queries from LDS ----
+// Unordered queries on an unreduced field WITHOUT any copy of it.  Rounds 1-5 sorted the queries by single cell (rocPRIM radix
+// sort, three passes) and let every lane gather its 16 coefficient pairs from the field: 16 load instructions per wave, each
+// touching up to 64 different lines -- the texture-data path's roof (TA / TD busy 0.94 / 0.95, 123 cycles per load instruction),
+// 0.72 ms per 10 M queries behind 0.46 ms of binning.  Now:
+//  (1) a sort on the 15-bit key of the query's TILE of kStageCells^3 cells (256^3: 32 768 tiles, 305 queries each): two radix
+//      passes instead of the three of the 24-bit cell key (rocPRIM onesweep; a counting sort through global atomics -- one
+//      returning atomic per query for its rank, a scattered 4-byte store per query -- measured 0.58 + 0.23 ms per 10 M against
+//      0.21: its LDS-local reordering is what makes a radix pass cheap), then k_tile_bounds (where each tile's run begins and
+//      ends) and k_tile_items (one block: the list of work items -- a tile's queries in chunks of kStageChunk);
+//  (2) k_interpolate_tiles: one block per work item copies the tile's part of the field -- 9^3 vertex nodes and 3 x 8 x 9 x 9 edges
+//      of two nodes = 4617 doubles (37 KB), whole rows, 16 bytes per lane side by side -- into LDS ONCE and every lane then
+//      takes its 32 coefficients from LDS: each coefficient crosses the texture path once per tile visit instead of once per
+//      query that uses it (121 instead of 256 bytes per query, in row-sized pieces instead of 16-byte ones).
+// Same locate_query / evaluate_cell statements as every other K2 path: same bits.  The key is computed from the query's CELL
+// exactly as locate_query computes it (a tile key of its own rounding could put a query next to a tile face into the
+// neighbour tile).  Batches too thin for staging to pay (fewer than kStageMinPerTile queries per tile on average) keep the
+// per-lane gather behind the radix sort by cell.
+static const uint32_t kStageChunk = 1024;   // queries per work item (a tile with more gets several items)
+static const uint32_t kStageMinPerTile = 24; // batches with fewer queries per tile on average take the per-lane gather behind the radix sort by cell
+static const uint32_t kStageMaxBits = 21;      // tile tables up to 2 M entries (16 MB); beyond: the per-lane path
+// the tile shape (cells per axis as powers of two) the gather is instantiated for
+static const int kStageShapes = 1;
+static const uint32_t kStageLog[kStageShapes][3] = {{3, 3, 3}};
+size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles); // rocPRIM's requirement for n pairs (dg_kernels_k2.hip)
+struct StageItem // 16 bytes: one load
+{
+	uint32_t key;    // tile
+	uint32_t q0, q1; // its queries [q0, q1) in tile order
+	uint32_t tijk;   // tile coordinates, 10 bits each
+};
+struct TileBin
+{
+	uint32_t* flag;        // [1] this batch is unordered (k_bin_probe; informational on this path)
+	uint32_t* flag_host;   // pinned: the prediction for the handle's next batch
+	uint32_t* keys;        // [n] tile key of every query
+	uint32_t* keys_out;    // [n] sorted
+	uint32_t* perm;        // [n] query indices in tile order
+	uint32_t* begin;       // [key_space] first query of the tile in tile order
+	uint32_t* end;         // [key_space] one past its last (begin == end == 0: none)
+	StageItem* items;      // [max_items]
+	uint32_t* n_items;     // [1]
+	uint32_t* row_items;   // [key_space / 1024] items per row of 1024 tiles
+	void* sort_tmp;        // rocPRIM's temporary storage
+	size_t sort_tmp_bytes;
+	uint32_t key_space, key_bits, max_items, n_queries;
+	uint32_t tdims[3];     // tiles per axis
+	uint32_t tlog[3];      // log2 of the cells per tile and axis
+	int shape;             // index into kStageLog
+	int sort_launched;
+};
+inline uint32_t stage_key_bits(const uint32_t res[3], int shape, uint32_t tdims[3], uint32_t tlog[3])
+{
+	TileGrid g;
+	for (int d = 0; d < 3; ++d)
+	{
+		tlog[d] = kStageLog[shape][d];
+		g.dims[d] = tdims[d] = (res[d] + (1u << tlog[d]) - 1) >> tlog[d];
+	}
+	return tile_key_bits(g);
+}
+inline uint32_t stage_max_items(uint32_t key_space, uint64_t n)
+{
+	const uint64_t m = (n < key_space ? n : key_space) + n / kStageChunk + 1;
+	return (uint32_t)(m < 0xffffffffull ? m : 0xffffffffull);
+}
+inline size_t tile_bin_bytes(uint32_t key_space, uint64_t n, size_t off[8])
+{
+	size_t o = 0;
+	auto take = [&](size_t b) { const size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+	off[0] = take(8 + 4 * ((size_t)key_space / 1024 + 1)); // flag, n_items, row_items
+	off[1] = take((size_t)n * 4);                       // keys
+	off[2] = take((size_t)n * 4);                       // keys_out
+	off[3] = take((size_t)n * 4);                       // perm
+	off[4] = take((size_t)key_space * 8);               // begin, end (cleared together)
+	off[5] = take((size_t)stage_max_items(key_space, n) * sizeof(StageItem));
+	off[6] = take(bin_sort_tmp_bytes(n, key_space));
+	return o;
+}
+inline void tile_bin_assign(TileBin& B, void* mem, const size_t off[8], uint32_t key_bits, uint64_t n)
+{
+	char* base = static_cast<char*>(mem);
+	const uint32_t key_space = 1u << key_bits;
+	B.flag = reinterpret_cast<uint32_t*>(base + off[0]);
+	B.n_items = B.flag + 1;
+	B.row_items = B.flag + 2;
+	B.keys = reinterpret_cast<uint32_t*>(base + off[1]);
+	B.keys_out = reinterpret_cast<uint32_t*>(base + off[2]);
+	B.perm = reinterpret_cast<uint32_t*>(base + off[3]);
+	B.begin = reinterpret_cast<uint32_t*>(base + off[4]);
+	B.end = B.begin + key_space;
+	B.items = reinterpret_cast<StageItem*>(base + off[5]);
+	B.sort_tmp = base + off[6];
+	B.sort_tmp_bytes = bin_sort_tmp_bytes(n, key_space);
+	B.key_space = key_space;
+	B.key_bits = key_bits;
+	B.max_items = stage_max_items(key_space, n);
+	B.n_queries = (uint32_t)n;
+}
+// probe (always; the prediction for the next batch) and, if B.sort_launched, the counting sort + the staged gather; otherwise
+// the caller runs the queries in the order they came (launch_interpolate).  xcd_chunk: consecutive work items per XCD (0: off)
+hipError_t launch_interpolate_tiles(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, const TileBin& B,
+									uint32_t xcd_chunk, hipStream_t stream);
 #ifndef DG_TILE_CELLS
 #define DG_TILE_CELLS 8
 #endif

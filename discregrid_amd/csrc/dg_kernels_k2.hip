@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t tile_of(const TileGrid& G, const double* __r
 	return tile_key(G.dims, t);
 }
 // one block: how often do consecutive queries (among the first 4096) change tile?
-__global__ __launch_bounds__(256) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S, uint32_t one_in)
+__global__ __launch_bounds__(1024) void k_bin_probe(const TileGrid F, const double* __restrict__ xyz, uint64_t n, BinScratch S, uint32_t one_in)
 {
 	__shared__ uint32_t changes;
 	if (threadIdx.x == 0)
@@ -140,6 +140,279 @@ __global__ __launch_bounds__(256, DG_K2_WAVES) void k_interpolate_binned(const F
 		grad_out[3 * gid] = g[0];
 		grad_out[3 * gid + 1] = g[1];
 		grad_out[3 * gid + 2] = g[2];
+	}
+}
+
+// ---- K2 on the plain layout, staged through LDS (dg_kernels.h: TileBin) ----------------------------------------------------
+// tile key of a query, from its CELL as locate_query computes it (same expression, same rounding); queries outside the domain
+// (and NaNs) land in some tile and are answered DBL_MAX by locate_query like everywhere else
+__device__ __forceinline__ uint32_t stage_key(const FieldDev& F, const uint32_t tdims[3], const uint32_t tlog[3], const double* __restrict__ xyz, uint64_t i)
+{
+	uint32_t t[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d)
+	{
+		const double u = (xyz[3 * i + d] - F.dmin[d]) * F.inv_cell[d];
+		uint32_t c = u > 0.0 ? (u < 4.0e9 ? (uint32_t)u : 0xffffffffu) : 0u; // NaN -> 0
+		c = c < F.res[d] ? c : F.res[d] - 1u;
+		t[d] = c >> tlog[d];
+	}
+	return tile_key(tdims, t);
+}
+__global__ __launch_bounds__(256) void k_tile_keys(const FieldDev F, const double* __restrict__ xyz, uint64_t n, TileBin B)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		B.keys[i] = stage_key(F, B.tdims, B.tlog, xyz, i);
+}
+// where the run of every tile begins and ends in the sorted keys (begin / end cleared before: tiles without a query keep 0, 0)
+__global__ __launch_bounds__(256) void k_tile_bounds(uint64_t n, TileBin B)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t k = B.keys_out[i];
+	if (i == 0 || B.keys_out[i - 1] != k)
+		B.begin[k] = (uint32_t)i;
+	if (i + 1 == n || B.keys_out[i + 1] != k)
+		B.end[k] = (uint32_t)i + 1u;
+}
+// The work items (tile, chunk of kStageChunk queries) of the non-empty tiles, in key order: rows of 1024 consecutive tiles, one row
+// per block, one tile per thread.  k_tile_row_items: items per row; k_tile_items: every block adds up the rows before its own (a few
+// hundred numbers at most), scans its row and writes its items.  (One block for the whole table -- whichever way its 32 768 loads
+// were arranged -- took 65-78 us on the one CU that ran it.)
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t mine, uint32_t* wave_sum, uint32_t* total)
+{
+	uint32_t incl = mine;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1)
+	{
+		const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+		if ((int)(threadIdx.x & 63u) >= off)
+			incl += up;
+	}
+	if ((threadIdx.x & 63u) == 63u)
+		wave_sum[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+#pragma unroll
+	for (uint32_t wv = 0; wv < 16; ++wv)
+	{
+		const uint32_t v = wave_sum[wv];
+		before += wv < (threadIdx.x >> 6) ? v : 0u;
+		all += v;
+	}
+	*total = all;
+	return before + incl - mine; // exclusive
+}
+__global__ __launch_bounds__(1024) void k_tile_row_items(TileBin B, uint32_t* __restrict__ row_items)
+{
+	__shared__ uint32_t wave_sum[16];
+	const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+	const uint32_t mine = t < B.key_space ? (B.end[t] - B.begin[t] + kStageChunk - 1u) / kStageChunk : 0u;
+	uint32_t total;
+	(void)block_scan_1024(mine, wave_sum, &total);
+	if (threadIdx.x == 0)
+		row_items[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_tile_items(TileBin B, const uint32_t* __restrict__ row_items)
+{
+	__shared__ uint32_t wave_sum[16], wave_sum2[16];
+	const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+	const uint32_t b = t < B.key_space ? B.begin[t] : 0u, e = t < B.key_space ? B.end[t] : 0u;
+	uint32_t rows_before = 0;
+	for (uint32_t r = threadIdx.x; r < blockIdx.x; r += 1024u)
+		rows_before += row_items[r];
+	uint32_t base;
+	{
+		uint32_t tot;
+		(void)block_scan_1024(rows_before, wave_sum2, &tot);
+		base = tot;
+	}
+	uint32_t total;
+	uint32_t it = base + block_scan_1024((e - b + kStageChunk - 1u) / kStageChunk, wave_sum, &total);
+	uint32_t tc[3];
+	tile_from_key(B.tdims, t, tc);
+	const uint32_t tijk = tc[0] | (tc[1] << 10) | (tc[2] << 20);
+	for (uint32_t q = b; q < e; q += kStageChunk)
+	{
+		StageItem item;
+		item.key = t;
+		item.q0 = q;
+		item.q1 = e - q > kStageChunk ? q + kStageChunk : e;
+		item.tijk = tijk;
+		B.items[it++] = item;
+	}
+	if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0)
+		*B.n_items = base + total;
+}
+// blockIdx -> logical work item with `chunk` consecutive items per XCD (the hardware deals consecutive workgroups to the 8 XCDs in
+// turn; neighbouring tiles share the lines their rows straddle); grid = a multiple of 8 chunk
+__device__ __forceinline__ uint32_t xcd_logical(uint32_t block_idx, uint32_t chunk)
+{
+	if (chunk == 0)
+		return block_idx;
+	const uint32_t xcd = block_idx & 7u, within = block_idx >> 3;
+	return ((within / chunk) * 8u + xcd) * chunk + within % chunk;
+}
+// LDS image of a tile of TX x TY x TZ cells: V[k][j][i], X[k][j][2 i + h], Y[i][k][2 j + h], Z[j][i][2 k + h]
+template <int LX, int LY, int LZ>
+struct StageShape
+{
+	static constexpr uint32_t TX = 1u << LX, TY = 1u << LY, TZ = 1u << LZ;
+	static constexpr uint32_t kV = 0, nV = (TX + 1) * (TY + 1) * (TZ + 1);
+	static constexpr uint32_t kX = (nV + 1u) & ~1u, nX = 2 * TX * (TY + 1) * (TZ + 1);
+	static constexpr uint32_t kY = kX + nX, nY = 2 * TY * (TX + 1) * (TZ + 1);
+	static constexpr uint32_t kZ = kY + nY, nZ = 2 * TZ * (TX + 1) * (TY + 1);
+	static constexpr uint32_t kDoubles = kZ + nZ;
+	// threads per block: about one per query of a tile at 0.6 queries per cell (config 5), at least a wave
+	static constexpr uint32_t NT = TX * TY * TZ >= 512 ? 256u : (TX * TY * TZ >= 256 ? 128u : 64u);
+};
+// one class of rows of the tile image: ROWS_A x ROWS_B rows (a fast) of WIDTH doubles in LDS, L lanes per row with 16 bytes each.
+// Every load is UNCONDITIONAL (rows and pieces a clipped tile does not have read a clamped, valid address and land in slots no cell of
+// the tile refers to): a load behind a branch costs the compiler its count of the loads in flight, and every wait becomes "all of them".
+template <uint32_t NT, uint32_t ROWS_A, uint32_t ROWS_B, uint32_t WIDTH>
+struct StageClass
+{
+	static constexpr uint32_t L = WIDTH > 8 ? 8u : (WIDTH > 4 ? 4u : 2u); // lanes per row (two doubles each)
+	static constexpr uint32_t kRowsPerStep = NT / L;
+	static constexpr uint32_t kRows = ROWS_A * ROWS_B;
+	static constexpr uint32_t kSteps = (kRows + kRowsPerStep - 1) / kRowsPerStep;
+	double v0[kSteps], v1[kSteps];
+	// first: index of the tile's first element of the class; last: the last index a 16-byte load may start at (n_coeffs - 2)
+	__device__ __forceinline__ void load(const double* __restrict__ coeffs, uint64_t first, uint64_t last, uint32_t sa, uint32_t sb, uint32_t na, uint32_t nb)
+	{
+		const uint32_t piece = threadIdx.x % L, rslot = threadIdx.x / L;
+#pragma unroll
+		for (uint32_t s = 0; s < kSteps; ++s)
+		{
+			const uint32_t r = s * kRowsPerStep + rslot;
+			uint32_t b = r / ROWS_A, a = r - ROWS_A * b;
+			a = a < na ? a : na - 1u;
+			b = b < nb ? b : nb - 1u;
+			uint64_t e = first + ((uint64_t)a * sa + (uint64_t)b * sb + 2u * piece);
+			e = e < last ? e : last;
+			v0[s] = coeffs[e];
+			v1[s] = coeffs[e + 1];
+		}
+	}
+	__device__ __forceinline__ void store(double* __restrict__ lds) const
+	{
+		const uint32_t piece = threadIdx.x % L, rslot = threadIdx.x / L;
+#pragma unroll
+		for (uint32_t s = 0; s < kSteps; ++s)
+		{
+			const uint32_t r = s * kRowsPerStep + rslot;
+			if (r < kRows)
+			{
+				double* dst = lds + r * WIDTH + 2u * piece;
+				if (2u * piece < WIDTH)
+					dst[0] = v0[s];
+				if (2u * piece + 1u < WIDTH)
+					dst[1] = v1[s];
+			}
+		}
+	}
+};
+// One block = one work item (a tile's queries, at most kStageChunk of them): the item, the first round's query indices, then the
+// query points and the tile's rows together, one barrier, then the evaluation from LDS, round by round.  (Also built and measured on the same boxes, round 6: PERSISTENT blocks that run the chains of the
+// next items -- descriptor three items ahead, query indices two, points and rows one -- under the evaluation of the current one.
+// With the rows prefetched into registers the loop needs 200-240 VGPRs, two waves per SIMD: 0.73-0.75 ms per 10 M queries; with only
+// the query chains prefetched, three waves: 0.82 ms; this form: 0.55-0.65 ms.  What the pipelining gains in hidden latency it loses in
+// occupancy: the evaluation is f64 dependency chains and LDS round trips that want four waves per SIMD.  The shapes 8 x 8 x 4 and
+// 8 x 4 x 4 -- half and a quarter of the LDS image, twice and four times the blocks -- measured 1.00 and 0.84 of this one's rate.)
+template <bool GRAD, int LX, int LY, int LZ>
+__global__ __launch_bounds__((StageShape<LX, LY, LZ>::NT), GRAD ? 3 : 4)
+void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, double* __restrict__ phi_out, double* __restrict__ grad_out, TileBin B,
+						 uint32_t chunk)
+{
+	typedef StageShape<LX, LY, LZ> S;
+	constexpr uint32_t TX = S::TX, TY = S::TY, TZ = S::TZ, NT = S::NT;
+	__shared__ double tile[S::kDoubles];
+	const uint32_t w = xcd_logical(blockIdx.x, chunk);
+	if (w >= *B.n_items)
+		return;
+	const StageItem it = B.items[w];
+	const uint32_t nx = F.res[0], ny = F.res[1], nz = F.res[2];
+	const uint64_t nv = (uint64_t)(nx + 1) * (ny + 1) * (nz + 1), nex = (uint64_t)nx * (ny + 1) * (nz + 1), ney = (uint64_t)(nx + 1) * ny * (nz + 1);
+	const uint64_t last = nv + 2 * (nex + ney) + 2 * (uint64_t)(nx + 1) * (ny + 1) * nz - 2;
+	const uint32_t i0 = (it.tijk & 1023u) << LX, j0 = ((it.tijk >> 10) & 1023u) << LY, k0 = (it.tijk >> 20) << LZ;
+	// the first round's query, fetched under the staging (lanes without one issue nothing: a clamped, unconditional load here was
+	// measured -- every lane of the block fetching a point for the second round that one wave in four has)
+	uint32_t q = it.q0 + threadIdx.x;
+	uint32_t gid = 0;
+	double x[3] = {0.0, 0.0, 0.0};
+	if (q < it.q1)
+		gid = B.perm[q];
+	{
+		StageClass<NT, TY + 1, TZ + 1, TX + 1> cv;  // rows a = j, b = k
+		StageClass<NT, TY + 1, TZ + 1, 2 * TX> cx;  // a = j, b = k
+		StageClass<NT, TZ + 1, TX + 1, 2 * TY> cy;  // a = k, b = i
+		StageClass<NT, TX + 1, TY + 1, 2 * TZ> cz;  // a = i, b = j
+		// cells of this tile per axis (tiles at the far faces of a resolution that is no multiple of the tile are smaller)
+		const uint32_t ex = nx - i0 < TX ? nx - i0 : TX, ey = ny - j0 < TY ? ny - j0 : TY, ez = nz - k0 < TZ ? nz - k0 : TZ;
+		cv.load(F.coeffs, (uint64_t)(nx + 1) * (ny + 1) * k0 + (uint64_t)(nx + 1) * j0 + i0, last, nx + 1, (nx + 1) * (ny + 1), ey + 1, ez + 1);
+		cx.load(F.coeffs, nv + 2 * ((uint64_t)nx * (ny + 1) * k0 + (uint64_t)nx * j0 + i0), last, 2 * nx, 2 * nx * (ny + 1), ey + 1, ez + 1);
+		cy.load(F.coeffs, nv + 2 * nex + 2 * ((uint64_t)ny * (nz + 1) * i0 + (uint64_t)ny * k0 + j0), last, 2 * ny, 2 * ny * (nz + 1), ez + 1, ex + 1);
+		cz.load(F.coeffs, nv + 2 * nex + 2 * ney + 2 * ((uint64_t)nz * (nx + 1) * j0 + (uint64_t)nz * i0 + k0), last, 2 * nz, 2 * nz * (nx + 1), ex + 1, ey + 1);
+		if (q < it.q1)
+		{
+			x[0] = xyz[3 * (uint64_t)gid];
+			x[1] = xyz[3 * (uint64_t)gid + 1];
+			x[2] = xyz[3 * (uint64_t)gid + 2];
+		}
+		cv.store(tile + S::kV);
+		cx.store(tile + S::kX);
+		cy.store(tile + S::kY);
+		cz.store(tile + S::kZ);
+	}
+	__syncthreads();
+	for (; q < it.q1; q += NT)
+	{
+		const CellQuery cq = locate_query<false>(F, x);
+		double cf[32];
+		double g[3] = {0.0, 0.0, 0.0};
+		double phi = 1.7976931348623157e308;
+		if (cq.valid)
+		{
+			// the query's cell is a cell of this tile: the key the queries were sorted by is (mi >> log2 tile), the very words
+			// locate_query computes (clamped all the same: an LDS address must not depend on the caller leaving xyz alone)
+			uint32_t li = cq.mi[0] - i0, lj = cq.mi[1] - j0, lk = cq.mi[2] - k0;
+			li = li < TX ? li : TX - 1u;
+			lj = lj < TY ? lj : TY - 1u;
+			lk = lk < TZ ? lk : TZ - 1u;
+			constexpr uint32_t vj = TX + 1, vk = (TX + 1) * (TY + 1);
+			const double* V = tile + S::kV + lk * vk + lj * vj + li;
+			cf[0] = V[0]; cf[1] = V[1]; cf[2] = V[vj]; cf[3] = V[vj + 1];
+			cf[4] = V[vk]; cf[5] = V[vk + 1]; cf[6] = V[vk + vj]; cf[7] = V[vk + vj + 1];
+			constexpr uint32_t xj = 2 * TX, xk = 2 * TX * (TY + 1);
+			const double* X = tile + S::kX + lk * xk + lj * xj + 2u * li; // x edges at (j, k), (j, k + 1), (j + 1, k), (j + 1, k + 1)
+			cf[8] = X[0]; cf[9] = X[1]; cf[10] = X[xk]; cf[11] = X[xk + 1];
+			cf[12] = X[xj]; cf[13] = X[xj + 1]; cf[14] = X[xk + xj]; cf[15] = X[xk + xj + 1];
+			constexpr uint32_t yk = 2 * TY, yi = 2 * TY * (TZ + 1);
+			const double* Y = tile + S::kY + li * yi + lk * yk + 2u * lj; // y edges at (i, k), (i + 1, k), (i, k + 1), (i + 1, k + 1)
+			cf[16] = Y[0]; cf[17] = Y[1]; cf[18] = Y[yi]; cf[19] = Y[yi + 1];
+			cf[20] = Y[yk]; cf[21] = Y[yk + 1]; cf[22] = Y[yi + yk]; cf[23] = Y[yi + yk + 1];
+			constexpr uint32_t zi = 2 * TZ, zj = 2 * TZ * (TX + 1);
+			const double* Z = tile + S::kZ + lj * zj + li * zi + 2u * lk; // z edges at (j, i), (j + 1, i), (j, i + 1), (j + 1, i + 1)
+			cf[24] = Z[0]; cf[25] = Z[1]; cf[26] = Z[zj]; cf[27] = Z[zj + 1];
+			cf[28] = Z[zi]; cf[29] = Z[zi + 1]; cf[30] = Z[zj + zi]; cf[31] = Z[zj + zi + 1];
+			phi = evaluate_cell<GRAD>(cf, cq.xi, cq.c0, g);
+		}
+		phi_out[gid] = phi;
+		if (GRAD)
+		{
+			grad_out[3 * (uint64_t)gid] = g[0];
+			grad_out[3 * (uint64_t)gid + 1] = g[1];
+			grad_out[3 * (uint64_t)gid + 2] = g[2];
+		}
+		if (q + NT < it.q1)
+		{
+			gid = B.perm[q + NT];
+			x[0] = xyz[3 * (uint64_t)gid];
+			x[1] = xyz[3 * (uint64_t)gid + 1];
+			x[2] = xyz[3 * (uint64_t)gid + 2];
+		}
 	}
 }
 
@@ -528,7 +801,7 @@ size_t bin_sort_tmp_bytes(uint64_t n, uint32_t n_tiles)
 // (S.sort_launched) -- tile keys + radix sort, which leaves the processing order in S.perm
 hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& tiles, const double* d_xyz, uint64_t n, const BinScratch& S, uint32_t one_in, hipStream_t stream)
 {
-	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(256), 0, stream, probe_tiles, d_xyz, n, S, one_in);
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(1024), 0, stream, probe_tiles, d_xyz, n, S, one_in);
 	if (S.sort_launched == 0)
 		return hipGetLastError();
 	const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256ull * 64ull);
@@ -537,6 +810,50 @@ hipError_t launch_binning(const TileGrid& probe_tiles, const TileGrid& tiles, co
 	const hipError_t e = rocprim::radix_sort_pairs(S.sort_tmp, bytes, (const uint32_t*)S.keys, S.keys_out, (const uint32_t*)S.vals, S.perm,
 												  (size_t)n, 0u, tile_key_bits(tiles), stream);
 	return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_interpolate_tiles(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, const TileBin& B,
+									uint32_t xcd_chunk, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	// the prediction for the next batch (K2: row-ordered queries are coherent enough; bin only if more than a quarter of the steps change tile)
+	BinScratch P{};
+	P.flag = B.flag;
+	P.flag_host = B.flag_host;
+	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(1024), 0, stream, field_tiles(f), d_xyz, n, P, 4u);
+	if (B.sort_launched == 0)
+		return hipGetLastError();
+	const uint32_t per_query = (uint32_t)((n + 255) / 256);
+	hipLaunchKernelGGL(k_tile_keys, dim3(per_query), dim3(256), 0, stream, f, d_xyz, n, B);
+	size_t bytes = B.sort_tmp_bytes;
+	hipError_t e = rocprim::radix_sort_pairs(B.sort_tmp, bytes, (const uint32_t*)B.keys, B.keys_out, rocprim::counting_iterator<uint32_t>(0u), B.perm, (size_t)n,
+											 0u, B.key_bits, stream);
+	if (e != hipSuccess)
+		return e;
+	e = hipMemsetAsync(B.begin, 0, (size_t)B.key_space * 2 * sizeof(uint32_t), stream);
+	if (e != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(k_tile_bounds, dim3(per_query), dim3(256), 0, stream, n, B);
+	const uint32_t rows = (B.key_space + 1023u) / 1024u;
+	hipLaunchKernelGGL(k_tile_row_items, dim3(rows), dim3(1024), 0, stream, B, B.row_items);
+	hipLaunchKernelGGL(k_tile_items, dim3(rows), dim3(1024), 0, stream, B, (const uint32_t*)B.row_items);
+	uint32_t grid = B.max_items;
+	if (xcd_chunk != 0)
+	{
+		const uint32_t round = 8u * xcd_chunk;
+		grid = (grid + round - 1) / round * round;
+	}
+#define DG_K2_TILES(LX, LY, LZ)                                                                                                                          \
+	if (d_grad)                                                                                                                                          \
+		hipLaunchKernelGGL((k_interpolate_tiles<true, LX, LY, LZ>), dim3(grid), dim3(StageShape<LX, LY, LZ>::NT), 0, stream, f, d_xyz, d_phi, d_grad, B, \
+						   xcd_chunk);                                                                                                                   \
+	else                                                                                                                                                 \
+		hipLaunchKernelGGL((k_interpolate_tiles<false, LX, LY, LZ>), dim3(grid), dim3(StageShape<LX, LY, LZ>::NT), 0, stream, f, d_xyz, d_phi, d_grad, B, \
+						   xcd_chunk);
+	DG_K2_TILES(3, 3, 3)
+#undef DG_K2_TILES
+	return hipGetLastError();
 }
 
 hipError_t launch_interpolate(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad,

@@ -552,6 +552,7 @@ struct CellQuery
 	uint32_t row;     // cell row (through cell_map for reduced fields)
 	double c0[3], xi[3];
 };
+template <bool MAP = true> // MAP = false: the caller knows that the field has no cell map (unreduced): no look-up in the way
 DG_HD CellQuery locate_query(const FieldDev& F, const double x[3])
 {
 	CellQuery q;
@@ -572,7 +573,7 @@ DG_HD CellQuery locate_query(const FieldDev& F, const double x[3])
 			q.mi[d] = F.res[d] - 1;
 	}
 	const uint32_t ci = F.res[1] * F.res[0] * q.mi[2] + F.res[0] * q.mi[1] + q.mi[0];
-	const uint32_t cm = F.cell_map ? F.cell_map[ci] : ci;
+	const uint32_t cm = (MAP && F.cell_map) ? F.cell_map[ci] : ci;
 	if (cm == 0xffffffffu)
 		return q;
 	q.row = cm;

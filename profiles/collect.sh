@@ -34,7 +34,7 @@ fi
 for w in k2 k2r k2b k3 u; do
   if [ $WHAT = $w ] || [ $WHAT = all ]; then
     GRP=("${GROUPS_BASE[@]}")
-    if [ $w = k3 ] || [ $w = k2r ] || [ $w = k2b ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}"); fi
+    if [ $w = k3 ] || [ $w = k2 ] || [ $w = k2r ] || [ $w = k2b ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}"); fi
     if [ $w = k3 ]; then GRP=("${GROUPS_BASE[@]}" "${GROUPS_VMEM[@]}" "${GROUPS_K1[@]}"); fi   # (+ instruction mix and the LDS pipe: k_density_cells keeps its tables and sums there)
     run_set $w python profiles/pmc_workloads.py $w
   fi

@@ -19,7 +19,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["k_sample_fast", "k_sample_nodes", "k_heavy_subtrees", "k_expand_tiles", "k_heavy_finish", "k_interpolate_binned", "k_interpolate_band", "k_interpolate_rows", "k_interpolate", "k_bin_probe",
+KERNELS = ["k_sample_fast", "k_sample_nodes", "k_heavy_subtrees", "k_expand_tiles", "k_heavy_finish", "k_interpolate_tiles", "k_tile_keys", "k_tile_bounds", "k_tile_row_items", "k_tile_items", "k_interpolate_binned", "k_interpolate_band", "k_interpolate_rows", "k_interpolate", "k_bin_probe",
            "k_bin_keys", "k_density_cells", "k_density_rows", "k_xmajor_copy", "k_xmajor_flags", "k_density_pairs", "k_density_bricks_lds", "k_density_bricks", "k_tile_flags", "k_field_check", "k_unpack_shards", "k_unpack_ranks", "k_expand_cells"]
 
 

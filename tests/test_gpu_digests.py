@@ -206,13 +206,15 @@ def cell_order(dom, res):
 
 
 @pytest.mark.parametrize("path", ["cell_major_rows", "cell_major_per_lane", "owned_auto_copy", "tile_major",
-                                  "cell_sorted_input", "cell_sorted_input_cell_major", "no_binning", "band_copy", "band_copy_thin"])
+                                  "cell_sorted_input", "cell_sorted_input_cell_major", "no_binning", "band_copy", "band_copy_thin",
+                                  "radix_sorted_gather", "tiles_plain_item_order"])
 def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, path, monkeypatch):
     """The same 2 x 3 x 10 digest blocks through EVERY other K2 path that carries a quoted number
     (secondary.k2_interpolate on the bench line): the cooperative row kernel on the cell-major copy
     (k_interpolate_rows: the 18 Gq/s figure), the per-lane kernels on that copy, an OWNED field that builds the
     copy by itself on its first large batch, the tile-major copy, cell-sorted input (the device-side "already
-    ordered" decision; results un-permuted before digesting) on both layouts, the unbinned gather, and (round 4) the
+    ordered" decision; results un-permuted before digesting) on both layouts, the unbinned gather, (round 6) the radix-sorted
+    per-lane gather that was the default until round 5 and the staged gather without its XCD-aware item order, and (round 4) the
     band-limited cell-major copy: rows for the cells that reach into |phi| <= 2h + cell diagonal (every shell query takes the
     row path, four uniform queries in five the gather, in one launch) and for a band so thin that most shell queries
     straddle it or miss it."""
@@ -234,6 +236,10 @@ def test_config5_interpolate_every_k2_path(dg, gold, ico256, config5_points, pat
         order = cell_order(dom, [256] * 3)
     if path == "no_binning":
         T.force(monkeypatch, k2_binning=0)
+    if path == "radix_sorted_gather":      # the default of rounds 1-5: radix sort by cell, per-lane gather
+        T.force(monkeypatch, k2_tiles=0)
+    if path == "tiles_plain_item_order":   # round 6's staged gather without the XCD-aware order of its work items
+        T.force(monkeypatch, k2_tile_chunk=0)
     if path.startswith("band_copy"):
         n_cells = 256 ** 3
         diag = float(np.linalg.norm((np.asarray(dom[3:]) - np.asarray(dom[:3])) / 256.0))

@@ -292,3 +292,53 @@ def test_comm_create_gives_up_when_a_rank_never_arrives():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, DG_COMM_TIMEOUT_S="4"))
     assert "FAILED AFTER" in out.stdout and "did not complete within 4 s" in out.stdout, out.stdout + out.stderr[-2000:]
+
+
+def _plain_env():
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e["DG_BENCH_SELFTEST_ONE_GPU"] = "1"
+    return e
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` typed PLAIN -- no torchrun, no WORLD_SIZE -- starts its two ranks itself (round 6; it used to exit
+    with rc 1): the preflight runs first (stderr), then the race over every exchange form with two ranks on the one GPU; ONE line
+    on stdout, n_gpus 2, the forms' times also as plain scalars inside roofline; every rank asserted field == direct launch."""
+    out = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pieces", "2"],
+                         capture_output=True, text=True, timeout=600, env=_plain_env())
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and "256x256x512" in rec["config"]["workload"]
+    rf = rec["roofline"]
+    assert rf["exchange_chosen"] == rec["config"]["exchange"]["chosen"] and rf["compulsory_hbm_frac"] > 0
+    assert {"exchange_ms_host", "exchange_ms_copy_shm", "exchange_ms_slabs", "exchange_ms_inplace", "exchange_ms_inplace_p2p", "exchange_ms_copy"} <= set(rf)
+    assert "starting the ranks myself" in out.stderr
+    for step in ("devices: ok", "shm: ok", "vmm: ok", "rccl: skipped", "host: ok"):
+        assert out.stderr.count(step) == 2, (step, out.stderr[-4000:])
+    assert "bench.py preflight: every form may run" in out.stderr
+
+
+def test_plain_bench_command_strong_scaling():
+    """--scaling strong: the metric's own 256^3 lattice shared by the ranks; the line says so."""
+    out = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pieces", "2",
+                          "--scaling", "strong", "--exchange", "copy-shm", "--no-preflight"], capture_output=True, text=True, timeout=600, env=_plain_env())
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "256x256x256 = 118425857 nodes" in rec["config"]["workload"]
+    assert "STRONG scaling" in rec["config"]["workload"] and rec["roofline"]["exchange_chosen"] == "copy-shm"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_scale_preflight_on_one_gpu(world):
+    """tools/scale_preflight.py stand-alone with several processes on the one GPU (importer and exporter of the hipMemCreate chunk
+    are then the same device): every step reports ok, RCCL is skipped, and the output has the documented format."""
+    import re
+    out = _torchrun(world, os.path.join(T.ROOT, "tools", "scale_preflight.py"), env=dict(os.environ, DG_BENCH_SELFTEST_ONE_GPU="1"), timeout=240)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    for step in ("devices", "gloo", "shm", "vmm", "host"):
+        assert len(re.findall(r"preflight\[rank \d/%d\] %s: ok \(" % (world, step), out.stderr)) == world, (step, out.stderr[-4000:])
+    assert out.stderr.count("rccl: skipped") == world and out.stderr.count("every form can run") == world

@@ -322,6 +322,43 @@ def test_interpolate_binned_path(dg, golden, monkeypatch, name):
     np.testing.assert_array_equal(f.interpolate(P[:5]), want["random"][0][:5])            # tiny batch
 
 
+@pytest.mark.parametrize("res", [[9, 14, 6], [16, 8, 24], [13, 21, 7], [1, 1, 1], [33, 2, 17]])
+def test_interpolate_staged_tiles_path(dg, monkeypatch, res):
+    """K2 on the plain layout, round 6: counting sort by tile of 8^3 cells + the gather that serves a tile's queries from an LDS image
+    of the tile (k_interpolate_tiles).  Lattices whose resolution is no multiple of the tile (clipped tiles), smaller than one tile,
+    with "no value" coefficients; queries inside, outside, ON cell / tile / domain faces, NaN, duplicated, and 5000 of them in ONE
+    cell (several work items for one tile); with and without the XCD-aware item order, the radix-sorted per-lane gather of rounds 1-5, the default routing: all the bits of the oracle's interpolate, value and gradient."""
+    rng = np.random.default_rng(sum(res))
+    lo, hi = np.array([-0.7, 0.1, -1.3]), np.array([1.1, 2.3, 0.9])
+    dom = np.concatenate([lo, hi])
+    n = T.n_nodes(res)
+    coeffs = rng.normal(size=n)
+    coeffs[rng.integers(0, n, size=max(1, n // 200))] = np.finfo(np.float64).max
+    P = rng.uniform(lo - 0.03 * (hi - lo), hi + 0.03 * (hi - lo), size=(60001, 3))
+    cells = (hi - lo) / np.array(res)
+    faces = lo + cells * rng.integers(0, np.array(res) + 1, size=(4000, 3))      # exactly on lattice planes (cell and tile faces, domain faces)
+    P[2000:6000] = np.where(rng.random((4000, 3)) < 0.6, faces, P[2000:6000])
+    P[6000:11000] = lo + cells * (np.minimum(np.array(res) - 1, [3, 5, 2]) + rng.random((5000, 3)))   # one cell, many queries
+    P[11000:11500] = P[11000]
+    P[11500:11510] = np.nan
+    P[11510] = hi
+    P[11511] = lo
+    want = T.oracle_interpolate(dom, res, coeffs, P, grad=True)
+    inside = np.all((P >= lo) & (P <= hi), axis=1)        # (the reference leaves the gradient of a query outside the domain untouched;
+    want[1][~inside] = 0.0                                #  the batched evaluator writes zeros)
+    assert (want[0][~inside] == np.finfo(np.float64).max).all() and 0.7 < inside.mean() < 0.95
+    f = dg.Field(grid_of(dg, dom, res), coeffs)
+    for force in (dict(k2_tiles=2), dict(k2_tiles=2, k2_tile_chunk=0), dict(k2_tiles=2, k2_tile_chunk=3), dict(k2_tiles=0), dict(k2_tiles=1)):
+        T.force(monkeypatch, k2_binning=2, **force)
+        for _ in range(2):        # (the second call runs on the prediction of the first)
+            phi, grad = f.interpolate(P, grad=True)
+            np.testing.assert_array_equal(phi, want[0], err_msg=str(force))
+            np.testing.assert_array_equal(grad, want[1], err_msg=str(force))
+            np.testing.assert_array_equal(f.interpolate(P), want[0], err_msg=str(force))
+        T.force(monkeypatch, **{k: None for k in force})
+    f.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8, 32])
 def test_shards_on_one_gpu_equal_unsharded(dg, torch, nranks, monkeypatch):
     """Multi-GPU path exercised on one device: every rank's shard is computed in turn, the
