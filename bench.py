@@ -530,7 +530,10 @@ def run_preflight(dist, rank, world, timeout_s):
     dist.broadcast_object_list(box, src=0)
     port, tag = box[0]
     out = os.path.join(tempfile.gettempdir(), "dg_preflight_%s_%d.json" % (tag, rank))
-    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    # (not the launcher's store: under torch.distributed.run TORCHELASTIC_USE_AGENT_STORE makes init_process_group look for the agent's
+    # TCPStore at MASTER_PORT -- the children meet at a port of their own, where rank 0 has to host the store itself)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
     results, note = {}, None
     try:
         proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--json-out", out, "--tag", tag],

@@ -92,7 +92,7 @@ struct IpcRecord // what travels through the control plane when a field is regis
 	uint64_t bytes;
 	uint64_t alloc_bytes; // size of that allocation / range
 	uint64_t chunk;       // kind 1: size of every chunk but the last
-	uint64_t serial;      // kind 1: names the unix socket that serves the chunks' descriptors ("dg_vmm_<pid>_<serial>")
+	uint64_t serial;      // kind 1: names the unix socket that serves the chunks' descriptors ("dg_vmm_<pid>_<64 random bits>")
 	int32_t device;
 	int32_t pid;
 	int32_t kind;   // 0: hipIpcMemHandle_t, 1: an array of dg_comm_field_alloc (hipMemCreate chunks, one descriptor each)
@@ -126,7 +126,6 @@ struct dg_comm
 	hipEvent_t entered = nullptr;
 	std::map<char*, dgvmm::Array> vmm_owned;  // dg_comm_field_alloc: base -> array
 	std::vector<dgvmm::Array> vmm_imported;   // peers' arrays mapped here
-	uint64_t vmm_serial = 0;
 	hipEvent_t t_last_sampled = nullptr, t_complete = nullptr; // timing: end of this rank's last sampling launch / field complete
 	bool wait_timed = false;
 	std::map<std::string, void*> opened_handles; // (pid, handle) -> mapping: an allocation is opened once however many fields live in it
@@ -652,7 +651,7 @@ static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, Pee
 			mine.alloc_bytes = arr->bytes;
 			mine.chunk = arr->chunk;
 			mine.n_chunks = (uint32_t)arr->handles.size();
-			mine.serial = ++c->vmm_serial;
+			mine.serial = dgvmm::random_token(); // names the socket: unguessable, travels through the control plane only
 			std::vector<int> fds;
 			if (dgvmm::export_fds(*arr, fds) != hipSuccess)
 			{
@@ -694,6 +693,14 @@ static dg_status register_field(dg_comm* c, double* d_field, uint64_t bytes, Pee
 		if (s != DG_OK)
 			return s;
 		comm_trace(c, "  records gathered");
+		{
+			// only now does the descriptor server accept: connections from the processes of this communicator and nobody else
+			std::vector<int32_t> pids;
+			for (int r = 0; r < N; ++r)
+				if (r != c->rank)
+					pids.push_back(all[(size_t)r].pid);
+			server.allow(pids);
+		}
 		// -- step 3: refuse together
 		// Measured on the MI355X boxes of rounds 4 and 5 (ROCm 7.2, dmabuf IPC, several processes on one device):
 		// hipIpcOpenMemHandle never returns for an allocation above 2 GiB (1.9 GB: fine with 2, 3 and 4 processes; 3.8 GB: hangs
@@ -1104,13 +1111,27 @@ dg_status dg_comm_field_free(dg_comm* comm, double* d_field)
 	auto it = comm->vmm_owned.find(reinterpret_cast<char*>(d_field));
 	if (it == comm->vmm_owned.end())
 		return fail(DG_ERR_INVALID, "not an array of dg_comm_field_alloc on this communicator");
-	if (comm->peer_fields.count(d_field) != 0 && comm->nranks > 1)
-		return fail(DG_ERR_INVALID, "the array is registered with the peers (they hold mappings of it): it lives until dg_comm_destroy");
+	// registered with the peers -- under its base pointer or under any pointer INSIDE the array (register_field accepts those):
+	// they hold mappings of it
+	if (comm->nranks > 1)
+		for (const auto& kv : comm->peer_fields)
+		{
+			const char* p = reinterpret_cast<const char*>(kv.first);
+			if (p >= it->second.base && p < it->second.base + it->second.bytes)
+				return fail(DG_ERR_INVALID, "the array is registered with the peers (they hold mappings of it): it lives until dg_comm_destroy");
+		}
 	DG_ON_DEVICE_OF(comm);
 	DG_HIP(hipDeviceSynchronize());
+	for (auto pf = comm->peer_fields.begin(); pf != comm->peer_fields.end();) // (one rank: entries of pointers inside the array go with it)
+	{
+		const char* p = reinterpret_cast<const char*>(pf->first);
+		if (p >= it->second.base && p < it->second.base + it->second.bytes)
+			pf = comm->peer_fields.erase(pf);
+		else
+			++pf;
+	}
 	dgvmm::destroy(it->second);
 	comm->vmm_owned.erase(it);
-	comm->peer_fields.erase(d_field);
 	return DG_OK;
 }
 

@@ -176,6 +176,15 @@ dg_status dg_sdf_sample_to_host_field(const dg_mesh* mesh, const dg_grid_desc* g
 			return s;
 		DG_HIP(hipEventRecord(hf->t_end[(size_t)p], st));
 		DG_HIP(hipEventRecord(hf->sampled[(size_t)p], st));
+		// Before this call's FIRST copy into the shared vector: every rank has entered the call, i.e. is done reading the result of
+		// the previous one (a fast rank would otherwise overwrite what a slower rank is still reading).  The first piece is being
+		// sampled meanwhile: the wait hides behind it.
+		if (p == 0 && N > 1)
+		{
+			const dg_status es = shm_barrier(hf);
+			if (es != DG_OK)
+				return es;
+		}
 		// piece p goes to the host while piece p + 1 is sampled
 		DG_HIP(hipStreamWaitEvent(hf->copy, hf->sampled[(size_t)p], 0));
 		for (int c = 0; c < 4; ++c)

@@ -74,3 +74,19 @@ def test_a_missing_rank_fails_the_others_instead_of_hanging():
 def test_a_missing_creator_fails_the_others():
     out = _run(2, 1000, missing=(0,), env={"DG_COMM_TIMEOUT_S": "2"})
     assert len(out) == 1 and not out[0][1] and "did not appear" in out[0][2], out
+
+
+def test_descriptor_server_serves_the_peers_and_nobody_else():
+    """The copy exchange hands the descriptors of a field's hipMemCreate chunks to the peers over an abstract unix socket
+    (dg_capi_vmm.h: FdServer).  The descriptors mean read / write access to device memory and an abstract socket has no permissions
+    (round-5 advisor, medium): the name ends in 64 random bits that travel through the control plane only, nothing is accepted before
+    the peers' process ids are known, and a connection from any other process is closed without a descriptor and WITHOUT using up a
+    peer's turn.  tests/cpp/fd_server_driver.cpp plays it through with a pipe instead of device memory (no GPU)."""
+    import json
+    import subprocess
+    exe = os.path.join(T.ROOT, "tests", "cpp", "build", "fd_server_driver")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(T.ROOT, "tests", "cpp")])
+    rec = json.loads(subprocess.check_output([exe], timeout=60).decode())
+    assert rec == {"started": True, "name_taken": True, "tokens_differ": True, "stranger_got_nothing": True, "peer_exit": 0,
+                   "peer_wrote": "through the served descriptor", "bytes": 30}, rec
