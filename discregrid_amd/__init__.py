@@ -140,6 +140,7 @@ SYMBOLS = {
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "dg_last_kernel_ms": (C.c_double, []),
     "dg_mesh_last_heavy_bricks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "dg_mesh_last_epilogue_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 
 _lib = None
@@ -253,6 +254,13 @@ class Mesh:
         heavy, split = C.c_uint32(0), C.c_uint32(0)
         _check(self._lib.dg_mesh_last_heavy_bricks(self.handle, C.byref(heavy), C.byref(split)))
         return int(heavy.value), int(split.value)
+
+    def last_epilogue_stats(self):
+        """dg_mesh_last_epilogue_stats: (waves that pooled their tails, waves that ran them lane by lane) of the last launch
+        made with DG_FORCE=pool_stats=1."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _check(self._lib.dg_mesh_last_epilogue_stats(self.handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- host-pointer entry points -----------------------------------------------------------
     def sample_nodes(self, grid, begin=0, end=None, invert=False, mask=None):

@@ -401,6 +401,7 @@ extern "C++" int acquire_bin_scratch(ScratchPool& pool, uint32_t** flag_host, co
 extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P, hipStream_t stream)
 {
 	std::memset(&P.ovf, 0, sizeof(P.ovf));
+	P.ovf.pool_cap = (uint32_t)force_int("pool_cap", 0x7fffffff, 0, 0x7fffffff); // (the epilogue's pool: its LDS capacity unless a test lowers it)
 	// Which K1 kernel: the filtered one (dg_kernels_k1.hip: k_sample_fast) or the exact one only.  By default: from dg::kFastMinTriangles triangles up, and for lattices only where a brick (3 cells) is not much
 	// smaller than a triangle -- the filter pays through the exact tests it saves, and a brick smaller than the
 	// triangles around it needs few (icosphere 100 820 triangles: 128^3 -27 %, 256^3 -9.5 %, 512^3 -2.3 %; brick /
@@ -462,12 +463,16 @@ extern "C++" int acquire_heavy_scratch(const dg_mesh* mesh, dg::SampleParams& P,
 	P.ovf.cand_tri = reinterpret_cast<int32_t*>(base + off[5]);
 	P.ovf.slots = slots;
 	P.ovf.heavy_work = force_int("heavy_work", dg::heavy_work_for(mesh->dev.n_positions), 1, 1 << 30);
-	if (hipMemsetAsync(P.ovf.count, 0, sizeof(uint32_t), stream) != hipSuccess)
+	// (test hooks of the pooled epilogue: the two counters live behind the slot counter, in the padding of its 256 bytes)
+	P.ovf.stats = force_int("pool_stats", 0, 0, 1) != 0 ? P.ovf.count + 1 : nullptr;
+	P.ovf.pool_cap = (uint32_t)force_int("pool_cap", 0x7fffffff, 0, 0x7fffffff);
+	if (hipMemsetAsync(P.ovf.count, 0, 4 * sizeof(uint32_t), stream) != hipSuccess)
 	{
 		(void)hipGetLastError();
 		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
 		mesh->scratch[(size_t)idx].busy = false;
 		std::memset(&P.ovf, 0, sizeof(P.ovf));
+		P.ovf.pool_cap = 0x7fffffffu;
 		return -1;
 	}
 	return idx;
@@ -509,6 +514,35 @@ dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32
 	DG_HIP(hipMemcpy(&count, mem, sizeof(count), hipMemcpyDeviceToHost)); // the counter is the first word
 	*heavy = count;
 	*split = std::min(count, slots);
+	return DG_OK;
+}
+
+dg_status dg_mesh_last_epilogue_stats(const dg_mesh* mesh, uint32_t* pooled, uint32_t* lane_by_lane)
+{
+	if (!mesh || !pooled || !lane_by_lane)
+		return fail(DG_ERR_INVALID, "null argument");
+	*pooled = *lane_by_lane = 0;
+	void* mem = nullptr;
+	hipEvent_t done = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mesh->scratch_mutex);
+		uint64_t newest = mesh->unsplit_serial;
+		for (const HeavyScratch& h : mesh->scratch)
+			if (!h.busy && h.serial > newest)
+			{
+				newest = h.serial;
+				mem = h.mem;
+				done = h.done;
+			}
+	}
+	if (!mem)
+		return DG_OK;
+	DG_ON_DEVICE_OF(mesh);
+	DG_HIP(hipEventSynchronize(done));
+	uint32_t words[4] = {0, 0, 0, 0};
+	DG_HIP(hipMemcpy(words, mem, sizeof(words), hipMemcpyDeviceToHost)); // slot counter, then the two test counters
+	*pooled = words[1];
+	*lane_by_lane = words[2];
 	return DG_OK;
 }
 

@@ -56,6 +56,11 @@ struct OverflowBuf // device scratch of one K1 launch (null count: splitting dis
 	int32_t* cand_tri;   // [slots][kSubtrees][64]
 	uint32_t slots;      // <= kOverflowSlots
 	int32_t heavy_work;  // work budget of a brick
+	// test hooks of the filtered kernel's pooled epilogue (DG_FORCE=pool_stats=1 / pool_cap=<n>): waves that pooled their tail / waves whose
+	// tail did not fit the pool and ran lane by lane (stats[0], stats[1]; null: not counted -- 1.85 M atomics on two words would cost
+	// more than the kernel), and a cap on the pool below its LDS capacity so that a test can reach the second branch
+	uint32_t* stats;
+	uint32_t pool_cap;
 };
 static const int kFastListCap = 10; // candidate triangles a lane can hold (a lane that fills its list gets the exact traversal)
 // The filtered traversal counts node steps + triangle PAIRS (the exact one: node steps + exact tests): about the

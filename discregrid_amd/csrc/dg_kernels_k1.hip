@@ -456,7 +456,10 @@ __global__ __launch_bounds__(64, DG_K1_MIN_WAVES) void k_sample_fast(const Sampl
 			T += (uint32_t)__popcll(m) << b;
 		}
 		const uint32_t item_cap = (uint32_t)P.mesh.stack_levels * 32u, res_cap = (uint32_t)(kFastListCap + 1) * 32u;
-		if (T <= item_cap && T <= res_cap)
+		const bool pooled = T <= item_cap && T <= res_cap && T <= P.ovf.pool_cap;
+		if (P.ovf.stats != nullptr && lane == 0) // (test hook, wave-uniform pointer: null in production)
+			atomicAdd(&P.ovf.stats[pooled ? 0 : 1], 1u);
+		if (pooled)
 		{
 			uint32_t* items = (uint32_t*)lds_lb16;
 			double* res = (double*)lds_list;

@@ -473,6 +473,12 @@ DG_API double dg_last_kernel_ms(void);
  * `*split` of them (the slot count) were actually split, the others ran on in their own wave.
  * Waits for that launch to finish.  Both zero if that launch ran without the split path. */
 DG_API dg_status dg_mesh_last_heavy_bricks(const dg_mesh* mesh, uint32_t* heavy, uint32_t* split);
+/* Test hook of the filtered sampling kernel's epilogue ("the per-lane double tests, pooled"): with DG_FORCE=pool_stats=1
+ * set at launch time, the number of wavefronts of the most recent launch on `mesh` that tested the tails of their lanes' candidate
+ * lists POOLED (64 owner / triangle pairs per round) and the number whose tails did not fit the pool and ran lane by lane
+ * (DG_FORCE=pool_cap=<pairs> lowers the pool's capacity so that a test reaches that branch).  Both zero without pool_stats.  Waits
+ * for the launch.  Nothing to replace in the reference: its per-node loop (TriangleMeshDistance.h:514-562) has no such stage. */
+DG_API dg_status dg_mesh_last_epilogue_stats(const dg_mesh* mesh, uint32_t* pooled, uint32_t* lane_by_lane);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,16 @@ def torus(nu=24, nv=12, R=1.0, r=0.35):
     return np.array(V, dtype=np.float64), np.array(F, dtype=np.uint32)
 
 
+def bipyramid(valence=40, radius=1.0, height=0.6):
+    """closed, outward-oriented bipyramid: a ring of `valence` vertices at z = 0 and two apexes of that valence -- the lanes of a brick
+    next to an apex hold long candidate lists in the filtered K1 kernel (its pooled epilogue's test mesh)"""
+    a = 2.0 * np.pi * np.arange(valence) / valence
+    V = np.vstack([np.stack([radius * np.cos(a), radius * np.sin(a), np.zeros(valence)], axis=1), [[0.0, 0.0, height]], [[0.0, 0.0, -height]]])
+    top, bot = valence, valence + 1
+    F = [[i, (i + 1) % valence, top] for i in range(valence)] + [[(i + 1) % valence, i, bot] for i in range(valence)]
+    return np.ascontiguousarray(V, dtype=np.float64), np.ascontiguousarray(F, dtype=np.uint32)
+
+
 def bunny_mesh():
     """Stanford bunny staged as tests/golden/bunny.npz by tests/golden/make_golden.py
     (the OBJ itself only exists under /root/reference)."""

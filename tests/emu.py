@@ -222,6 +222,20 @@ def set_fast(on=1):
     lib().emu_set_fast(int(on))
 
 
+def set_pool_cap(cap=0x7fffffff):
+    """DG_FORCE=pool_cap: the most (owner, triangle) pairs the pooled epilogue of the filtered kernel takes (default: its LDS capacity)"""
+    L = lib()
+    L.emu_set_pool_cap.argtypes = [C.c_uint32]
+    L.emu_set_pool_cap(int(cap))
+
+
+def pool_stats():
+    """(waves whose tails were pooled, waves whose tails ran lane by lane) since the last set_fast()"""
+    st = np.zeros(2, dtype=np.uint64)
+    lib().emu_pool_stats(st.ctypes.data_as(T.c_u64p))
+    return int(st[0]), int(st[1])
+
+
 def fast_stats():
     st = np.zeros(28, dtype=np.uint64)
     lib().emu_fast_stats(st.ctypes.data_as(T.c_u64p))

@@ -92,16 +92,17 @@ extern "C" void emu_need(unsigned long long* o) { o[0] = g_need_sum; o[1] = g_ne
 struct FastStats
 {
 	uint64_t bricks = 0, pair_steps = 0, leaf_visits = 0, tri_pairs = 0, appends = 0, resets = 0, redo_bricks = 0,
-			 sum_max_list = 0, sum_list = 0, lanes = 0, parked = 0, hist[17] = {0};
+			 sum_max_list = 0, sum_list = 0, lanes = 0, parked = 0, pooled_waves = 0, unpooled_waves = 0, hist[17] = {0};
 	void add(const FastStats& o)
 	{
 		bricks += o.bricks; pair_steps += o.pair_steps; leaf_visits += o.leaf_visits; tri_pairs += o.tri_pairs;
 		appends += o.appends; resets += o.resets; redo_bricks += o.redo_bricks; sum_max_list += o.sum_max_list;
-		sum_list += o.sum_list; lanes += o.lanes; parked += o.parked;
+		sum_list += o.sum_list; lanes += o.lanes; parked += o.parked; pooled_waves += o.pooled_waves; unpooled_waves += o.unpooled_waves;
 		for (int k = 0; k < 17; ++k) hist[k] += o.hist[k];
 	}
 };
 int g_fast = 1;     // 0: emulate a launch without the filtered kernel (DG_FORCE=k1_fast=0)
+uint32_t g_pool_cap = 0x7fffffffu; // DG_FORCE=pool_cap: pairs the epilogue's pool holds at most (tests: below its LDS capacity)
 int g_seed_study = 0; // 1: the filtered traversal starts from an oracle-tight upper bound per lane (design study)
 int g_brick_blocking = 0; // 1: the blocked brick order K3 launches use (dg_kernels.h: map_lane)
 FastStats g_fs;
@@ -342,6 +343,12 @@ void emu_set_fast(int on)
 {
 	g_fast = on;
 	g_fs = FastStats();
+}
+void emu_set_pool_cap(uint32_t cap) { g_pool_cap = cap; }
+void emu_pool_stats(uint64_t* out /*2*/)
+{
+	out[0] = g_fs.pooled_waves;
+	out[1] = g_fs.unpooled_waves;
 }
 void emu_fast_stats(uint64_t* out /*28*/)
 {
@@ -689,8 +696,17 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 					else
 					{
 						int mx = 0, mx2 = 0;
+						// The epilogue of k_sample_fast as the device runs it (dg_kernels_k1.hip): every lane tests the first candidate of its
+						// list itself; what is left of the lists is POOLED -- (owner, triangle) pairs laid out contiguously in list order
+						// behind the pairs of the lanes below (`before`, by bit planes of the tail lengths as the device's ballots count
+						// them), tested 64 per round with the OWNER's point, the values handed back to the owners in list order -- unless
+						// the pool does not hold them (stack_levels x 32 items, (kFastListCap + 1) x 32 results, or g_pool_cap): then lane
+						// by lane.  Same values in the same order either way: what this model pins is the index arithmetic.
+						int n_cand[64], tail_n[64];
 						for (int l = 0; l < 64; ++l)
 						{
+							n_cand[l] = (sample[l] && !exact[l]) ? FastLists::count(fl[l], l) : 0;
+							tail_n[l] = n_cand[l] > 1 ? n_cand[l] - 1 : 0;
 							if (!sample[l])
 								continue;
 							if (exact[l])
@@ -700,20 +716,66 @@ int emu_sample_nodes(void* h, const double dmin[3], const double cell[3], const 
 								continue;
 							}
 							fs.lanes++;
-							const int n_cand = FastLists::count(fl[l], l);
-							fs.sum_list += n_cand;
-							fs.hist[n_cand]++;
-							mx = n_cand > mx ? n_cand : mx;
+							fs.sum_list += n_cand[l];
+							fs.hist[n_cand[l]]++;
+							mx = n_cand[l] > mx ? n_cand[l] : mx;
 							int need = 0;
-							for (int k = 0; k < n_cand; ++k)
-							{
-								const int t = lists.at(l, k);
-								const Hit h = tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz);
-								offer(w.q[l], h.d2, t);
-								need += h.d2 <= (double)fl[l].U * 1.00001;
-							}
+							for (int k = 0; k < n_cand[l]; ++k)
+								need += tri_closest<false>(P.mesh.tris[lists.at(l, k)], w.q[l].px, w.q[l].py, w.q[l].pz).d2 <= (double)fl[l].U * 1.00001;
 							g_need_sum += need;
 							mx2 = need > mx2 ? need : mx2;
+							if (n_cand[l] > 0) // the head round
+							{
+								const int t = lists.at(l, 0);
+								offer(w.q[l], tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz).d2, t);
+							}
+						}
+						uint32_t before[64], T = 0;
+						for (int l = 0; l < 64; ++l)
+							before[l] = 0;
+						for (int b = 3; b >= 0; --b)
+						{
+							unsigned long long m = 0;
+							for (int l = 0; l < 64; ++l)
+								m |= (unsigned long long)((tail_n[l] >> b) & 1) << l;
+							for (int l = 0; l < 64; ++l)
+								before[l] += (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull)) << b; // mbcnt: set lanes BELOW l
+							T += (uint32_t)__builtin_popcountll(m) << b;
+						}
+						if (T > 0)
+						{
+							const uint32_t item_cap = (uint32_t)P.mesh.stack_levels * 32u, res_cap = (uint32_t)(kFastListCap + 1) * 32u;
+							if (T <= item_cap && T <= res_cap && T <= g_pool_cap)
+							{
+								fs.pooled_waves++;
+								std::vector<uint32_t> items(T, 0xffffffffu);
+								std::vector<double> res(T, -1.0);
+								for (int l = 0; l < 64; ++l)
+									for (int j = 0; j < tail_n[l]; ++j)
+										items[before[l] + (uint32_t)j] = ((uint32_t)l << 26) | (uint32_t)lists.at(l, 1 + j);
+								for (uint32_t base = 0; base < T; base += 64u)
+									for (int l = 0; l < 64; ++l)
+									{
+										const uint32_t i = base + (uint32_t)l;
+										if (i >= T)
+											continue;
+										const int owner = (int)(items[i] >> 26);
+										res[i] = tri_closest<false>(P.mesh.tris[items[i] & 0x3ffffffu], w.q[owner].px, w.q[owner].py, w.q[owner].pz).d2;
+									}
+								for (int l = 0; l < 64; ++l)
+									for (int j = 0; j < tail_n[l]; ++j)
+										offer(w.q[l], res[before[l] + (uint32_t)j], (int)(items[before[l] + (uint32_t)j] & 0x3ffffffu));
+							}
+							else
+							{
+								fs.unpooled_waves++;
+								for (int l = 0; l < 64; ++l)
+									for (int k = 1; k < n_cand[l]; ++k)
+									{
+										const int t = lists.at(l, k);
+										offer(w.q[l], tri_closest<false>(P.mesh.tris[t], w.q[l].px, w.q[l].py, w.q[l].pz).d2, t);
+									}
+							}
 						}
 						g_need_max += mx2;
 						fs.sum_max_list += mx;

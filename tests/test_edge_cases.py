@@ -47,19 +47,15 @@ def test_unusual_meshes(name):
     rng = np.random.default_rng(17)
     P = rng.uniform(lo - ext, hi + ext, size=(3000, 3))
     a, b = em.signed_distance(P), om.signed_distance(P)
-    # unsigned distances agree bit for bit even on open / degenerate meshes; the sign is only
-    # defined for closed meshes (the reference warns, TriangleMeshDistance.h:422-438) -- but it
-    # is still the same wherever the winning triangle is the same
-    np.testing.assert_array_equal(np.abs(a), np.abs(b))
-    if name in ("far_from_origin", "tiny", "huge"):
-        np.testing.assert_array_equal(a, b)        # closed, well-conditioned: signs as well
-    if name in ("degenerate_and_duplicate", "needle_box"):
-        off = np.abs(b) > 1e-7 * ext
-        np.testing.assert_array_equal(a[off], b[off])
+    # FULL equality, sign included, on every one of these meshes -- open, soup, degenerate, non-manifold: the sign only MEANS something
+    # on closed meshes (the reference warns, TriangleMeshDistance.h:422-438), but it is a deterministic function of the winning
+    # triangle's feature and its pseudonormal, and both are the reference's (round-5 review: 220 000 points against the unmodified
+    # reference, no differing bit; until round 5 this test compared magnitudes only)
+    np.testing.assert_array_equal(a, b)
     dom = np.concatenate([lo - 0.1 * ext, hi + 0.1 * ext])
     got = em.sample_range(dom, [5, 4, 3])
     want = om.sample_nodes(dom, [5, 4, 3])
-    np.testing.assert_array_equal(np.abs(got), np.abs(want))
+    np.testing.assert_array_equal(got, want)
 
 
 @pytest.mark.parametrize("res", [[1, 1, 1], [1, 7, 2], [33, 1, 1], [2, 2, 64], [3, 5, 4]])

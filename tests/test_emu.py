@@ -364,6 +364,49 @@ def test_filtered_kernel_equals_exact_kernel_and_counts_its_paths():
         emu.set_fast(1)
 
 
+def _apex_lattice(valence=40, res=(24, 24, 24), half=0.02):
+    """a valence-`valence` bipyramid and a dense lattice around its upper apex"""
+    V, F = T.bipyramid(valence)
+    apex = V[valence]
+    dom = np.concatenate([apex - half, apex + half])
+    return V, F, dom, list(res)
+
+
+def test_pooled_epilogue_of_the_filtered_kernel_both_branches():
+    """The epilogue of k_sample_fast (dg_kernels_k1.hip, round 5): one candidate per lane tested by its owner, the tails of the lists
+    pooled as (owner, triangle) pairs in list order and tested 64 per round, or -- when the pool does not hold them -- lane by lane.
+    The emulator models the pool's index arithmetic (`before` from bit planes of the tail lengths, T, items, results handed back in
+    list order) as the device computes it; on a valence-40 apex with a dense lattice BOTH branches occur by themselves (64 lanes with up
+    to nine candidates exceed the 352 pairs the pool holds), a pool capped at 8 pairs sends nearly every wave down the second branch,
+    a cap of 0 all of them: every variant the bits of the oracle, sign included."""
+    V, F, dom, res = _apex_lattice()
+    want = T.OracleMesh(V, F).sample_nodes(dom, res)
+    em = emu.EmuMesh(V, F)
+    try:
+        seen = {}
+        for cap in (0x7fffffff, 8, 0):
+            emu.set_pool_cap(cap)
+            emu.set_fast(1)
+            got = em.sample_range(dom, res)
+            np.testing.assert_array_equal(got, want, err_msg="pool_cap=%d" % cap)
+            seen[cap] = emu.pool_stats()
+            st = emu.fast_stats()
+            assert max(k for k, c in enumerate(st["hist"]) if c) >= 6      # long lists exist: the lanes around the apex
+        pooled, unpooled = seen[0x7fffffff]
+        assert pooled > 0 and unpooled > 0, seen                          # the natural overflow (T > 352) happens on this lattice
+        assert seen[8][1] > seen[0x7fffffff][1] and seen[0][0] == 0 and seen[0][1] == pooled + unpooled, seen
+        # ... and on an ordinary mesh everything pools
+        V2, F2 = T.icosphere(12)
+        d2 = T.oracle_default_domain(V2)
+        emu.set_pool_cap()
+        emu.set_fast(1)
+        np.testing.assert_array_equal(emu.EmuMesh(V2, F2).sample_range(d2, [21, 18, 24]), T.OracleMesh(V2, F2).sample_nodes(d2, [21, 18, 24]))
+        assert emu.pool_stats()[0] > 0 and emu.pool_stats()[1] == 0
+    finally:
+        emu.set_pool_cap()
+        emu.set_fast(1)
+
+
 def test_filtered_kernel_fallbacks_degenerate_triangles_and_far_points():
     """What the float filter cannot serve gets the exact traversal in the same wave: degenerate triangles
     (zero area, duplicated vertices), points whose coordinates leave the filter's range (1e20) next to

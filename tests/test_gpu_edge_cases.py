@@ -30,16 +30,57 @@ def test_unusual_meshes(dg, name):
     ext = max((hi - lo).max(), 1e-3)
     P = np.random.default_rng(17).uniform(lo - ext, hi + ext, size=(3000, 3))
     a, b = m.signed_distance(P), om.signed_distance(P)
-    np.testing.assert_array_equal(np.abs(a), np.abs(b))
-    if name in ("far_from_origin", "tiny", "huge"):
-        np.testing.assert_array_equal(a, b)
-    if name in ("degenerate_and_duplicate", "needle_box"):
-        off = np.abs(b) > 1e-7 * ext
-        np.testing.assert_array_equal(a[off], b[off])
+    # full equality, sign included, on open / soup / degenerate / non-manifold meshes too (see tests/test_edge_cases.py)
+    np.testing.assert_array_equal(a, b)
     dom = np.concatenate([lo - 0.1 * ext, hi + 0.1 * ext])
     got = m.sample_nodes(dg.grid_desc(dom[:3], dom[3:], [5, 4, 3]))
-    np.testing.assert_array_equal(np.abs(got), np.abs(om.sample_nodes(dom, [5, 4, 3])))
+    np.testing.assert_array_equal(got, om.sample_nodes(dom, [5, 4, 3]))
     assert m.info()["not_watertight"] == (0 if name in ("needle_box",) else m.info()["not_watertight"])
+
+
+def test_pooled_epilogue_of_the_filtered_kernel_both_branches(dg, monkeypatch):
+    """k_sample_fast's epilogue on the device (dg_kernels_k1.hip): a valence-40 apex under a dense lattice, the filtered kernel forced
+    (80 triangles are below its default threshold), the test counters on (DG_FORCE=pool_stats=1): waves pool the tails of their lists
+    AND waves whose tails do not fit the pool run them lane by lane in the same launch (64 lanes x up to nine candidates against 352
+    pairs); a pool capped at 8 pairs / at none moves the waves to the second branch.  Every variant: the bits of the oracle, sign
+    included.  (The emulator's model of the same arithmetic: tests/test_emu.py, same name.)"""
+    V, F = T.bipyramid(40)
+    apex = V[40]
+    dom = np.concatenate([apex - 0.02, apex + 0.02])
+    res = [24, 24, 24]
+    want = T.OracleMesh(V, F).sample_nodes(dom, res)
+    m = dg.Mesh(V, F)
+    g = dg.grid_desc(dom[:3], dom[3:], res)
+    import torch
+    n = dg.n_nodes(g)
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def launch():                 # ONE launch over the whole lattice (the host entry point samples in chunks)
+        out.fill_(float("nan"))
+        m.sample_nodes_device(g, 0, n, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    seen = {}
+    for cap in (None, 8, 0):
+        T.force(monkeypatch, k1_fast=1, pool_stats=1, pool_cap=cap)
+        np.testing.assert_array_equal(launch(), want, err_msg="pool_cap=%s" % cap)
+        seen[cap] = m.last_epilogue_stats()
+        np.testing.assert_array_equal(m.sample_nodes(g), want, err_msg="pool_cap=%s, host entry point" % cap)
+    pooled, unpooled = seen[None]
+    assert pooled > 0 and unpooled > 0, seen
+    assert seen[8][1] > unpooled and seen[0][0] == 0 and seen[0][1] == pooled + unpooled, seen
+    T.force(monkeypatch, pool_stats=None, pool_cap=None)
+    np.testing.assert_array_equal(launch(), want)
+    assert m.last_epilogue_stats() == (0, 0)          # not counted in production
+    # the same lattice through the emulator's model: the same waves take the same branch
+    import emu
+    try:
+        emu.set_pool_cap()
+        emu.set_fast(1)
+        np.testing.assert_array_equal(emu.EmuMesh(V, F).sample_range(dom, res), want)
+        assert emu.pool_stats() == seen[None], (emu.pool_stats(), seen[None])
+    finally:
+        emu.set_fast(1)
 
 
 @pytest.mark.parametrize("res", [[1, 1, 1], [1, 7, 2], [33, 1, 1], [2, 2, 64], [3, 5, 4]])
