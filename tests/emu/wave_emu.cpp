@@ -63,6 +63,10 @@ struct EmuCounters
 	void filter_pair();
 	void filter_rest();
 	void append(bool reset);
+	// design study "a bound per leaf half" (round 6): which pairs of the leaf being visited went on to step 2
+	int leaf_pairs = 0;
+	unsigned leaf_mask = 0;
+	void flush_leaf();
 };
 typedef dg::host::HostWave<64, EmuCounters, false> EmuWave;   // bounds parked as floats (k_sample_nodes, k_heavy_subtrees)
 typedef dg::host::HostWave<64, EmuCounters, true> EmuWave16;  // ... in 16 bits (k_sample_fast: both of its traversals)
@@ -161,6 +165,7 @@ int walk_fast_with(const MeshDev& M, FastLane* fl, FastLists& lists, FastStats& 
 	const bool budgeted = ovf && ovf->count;
 	const int parked = packet_walk(ew, pol, M, start, budgeted ? ovf->count : nullptr, budgeted ? ovf->slots : 0u,
 								   budgeted ? kFastWorkFactor * ovf->heavy_work : 0);
+	c.flush_leaf();
 	if (parked >= 0)
 		return parked;
 	return pol.degenerate ? -2 : -1;
@@ -191,8 +196,46 @@ void EmuCounters::pair_step(const MeshDev& M, int cur)
 			depth_hist_note(M, cur);
 	}
 }
+// Leaf-half study: [0] leaves, [1] pairs at step 1, [2] pairs at step 2, [3] leaves none of whose pairs reached step 2, [4] their
+// pairs, [5] groups of two consecutive pairs (4 triangles: (0,1), (2,3) ...), [6] groups neither of whose pairs reached step 2,
+// [7] leaves by number of pairs 1..8 -> [8..15]
+static uint64_t g_half[16];
+extern "C" void emu_leaf_half_stats(uint64_t* out, int reset)
+{
+	for (int i = 0; i < 16; ++i)
+	{
+		out[i] = g_half[i];
+		if (reset) g_half[i] = 0;
+	}
+}
+void EmuCounters::flush_leaf()
+{
+	if (!fs || leaf_pairs == 0)
+		return;
+	uint64_t add[16] = {0};
+	add[0] = 1;
+	add[1] = (uint64_t)leaf_pairs;
+	add[2] = (uint64_t)__builtin_popcount(leaf_mask);
+	if (leaf_mask == 0u)
+	{
+		add[3] = 1;
+		add[4] = (uint64_t)leaf_pairs;
+	}
+	for (int g = 0; g + 1 < leaf_pairs; g += 2)
+	{
+		add[5]++;
+		add[6] += ((leaf_mask >> g) & 3u) == 0u;
+	}
+	add[7 + (leaf_pairs < 8 ? leaf_pairs : 8)]++;
+	for (int i = 0; i < 16; ++i)
+		if (add[i])
+			__atomic_fetch_add(&g_half[i], add[i], __ATOMIC_RELAXED);
+	leaf_pairs = 0;
+	leaf_mask = 0;
+}
 void EmuCounters::leaf(int first, int cnt)
 {
+	flush_leaf();
 	if (st) st->leaf_visits++;
 	if (fs)
 	{
@@ -238,8 +281,22 @@ void EmuCounters::stale_pop()
 	if (st) st->stale_pops++;
 	if (fs) __atomic_fetch_add(&g_fast_events[3], 1, __ATOMIC_RELAXED);
 }
-void EmuCounters::filter_pair() { if (fs) fs->hist[16] += 1; } // (pairs that reached step 1)
-void EmuCounters::filter_rest() { if (fs) fs->tri_pairs++; }
+void EmuCounters::filter_pair() // (pairs that reached step 1)
+{
+	if (fs)
+	{
+		fs->hist[16] += 1;
+		++leaf_pairs;
+	}
+}
+void EmuCounters::filter_rest()
+{
+	if (fs)
+	{
+		fs->tri_pairs++;
+		leaf_mask |= 1u << (leaf_pairs - 1);
+	}
+}
 void EmuCounters::append(bool reset)
 {
 	if (fs)
