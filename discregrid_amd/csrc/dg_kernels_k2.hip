@@ -159,11 +159,34 @@ __device__ __forceinline__ uint32_t stage_key(const FieldDev& F, const uint32_t 
 	}
 	return tile_key(tdims, t);
 }
-__global__ __launch_bounds__(256) void k_tile_keys(const FieldDev F, const double* __restrict__ xyz, uint64_t n, TileBin B)
+// keys of all queries; on the side (nothing here depends on them, and a launch of its own costs 5-16 us of an otherwise idle device):
+// the tile tables cleared for k_tile_bounds, and -- block 0 -- the probe "is this batch ordered?" for the handle's next batch
+__global__ __launch_bounds__(256) void k_tile_keys(const FieldDev F, const TileGrid probe_tiles, const double* __restrict__ xyz, uint64_t n, TileBin B)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n)
 		B.keys[i] = stage_key(F, B.tdims, B.tlog, xyz, i);
+	for (uint64_t j = i; j < 2ull * B.key_space; j += (uint64_t)gridDim.x * blockDim.x)
+		B.begin[j] = 0u; // (begin and end are one array)
+	if (blockIdx.x == 0)
+	{
+		__shared__ uint32_t changes;
+		if (threadIdx.x == 0)
+			changes = 0;
+		__syncthreads();
+		const uint64_t m = n < 4096 ? n : 4096;
+		uint32_t mine = 0;
+		for (uint64_t k = threadIdx.x; k + 1 < m; k += blockDim.x)
+			mine += tile_of(probe_tiles, xyz, k) != tile_of(probe_tiles, xyz, k + 1);
+		atomicAdd(&changes, mine);
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			const uint32_t unordered = (4ull * changes > m) ? 1u : 0u; // (K2: more than one change of tile in four steps)
+			B.flag[0] = unordered;
+			*(volatile uint32_t*)B.flag_host = unordered;
+		}
+	}
 }
 // where the run of every tile begins and ends in the sorted keys (begin / end cleared before: tiles without a query keep 0, 0)
 __global__ __launch_bounds__(256) void k_tile_bounds(uint64_t n, TileBin B)
@@ -817,21 +840,21 @@ hipError_t launch_interpolate_tiles(const FieldDev& f, const double* d_xyz, uint
 {
 	if (n == 0)
 		return hipSuccess;
-	// the prediction for the next batch (K2: row-ordered queries are coherent enough; bin only if more than a quarter of the steps change tile)
-	BinScratch P{};
-	P.flag = B.flag;
-	P.flag_host = B.flag_host;
-	hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(1024), 0, stream, field_tiles(f), d_xyz, n, P, 4u);
 	if (B.sort_launched == 0)
+	{
+		// predicted ordered: only the probe (the prediction for the next batch: row-ordered queries are coherent enough; bin only if more
+		// than a quarter of the steps change tile); the caller runs the queries as they came
+		BinScratch P{};
+		P.flag = B.flag;
+		P.flag_host = B.flag_host;
+		hipLaunchKernelGGL(k_bin_probe, dim3(1), dim3(1024), 0, stream, field_tiles(f), d_xyz, n, P, 4u);
 		return hipGetLastError();
+	}
 	const uint32_t per_query = (uint32_t)((n + 255) / 256);
-	hipLaunchKernelGGL(k_tile_keys, dim3(per_query), dim3(256), 0, stream, f, d_xyz, n, B);
+	hipLaunchKernelGGL(k_tile_keys, dim3(per_query), dim3(256), 0, stream, f, field_tiles(f), d_xyz, n, B);
 	size_t bytes = B.sort_tmp_bytes;
 	hipError_t e = rocprim::radix_sort_pairs(B.sort_tmp, bytes, (const uint32_t*)B.keys, B.keys_out, rocprim::counting_iterator<uint32_t>(0u), B.perm, (size_t)n,
 											 0u, B.key_bits, stream);
-	if (e != hipSuccess)
-		return e;
-	e = hipMemsetAsync(B.begin, 0, (size_t)B.key_space * 2 * sizeof(uint32_t), stream);
 	if (e != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(k_tile_bounds, dim3(per_query), dim3(256), 0, stream, n, B);
