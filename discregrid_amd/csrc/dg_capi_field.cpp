@@ -806,12 +806,17 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 			}
 			size_t off[8];
 			void* mem = nullptr;
-			const int idx = field->bin_flag_host ? field->scratch.acquire(dg::tile_bin_bytes(1u << key_bits, n, off), st, &mem) : -1;
+			// gradient batches: value + gradient leave the gather as one aligned 32-byte store per query into a scratch array and a
+			// streaming pass splits it into the caller's arrays (DG_FORCE=k2_grad_packed=0: the 8 + 24 byte stores of rounds 1-5)
+			const bool packed = d_grad != nullptr && force_int("k2_grad_packed", 1, 0, 1) != 0;
+			const int idx = field->bin_flag_host ? field->scratch.acquire(dg::tile_bin_bytes(1u << key_bits, n, off, packed), st, &mem) : -1;
 			if (idx >= 0)
 			{
 				const dg::TileBin shape_of = B;
 				dg::tile_bin_assign(B, mem, off, key_bits, n);
 				B.shape = shape_of.shape;
+				if (packed)
+					B.packed = reinterpret_cast<double*>(static_cast<char*>(mem) + off[7]);
 				B.flag_host = field->bin_flag_host;
 				B.sort_launched = *reinterpret_cast<volatile uint32_t*>(field->bin_flag_host) != 0u ? 1 : 0;
 				hipError_t e = dg::launch_interpolate_tiles(dev, d_xyz, n, d_phi, d_grad, B, (uint32_t)force_int("k2_tile_chunk", 64, 0, 4096), st);

@@ -481,6 +481,7 @@ struct TileBin
 	StageItem* items;      // [max_items]
 	uint32_t* n_items;     // [1]
 	uint32_t* row_items;   // [key_space / 1024] items per row of 1024 tiles
+	double* packed;        // [4 n] value + gradient per query, query order (gradient batches; null: results go straight to the caller's arrays)
 	void* sort_tmp;        // rocPRIM's temporary storage
 	size_t sort_tmp_bytes;
 	uint32_t key_space, key_bits, max_items, n_queries;
@@ -504,7 +505,7 @@ inline uint32_t stage_max_items(uint32_t key_space, uint64_t n)
 	const uint64_t m = (n < key_space ? n : key_space) + n / kStageChunk + 1;
 	return (uint32_t)(m < 0xffffffffull ? m : 0xffffffffull);
 }
-inline size_t tile_bin_bytes(uint32_t key_space, uint64_t n, size_t off[8])
+inline size_t tile_bin_bytes(uint32_t key_space, uint64_t n, size_t off[8], bool packed_results = false)
 {
 	size_t o = 0;
 	auto take = [&](size_t b) { const size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
@@ -515,6 +516,7 @@ inline size_t tile_bin_bytes(uint32_t key_space, uint64_t n, size_t off[8])
 	off[4] = take((size_t)key_space * 8);               // begin, end (cleared together)
 	off[5] = take((size_t)stage_max_items(key_space, n) * sizeof(StageItem));
 	off[6] = take(bin_sort_tmp_bytes(n, key_space));
+	off[7] = take(packed_results ? (size_t)n * 32 : 0);
 	return o;
 }
 inline void tile_bin_assign(TileBin& B, void* mem, const size_t off[8], uint32_t key_bits, uint64_t n)
@@ -531,6 +533,7 @@ inline void tile_bin_assign(TileBin& B, void* mem, const size_t off[8], uint32_t
 	B.end = B.begin + key_space;
 	B.items = reinterpret_cast<StageItem*>(base + off[5]);
 	B.sort_tmp = base + off[6];
+	B.packed = nullptr; // (the caller points it at off[7] for gradient batches)
 	B.sort_tmp_bytes = bin_sort_tmp_bytes(n, key_space);
 	B.key_space = key_space;
 	B.key_bits = key_bits;

@@ -347,7 +347,7 @@ struct StageClass
 template <bool GRAD, int LX, int LY, int LZ>
 __global__ __launch_bounds__((StageShape<LX, LY, LZ>::NT), GRAD ? 3 : 4)
 void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, double* __restrict__ phi_out, double* __restrict__ grad_out, TileBin B,
-						 uint32_t chunk)
+						 uint32_t chunk, double* __restrict__ packed)
 {
 	typedef StageShape<LX, LY, LZ> S;
 	constexpr uint32_t TX = S::TX, TY = S::TY, TZ = S::TZ, NT = S::NT;
@@ -422,12 +422,27 @@ void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, doubl
 			cf[28] = Z[zi]; cf[29] = Z[zi + 1]; cf[30] = Z[zj + zi]; cf[31] = Z[zj + zi + 1];
 			phi = evaluate_cell<GRAD>(cf, cq.xi, cq.c0, g);
 		}
-		phi_out[gid] = phi;
-		if (GRAD)
+		if (GRAD && packed != nullptr)
 		{
-			grad_out[3 * (uint64_t)gid] = g[0];
-			grad_out[3 * (uint64_t)gid + 1] = g[1];
-			grad_out[3 * (uint64_t)gid + 2] = g[2];
+			// value and gradient as ONE aligned 32-byte store into the query's slot of a scratch array (k_unpack_results splits it into the
+			// caller's two arrays): scattered in query order a result is then one whole sector instead of an 8-byte and a 24-byte piece
+			// of three, each of which the memory system has to merge into a sector it holds only in part
+			double4 r4;
+			r4.x = phi;
+			r4.y = g[0];
+			r4.z = g[1];
+			r4.w = g[2];
+			*reinterpret_cast<double4*>(packed + 4 * (uint64_t)gid) = r4;
+		}
+		else
+		{
+			phi_out[gid] = phi;
+			if (GRAD)
+			{
+				grad_out[3 * (uint64_t)gid] = g[0];
+				grad_out[3 * (uint64_t)gid + 1] = g[1];
+				grad_out[3 * (uint64_t)gid + 2] = g[2];
+			}
 		}
 		if (q + NT < it.q1)
 		{
@@ -437,6 +452,19 @@ void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, doubl
 			x[2] = xyz[3 * (uint64_t)gid + 2];
 		}
 	}
+}
+
+// packed (phi, gx, gy, gz) per query -> the caller's phi[n] and grad[3 n]: streaming, everything coalesced
+__global__ __launch_bounds__(256) void k_unpack_results(const double* __restrict__ packed, uint64_t n, double* __restrict__ phi_out, double* __restrict__ grad_out)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const double4 r4 = *reinterpret_cast<const double4*>(packed + 4 * i);
+	phi_out[i] = r4.x;
+	grad_out[3 * i] = r4.y;
+	grad_out[3 * i + 1] = r4.z;
+	grad_out[3 * i + 2] = r4.w;
 }
 
 // K2 over a field with a CELL-MAJOR copy, queries in ANY order, no binning: one wave = 64 queries.  A query's 32
@@ -870,12 +898,14 @@ hipError_t launch_interpolate_tiles(const FieldDev& f, const double* d_xyz, uint
 #define DG_K2_TILES(LX, LY, LZ)                                                                                                                          \
 	if (d_grad)                                                                                                                                          \
 		hipLaunchKernelGGL((k_interpolate_tiles<true, LX, LY, LZ>), dim3(grid), dim3(StageShape<LX, LY, LZ>::NT), 0, stream, f, d_xyz, d_phi, d_grad, B, \
-						   xcd_chunk);                                                                                                                   \
+						   xcd_chunk, B.packed);                                                                                                         \
 	else                                                                                                                                                 \
 		hipLaunchKernelGGL((k_interpolate_tiles<false, LX, LY, LZ>), dim3(grid), dim3(StageShape<LX, LY, LZ>::NT), 0, stream, f, d_xyz, d_phi, d_grad, B, \
-						   xcd_chunk);
+						   xcd_chunk, (double*)nullptr);
 	DG_K2_TILES(3, 3, 3)
 #undef DG_K2_TILES
+	if (d_grad && B.packed != nullptr)
+		hipLaunchKernelGGL(k_unpack_results, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, (const double*)B.packed, n, d_phi, d_grad);
 	return hipGetLastError();
 }
 
