@@ -6,6 +6,7 @@
 #include "dg_capi_internal.h"
 
 #include <atomic>
+#include <csignal>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -25,8 +26,9 @@ struct Header // the first page of every segment; every member is address-free
 	std::atomic<uint32_t> arrived;    // barrier: ranks that have arrived in the current generation
 	std::atomic<uint32_t> generation; // barrier: bumped by the last arrival
 	std::atomic<uint32_t> attached;   // ranks that mapped the segment
-	uint32_t pad;
-	uint64_t user[496]; // the owner's words (the cuts' hashes of the host-vector form, the slots of the control plane)
+	std::atomic<uint32_t> failed;     // a barrier of this segment timed out: its counters mean nothing any more, every later barrier fails at once
+	int64_t creator_pid;              // the creating rank's process (a segment whose creator is gone is a leftover of a crashed job)
+	uint64_t user[495]; // the owner's words (the cuts' hashes of the host-vector form, the slots of the control plane)
 };
 static_assert(sizeof(Header) <= kHeaderBytes, "header page");
 static_assert(std::atomic<uint32_t>::is_always_lock_free && std::atomic<uint64_t>::is_always_lock_free, "shared-memory atomics");
@@ -41,7 +43,19 @@ struct Segment
 	char* payload = nullptr;
 	int rank = 0, nranks = 1;
 	double timeout_s = 180.0;
+	bool (*stale_check)(Segment&) = nullptr; // set during open() on ranks > 0: has the name been given to another segment meanwhile?
 };
+// is the file behind s.fd still what s.name refers to?  (false: the name is gone -- rank 0 removes it after the first barrier -- or the same)
+inline bool name_moved_on(Segment& s)
+{
+	struct stat mine, now;
+	if (fstat(s.fd, &mine) != 0)
+		return false;
+	const std::string path = "/dev/shm" + s.name;
+	if (stat(path.c_str(), &now) != 0)
+		return false;
+	return now.st_ino != mine.st_ino || now.st_dev != mine.st_dev;
+}
 
 // sense-reversing barrier of all ranks; fails after the deadline instead of hanging
 inline dg_status barrier(Segment& s)
@@ -49,6 +63,8 @@ inline dg_status barrier(Segment& s)
 	if (s.nranks <= 1)
 		return DG_OK;
 	Header* h = s.hdr;
+	if (h->failed.load(std::memory_order_acquire) != 0u)
+		return fail(DG_ERR_HIP, "shared-memory barrier: an earlier barrier of this segment timed out (rank %d of %d): the segment is unusable", s.rank, s.nranks);
 	const uint32_t gen = h->generation.load(std::memory_order_acquire);
 	if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)s.nranks)
 	{
@@ -62,9 +78,16 @@ inline dg_status barrier(Segment& s)
 		if (spins < 2000)
 			continue;
 		(void)sched_yield();
+		if ((spins & 1023) == 0 && h->failed.load(std::memory_order_acquire) != 0u)
+			return fail(DG_ERR_HIP, "shared-memory barrier: another rank gave up on this segment (rank %d of %d)", s.rank, s.nranks);
+		if ((spins & 1023) == 0 && s.stale_check && s.stale_check(s))
+			return DG_ERR_INVALID; // (open(): the name now belongs to another segment -- the caller detaches and looks again)
 		if ((spins & 1023) == 0 && s.timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s.timeout_s)
+		{
+			h->failed.store(1u, std::memory_order_release); // (`arrived` stays incremented: nobody may trust the counters again)
 			return fail(DG_ERR_HIP, "shared-memory barrier: the other ranks did not arrive within %.0f s (rank %d of %d): is every rank running?", s.timeout_s,
 						s.rank, s.nranks);
+		}
 	}
 	return DG_OK;
 }
@@ -141,27 +164,56 @@ inline dg_status open(Segment& s, const char* name, size_t payload_bytes, uint32
 		s.hdr->payload_bytes = payload_bytes; // (fresh pages are zero: counters and user words start at 0)
 		s.hdr->nranks = (uint32_t)nranks;
 		s.hdr->kind = kind;
+		s.hdr->creator_pid = (int64_t)getpid();
 		s.hdr->magic.store(kMagic, std::memory_order_release);
 	}
 	else
 	{
-		while (s.hdr->magic.load(std::memory_order_acquire) != kMagic)
+		// A segment of this name that a crashed job left behind (rank 0 removes the name after the first barrier, so only a crash
+		// during set-up leaves one) must not be taken for ours: rank 0 unlinks and re-creates the name when it arrives, and an early
+		// rank that attached to the leftover would sit in a different segment until the deadline.  Three guards: the creator's
+		// process must be alive, no more ranks than the job has may have attached, and while this rank waits at the first barrier
+		// it keeps checking that the name still refers to the file it mapped; on any of them it detaches and looks again.
+		bool stale = false;
+		while (!stale && s.hdr->magic.load(std::memory_order_acquire) != kMagic)
 		{
 			if (expired())
 			{
 				close(s);
 				return fail(DG_ERR_HIP, "shared-memory segment %s was never initialised by rank 0", name);
 			}
+			stale = name_moved_on(s);
 			(void)usleep(1000);
 		}
-		if (s.hdr->payload_bytes != payload_bytes || s.hdr->nranks != (uint32_t)nranks || s.hdr->kind != kind)
+		stale = stale || s.hdr->failed.load(std::memory_order_acquire) != 0u || (s.hdr->creator_pid > 0 && kill((pid_t)s.hdr->creator_pid, 0) != 0 && errno == ESRCH) ||
+				s.hdr->attached.load(std::memory_order_acquire) >= (uint32_t)nranks;
+		if (!stale && (s.hdr->payload_bytes != payload_bytes || s.hdr->nranks != (uint32_t)nranks || s.hdr->kind != kind))
+		{
+			if (!name_moved_on(s))
+			{
+				close(s);
+				return fail(DG_ERR_INVALID, "shared-memory segment %s was created for another size, rank count or purpose", name);
+			}
+			stale = true;
+		}
+		if (stale)
 		{
 			close(s);
-			return fail(DG_ERR_INVALID, "shared-memory segment %s was created for another size, rank count or purpose", name);
+			if (expired())
+				return fail(DG_ERR_HIP, "shared-memory segment %s: only a leftover of an earlier job was found (rank %d of %d): is rank 0 running?", name, rank, nranks);
+			(void)usleep(5000);
+			return open(s, name, payload_bytes, kind, rank, nranks); // (the deadline starts again: a leftover is rare, a loop of them is not expected)
 		}
+		s.stale_check = name_moved_on;
 	}
 	s.hdr->attached.fetch_add(1, std::memory_order_acq_rel);
 	const dg_status bs = barrier(s);
+	s.stale_check = nullptr;
+	if (bs == DG_ERR_INVALID && rank != 0) // the name went to another segment while this rank waited in a leftover
+	{
+		close(s);
+		return open(s, name, payload_bytes, kind, rank, nranks);
+	}
 	if (rank == 0)
 		(void)shm_unlink(s.name.c_str());
 	if (bs != DG_OK)
