@@ -747,12 +747,8 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 	{
 		if (band_ready)
 			DG_HIP(hipStreamWaitEvent(st, band_ready, 0));
-		bool through_band = true, split = false;
-		const int split_mode = force_int("k2_band_split", 1, 0, 2); // (2: every batch on a band copy is split, whatever its size and the probe: tests)
-		const bool can_split = dev.cells == nullptr && dev.cell_map == nullptr && n < 0xffffffffull;
-		if (split_mode == 2 && can_split)
-			split = true;
-		else if (big)
+		bool through_band = true;
+		if (big)
 		{
 			if (field->band_probe_host == nullptr)
 			{
@@ -769,48 +765,8 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 			{
 				const uint32_t valid = reinterpret_cast<volatile uint32_t*>(field->band_probe_host)[0];
 				const uint32_t mapped = reinterpret_cast<volatile uint32_t*>(field->band_probe_host)[1];
-				// Round 6, lane by lane: a MIXED batch (10 % ... 90 % of its queries in the band) is answered in two parts within this call --
-				// the band kernel takes the queries whose cell has a row and hands the others, as tile keys, to the staged gather of the plain
-				// layout (sorted, from LDS) instead of gathering for them unsorted (0.35 ns each) or giving the whole batch away
-				// (DG_FORCE=k2_band_split=0: the batch-wise routing of round 5: band kernel from 75 % mapped, the plain path below it).
-				const bool may_split = split_mode != 0 && can_split;
-				if (band_mode == 2 || valid == 0u)
-					through_band = true;
-				else if (may_split)
-				{
-					through_band = 10ull * mapped >= 9ull * valid;
-					split = !through_band && 10ull * mapped >= 1ull * valid;
-				}
-				else
-					through_band = 4ull * mapped >= 3ull * valid;
+				through_band = band_mode == 2 || valid == 0u || 4ull * mapped >= 3ull * valid;
 				DG_HIP(dg::launch_band_probe(dev, d_xyz, n, field->band_probe_host, st));
-			}
-		}
-		if (split)
-		{
-			dg::TileBin B;
-			std::memset(&B, 0, sizeof(B));
-			const uint32_t key_bits = dg::stage_key_bits(dev.res, 0, B.tdims, B.tlog);
-			if (key_bits + 1 <= dg::kStageMaxBits && B.tdims[0] <= 1024u && B.tdims[1] <= 1024u && B.tdims[2] <= 1024u)
-			{
-				size_t off[8];
-				void* mem = nullptr;
-				const int idx = field->scratch.acquire(dg::tile_bin_bytes(1u << key_bits, n, off), st, &mem);
-				if (idx >= 0)
-				{
-					const dg::TileBin shape_of = B;
-					dg::tile_bin_assign(B, mem, off, key_bits, n);
-					B.shape = shape_of.shape;
-					B.flag_host = nullptr; // (this path's prediction is the band probe's)
-					B.sort_launched = 1;
-					B.keys_ready = 1;
-					hipError_t e = dg::launch_interpolate_band_split(dev, d_xyz, n, d_phi, d_grad, B, st);
-					if (e == hipSuccess)
-						e = dg::launch_interpolate_tiles(dev, d_xyz, n, d_phi, d_grad, B, (uint32_t)force_int("k2_tile_chunk", 64, 0, 4096), st);
-					field->scratch.release(idx, st);
-					DG_HIP(e);
-					return DG_OK;
-				}
 			}
 		}
 		if (through_band)

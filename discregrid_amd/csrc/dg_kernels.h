@@ -489,7 +489,6 @@ struct TileBin
 	uint32_t tlog[3];      // log2 of the cells per tile and axis
 	int shape;             // index into kStageLog
 	int sort_launched;
-	int keys_ready;        // 1: the keys were written by k_interpolate_band<..., SPLIT> (key_space = answered there): not recomputed
 };
 inline uint32_t stage_key_bits(const uint32_t res[3], int shape, uint32_t tdims[3], uint32_t tlog[3])
 {
@@ -514,7 +513,7 @@ inline size_t tile_bin_bytes(uint32_t key_space, uint64_t n, size_t off[8], bool
 	off[1] = take((size_t)n * 4);                       // keys
 	off[2] = take((size_t)n * 4);                       // keys_out
 	off[3] = take((size_t)n * 4);                       // perm
-	off[4] = take(((size_t)key_space + 1) * 8);         // begin, end (cleared together; one more entry each: split batches' "answered elsewhere" key)
+	off[4] = take((size_t)key_space * 8);               // begin, end (cleared together)
 	off[5] = take((size_t)stage_max_items(key_space, n) * sizeof(StageItem));
 	off[6] = take(bin_sort_tmp_bytes(n, key_space));
 	off[7] = take(packed_results ? (size_t)n * 32 : 0);
@@ -531,7 +530,7 @@ inline void tile_bin_assign(TileBin& B, void* mem, const size_t off[8], uint32_t
 	B.keys_out = reinterpret_cast<uint32_t*>(base + off[2]);
 	B.perm = reinterpret_cast<uint32_t*>(base + off[3]);
 	B.begin = reinterpret_cast<uint32_t*>(base + off[4]);
-	B.end = B.begin + key_space + 1;
+	B.end = B.begin + key_space;
 	B.items = reinterpret_cast<StageItem*>(base + off[5]);
 	B.sort_tmp = base + off[6];
 	B.packed = nullptr; // (the caller points it at off[7] for gradient batches)
@@ -636,9 +635,6 @@ inline void bin_scratch_assign(BinScratch& S, void* mem, const size_t off[6], ui
 }
 // K2 through the band-limited cell-major copy (FieldDev::band_rows / band_map) and the copy's builders
 hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, hipStream_t stream);
-// mixed batches: the band kernel answers the queries whose cell has a row (and those outside the domain) and writes every query's key into
-// B.keys; launch_interpolate_tiles with B.keys_ready = 1 then serves the rest
-hipError_t launch_interpolate_band_split(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, const TileBin& B, hipStream_t stream);
 // host_counts (pinned, 2 words): sampled queries with a cell / of those with a row in the band copy -- the routing prediction
 hipError_t launch_band_probe(const FieldDev& f, const double* d_xyz, uint64_t n, uint32_t* host_counts, hipStream_t stream);
 hipError_t launch_band_flags(const FieldDev& f, uint64_t n_rows, double lo, double hi, uint32_t* d_flag, hipStream_t stream);

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void k_tile_keys(const FieldDev F, const TileG
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n)
 		B.keys[i] = stage_key(F, B.tdims, B.tlog, xyz, i);
-	for (uint64_t j = i; j < 2ull * (B.key_space + 1u); j += (uint64_t)gridDim.x * blockDim.x)
-		B.begin[j] = 0u; // (begin and end are one array of key_space + 1 entries each: the last one is the "answered elsewhere" key of split batches)
+	for (uint64_t j = i; j < 2ull * B.key_space; j += (uint64_t)gridDim.x * blockDim.x)
+		B.begin[j] = 0u; // (begin and end are one array)
 	if (blockIdx.x == 0)
 	{
 		__shared__ uint32_t changes;
@@ -557,12 +557,9 @@ __device__ __forceinline__ BandQuery band_locate(const FieldDev& F, const double
 	b.row = b.q.valid ? band_row_of(F, b.q.row) : 0xffffffffu;
 	return b;
 }
-// SPLIT (round 6, mixed batches routed lane by lane): the lanes whose cell has no row do NOT gather here -- the kernel writes the tile key
-// of their query (TileBin: the staged gather k_interpolate_tiles then serves them, sorted, in the same call) and a key behind all tiles
-// for every query it answered itself (mapped, or outside the domain).
-template <bool GRAD, int MODE, bool SPLIT = false>
+template <bool GRAD, int MODE>
 __global__ __launch_bounds__(64) void k_interpolate_band(const FieldDev F, const double* __restrict__ xyz, uint64_t n,
-														   double* __restrict__ phi_out, double* __restrict__ grad_out, TileBin B = TileBin())
+														   double* __restrict__ phi_out, double* __restrict__ grad_out)
 {
 	__shared__ double rows[64 * kRowStride];
 	const int lane = (int)threadIdx.x;
@@ -606,24 +603,13 @@ __global__ __launch_bounds__(64) void k_interpolate_band(const FieldDev F, const
 			for (int j = 0; j < 32; ++j)
 				cf[j] = rows[lane * kRowStride + j];
 		}
-		else if (cur.q.valid && !SPLIT)
+		else if (cur.q.valid)
 			fetch_cell<MODE>(F, cur.q.mi[0], cur.q.mi[1], cur.q.mi[2], cur.q.row, cf);
 		double g[3] = {0.0, 0.0, 0.0};
 		double phi = 1.7976931348623157e308;
-		const bool later = SPLIT && cur.q.valid && !mapped; // (answered by the staged gather)
-		if (cur.q.valid && !later)
+		if (cur.q.valid)
 			phi = evaluate_cell<GRAD>(cf, cur.q.xi, cur.q.c0, g);
-		if (SPLIT && cur.have)
-		{
-			uint32_t key = B.key_space; // behind every tile
-			if (later)
-			{
-				const uint32_t t[3] = {cur.q.mi[0] >> B.tlog[0], cur.q.mi[1] >> B.tlog[1], cur.q.mi[2] >> B.tlog[2]};
-				key = tile_key(B.tdims, t);
-			}
-			B.keys[gid] = key;
-		}
-		if (cur.have && !later)
+		if (cur.have)
 		{
 			phi_out[gid] = phi;
 			if (GRAD)
@@ -811,17 +797,6 @@ hipError_t launch_interpolate_band(const FieldDev& f, const double* d_xyz, uint6
 #undef DG_K2_BAND
 	return hipGetLastError();
 }
-hipError_t launch_interpolate_band_split(const FieldDev& f, const double* d_xyz, uint64_t n, double* d_phi, double* d_grad, const TileBin& B, hipStream_t stream)
-{
-	if (n == 0)
-		return hipSuccess;
-	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 63) / 64, 256ull * 64ull);
-	if (d_grad)
-		hipLaunchKernelGGL((k_interpolate_band<true, kFieldClosed, true>), dim3(blocks), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad, B);
-	else
-		hipLaunchKernelGGL((k_interpolate_band<false, kFieldClosed, true>), dim3(blocks), dim3(64), 0, stream, f, d_xyz, n, d_phi, d_grad, B);
-	return hipGetLastError();
-}
 hipError_t launch_band_probe(const FieldDev& f, const double* d_xyz, uint64_t n, uint32_t* host_counts, hipStream_t stream)
 {
 	if (n == 0 || !host_counts)
@@ -904,16 +879,10 @@ hipError_t launch_interpolate_tiles(const FieldDev& f, const double* d_xyz, uint
 		return hipGetLastError();
 	}
 	const uint32_t per_query = (uint32_t)((n + 255) / 256);
-	hipError_t e = hipSuccess;
-	if (B.keys_ready == 0)
-		hipLaunchKernelGGL(k_tile_keys, dim3(per_query), dim3(256), 0, stream, f, field_tiles(f), d_xyz, n, B);
-	else // (split batch: k_interpolate_band<..., SPLIT> wrote the keys, with key_space for the queries it answered: one more key bit)
-		e = hipMemsetAsync(B.begin, 0, 2 * ((size_t)B.key_space + 1) * sizeof(uint32_t), stream);
-	if (e != hipSuccess)
-		return e;
+	hipLaunchKernelGGL(k_tile_keys, dim3(per_query), dim3(256), 0, stream, f, field_tiles(f), d_xyz, n, B);
 	size_t bytes = B.sort_tmp_bytes;
-	e = rocprim::radix_sort_pairs(B.sort_tmp, bytes, (const uint32_t*)B.keys, B.keys_out, rocprim::counting_iterator<uint32_t>(0u), B.perm, (size_t)n,
-								  0u, B.key_bits + (B.keys_ready ? 1u : 0u), stream);
+	hipError_t e = rocprim::radix_sort_pairs(B.sort_tmp, bytes, (const uint32_t*)B.keys, B.keys_out, rocprim::counting_iterator<uint32_t>(0u), B.perm, (size_t)n,
+											 0u, B.key_bits, stream);
 	if (e != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(k_tile_bounds, dim3(per_query), dim3(256), 0, stream, n, B);

@@ -239,15 +239,6 @@ def test_interpolate_vs_golden(dg, golden, name, monkeypatch):
         np.testing.assert_array_equal(grad4, grad)
         for m in (1, 63, 65, 1000):
             np.testing.assert_array_equal(f.interpolate(P[:m]), golden[name + "_phi"][:m])
-        # round 6, mixed batches lane by lane: the band kernel answers the queries whose cell has a row (and those outside the domain),
-        # the staged gather of the plain layout the others, in one call (forced here: a batch this small is never split by itself)
-        T.force(monkeypatch, k2_band_split=2)
-        phi5, grad5 = f.interpolate(P, grad=True)
-        np.testing.assert_array_equal(phi5, phi)
-        np.testing.assert_array_equal(grad5, grad)
-        for m in (1, 63, 65, 1000):
-            np.testing.assert_array_equal(f.interpolate(P[:m]), golden[name + "_phi"][:m])
-        T.force(monkeypatch, k2_band_split=None)
         f.drop_cell_major()
         assert f.info()["band_rows"] == 0
     assert rows == int(np.prod(res))            # (the last band holds every value: every cell has a row)
