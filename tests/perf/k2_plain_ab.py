@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--variants", default="k2_tiles=0|k2_tiles=1|k2_tile_chunk=0|k2_tile_chunk=16|k2_tile_chunk=256|k2_stage_min=0|k2_stage_min=100")
     ap.add_argument("--once", action="store_true", help="one call per variant and case, no timing loop (profiling runs)")
+    ap.add_argument("--band", action="store_true", help="build the band-limited cell-major copy (|phi| <= 2h + cell diagonal, h = 0.1) first: the variants then "
+                                                        "compare routings of a field WITH that copy (k2_band_split=0|1, k2_band=0)")
     args = ap.parse_args()
     import torch
     import dgtest as T
@@ -54,6 +56,11 @@ def main():
     del C, phic
     phi = torch.empty(nq, dtype=torch.float64, device="cuda")
     grad = torch.empty(3 * nq, dtype=torch.float64, device="cuda")
+    if args.band:
+        diag = float(np.linalg.norm((dom[3:] - dom[:3]) / np.array(res, dtype=np.float64)))
+        rows = fld.build_cell_major_band(-(0.2 + diag), 0.2 + diag, s)
+        torch.cuda.synchronize()
+        print(json.dumps({"band_rows": rows, "fraction_of_cells": rows / float(np.prod(res))}), flush=True)
     variants = [v for v in args.variants.split("|") if v]
     cases = [("uniform", P, False), ("uniform", P, True), ("shell", S, False), ("shell", S, True)]
     base = os.environ.get("DG_FORCE")
@@ -68,6 +75,8 @@ def main():
                 fn = (lambda: fld.interpolate_device(Q.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
                 phi.fill_(float("nan"))
                 fn()
+                torch.cuda.synchronize()
+                fn()                      # (routing probes: the verdict of the previous batch routes the next)
                 torch.cuda.synchronize()
                 if rnd == 0:
                     got = (phi.clone(), grad.clone() if g else None)
