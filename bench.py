@@ -232,7 +232,8 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
             k2["%s_%s" % (name, "grad" if g else "value")] = {
                 "gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms, "algorithmic_gbs": nq * bytes_q / (ms * 1e-3) / 1e9,
                 "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    k2["what"] = "10 M queries (std::mt19937_64 seed 1234 uniform; |phi| < 2h shell, h = 0.1) on the 256^3 field, device-resident, unordered input incl. the on-device binning"
+    k2["what"] = ("10 M queries (std::mt19937_64 seed 1234 uniform; |phi| < 2h shell, h = 0.1) on the 256^3 field, device-resident, unordered input incl. "
+                  "the on-device sort by tile of 8^3 cells and the LDS-staged gather (k_interpolate_tiles, round 6)")
     # the same with the optional tile-major copy of the field (dg_field_build_tile_major: 1.5 GB, built once per field)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -375,6 +376,14 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
                 "256 B of row + 24 B of point + 8 B of result are the algorithmic 288 B; on top come the look-up's bit and rank words (two "
                 "loads per query from 3 MB of tables that do not all stay in L2 beside 2.9 GB of streaming rows: ~64 B of sector traffic per "
                 "query) and the sectors of rows that straddle two 128-byte lines as seen by their four 64-byte quarter fetches"}
+    k2p = ((counters or {}).get("workloads", {}).get("k2") or {})
+    k2t = next((v for k, v in k2p.items() if k.startswith("k_interpolate_tiles<false")), None)
+    k2["roofline_tiles_kernel"] = None if k2t is None else {
+        "bound": "latency of a block's load chain (item -> query index -> point, rows; 4 blocks per CU by the 37 KB LDS image)", "achieved": k2t["hbm_gbs"],
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k2t["hbm_frac"], "traffic": k2t["hbm_bytes_per_launch"], "algorithmic_bytes": 288 * nq,
+        "valu_busy": k2t.get("valu_busy"), "l2_hit_rate": k2t.get("l2_hit_rate"), "kernel_ms_when_profiled": k2t["kernel_ms"], "replayed": True,
+        "what": "k_interpolate_tiles (round 6), 10 M uniform queries (value), plain layout: the staged gather alone, behind keys + two radix passes + "
+                "bounds + items (0.30 ms).  traffic < algorithmic_bytes: a tile's rows are fetched once for all its queries"}
     k2c = ((counters or {}).get("workloads", {}).get("k2r") or {})
     k2k = next((v for k, v in k2c.items() if k.startswith("k_interpolate_rows<false")), None)
     k2["roofline_rows_kernel"] = None if k2k is None else {
@@ -457,7 +466,10 @@ def user_facing_scalars(out):
         "k2_rows_frac": get(k2, "uniform_value_cell_major", "hbm_frac_algorithmic"),   # 10 M uniform queries, cell-major copy: 288 B / query / 8 TB/s
         "k2_band_frac": get(k2, "shell_value_band_copy", "hbm_frac_algorithmic"),      # 10 M shell queries, band-limited copy
         "k2_band_uniform_gq_s": get(k2, "uniform_value_band_copy", "gq_s"),            # ... and uniform queries through the same copy (43 % miss the band)
-        "k2_plain_frac": get(k2, "uniform_value", "hbm_frac_algorithmic"),             # plain layout incl. the on-device binning
+        "k2_plain_frac": get(k2, "uniform_value", "hbm_frac_algorithmic"),             # plain layout incl. the on-device sort (round 6: by tile + staged gather)
+        "k2_plain_gq_s": get(k2, "uniform_value", "gq_s"), "k2_plain_grad_gq_s": get(k2, "uniform_grad", "gq_s"),
+        "k2_plain_shell_gq_s": get(k2, "shell_value", "gq_s"),
+        "k2_tiles_kernel_hbm_frac": get(k2, "roofline_tiles_kernel", "frac"),
         "k3_seconds": get(k3, "seconds"),                                              # density map of the 256^3 SDF, whole lattice
         "k3_td_busy": get(k3, "roofline", "td_busy"),
         "k3_traffic_over_compulsory": (traffic / compulsory) if traffic and compulsory else None,
