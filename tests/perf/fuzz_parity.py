@@ -76,6 +76,19 @@ def main():
         same_field = np.array_equal(got, want)
         if same_field:
             ok = ok and np.array_equal(phi, wphi) and np.array_equal(grad[inside], wgrad[inside])
+        # K2 through the staged gather of the plain layout (round 6: sort by tile of 8^3 cells, tile image in LDS), forced for this small
+        # batch, with and without the XCD-aware item order; and through the radix-sorted per-lane gather of rounds 1-5: the same bits
+        if rounds % 2 == 0:
+            for force in (dict(k2_binning=2, k2_tiles=2), dict(k2_binning=2, k2_tiles=2, k2_tile_chunk=int(rng.integers(0, 5))), dict(k2_binning=2, k2_tiles=0)):
+                os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), **force)
+                phi_t, grad_t = f.interpolate(Q, grad=True)
+                ok = ok and np.array_equal(phi_t, phi) and np.array_equal(grad_t, grad) and np.array_equal(f.interpolate(Q), phi)
+                os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), **{k: None for k in force})
+        # K1 through the FILTERED kernel whatever the mesh's size, its epilogue's pool capped at random (round 6): the same lattice
+        if rounds % 5 == 0:
+            os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), k1_fast=1, pool_cap=int(rng.integers(0, 400)))
+            ok = ok and np.array_equal(m.sample_nodes(grid), got)
+            os.environ["DG_FORCE"] = T.force_string(os.environ.get("DG_FORCE"), k1_fast=None, pool_cap=None)
         # K2 through a band-limited cell-major copy with a random band (round 4): the same bits
         if rounds % 3 == 0:
             fin = got[np.isfinite(got) & (got != np.finfo(np.float64).max)]
