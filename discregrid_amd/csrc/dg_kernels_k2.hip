@@ -315,8 +315,14 @@ struct StageClass
 			b = b < nb ? b : nb - 1u;
 			uint64_t e = first + ((uint64_t)a * sa + (uint64_t)b * sb + 2u * piece);
 			e = e < last ? e : last;
+#if DG_K2_ABLATE & 2
+			v0[s] = v1[s] = 0.0;
+			(void)coeffs;
+			(void)e;
+#else
 			v0[s] = coeffs[e];
 			v1[s] = coeffs[e + 1];
+#endif
 		}
 	}
 	__device__ __forceinline__ void store(double* __restrict__ lds) const
@@ -344,6 +350,12 @@ struct StageClass
 // the query chains prefetched, three waves: 0.82 ms; this form: 0.55-0.65 ms.  What the pipelining gains in hidden latency it loses in
 // occupancy: the evaluation is f64 dependency chains and LDS round trips that want four waves per SIMD.  The shapes 8 x 8 x 4 and
 // 8 x 4 x 4 -- half and a quarter of the LDS image, twice and four times the blocks -- measured 1.00 and 0.84 of this one's rate.)
+// (measurement builds only, tools/gpu_k2_ablate.sh: -DDG_K2_ABLATE=<bits> removes one phase at a time -- 1: the query points come from
+// the tile's own cells instead of xyz[perm[q]]; 2: no row loads (the LDS image holds zeros); 4: no evaluation; 8: results stored in tile
+// order instead of scattered in query order.  Results are then wrong; the product is built without it.)
+#ifndef DG_K2_ABLATE
+#define DG_K2_ABLATE 0
+#endif
 template <bool GRAD, int LX, int LY, int LZ>
 __global__ __launch_bounds__((StageShape<LX, LY, LZ>::NT), GRAD ? 3 : 4)
 void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, double* __restrict__ phi_out, double* __restrict__ grad_out, TileBin B,
@@ -380,9 +392,15 @@ void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, doubl
 		cz.load(F.coeffs, nv + 2 * nex + 2 * ney + 2 * ((uint64_t)nz * (nx + 1) * j0 + (uint64_t)nz * i0 + k0), last, 2 * nz, 2 * nz * (nx + 1), ex + 1, ey + 1);
 		if (q < it.q1)
 		{
+#if DG_K2_ABLATE & 1
+			x[0] = F.dmin[0] + ((double)i0 + 0.37 + (double)(q % TX)) * F.cell[0];
+			x[1] = F.dmin[1] + ((double)j0 + 0.21 + (double)((q / TX) % TY)) * F.cell[1];
+			x[2] = F.dmin[2] + ((double)k0 + 0.63 + (double)((q / (TX * TY)) % TZ)) * F.cell[2];
+#else
 			x[0] = xyz[3 * (uint64_t)gid];
 			x[1] = xyz[3 * (uint64_t)gid + 1];
 			x[2] = xyz[3 * (uint64_t)gid + 2];
+#endif
 		}
 		cv.store(tile + S::kV);
 		cx.store(tile + S::kX);
@@ -420,8 +438,17 @@ void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, doubl
 			const double* Z = tile + S::kZ + lj * zj + li * zi + 2u * lk; // z edges at (j, i), (j + 1, i), (j, i + 1), (j + 1, i + 1)
 			cf[24] = Z[0]; cf[25] = Z[1]; cf[26] = Z[zj]; cf[27] = Z[zj + 1];
 			cf[28] = Z[zi]; cf[29] = Z[zi + 1]; cf[30] = Z[zj + zi]; cf[31] = Z[zj + zi + 1];
+#if DG_K2_ABLATE & 4
+			phi = cq.xi[0] + cq.xi[1] + cq.xi[2];
+			for (int m = 0; m < 32; ++m)
+				phi += cf[m];
+#else
 			phi = evaluate_cell<GRAD>(cf, cq.xi, cq.c0, g);
+#endif
 		}
+#if DG_K2_ABLATE & 8
+		gid = q; // (tile order: coalesced)
+#endif
 		if (GRAD && packed != nullptr)
 		{
 			// value and gradient as ONE aligned 32-byte store into the query's slot of a scratch array (k_unpack_results splits it into the
@@ -447,9 +474,13 @@ void k_interpolate_tiles(const FieldDev F, const double* __restrict__ xyz, doubl
 		if (q + NT < it.q1)
 		{
 			gid = B.perm[q + NT];
+#if !(DG_K2_ABLATE & 1)
 			x[0] = xyz[3 * (uint64_t)gid];
 			x[1] = xyz[3 * (uint64_t)gid + 1];
 			x[2] = xyz[3 * (uint64_t)gid + 2];
+#else
+			x[0] += 0.03 * F.cell[0];
+#endif
 		}
 	}
 }
