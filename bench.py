@@ -833,6 +833,8 @@ def main():
 
     def prepare(form):
         """what a form needs before its first step (collective: every rank gets here for every candidate)"""
+        if os.environ.get("DG_BENCH_FAIL_FORM") == form:    # (tests: a form that cannot come up, e.g. RCCL that does not initialise)
+            raise RuntimeError("simulated failure of form %s before its first step" % form)
         if form == "host":
             if hostf[0] is None:
                 name = [None]
@@ -1143,7 +1145,7 @@ def main():
             failed = ctl_max(failed)     # (a form that failed on any rank is out on all of them)
             early = ctl_max(early)
         dog.disarm()
-        if failed and early and cand in RCCL_FORMS and not selftest:
+        if failed and early and cand in RCCL_FORMS and (not selftest or os.environ.get("DG_BENCH_FAIL_FORM")):
             rccl_out = (cand, note or "failed on another rank")
         if failed:
             errors[cand] = note or "failed on another rank"

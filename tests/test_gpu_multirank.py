@@ -342,3 +342,31 @@ def test_scale_preflight_on_one_gpu(world):
     for step in ("devices", "gloo", "shm", "vmm", "host"):
         assert len(re.findall(r"preflight\[rank \d/%d\] %s: ok \(" % (world, step), out.stderr)) == world, (step, out.stderr[-4000:])
     assert out.stderr.count("rccl: skipped") == world and out.stderr.count("every form can run") == world
+
+
+def test_race_does_not_retry_rccl_after_it_failed_to_come_up():
+    """The first RCCL form that fails BEFORE its first step completes takes the other RCCL forms out of the race (they would fail the same
+    way, each after its own time-out on a real node); the forms that need no RCCL are measured and one of them is reported."""
+    env = dict(_plain_env(), DG_BENCH_FAIL_FORM="slabs")
+    out = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--pieces", "2", "--no-preflight"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    ex = rec["config"]["exchange"]
+    assert set(ex["ms_by_form"]) == {"host", "copy-shm"} and ex["chosen"] in ("host", "copy-shm"), ex
+    assert "simulated failure" in ex["errors"]["slabs"]
+    for form in ("inplace", "inplace-p2p", "copy"):
+        assert ex["errors"][form].startswith("not run: RCCL did not come up for form slabs"), ex["errors"]
+    assert rec["roofline"]["exchange_error_slabs"].startswith("RuntimeError") and "exchange_ms_host" in rec["roofline"]
+
+
+def test_eight_ranks_strong_scaling_on_one_gpu():
+    """The 8-rank code paths (cuts for 8 x pieces virtual ranks, 7 peers per rank in the copy form, eight processes at the shared-memory
+    barriers) with real kernels on the one GPU: the metric's own 256^3 lattice shared by eight processes, the two forms that run with
+    real library paths on the rig; every rank asserts field == direct launch."""
+    out = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--pieces", "2", "--scaling", "strong",
+                          "--exchange", "copy-shm", "--form-timeout", "300"], capture_output=True, text=True, timeout=900, env=_plain_env())
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["value"] > 0 and len(rec["config"]["exchange"]["per_rank"]["sample_ms"]) == 8
+    assert out.stderr.count("vmm: ok") == 8 and out.stderr.count("host: ok") == 8
