@@ -18,10 +18,19 @@ def lib():
         so = os.path.join(HERE, "libwave_emu.so")
         csrc = os.path.join(T.ROOT, "discregrid_amd", "csrc")
         deps = [os.path.join(HERE, "wave_emu.cpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
-        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
-                                   "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                                   os.path.join(HERE, "wave_emu.cpp"), os.path.join(csrc, "dg_build.cpp"), "-o", so])
+        def stale():
+            return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+        if stale():
+            # (pytest -n: several workers arrive here at once; one builds -- into a temporary name, renamed when complete -- the others wait)
+            import fcntl
+            with open(so + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if stale():
+                    tmp = so + ".%d.tmp" % os.getpid()
+                    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+                                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                                           os.path.join(HERE, "wave_emu.cpp"), os.path.join(csrc, "dg_build.cpp"), "-o", tmp])
+                    os.replace(tmp, so)
         L = C.CDLL(so)
         L.emu_mesh_create.restype = C.c_void_p
         L.emu_mesh_create.argtypes = [T.c_dp, C.c_size_t, T.c_up, C.c_size_t, C.c_int]
