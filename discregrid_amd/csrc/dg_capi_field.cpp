@@ -790,7 +790,8 @@ dg_status dg_interpolate_batch_device(const dg_field* field, const double* d_xyz
 		B.shape = 0;
 		const uint32_t key_bits = dg::stage_key_bits(dev.res, B.shape, B.tdims, B.tlog);
 		// (k2_tiles=2: whatever the batch's size)
-		const bool dense = n >= (uint64_t)dg::kStageMinPerTile * B.tdims[0] * B.tdims[1] * B.tdims[2] || force_int("k2_tiles", 1, 0, 2) == 2;
+		const bool dense = n >= (uint64_t)(d_grad ? dg::kStageMinPerTileGrad : dg::kStageMinPerTile) * B.tdims[0] * B.tdims[1] * B.tdims[2] ||
+						   force_int("k2_tiles", 1, 0, 2) == 2;
 		if (dense && key_bits <= dg::kStageMaxBits && B.tdims[0] <= 1024u && B.tdims[1] <= 1024u && B.tdims[2] <= 1024u)
 		{
 			if (field->bin_flag_host == nullptr)

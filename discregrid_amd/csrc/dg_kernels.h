@@ -457,7 +457,10 @@ DG_HD void tile_from_key(const uint32_t dims[3], uint32_t key, uint32_t t[3])
 // neighbour tile).  Batches too thin for staging to pay (fewer than kStageMinPerTile queries per tile on average) keep the
 // per-lane gather behind the radix sort by cell.
 static const uint32_t kStageChunk = 1024;   // queries per work item (a tile with more gets several items)
-static const uint32_t kStageMinPerTile = 24; // batches with fewer queries per tile on average take the per-lane gather behind the radix sort by cell
+// batches with fewer queries per tile on average take the per-lane gather behind the radix sort by cell.  Measured at 512^3 (262 144 tiles,
+// profiles/r06_k2_tile_density.txt; ms staged / per lane): 38 queries per tile 3.18 / 2.80 (value), 3.27 / 3.24 (gradient); 114 per tile
+// 4.77 / 5.07, 5.08 / 6.40; at 256^3 (305 per tile) 0.91 / 1.17; at 128^3 (2 441) 0.72 / 0.86
+static const uint32_t kStageMinPerTile = 64, kStageMinPerTileGrad = 32;
 static const uint32_t kStageMaxBits = 21;      // tile tables up to 2 M entries (16 MB); beyond: the per-lane path
 // the tile shape (cells per axis as powers of two) the gather is instantiated for
 static const int kStageShapes = 1;
