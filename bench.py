@@ -622,7 +622,7 @@ def main():
                          "strong = the metric's own 256^3 lattice at every N (1.8 ms of kernel per GPU at N = 8: launch, barrier and "
                          "exchange latency decide)")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip tools/scale_preflight.py (run by default before the race, stderr only)")
-    ap.add_argument("--preflight-timeout", type=int, default=90, help="N > 1: seconds the preflight child may take before it is killed")
+    ap.add_argument("--preflight-timeout", type=int, default=150, help="N > 1: seconds the preflight child may take before it is killed")
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="ceiling of the cpu_baseline leg, which samples 40 %% of the lattice (about 30 s on 256 cores; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed K1 steps (profiling runs)")
     ap.add_argument("--pieces", type=int, default=4,
@@ -1115,9 +1115,10 @@ def main():
     if sharded and world > 1 and not args.no_preflight:
         # tools/scale_preflight.py: which building blocks (shared memory, chunk export / import / peer copy, RCCL) work on this box;
         # a failing step removes only the forms that need it
-        dog.arm("the preflight")
+        pre_dog = Watchdog(args.preflight_timeout + 60, rank, state)   # (the children are killed after --preflight-timeout by themselves)
+        pre_dog.arm("the preflight")
         removed, preflight = run_preflight(dist, rank, world, args.preflight_timeout)
-        dog.disarm()
+        pre_dog.disarm()
         if len(candidates) > 1 and all(c in removed for c in candidates):
             removed = {}          # (nothing would be left: the preflight is then the suspect; race them all)
         preflight_summary[0] = {"rank0_steps": {k: (v.get("ok") if isinstance(v, dict) and "ok" in v else v) for k, v in (preflight or {}).items()},

@@ -75,7 +75,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    os.environ.setdefault("DG_COMM_TIMEOUT_S", "20")      # (the library's own barriers give up after this)
+    os.environ.setdefault("DG_COMM_TIMEOUT_S", "60")      # (the library's own set-up steps and barriers give up after this: RCCL's first
+                                                          #  initialisation on eight GPUs can take tens of seconds)
     results = {}
     who = "preflight[rank %d/%d]" % (rank, world)
 
