@@ -35,7 +35,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 STEPS = ["devices", "gloo", "shm", "vmm", "rccl", "host"]
 # exchange forms of bench.py that cannot work without the step
@@ -108,7 +107,6 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    import dgtest as T
     import discregrid_amd as dg
 
     state = {}
@@ -145,7 +143,9 @@ def main():
         """the small problem every data step runs: a cube's SDF on a 48 x 40 x 44 lattice (0.6 M nodes; enough planes for slabs of four on
         eight ranks), and the direct launch it must equal"""
         if "mesh" not in state:
-            V, F = T.box_mesh()
+            V = np.array([[1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, -1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1], [-1, 1, -1]], dtype=np.float64)
+            F = np.array([[2, 3, 4], [8, 7, 6], [5, 6, 2], [6, 7, 3], [3, 7, 8], [1, 4, 8], [1, 2, 4], [5, 8, 6], [1, 5, 2], [2, 6, 3], [4, 3, 8], [5, 1, 8]],
+                         dtype=np.uint32) - 1    # (a cube: the product is all this tool uses, no test helper, no checker)
             dom = dg.default_domain(V)
             state["grid"] = dg.grid_desc(dom[:3], dom[3:], [48, 40, 44])
             state["n"] = dg.n_nodes(state["grid"])
