@@ -647,6 +647,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         grid_for(args.gpus)                       # (a bad --gpus fails here, not N times)
+        if os.environ.get("DG_BENCH_DRY_RANKS") != "1":
+            import torch
+            have = torch.cuda.device_count()
+            if have < (1 if os.environ.get("DG_BENCH_SELFTEST_ONE_GPU") == "1" else args.gpus):
+                raise SystemExit("bench.py: --gpus %d but %d HIP device(s) visible (the product has no CPU path; DG_BENCH_SELFTEST_ONE_GPU=1 runs "
+                                 "the N > 1 protocol with every rank on device 0)" % (args.gpus, have))
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
@@ -666,6 +672,8 @@ def main():
     import dgtest as T
     import discregrid_amd as dg
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device visible -- the product has no CPU path (tests/ -m 'not gpu' is what runs without one)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
