@@ -308,6 +308,25 @@ def extras(torch, dg, T, mesh, grid, field, V, F, dom, res, kernel_ms):
         k2["uniform_sorted_%s" % ("grad" if g else "value")] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms,
                                                                 "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     del Ps
+    # ... and in z-order of their cells (what SPlisHSPlasH's z-sort hands over): lanes side by side sit in neighbouring cells in all three directions
+    cell = ((P - torch.tensor(dom[:3], device="cuda")) / h3).floor().clamp(0, res[0] - 1).long()
+    z = torch.zeros(nq, dtype=torch.long, device="cuda")
+    for b in range(10):
+        for d in range(3):
+            z |= ((cell[:, d] >> b) & 1) << (3 * b + d)
+    Pz = P[torch.argsort(z)].contiguous()
+    del cell, z
+    for g in (False, True):
+        fn = (lambda g=g: fld.interpolate_device(Pz.data_ptr(), nq, phi.data_ptr(), grad.data_ptr() if g else 0, stream=s))
+        fn()
+        torch.cuda.synchronize()
+        fn()
+        torch.cuda.synchronize()
+        ms = timed(torch, stream, fn, 5)
+        bytes_q = 312 if g else 288
+        k2["uniform_zorder_%s" % ("grad" if g else "value")] = {"gq_s": nq / (ms * 1e-3) / 1e9, "ms": ms,
+                                                                "hbm_frac_algorithmic": nq * bytes_q / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del Pz
     out_secondary = {"k2_interpolate": k2}
     del P, S, phi, grad
     # -- K1 on the other judged lattices (BASELINE configs[1] and the lattice of configs[3] on ONE GPU), device-resident
@@ -469,6 +488,7 @@ def user_facing_scalars(out):
         "k2_plain_frac": get(k2, "uniform_value", "hbm_frac_algorithmic"),             # plain layout incl. the on-device sort (round 6: by tile + staged gather)
         "k2_plain_gq_s": get(k2, "uniform_value", "gq_s"), "k2_plain_grad_gq_s": get(k2, "uniform_grad", "gq_s"),
         "k2_plain_shell_gq_s": get(k2, "shell_value", "gq_s"),
+        "k2_plain_zorder_gq_s": get(k2, "uniform_zorder_value", "gq_s"),                # plain layout, queries in z-order of their cells (sorted particles)
         "k2_tiles_kernel_hbm_frac": get(k2, "roofline_tiles_kernel", "frac"),
         "k3_seconds": get(k3, "seconds"),                                              # density map of the 256^3 SDF, whole lattice
         "k3_td_busy": get(k3, "roofline", "td_busy"),

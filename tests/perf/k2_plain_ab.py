@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--variants", default="k2_tiles=0|k2_tiles=1|k2_tile_chunk=0|k2_tile_chunk=16|k2_tile_chunk=256|k2_stage_min=0|k2_stage_min=100")
     ap.add_argument("--once", action="store_true", help="one call per variant and case, no timing loop (profiling runs)")
+    ap.add_argument("--ordered", action="store_true", help="ordered batches instead: the uniform queries in z-order and in row order of their cells")
     ap.add_argument("--band", action="store_true", help="build the band-limited cell-major copy (|phi| <= 2h + cell diagonal, h = 0.1) first: the variants then "
                                                         "compare routings of a field WITH that copy (k2_band_split=0|1, k2_band=0)")
     args = ap.parse_args()
@@ -63,6 +64,19 @@ def main():
         print(json.dumps({"band_rows": rows, "fraction_of_cells": rows / float(np.prod(res))}), flush=True)
     variants = [v for v in args.variants.split("|") if v]
     cases = [("uniform", P, False), ("uniform", P, True), ("shell", S, False), ("shell", S, True)]
+    if args.ordered:
+        # the same uniform queries as a caller with spatially sorted particles hands them over: in z-order of their cells (SPlisHSPlasH's sort) and in
+        # row order of their cells
+        h3 = torch.tensor((dom[3:] - dom[:3]) / np.array(res, dtype=np.float64), device="cuda")
+        cell = ((P - torch.tensor(dom[:3], device="cuda")) / h3).floor().clamp(0, res[0] - 1).long()
+        z = torch.zeros(nq, dtype=torch.long, device="cuda")
+        for b in range(10):
+            for d in range(3):
+                z |= ((cell[:, d] >> b) & 1) << (3 * b + d)
+        Pz = P[torch.argsort(z)].contiguous()
+        Pr = P[torch.argsort((cell[:, 2] * res[1] + cell[:, 1]) * res[0] + cell[:, 0])].contiguous()
+        del cell, z
+        cases = [("zorder", Pz, False), ("zorder", Pz, True), ("rows", Pr, False), ("rows", Pr, True), ("uniform", P, False)]
     base = os.environ.get("DG_FORCE")
     times = {v: {"%s_%s" % (c[0], "grad" if c[2] else "value"): [] for c in cases} for v in variants}
     ref = {}

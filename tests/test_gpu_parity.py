@@ -356,6 +356,26 @@ def test_interpolate_staged_tiles_path(dg, monkeypatch, res):
             np.testing.assert_array_equal(grad, want[1], err_msg=str(force))
             np.testing.assert_array_equal(f.interpolate(P), want[0], err_msg=str(force))
         T.force(monkeypatch, **{k: None for k in force})
+    # ORDERED batches through the same paths -- queries in z-order of their cells (as an SPH code's spatially sorted particles arrive), in row
+    # order of their cells, and half ordered, half not: the device-side "is this batch ordered?" verdict of one call routes the next
+    cell = np.clip(np.floor((np.clip(P, lo, hi) - lo) / cells), 0, np.array(res) - 1).astype(np.int64)
+    zkey = np.zeros(len(P), dtype=np.int64)
+    for b in range(10):
+        for d in range(3):
+            zkey |= ((cell[:, d] >> b) & 1) << (3 * b + d)
+    rowkey = (cell[:, 2] * res[1] + cell[:, 1]) * res[0] + cell[:, 0]
+    orders = {"z-order": np.argsort(zkey, kind="stable"), "rows": np.argsort(rowkey, kind="stable"), "random": np.arange(len(P))}
+    orders["half"] = np.concatenate([orders["z-order"][: len(P) // 2], orders["random"][len(P) // 2:]])
+    T.force(monkeypatch, k2_binning=2, k2_tiles=2)
+    for name, o in orders.items():
+        Q = np.ascontiguousarray(P[o])
+        phi, grad = f.interpolate(Q, grad=True)
+        np.testing.assert_array_equal(phi, want[0][o], err_msg=name)
+        np.testing.assert_array_equal(grad, want[1][o], err_msg=name)
+        np.testing.assert_array_equal(f.interpolate(Q), want[0][o], err_msg=name)
+        for m in (1, 255, 257, 2049):
+            np.testing.assert_array_equal(f.interpolate(Q[:m]), want[0][o][:m], err_msg=name)
+    T.force(monkeypatch, k2_binning=None, k2_tiles=None)
     f.close()
 
 
