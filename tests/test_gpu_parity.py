@@ -358,7 +358,7 @@ def test_interpolate_staged_tiles_path(dg, monkeypatch, res):
         T.force(monkeypatch, **{k: None for k in force})
     # ORDERED batches through the same paths -- queries in z-order of their cells (as an SPH code's spatially sorted particles arrive), in row
     # order of their cells, and half ordered, half not: the device-side "is this batch ordered?" verdict of one call routes the next
-    cell = np.clip(np.floor((np.clip(P, lo, hi) - lo) / cells), 0, np.array(res) - 1).astype(np.int64)
+    cell = np.clip(np.floor((np.clip(np.nan_to_num(P), lo, hi) - lo) / cells), 0, np.array(res) - 1).astype(np.int64)   # (the NaN queries: anywhere)
     zkey = np.zeros(len(P), dtype=np.int64)
     for b in range(10):
         for d in range(3):
