@@ -105,14 +105,15 @@ inline void close(Segment& s)
 // Collective over the ranks: rank 0 creates "/name" with `payload_bytes` behind the header page, the others wait for it to
 // appear at its full size and to be initialised; everybody maps it, meets at the barrier, and rank 0 removes the name (the memory
 // lives until the last rank unmaps it).  `name` must be unique to the job.
-inline dg_status open(Segment& s, const char* name, size_t payload_bytes, uint32_t kind, int rank, int nranks)
+inline dg_status open(Segment& s, const char* name, size_t payload_bytes, uint32_t kind, int rank, int nranks,
+					  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now())
 {
 	s.name = name[0] == '/' ? std::string(name) : "/" + std::string(name);
 	s.rank = rank;
 	s.nranks = nranks;
 	s.timeout_s = (double)env_int("DG_COMM_TIMEOUT_S", 180, 0, 86400);
 	s.map_bytes = kHeaderBytes + payload_bytes;
-	const auto t0 = std::chrono::steady_clock::now();
+	// (t0: when the caller's attempt began -- a rank that detaches from a leftover and looks again keeps ITS deadline)
 	auto expired = [&]() { return s.timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s.timeout_s; };
 	if (rank == 0)
 	{
@@ -202,7 +203,7 @@ inline dg_status open(Segment& s, const char* name, size_t payload_bytes, uint32
 			if (expired())
 				return fail(DG_ERR_HIP, "shared-memory segment %s: only a leftover of an earlier job was found (rank %d of %d): is rank 0 running?", name, rank, nranks);
 			(void)usleep(5000);
-			return open(s, name, payload_bytes, kind, rank, nranks); // (the deadline starts again: a leftover is rare, a loop of them is not expected)
+			return open(s, name, payload_bytes, kind, rank, nranks, t0);
 		}
 		s.stale_check = name_moved_on;
 	}
@@ -212,7 +213,7 @@ inline dg_status open(Segment& s, const char* name, size_t payload_bytes, uint32
 	if (bs == DG_ERR_INVALID && rank != 0) // the name went to another segment while this rank waited in a leftover
 	{
 		close(s);
-		return open(s, name, payload_bytes, kind, rank, nranks);
+		return open(s, name, payload_bytes, kind, rank, nranks, t0);
 	}
 	if (rank == 0)
 		(void)shm_unlink(s.name.c_str());

@@ -138,3 +138,29 @@ def test_descriptor_server_serves_the_peers_and_nobody_else():
     rec = json.loads(subprocess.check_output([exe], timeout=60).decode())
     assert rec == {"started": True, "name_taken": True, "tokens_differ": True, "stranger_got_nothing": True, "peer_exit": 0,
                    "peer_wrote": "through the served descriptor", "bytes": 30}, rec
+
+
+def test_a_leftover_segment_without_a_creator_fails_after_the_deadline():
+    """... and if rank 0 never comes, a rank that keeps finding the leftover gives up when ITS deadline has passed (it used to start a new
+    deadline with every look)."""
+    name = "dg_test_stale2_%d_%d" % (os.getpid(), int(time.time() * 1e6) % 1000000007)
+    path = _leftover(name, 3000, 2, 1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    old = os.environ.get("DG_COMM_TIMEOUT_S")
+    os.environ["DG_COMM_TIMEOUT_S"] = "2"
+    try:
+        t0 = time.time()
+        p = ctx.Process(target=_rank, args=(1, 2, name, 3000, 1, q))
+        p.start()
+        out = q.get(timeout=60)
+        p.join(30)
+        assert time.time() - t0 < 30
+    finally:
+        if old is None:
+            os.environ.pop("DG_COMM_TIMEOUT_S", None)
+        else:
+            os.environ["DG_COMM_TIMEOUT_S"] = old
+        if os.path.exists(path):
+            os.unlink(path)
+    assert out[1] is False and "leftover" in out[2], out
