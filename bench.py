@@ -1053,7 +1053,9 @@ def main():
         form, elapsed, kernel_ms = r["form"], r["elapsed"], r["kernel_ms"]
         balg = load_balg()
         counters, counters_note = load_counters()
-        k1 = (counters or {}).get("k1") if world == 1 else None
+        # (the counters are of the N = 1 launch -- 118.4 M nodes of the 256^3 lattice; at N > 1 with weak scaling every GPU runs the same kernel
+        # over as many nodes of a finer lattice: the replayed utilisation figures are reported there too and `counters_of` says what they are)
+        k1 = (counters or {}).get("k1")
         rccl_nranks = comm.info()["rccl_nranks"] if (comm is not None and form not in (None, "host", "copy-shm")) else None
         return {
             "metric": "Mnodes/s SDF sampling (256³ grid, 100k-tri mesh) + % HBM roofline, 1/2/4/8 GPU",
@@ -1102,6 +1104,7 @@ def main():
                 # the counter-derived figures (achieved / frac / traffic / per_brick) are REPLAYED from profiles/counters.json
                 # (rocprofv3 PMC passes cannot run inside the driver's bench); kernel_ms is measured live
                 "replayed": True, "counters_sha": (counters or {}).get("csrc_sha256"),
+                "counters_of": "the N = 1 launch (118 425 857 nodes of the 256^3 lattice), one GPU",
                 "per_brick": k1.get("per_brick") if k1 else None,
                 # frac above is UTILISATION of the vector issue slots; these say how much of it is arithmetic and how full the scalar unit is:
                 # arith_frac = (f32 + f64 arithmetic instructions) / all vector instructions (the rest: compares, selects, moves, integer);
