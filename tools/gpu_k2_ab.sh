@@ -1,5 +1,6 @@
 #!/bin/bash
-# gpurun helper (round 6): parity of the staged K2 path, the same-box A/B, a kernel trace of one call per variant
+# gpurun helper (round 6): parity of the staged K2 path, the same-box A/B (K2_VARIANTS="a|b|..." overrides the variants), a kernel trace of
+# one call per variant (-> $O/k2_kernel_stats.txt, $O/k2_dispatches.txt)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r06b}
@@ -20,5 +21,3 @@ for r in c.execute("select name,duration,grid_x,workgroup_x,vgpr_count,lds_size 
     print("%-50s %10d ns grid=%d wg=%d vgpr=%d lds=%d" % (n[:50], r[1], r[2], r[3], r[4], r[5]))
 PY
 rm -rf $O/trace
-# the preflight stand-alone, two processes on the one GPU
-DG_BENCH_SELFTEST_ONE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 tools/scale_preflight.py > $O/preflight2.txt 2>&1; grep preflight $O/preflight2.txt | cut -c1-300
